@@ -1,0 +1,218 @@
+"""Pins the CPU oracle (oracle/, plain C) to the reference: every oracle
+function is compared with golden vectors captured from anassinator/pddp itself
+(tools/make_golden.py).  CPU-only."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from golden_util import (DT, FWD_NAMES, load, np_dtype, rel_err, tags)
+
+PROBLEMS = ["cartpole", "pendulum", "double_cartpole", "rendezvous"]
+# fp64: restatement vs reference differ only by summation order / LAPACK
+# rounding.  fp32: same, at float epsilon, amplified through the horizon.
+TOL = {"f64": 1e-9, "f32": 2e-3}
+TOL_FWD = {"f64": 1e-11, "f32": 3e-4}
+
+
+@pytest.mark.parametrize("problem", PROBLEMS)
+def test_constants_match_reference(problem):
+    g = load(problem)
+    p = orc.make_problem(problem, DT[problem])
+    na, m = p.aug_size, p.action_size
+    Q = np.array(p.Q).reshape(8, 8)[:na, :na]
+    Qt = np.array(p.Q_term).reshape(8, 8)[:na, :na]
+    R = np.array(p.R).reshape(4, 4)[:m, :m]
+    assert np.array_equal(Q, g["const/cost/Q"])
+    assert np.array_equal(Qt, g["const/cost/Q_term"])
+    assert np.array_equal(R, g["const/cost/R"])
+    goal = np.broadcast_to(g["const/cost/x_goal"], (na,))
+    assert np.allclose(np.array(p.x_goal)[:na], goal, rtol=0, atol=1e-15)
+    names = {"cartpole": ["dt", "mc", "mp", "l", "mu", "g"],
+             "pendulum": ["dt", "m", "l", "mu", "g"],
+             "double_cartpole": ["dt", "mc", "mp1", "mp2", "l1", "l2", "mu",
+                                 "g"],
+             "rendezvous": ["dt", "m", "alpha"]}[problem]
+    for i, nm in enumerate(names):
+        assert p.params[i] == float(g["const/model/" + nm]), nm
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("problem", PROBLEMS)
+def test_forward_matches_reference(problem, dtype):
+    g = load(problem, dtype=dtype)
+    o = orc.load(np_dtype(dtype))
+    p = orc.make_problem(problem, DT[problem])
+    for tag in tags(problem):
+        for sub, bounded in (("fwd", False), ("fwd_bounded", True)):
+            kw = dict(u_min=g["u_min"], u_max=g["u_max"]) if bounded else {}
+            out = o.forward(p, g["z0"], g[tag + "/U"], **kw)
+            for nm in FWD_NAMES:
+                ref = g["%s/%s/%s" % (tag, sub, nm)]
+                err = rel_err(out[nm], ref)
+                assert err < TOL_FWD[dtype], (tag, sub, nm, err)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("problem", PROBLEMS)
+def test_backward_matches_reference(problem, dtype):
+    g = load(problem, dtype=dtype)
+    o = orc.load(np_dtype(dtype))
+    n_ok = n_fail = 0
+    for tag in tags(problem):
+        f = {nm: g["%s/fwd_bounded/%s" % (tag, nm)] for nm in FWD_NAMES}
+        for branch in "ABCD":
+            for reg in (0.0, 1e-6, 1.0, 100.0):
+                key = "%s/bwd/%s/%g" % (tag, branch, reg)
+                kw = dict(reg=reg, V_zz_reg=branch in "CD")
+                if branch in "BD":
+                    kw.update(u_min=g["u_min"], u_max=g["u_max"],
+                              U=g[tag + "/U"])
+                k, K, status = o.backward(f["F_z"], f["F_u"], f["L_z"],
+                                          f["L_u"], f["L_zz"], f["L_uz"],
+                                          f["L_uu"], **kw)
+                ok = int(g[key + "/ok"])
+                if problem == "rendezvous" and branch in "AB":
+                    # Reference defect (documented in DESIGN.md): ilqr.py:631
+                    # uses the NON-symmetric eig (geev); for repeated
+                    # eigenvalues (rendezvous is x/y symmetric) its
+                    # eigenvectors are not orthogonal, so E diag(1/e) E^T is
+                    # not Q_uu^-1 and the output is LAPACK-internal.  The
+                    # oracle uses the intended symmetric decomposition; it
+                    # is checked against numpy eigh in
+                    # test_backward_eig_branch_vs_numpy instead.
+                    continue
+                if dtype == "f32" and ok != (status == 0):
+                    # knife-edge PD tests may flip in float; must not in f64
+                    continue
+                assert ok == (status == 0), (key, status)
+                if ok:
+                    n_ok += 1
+                    ek = rel_err(k, g[key + "/k"])
+                    eK = rel_err(K, g[key + "/K"])
+                    assert ek < TOL[dtype] and eK < TOL[dtype], (key, ek, eK)
+                else:
+                    n_fail += 1
+    assert n_ok >= 12
+
+
+def test_boxqp_matches_reference():
+    g = np.load(__import__("os").path.join(
+        __import__("golden_util").GOLDEN_DIR, "boxqp.npz"))
+    for case in range(int(g["n_cases"])):
+        key = "case%d" % case
+        dt = g[key + "/Q"].dtype
+        o = orc.load(dt)
+        x, result, Uf, free = o.boxqp(g[key + "/x0"], g[key + "/Q"],
+                                      g[key + "/c"], g[key + "/lower"],
+                                      g[key + "/upper"])
+        ref = int(g[key + "/result"])
+        if dt == np.float64:
+            assert result == ref, (key, result)
+        else:  # float: the exit test taken at the optimum is a knife edge
+            assert (result >= 1) == (ref >= 1), (key, result, ref)
+        if result >= 1:
+            tol = 1e-10 if dt == np.float64 else 1e-4
+            assert np.allclose(x, g[key + "/x"], rtol=tol, atol=tol), key
+            assert np.array_equal(free, g[key + "/free"]), key
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("problem", PROBLEMS)
+def test_line_search_matches_reference(problem, dtype):
+    g = load(problem, dtype=dtype)
+    o = orc.load(np_dtype(dtype))
+    p = orc.make_problem(problem, DT[problem])
+    for tag in tags(problem):
+        f = {nm: g["%s/fwd_bounded/%s" % (tag, nm)] for nm in FWD_NAMES}
+        U = g[tag + "/U"]
+        k = g[tag + "/bwd/B/1/k"]
+        K = g[tag + "/bwd/B/1/K"]
+        for sched in ("fit", "mpc"):
+            alphas = g["%s/ls_%s/alphas" % (tag, sched)]
+            Zn, Un = o.control_law(p, f["Z"], U, k, K, alphas, g["u_min"],
+                                   g["u_max"])
+            J = o.trajectory_cost(p, Zn, Un)
+            Zr = g["%s/ls_%s/Z_new" % (tag, sched)]
+            Ur = g["%s/ls_%s/U_new" % (tag, sched)]
+            Jr = g["%s/ls_%s/J" % (tag, sched)]
+            N = Ur.shape[0]
+            if N <= 5:
+                tol = 1e-12 if dtype == "f64" else 1e-5
+                assert rel_err(Zn, Zr) < tol
+                assert rel_err(Un, Ur) < tol
+                assert rel_err(J, Jr) < tol
+            else:
+                # Long horizons with reg=1 gains give DIVERGING candidate
+                # rollouts (|z| up to 1e246, inf, NaN): rounding differences
+                # grow exponentially with t.  Check the stable prefix tightly
+                # and the non-finite pattern of the costs.
+                T = 12
+                tol = 1e-9 if dtype == "f64" else 2e-3
+                assert rel_err(Zn[:T], Zr[:T]) < tol
+                assert rel_err(Un[:T], Ur[:T]) < tol
+                assert np.array_equal(np.isfinite(J), np.isfinite(Jr))
+                if dtype == "f64":
+                    fin = np.isfinite(Jr)
+                    assert np.allclose(J[fin], Jr[fin], rtol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_backward_eig_branch_vs_numpy(dtype):
+    """m = 4 (rendezvous): the eig-clamp branch against an independent numpy
+    restatement with the symmetric eigendecomposition (see the note in
+    test_backward_matches_reference)."""
+    g = load("rendezvous", dtype=dtype)
+    o = orc.load(np_dtype(dtype))
+    for tag in tags("rendezvous"):
+        f = {nm: g["%s/fwd_bounded/%s" % (tag, nm)].astype(np.float64)
+             for nm in FWD_NAMES}
+        for reg in (0.0, 1.0):
+            k, K, status = o.backward(f["F_z"], f["F_u"], f["L_z"], f["L_u"],
+                                      f["L_zz"], f["L_uz"], f["L_uu"], reg=reg)
+            assert status == 0
+            N = f["F_u"].shape[0]
+            Vz, Vzz = f["L_z"][N], f["L_zz"][N]
+            for t in range(N - 1, -1, -1):
+                Fz, Fu = f["F_z"][t], f["F_u"][t]
+                Qz = f["L_z"][t] + Fz.T @ Vz
+                Qu = f["L_u"][t] + Fu.T @ Vz
+                Qzz = f["L_zz"][t] + Fz.T @ Vzz @ Fz
+                Qzz = 0.5 * (Qzz + Qzz.T)
+                Quz = f["L_uz"][t] + Fu.T @ Vzz @ Fz
+                Quu = f["L_uu"][t] + Fu.T @ Vzz @ Fu
+                Quu = 0.5 * (Quu + Quu.T)
+                e, E = np.linalg.eigh(Quu)
+                e = np.where(e < 0, 1e-12, e) + reg
+                inv = (E / e) @ E.T
+                kt, Kt = -inv @ Qu, -inv @ Quz
+                tol = 1e-9 if dtype == "f64" else 2e-3
+                assert np.allclose(k[t], kt, rtol=tol, atol=tol * 10)
+                assert np.allclose(K[t], Kt, rtol=tol, atol=tol * 10)
+                Vz = Qz + Kt.T @ Qu + Kt.T @ Quu @ kt + Quz.T @ kt
+                Vzz = Qzz + Kt.T @ Quu @ Kt + Kt.T @ Quz + Quz.T @ Kt
+                Vzz = 0.5 * (Vzz + Vzz.T)
+
+
+@pytest.mark.parametrize("mode", ["bounded", "free"])
+@pytest.mark.parametrize("problem", PROBLEMS[:3])
+def test_fit_trace_matches_reference(problem, mode):
+    """Whole controller: same state sequence, mu/delta schedule and costs as
+    iLQRController.fit (fp64)."""
+    g = load(problem)
+    o = orc.load(np.float64)
+    p = orc.make_problem(problem, DT[problem])
+    ft = "fit_" + mode
+    alphas = 1.025 ** (-np.arange(10.0) ** 2)
+    kw = dict(u_min=g["u_min"], u_max=g["u_max"]) if mode == "bounded" else {}
+    Z, U, K, state, trace = o.fit(p, g["z0"], g[ft + "/U0"], alphas,
+                                  n_iterations=int(g[ft + "/n_iterations"]),
+                                  **kw)
+    ref = g[ft + "/trace"]
+    assert trace.shape == ref.shape
+    assert np.array_equal(trace[:, :2], ref[:, :2])  # iteration, state
+    assert np.allclose(trace[:, 3:], ref[:, 3:], rtol=1e-12)  # mu, delta
+    assert np.allclose(trace[:, 2], ref[:, 2], rtol=1e-7)  # J_opt
+    assert state == int(g[ft + "/state"])
+    assert rel_err(U, g[ft + "/U"]) < 1e-5
+    assert rel_err(Z, g[ft + "/Z"]) < 1e-5
+    assert rel_err(K, g[ft + "/K"]) < 1e-5

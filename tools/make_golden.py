@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""Captures golden vectors from the reference (anassinator/pddp, imported
+read-only from /root/reference through tools/ref_shims.py) into
+tests/golden/*.npz.
+
+Run in the build container only (the GPU box has no /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+
+Each fixture holds inputs AND the reference's outputs for one
+(problem, encoding, dtype): the nominal inputs (z0, U, bounds), the
+float32-rounded model/cost constants the reference ended up with, the outputs of
+`pddp.controllers.ilqr.forward` (ilqr.py:393), of `backward` (ilqr.py:530) for
+the four gain branches x several regularisation values (including failing
+ones), of `_control_law` + `_trajectory_cost` (ilqr.py:678,765) for both alpha
+schedules, `boxqp` (constraint.py:150) unit cases and complete
+`iLQRController.fit` traces (ilqr.py:237).  Only data is stored - no reference
+source text.
+"""
+import math
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from ref_shims import import_reference  # noqa: E402
+
+warnings.simplefilter("ignore")
+pddp = import_reference()
+
+from pddp.controllers.ilqr import (  # noqa: E402
+    forward, backward, _control_law, _trajectory_cost, iLQRController)
+from pddp.utils.constraint import boxqp  # noqa: E402
+from pddp.utils.encoding import StateEncoding  # noqa: E402
+from pddp.utils.gaussian_variable import GaussianVariable  # noqa: E402
+from pddp.examples import (  # noqa: E402
+    cartpole, pendulum, double_cartpole, rendezvous)
+
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+PROBLEMS = {
+    # name: (model cls, cost cls, env cls, dt, bound, mean of z0)
+    "cartpole": (cartpole.CartpoleDynamicsModel, cartpole.CartpoleCost,
+                 cartpole.CartpoleEnv, 0.1, 10.0,
+                 [0.01, -0.02, 0.015, 0.0]),
+    "pendulum": (pendulum.PendulumDynamicsModel, pendulum.PendulumCost,
+                 pendulum.PendulumEnv, 0.1, 2.5, [0.02, -0.01]),
+    "double_cartpole": (double_cartpole.DoubleCartpoleDynamicsModel,
+                        double_cartpole.DoubleCartpoleCost,
+                        double_cartpole.DoubleCartpoleEnv, 0.05, 20.0,
+                        [0.01, -0.02, math.pi - 0.015, 0.0, math.pi + 0.02,
+                         0.01]),
+    "rendezvous": (rendezvous.RendezvousDynamicsModel,
+                   rendezvous.RendezvousCost, rendezvous.RendezvousEnv, 0.1,
+                   5.0, [-10.0, -10.0, 10.0, 10.0, 0.0, -5.0, 5.0, 0.0]),
+}
+
+ENCODINGS = {
+    "ignore": StateEncoding.IGNORE_UNCERTAINTY,
+    "default": StateEncoding.DEFAULT,
+}
+
+ALPHAS_FIT = lambda: 1.025**(-torch.arange(10.0)**2)  # ilqr.py:282
+ALPHAS_MPC = lambda: 10.0**torch.linspace(0, -3, 11)  # ilqr.py:116
+
+
+def np_(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def nominal_controls(N, m, dtype, kind):
+    t = torch.arange(N, dtype=torch.float64)
+    cols = []
+    for j in range(m):
+        if kind == "cos":
+            cols.append(0.1 * torch.cos(t + 0.7 * j))
+        else:  # seeded
+            g = torch.Generator().manual_seed(1234 + j)
+            cols.append(0.1 * torch.randn(N, generator=g, dtype=torch.float64))
+    return torch.stack(cols, -1).to(dtype)
+
+
+def capture_backward(store, prefix, Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu,
+                     U, u_min, u_max, regs):
+    for branch in "ABCD":
+        V_zz_reg = branch in "CD"
+        bounded = branch in "BD"
+        for reg in regs:
+            key = "%s/%s/%g" % (prefix, branch, reg)
+            kw = dict(reg=reg, V_zz_reg=V_zz_reg)
+            if bounded:
+                kw.update(u_min=u_min, u_max=u_max, U=U)
+            try:
+                k, K = backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu,
+                                **kw)
+                store[key + "/ok"] = np.array(1)
+                store[key + "/k"] = np_(k)
+                store[key + "/K"] = np_(K)
+            except RuntimeError as e:
+                store[key + "/ok"] = np.array(0)
+                store[key + "/err"] = np.array(str(e)[:60])
+
+
+def capture_problem(name, enc_name, dtype, Ns, with_fit):
+    model_cls, cost_cls, env_cls, dt, bound, mean0 = PROBLEMS[name]
+    encoding = ENCODINGS[enc_name]
+    store = {}
+    model = model_cls(dt).to(dtype)
+    cost = cost_cls().to(dtype)
+    for pname, p in model.named_parameters():
+        store["const/model/" + pname] = np_(p)
+    for pname, p in cost.named_parameters():
+        store["const/cost/" + pname] = np_(p)
+    m = model.action_size
+    u_min = torch.full((m,), -bound, dtype=dtype)
+    u_max = torch.full((m,), bound, dtype=dtype)
+    store["u_min"] = np_(u_min)
+    store["u_max"] = np_(u_max)
+    store["dt"] = np.array(dt)
+    store["encoding"] = np.array(int(encoding))
+
+    mean = torch.tensor(mean0, dtype=dtype)
+    z0 = GaussianVariable(
+        mean, var=1e-2 * torch.ones_like(mean)).encode(encoding).detach()
+    store["z0"] = np_(z0)
+
+    for N in Ns:
+        for kind in ("cos", "seeded"):
+            if kind == "seeded" and N != Ns[0]:
+                continue
+            tag = "N%d_%s" % (N, kind)
+            U = nominal_controls(N, m, dtype, kind)
+            if kind == "seeded":
+                U = 30 * U  # exercises the clamp in forward() on pendulum
+            store[tag + "/U"] = np_(U)
+            for bounded in (False, True):
+                bt = tag + ("/fwd_bounded" if bounded else "/fwd")
+                kw = dict(u_min=u_min, u_max=u_max) if bounded else {}
+                out = forward(z0, U.clone(), model, cost, encoding, **kw)
+                names = ["Z", "F_z", "F_u", "L", "L_z", "L_u", "L_zz", "L_uz",
+                         "L_uu"]
+                for nm, t in zip(names, out):
+                    store[bt + "/" + nm] = np_(t)
+                if not bounded:
+                    out_free = out
+                else:
+                    out_b = out
+            # backward uses the bounded forward outputs when bounds are given
+            # (this is what iLQRController.step does, ilqr.py:198-208).
+            Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu = out_b
+            regs = [0.0, 1e-6, 1.0, 100.0]
+            capture_backward(store, tag + "/bwd", Z, F_z, F_u, L, L_z, L_u,
+                             L_zz, L_uz, L_uu, U, u_min, u_max, regs)
+
+            # Line search from the branch-B (controller default) gains, reg=1.
+            k, K = backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu,
+                            reg=1.0, u_min=u_min, u_max=u_max, U=U)
+            for aname, alphas in (("fit", ALPHAS_FIT()), ("mpc", ALPHAS_MPC())):
+                alphas = alphas.to(dtype)
+                Zb, Ub = _control_law(model, Z, U, k, K, alphas, encoding, {},
+                                      u_min=u_min, u_max=u_max)
+                J = _trajectory_cost(cost, Zb, Ub, encoding, {})
+                store["%s/ls_%s/alphas" % (tag, aname)] = np_(alphas)
+                store["%s/ls_%s/Z_new" % (tag, aname)] = np_(Zb)
+                store["%s/ls_%s/U_new" % (tag, aname)] = np_(Ub)
+                store["%s/ls_%s/J" % (tag, aname)] = np_(J)
+
+    if with_fit:
+        N = with_fit
+        for n_iter, bounded in ((25, True), (8, False)):
+            env = env_cls(dt=dt, model=model_cls(dt))
+            env._state = mean.clone()
+            ctrl = iLQRController(env, model, cost)
+            U = nominal_controls(N, m, dtype, "cos")
+            trace = []
+
+            def on_iteration(i, state, Z, U_, J, ctrl=ctrl, trace=trace):
+                trace.append((i, int(state), float(J), ctrl._mu, ctrl._delta))
+
+            kw = dict(u_min=u_min, u_max=u_max) if bounded else {}
+            Zf, Uf, state = ctrl.fit(U.clone(), encoding=encoding,
+                                     n_iterations=n_iter, quiet=True,
+                                     on_iteration=on_iteration, **kw)
+            ft = "fit_%s" % ("bounded" if bounded else "free")
+            store[ft + "/N"] = np.array(N)
+            store[ft + "/n_iterations"] = np.array(n_iter)
+            store[ft + "/U0"] = np_(U)
+            store[ft + "/trace"] = np.array(trace, dtype=np.float64)
+            store[ft + "/Z"] = np_(Zf)
+            store[ft + "/U"] = np_(Uf)
+            store[ft + "/K"] = np_(ctrl._K)
+            store[ft + "/state"] = np.array(int(state))
+
+    dname = "f64" if dtype == torch.float64 else "f32"
+    path = os.path.join(OUT, "%s_%s_%s.npz" % (name, enc_name, dname))
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
+def capture_boxqp():
+    """Unit vectors for boxqp (constraint.py:150-266), m in {1,2,4}."""
+    store = {}
+    g = torch.Generator().manual_seed(7)
+    case = 0
+    for dtype in (torch.float64, torch.float32):
+        for m in (1, 2, 4):
+            for trial in range(6):
+                A = torch.randn(m, m, generator=g, dtype=torch.float64)
+                Q = (A.t().mm(A) + 0.1 * torch.eye(m, dtype=torch.float64))
+                c = 3.0 * torch.randn(m, generator=g, dtype=torch.float64)
+                lower = -torch.rand(m, generator=g, dtype=torch.float64) - 0.1
+                upper = torch.rand(m, generator=g, dtype=torch.float64) + 0.1
+                x0 = torch.randn(m, generator=g, dtype=torch.float64)
+                if trial == 0:  # interior optimum
+                    lower, upper = lower * 100, upper * 100
+                if trial == 1:  # warm start exactly at a bound
+                    x0 = upper.clone()
+                if trial == 2:  # pinned
+                    upper = lower.clone()
+                if trial == 3:  # indefinite Q
+                    Q = Q - 2.0 * torch.eye(m, dtype=torch.float64) * Q.diag().max()
+                Q, c, lower, upper, x0 = [
+                    t.to(dtype) for t in (Q, c, lower, upper, x0)]
+                # boxqp allocates float32 scratch under the default dtype and
+                # the reference indexes with it; keep default dtype = dtype.
+                torch.set_default_dtype(dtype)
+                x, result, Ufree, free = boxqp(x0, Q, c, lower, upper)
+                torch.set_default_dtype(torch.float32)
+                key = "case%d" % case
+                store[key + "/x0"] = np_(x0)
+                store[key + "/Q"] = np_(Q)
+                store[key + "/c"] = np_(c)
+                store[key + "/lower"] = np_(lower)
+                store[key + "/upper"] = np_(upper)
+                store[key + "/x"] = np_(x)
+                store[key + "/result"] = np.array(int(result))
+                store[key + "/free"] = np_(free).astype(np.uint8)
+                case += 1
+    store["n_cases"] = np.array(case)
+    path = os.path.join(OUT, "boxqp.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    capture_boxqp()
+    for dtype in (torch.float64, torch.float32):
+        capture_problem("cartpole", "ignore", dtype, [5, 100], with_fit=30)
+        capture_problem("pendulum", "ignore", dtype, [5, 50], with_fit=25)
+        capture_problem("double_cartpole", "ignore", dtype, [5, 60],
+                        with_fit=20)
+        capture_problem("rendezvous", "ignore", dtype, [5, 40], with_fit=20)
+    # DEFAULT (upper-triangular Cholesky) encoding: captured for the next
+    # rows of SURVEY 8(f); fp64 only, short horizons (n = 14 / 5).
+    capture_problem("cartpole", "default", torch.float64, [5, 25], with_fit=0)
+    capture_problem("pendulum", "default", torch.float64, [5, 25], with_fit=0)
+
+
+if __name__ == "__main__":
+    main()
