@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched iLQR iterations on MI355X.
+
+Workload = BASELINE.json configs[1]: cartpole (n=4, m=1), known dynamics,
+horizon N=100, B=4096 trajectories per GPU, fp32, control bounds +-10
+(controller default branch: eig-clamp + BoxQP), alphas of ilqr.py:282.
+Synthetic inputs as SURVEY.md 8(d): z0 = 1e-2 N(0,1), U = 0.1 N(0,1),
+seed = rank.
+
+A "step" is one pass of the hot path over the whole batch: derivative records
+for every trajectory whose nominal changed, the backward Riccati sweep, the
+10-candidate line search with costs, and the accept / regularisation update.
+Inputs are resident in HBM before the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+
+prints ONE JSON line (rank 0).  For N > 1 launch through torch.distributed.run;
+ranks own disjoint shards (weak scaling, no data-path collective) and exchange
+their best rollout once through RCCL.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_trajectory(N, n, m, itemsize, bounded):
+    """BASELINE.md 3 / SURVEY.md 8(d): bytes the backward sweep must move."""
+    per_step = 2 * n * n + 3 * n * m + n + 2 * m + m * m + (m if bounded else 0)
+    return itemsize * (N * per_step + n + n * n)
+
+
+def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
+    """Times the oracle (plain C port of the reference's algorithm, one core)
+    on a bounded sample of the same workload; unit = the same
+    trajectory-iterations/s."""
+    import oracle as orc
+    o = orc.load(np.float32)
+    op = orc.make_problem(problem_name, dt)
+    rng = np.random.RandomState(12345)
+    alphas = (1.025 ** (-np.arange(10.0) ** 2)).astype(np.float32)
+    u_min = np.full(op.action_size, -bound, np.float32)
+    u_max = np.full(op.action_size, bound, np.float32)
+    attempts, trajs = 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        z0 = (1e-2 * rng.randn(op.encoded_size)).astype(np.float32)
+        U = (0.1 * rng.randn(N, op.action_size)).astype(np.float32)
+        _, _, _, _, trace = o.fit(op, z0, U, alphas, n_iterations=8,
+                                  u_min=u_min, u_max=u_max)
+        attempts += trace.shape[0]
+        trajs += 1
+    el = time.perf_counter() - t0
+    return {"value": attempts / el, "unit": "trajectory-iterations/s",
+            "cores": 1, "kind": "port",
+            "sample": "%d cartpole trajectories x up to 8 iLQR iterations "
+                      "(%d attempts) in %.1f s, oracle C port, fp32, "
+                      "host has %d cores" % (trajs, attempts, el,
+                                             os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--horizon", type=int, default=100)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--generic-kernel", action="store_true",
+                    help="force the generic backward kernel (A/B)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(
+            "cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+
+    import pddp_amd
+    from pddp_amd import _native
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.examples import cartpole
+    from pddp_amd.parallel import gather_best_rollout
+
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    B, N = args.batch, args.horizon
+    enc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
+    model, cost = cartpole.CartpoleDynamicsModel(0.1), cartpole.CartpoleCost()
+    prob = model.native_problem(enc, cost)
+    n, m = prob.encoded_size, prob.action_size
+    bound = 10.0
+    u_min = torch.full((m,), -bound, dtype=dtype)
+    u_max = torch.full((m,), bound, dtype=dtype)
+    s = ILQRSolver(prob, B, N, dtype, device, u_min, u_max)
+    g = torch.Generator().manual_seed(rank)
+    z0 = (1e-2 * torch.randn(B, n, generator=g, dtype=torch.float64)).to(dtype)
+    U = (0.1 * torch.randn(B, N, m, generator=g, dtype=torch.float64)).to(dtype)
+    s.set_nominal(z0.to(device), U.to(device))
+
+    lib = _native.lib()
+    K, W = args.steps, args.warmup
+    n_iter = 1 << 30  # the fit loop never runs out inside the benchmark
+
+    def one_round(ev=None):
+        s.derivs(mask=s.fresh)
+        if ev is not None:
+            lib.pddp_event_record(ev[0], s._s())
+        s.backward(active=s.active, generic=args.generic_kernel)
+        if ev is not None:
+            lib.pddp_event_record(ev[1], s._s())
+        s.line_search(active=s.active)
+        s.accept(5e-6, 1e10, n_iter)
+
+    for _ in range(W):
+        one_round()
+    torch.cuda.synchronize(device)
+    events = []
+    for _ in range(K):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        lib.pddp_event_create(ctypes.byref(a))
+        lib.pddp_event_create(ctypes.byref(b))
+        events.append((a, b))
+    s.n_live.zero_()
+    live0 = int(s.active.sum().item())
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        one_round(events[i])
+    if world > 1:  # the one exchange of the path: best rollout over RCCL
+        lo = rank * B
+        Jb, idx, Zb, Ub = gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # units processed: attempts actually made (live trajectories per round)
+    liveK = int(s.active.sum().item())
+    cum_live = int(s.n_live.item())          # sum over rounds of live-after
+    attempted = live0 + cum_live - liveK     # sum over rounds of live-before
+    total_attempted = attempted
+    if world > 1:
+        t = torch.tensor([attempted], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        total_attempted = int(t.item())
+
+    durs = []
+    for a, b in events:
+        ms = ctypes.c_float()
+        lib.pddp_event_elapsed_ms(a, b, ctypes.byref(ms))
+        durs.append(ms.value * 1e-3)
+        lib.pddp_event_destroy(a)
+        lib.pddp_event_destroy(b)
+    itemsize = 4 if dtype == torch.float32 else 8
+    per_traj = algorithmic_bytes_per_trajectory(N, n, m, itemsize, True)
+    avg_dur = float(np.mean(durs))
+    # every timed launch swept `attempted / K` trajectories on average
+    achieved = (attempted / K) * per_traj / avg_dur / 1e9
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "pddp_iterations_per_sec",
+            "value": total_attempted / elapsed,
+            "unit": "trajectory-iterations/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE.json configs[1]: cartpole n=4 m=1, "
+                            "known-dynamics iLQR, horizon=%d, batch=%d "
+                            "trajectories per GPU, bounds +-10 (eig-clamp + "
+                            "BoxQP branch), 10 line-search alphas" % (N, B),
+                "batch_per_gpu": B, "horizon": N, "alphas": int(s.A),
+                "unit_definition": "one iLQR attempt of one trajectory: "
+                                   "derivative records when its nominal "
+                                   "changed + backward sweep + line search + "
+                                   "accept",
+                "batched_iterations_per_s": K / elapsed,
+                "trajectory_timesteps_per_s": total_attempted * N / elapsed,
+                "live_trajectories_start_end": [live0, liveK],
+                "backward_kernel": "generic" if args.generic_kernel
+                                   else "specialised",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "backward Riccati sweep",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "avg_launch_us": avg_dur * 1e6,
+                "min_launch_us": float(np.min(durs)) * 1e6,
+                "algorithmic_bytes_per_launch": (attempted / K) * per_traj,
+                "traffic": None,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline("cartpole", 0.1, N, bound)
+        else:
+            out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

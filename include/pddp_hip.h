@@ -1,0 +1,194 @@
+/*
+ * pddp_hip.h - C ABI of libpddp_hip.so, the MI355X (gfx950) implementation of
+ * the PDDP / iLQR data-parallel hot path.
+ *
+ * The reference (anassinator/pddp) is pure Python on torch 0.4.1 and has NO
+ * native boundary; this ABI is what a native extension
+ * of the reference would bind for its hot path.  Each entry point names the
+ * reference function it replaces.  The Python plugin API on top
+ * (pddp_amd.controllers / costs / models) mirrors the reference's classes and
+ * calls these through ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless marked "host";
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered,
+ *     nothing allocates, nothing synchronises the host, nothing throws;
+ *   - return value: 0 on success, <0 PDDP_E_* for argument errors, >0 a
+ *     hipError_t from the launch;
+ *   - numerical failures the reference signals with RuntimeError
+ *     (ilqr.py:608,639,653 and potrf at :595) are reported per trajectory in
+ *     `status[b]` (PDDP_BWD_* of pddp_problem.h);
+ *   - B independent trajectories (the batch axis the reference does not have:
+ *     every trajectory is one reference controller call), N horizon,
+ *     n encoded state size, m action size;
+ *   - _f32 / _f64 suffix = arithmetic type of the whole path.
+ *
+ * Record layout (the HBM format the backward sweep streams; one record per
+ * trajectory and time step, trajectory-major, N+1 records per trajectory, the
+ * last one holding the terminal L_z, L_zz of ilqr.py:471-473):
+ *
+ *   rec[b][t][ F_z n*n | L_zz n*n | F_u n*m | L_uz m*n | L_z n | L_uu m*m |
+ *              L_u m | U m | pad ]          stride = roundup4(total) scalars
+ *
+ * (cartpole n=4,m=1: 47 -> 48 floats = 192 B.)  `U` is the un-clamped nominal
+ * action (ilqr.py:602,647 read it for the BoxQP bounds).  Gains come back as
+ *
+ *   gains[b][t][ k m | K m*n ]              (ilqr.py:581-582 k, K)
+ */
+#ifndef PDDP_HIP_H
+#define PDDP_HIP_H
+
+#include <stdint.h>
+
+#include "pddp_problem.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  PDDP_E_BADARG = -1,      /* null pointer / non-positive size */
+  PDDP_E_UNSUPPORTED = -2, /* (n, m, model, encoding) not built */
+  PDDP_E_NODEVICE = -3
+};
+
+typedef struct pddp_record_layout {
+  int n, m;
+  int o_Fz, o_Lzz, o_Fu, o_Luz, o_Lz, o_Luu, o_Lu, o_U;
+  int stride;      /* scalars per record */
+  int gain_stride; /* m + m*n */
+} pddp_record_layout;
+
+/* Library / device probes (host). */
+int pddp_hip_abi_version(void);
+int pddp_hip_device_count(void);
+const char* pddp_hip_arch(void); /* "gfx950" */
+int pddp_record_layout_of(int n, int m, pddp_record_layout* out /* host */);
+
+/* ---- ilqr.py:529-674 backward(): the Riccati sweep --------------------- */
+/* rec    [B][N+1][stride]   records (see above)
+ * u_min, u_max [m] or both NULL -> branch A/C (no BoxQP), else B/D
+ * reg    [B] per-trajectory mu (ilqr.py:135 passes self._mu), host-side type
+ *        double like the reference's python float
+ * branch PDDP_BRANCH_EIG (controller default, V_zz_reg=False) or _CHOLESKY
+ * active [B] nullable; trajectories with active[b]==0 are skipped untouched
+ * gains  [B][N][m + m*n] out
+ * status [B] out (PDDP_BWD_*) */
+int pddp_riccati_backward_f32(int B, int N, int n, int m, const float* rec,
+                              const float* u_min, const float* u_max,
+                              const double* reg, int branch,
+                              const uint8_t* active, float* gains,
+                              int32_t* status, void* stream);
+int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
+                              const double* u_min, const double* u_max,
+                              const double* reg, int branch,
+                              const uint8_t* active, double* gains,
+                              int32_t* status, void* stream);
+
+/* Packs reference-layout tensors (what ilqr.py:393-486 forward() returns,
+ * with a leading batch axis) into records, for plugin models whose
+ * derivatives come from elsewhere.  F_z [B][N][n][n], F_u [B][N][n][m],
+ * L_z [B][N+1][n], L_u [B][N][m], L_zz [B][N+1][n][n], L_uz [B][N][m][n],
+ * L_uu [B][N][m][m], U [B][N][m] (nullable -> zeros). */
+int pddp_pack_records_f32(int B, int N, int n, int m, const float* F_z,
+                          const float* F_u, const float* L_z, const float* L_u,
+                          const float* L_zz, const float* L_uz,
+                          const float* L_uu, const float* U, float* rec,
+                          void* stream);
+int pddp_pack_records_f64(int B, int N, int n, int m, const double* F_z,
+                          const double* F_u, const double* L_z,
+                          const double* L_u, const double* L_zz,
+                          const double* L_uz, const double* L_uu,
+                          const double* U, double* rec, void* stream);
+
+/* ---- ilqr.py:393-486 forward(): derivative rollout for the sample
+ * problems (analytic; replaces utils/evaluation.py:134-288 autograd) ------ */
+/* Nominal rollout Z[b][0] = z0[b], Z[b][t+1] = model(Z[b][t], clamp(U[b][t]))
+ * (ilqr.py:457-468).  problem: host pointer, copied by value into the launch.
+ * z0 [B][n]; U [B][N][m]; u_min/u_max [m] nullable (ilqr.py:461-462);
+ * mask [B] nullable (0 -> trajectory skipped); Z [B][N+1][n] out. */
+int pddp_nominal_rollout_f32(const pddp_problem* problem, int B, int N,
+                             const float* z0, const float* U,
+                             const float* u_min, const float* u_max,
+                             const uint8_t* mask, float* Z, void* stream);
+int pddp_nominal_rollout_f64(const pddp_problem* problem, int B, int N,
+                             const double* z0, const double* U,
+                             const double* u_min, const double* u_max,
+                             const uint8_t* mask, double* Z, void* stream);
+
+/* Derivative records along a given nominal (Z, U): F_z, F_u, L_z .. L_uu at
+ * every (b, t) (ilqr.py:464-473), parallel over b AND t.
+ * rec [B][N+1][stride] out; L [B][N+1] out; J [B] out = L.sum() (ilqr.py:209);
+ * state [B] nullable: set to UNDEFINED for computed trajectories
+ * (ilqr.py:212). */
+int pddp_derivs_f32(const pddp_problem* problem, int B, int N, const float* Z,
+                    const float* U, const float* u_min, const float* u_max,
+                    const uint8_t* mask, float* rec, float* L, float* J,
+                    int32_t* state, void* stream);
+int pddp_derivs_f64(const pddp_problem* problem, int B, int N, const double* Z,
+                    const double* U, const double* u_min, const double* u_max,
+                    const uint8_t* mask, double* rec, double* L, double* J,
+                    int32_t* state, void* stream);
+
+/* ---- ilqr.py:677-723 _control_law() + :764-791 _trajectory_cost() ------- */
+/* A candidate step sizes per trajectory.  Z [B][N+1][n], U [B][N][m] nominal;
+ * gains [B][N][m+m*n]; alphas [A]; bwd_status [B] nullable (non-zero ->
+ * skipped, the reference never reaches the line search then, ilqr.py:140-145);
+ * Zc [N+1][B*A][n], Uc [N][B*A][m] candidates out (time-major so that a
+ * wavefront's stores coalesce), Jc [B][A] out. */
+int pddp_line_search_f32(const pddp_problem* problem, int B, int N, int A,
+                         const float* Z, const float* U, const float* gains,
+                         const float* alphas, const float* u_min,
+                         const float* u_max, const uint8_t* active,
+                         const int32_t* bwd_status, float* Zc, float* Uc,
+                         float* Jc, void* stream);
+int pddp_line_search_f64(const pddp_problem* problem, int B, int N, int A,
+                         const double* Z, const double* U, const double* gains,
+                         const double* alphas, const double* u_min,
+                         const double* u_max, const uint8_t* active,
+                         const int32_t* bwd_status, double* Zc, double* Uc,
+                         double* Jc, void* stream);
+
+/* ---- ilqr.py:102-181 _step() accept / reject, :364-390 mu schedule and the
+ * fit() loop bookkeeping (:298-314), per trajectory, device resident -------- */
+/* Controller state arrays (all [B]):
+ *   J_opt (T), mu, delta (double, the reference's python floats), state
+ *   (iLQRState), iter (number of step() calls started, ilqr.py:298),
+ *   active (attempted this round), fresh (needs new derivatives next round).
+ * For each trajectory with active[b] != 0:
+ *   bwd_status != 0 -> _increase_reg, NOT_PD / MAX_REG          (:140-145)
+ *   else amin = argmin Jc[b], accept iff J_new < J_opt           (:161-166)
+ *     accept: Z, U <- candidate amin; gains_acc <- gains (self._K);
+ *             _decrease_reg; CONVERGED iff |dJ|/J_opt < tol      (:167-176)
+ *     reject: _increase_reg, REJECTED / MAX_REG                  (:178-181)
+ * then the masks of the NEXT round: retry states keep active=1, fresh=0;
+ * ACCEPTED starts the next step() (iter+1, fresh=1) unless iter == n_iterations;
+ * CONVERGED / MAX_REG leave the loop (:313).  n_live (device int32, nullable)
+ * accumulates the number of trajectories still active after this round. */
+int pddp_accept_f32(int B, int N, int n, int m, int A, const float* Zc,
+                    const float* Uc, const float* Jc, const float* gains,
+                    const int32_t* bwd_status, double tol, double max_reg,
+                    int n_iterations, float* Z, float* U, float* gains_acc,
+                    float* J_opt, double* mu, double* delta, int32_t* state,
+                    int32_t* iter, uint8_t* active, uint8_t* fresh,
+                    int32_t* n_live, void* stream);
+int pddp_accept_f64(int B, int N, int n, int m, int A, const double* Zc,
+                    const double* Uc, const double* Jc, const double* gains,
+                    const int32_t* bwd_status, double tol, double max_reg,
+                    int n_iterations, double* Z, double* U, double* gains_acc,
+                    double* J_opt, double* mu, double* delta, int32_t* state,
+                    int32_t* iter, uint8_t* active, uint8_t* fresh,
+                    int32_t* n_live, void* stream);
+
+/* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only
+ * sees torch's current stream). Host functions. */
+int pddp_event_create(void** ev);
+int pddp_event_record(void* ev, void* stream);
+int pddp_event_elapsed_ms(void* start, void* stop, float* ms); /* syncs stop */
+int pddp_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDDP_HIP_H */

@@ -1,0 +1,155 @@
+"""ctypes binding of the C ABI in include/pddp_hip.h (libpddp_hip.so).
+
+There is NO fallback: if the HIP library is missing or a call fails, this
+module raises.  PyTorch is only used by callers for device memory and streams;
+no torch type crosses this boundary (pointers and sizes only).
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpddp_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MAX_AUG, MAX_ACTION, MAX_PARAMS = 8, 4, 8
+
+c_int, c_double, c_void_p = ctypes.c_int, ctypes.c_double, ctypes.c_void_p
+
+
+class PddpProblem(ctypes.Structure):
+    """include/pddp_problem.h `pddp_problem`."""
+    _fields_ = [
+        ("model", c_int), ("encoding", c_int), ("state_size", c_int),
+        ("action_size", c_int), ("encoded_size", c_int), ("aug_size", c_int),
+        ("params", c_double * MAX_PARAMS),
+        ("Q", c_double * (MAX_AUG * MAX_AUG)),
+        ("Q_term", c_double * (MAX_AUG * MAX_AUG)),
+        ("R", c_double * (MAX_ACTION * MAX_ACTION)),
+        ("x_goal", c_double * MAX_AUG),
+        ("u_goal", c_double * MAX_ACTION),
+    ]
+
+
+class RecordLayout(ctypes.Structure):
+    """include/pddp_hip.h `pddp_record_layout`."""
+    _fields_ = [(k, c_int) for k in (
+        "n", "m", "o_Fz", "o_Lzz", "o_Fu", "o_Luz", "o_Lz", "o_Luu", "o_Lu",
+        "o_U", "stride", "gain_stride")]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compiles libpddp_hip.so for gfx950 with hipcc (no GPU needed)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
+    return LIB_PATH
+
+
+_P = c_void_p
+_SIGS = {
+    "pddp_hip_abi_version": [],
+    "pddp_hip_device_count": [],
+    "pddp_record_layout_of": [c_int, c_int, _P],
+    "pddp_riccati_backward": [c_int] * 4 + [_P] * 4 + [c_int] + [_P] * 4,
+    "pddp_riccati_backward_generic": [c_int] * 4 + [_P] * 4 + [c_int] + [_P] * 4,
+    "pddp_pack_records": [c_int] * 4 + [_P] * 10,
+    "pddp_nominal_rollout": [_P, c_int, c_int] + [_P] * 7,
+    "pddp_derivs": [_P, c_int, c_int] + [_P] * 10,
+    "pddp_line_search": [_P, c_int, c_int, c_int] + [_P] * 12,
+    "pddp_accept": [c_int] * 5 + [_P] * 5 + [c_double, c_double, c_int] +
+                   [_P] * 12,
+    "pddp_event_create": [_P],
+    "pddp_event_record": [_P, _P],
+    "pddp_event_elapsed_ms": [_P, _P, _P],
+    "pddp_event_destroy": [_P],
+}
+_TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_generic",
+          "pddp_pack_records", "pddp_nominal_rollout", "pddp_derivs",
+          "pddp_line_search", "pddp_accept")
+
+_lib = None
+
+
+def exported_symbols():
+    """Every symbol include/pddp_hip.h declares."""
+    names = []
+    for k in _SIGS:
+        if k in _TYPED:
+            names += [k + "_f32", k + "_f64"]
+        else:
+            names.append(k)
+    names.append("pddp_hip_arch")
+    return names
+
+
+def lib():
+    """Loads the HIP library; raises NativeError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "libpddp_hip.so is not built (%s). Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` - there "
+                "is no CPU fallback." % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, sig in _SIGS.items():
+            for full in ([name + "_f32", name + "_f64"]
+                         if name in _TYPED else [name]):
+                fn = getattr(l, full)
+                fn.argtypes = sig
+                fn.restype = c_int
+        l.pddp_hip_arch.restype = ctypes.c_char_p
+        _lib = l
+    return _lib
+
+
+def suffix(dtype):
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    raise NativeError("unsupported dtype %s (f32 / f64 only)" % dtype)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL). Must be contiguous."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise NativeError("non-contiguous tensor passed to the C ABI")
+    return t.data_ptr()
+
+
+def stream_handle(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NativeError("%s failed with code %d" % (what, rc))
+
+
+def call(name, dtype, *args):
+    fn = getattr(lib(), "%s_%s" % (name, suffix(dtype)))
+    check(fn(*args), name)
+
+
+def record_layout(n, m):
+    out = RecordLayout()
+    check(lib().pddp_record_layout_of(n, m, ctypes.addressof(out)),
+          "pddp_record_layout_of")
+    return out
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise NativeError(
+            "pddp_amd runs its hot path on the MI355X only; got a %s tensor "
+            "(no CPU fallback)" % t.device)

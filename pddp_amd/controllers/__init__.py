@@ -1,0 +1,5 @@
+"""Controllers (reference: pddp/controllers/__init__.py)."""
+from .base import Controller
+from .ilqr import iLQRController, iLQRState
+
+__all__ = ["Controller", "iLQRController", "iLQRState"]

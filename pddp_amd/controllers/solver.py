@@ -1,0 +1,191 @@
+"""Device-resident batched iLQR engine: owns the HBM buffers of B independent
+trajectories and drives the HIP kernels of libpddp_hip.so through the C ABI.
+
+One `round()` = what the reference does in one pass of the retry loop of
+`iLQRController.step` (pddp/controllers/ilqr.py:183-235) for EVERY live
+trajectory at once:
+
+    derivatives (only trajectories whose nominal changed, ilqr.py:198-209)
+    -> backward Riccati sweep (ilqr.py:125-139)
+    -> line search over A step sizes + costs (ilqr.py:148-160)
+    -> accept / reject, mu schedule, fit-loop bookkeeping (ilqr.py:161-181,
+       298-314)
+
+with per-trajectory masks instead of Python control flow, so a round is a
+fixed launch sequence with no host synchronisation.
+"""
+import ctypes
+
+import torch
+
+from .. import _native
+from ..utils.encoding import StateEncoding
+
+BRANCH_EIG, BRANCH_CHOLESKY = 0, 1
+
+
+def fit_alphas(dtype, device):
+    """ilqr.py:282 (the schedule `fit` actually uses)."""
+    return (1.025 ** (-torch.arange(10.0, dtype=torch.float64) ** 2)).to(
+        dtype=dtype, device=device)
+
+
+def mpc_alphas(dtype, device):
+    """ilqr.py:116,189 default of `step` (used by forward(mpc=True))."""
+    return (10.0 ** torch.linspace(0, -3, 11)).to(dtype=dtype, device=device)
+
+
+class ILQRSolver(object):
+
+    def __init__(self, problem, B, N, dtype, device, u_min=None, u_max=None,
+                 alphas=None, branch=BRANCH_EIG):
+        self.problem = problem
+        self.B, self.N = int(B), int(N)
+        self.n, self.m = problem.encoded_size, problem.action_size
+        self.dtype, self.device = dtype, torch.device(device)
+        if self.device.type != "cuda":
+            raise _native.NativeError(
+                "ILQRSolver needs a GPU device (no CPU fallback)")
+        self.lay = _native.record_layout(self.n, self.m)
+        self.branch = branch
+        opts = dict(dtype=dtype, device=self.device)
+        B, N, n, m = self.B, self.N, self.n, self.m
+        S, gs = self.lay.stride, self.lay.gain_stride
+        self.u_min = None if u_min is None else \
+            torch.as_tensor(u_min).to(**opts).reshape(m).contiguous()
+        self.u_max = None if u_max is None else \
+            torch.as_tensor(u_max).to(**opts).reshape(m).contiguous()
+        self.alphas = (fit_alphas(dtype, self.device) if alphas is None
+                       else torch.as_tensor(alphas).to(**opts).contiguous())
+        A = self.A = self.alphas.numel()
+        self.z0 = torch.zeros(B, n, **opts)
+        self.Z = torch.zeros(B, N + 1, n, **opts)
+        self.U = torch.zeros(B, N, m, **opts)
+        self.rec = torch.zeros(B, N + 1, S, **opts)
+        self.L = torch.zeros(B, N + 1, **opts)
+        self.J_opt = torch.zeros(B, **opts)
+        self.gains = torch.zeros(B, N, gs, **opts)
+        self.gains_acc = torch.zeros(B, N, gs, **opts)
+        self.Zc = torch.zeros(N + 1, B * A, n, **opts)
+        self.Uc = torch.zeros(N, B * A, m, **opts)
+        self.Jc = torch.zeros(B, A, **opts)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        u8 = dict(dtype=torch.uint8, device=self.device)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.bwd_status = torch.zeros(B, **i32)
+        self.state = torch.zeros(B, **i32)
+        self.iter = torch.zeros(B, **i32)
+        self.mu = torch.zeros(B, **f64)
+        self.delta = torch.full((B,), 2.0, **f64)
+        self.active = torch.zeros(B, **u8)
+        self.fresh = torch.zeros(B, **u8)
+        self.n_live = torch.zeros(1, **i32)
+        self._pp = ctypes.addressof(self.problem)
+
+    # -- views in the reference's tensor layout -----------------------------
+    def record_views(self):
+        """(F_z, F_u, L_z, L_u, L_zz, L_uz, L_uu) as zero-copy views of the
+        record buffer, shaped like ilqr.py:445-455 with a leading batch."""
+        l, n, m, N = self.lay, self.n, self.m, self.N
+        r = self.rec
+        B = self.B
+        F_z = r[:, :N, l.o_Fz:l.o_Fz + n * n].unflatten(-1, (n, n))
+        F_u = r[:, :N, l.o_Fu:l.o_Fu + n * m].unflatten(-1, (n, m))
+        L_z = r[:, :, l.o_Lz:l.o_Lz + n]
+        L_u = r[:, :N, l.o_Lu:l.o_Lu + m]
+        L_zz = r[:, :, l.o_Lzz:l.o_Lzz + n * n].unflatten(-1, (n, n))
+        L_uz = r[:, :N, l.o_Luz:l.o_Luz + m * n].unflatten(-1, (m, n))
+        L_uu = r[:, :N, l.o_Luu:l.o_Luu + m * m].unflatten(-1, (m, m))
+        return F_z, F_u, L_z, L_u, L_zz, L_uz, L_uu
+
+    def gain_views(self, accepted=False):
+        g = self.gains_acc if accepted else self.gains
+        m, n = self.m, self.n
+        return g[..., :m], g[..., m:].unflatten(-1, (m, n))
+
+    # -- kernels --------------------------------------------------------------
+    def _s(self):
+        return _native.stream_handle(self.device)
+
+    def set_nominal(self, z0, U):
+        """ilqr.py:274-277: new nominal controls, regularisation reset."""
+        self.z0.copy_(z0.reshape(self.B, self.n))
+        self.U.copy_(U.reshape(self.B, self.N, self.m))
+        self.reset_controller_state()
+        self.nominal_rollout()
+
+    def reset_controller_state(self):
+        self.mu.zero_()          # _reset_reg ilqr.py:364-367
+        self.delta.fill_(2.0)
+        self.state.zero_()       # UNDEFINED
+        self.iter.fill_(1)       # first step() call is under way
+        self.active.fill_(1)
+        self.fresh.fill_(1)
+
+    def nominal_rollout(self, mask=None):
+        p = _native.ptr
+        _native.call("pddp_nominal_rollout", self.dtype, self._pp, self.B,
+                     self.N, p(self.z0), p(self.U), p(self.u_min),
+                     p(self.u_max), p(mask), p(self.Z), self._s())
+
+    def derivs(self, mask=None, set_state=True):
+        p = _native.ptr
+        _native.call("pddp_derivs", self.dtype, self._pp, self.B, self.N,
+                     p(self.Z), p(self.U), p(self.u_min), p(self.u_max),
+                     p(mask), p(self.rec), p(self.L), p(self.J_opt),
+                     p(self.state) if set_state else None, self._s())
+
+    def backward(self, active=None, reg=None, branch=None, bounded=True,
+                 generic=False):
+        p = _native.ptr
+        reg = self.mu if reg is None else reg
+        branch = self.branch if branch is None else branch
+        umin = self.u_min if bounded else None
+        umax = self.u_max if bounded else None
+        name = "pddp_riccati_backward_generic" if generic else \
+            "pddp_riccati_backward"
+        _native.call(name, self.dtype, self.B, self.N, self.n, self.m,
+                     p(self.rec), p(umin), p(umax), p(reg), int(branch),
+                     p(active), p(self.gains), p(self.bwd_status), self._s())
+
+    def line_search(self, active=None, use_status=True):
+        p = _native.ptr
+        _native.call("pddp_line_search", self.dtype, self._pp, self.B, self.N,
+                     self.A, p(self.Z), p(self.U), p(self.gains),
+                     p(self.alphas), p(self.u_min), p(self.u_max), p(active),
+                     p(self.bwd_status) if use_status else None, p(self.Zc),
+                     p(self.Uc), p(self.Jc), self._s())
+
+    def accept(self, tol, max_reg, n_iterations):
+        p = _native.ptr
+        _native.call("pddp_accept", self.dtype, self.B, self.N, self.n, self.m,
+                     self.A, p(self.Zc), p(self.Uc), p(self.Jc), p(self.gains),
+                     p(self.bwd_status), float(tol), float(max_reg),
+                     int(n_iterations), p(self.Z), p(self.U),
+                     p(self.gains_acc), p(self.J_opt), p(self.mu),
+                     p(self.delta), p(self.state), p(self.iter),
+                     p(self.active), p(self.fresh), p(self.n_live), self._s())
+
+    def round(self, tol=5e-6, max_reg=1e10, n_iterations=50):
+        """One attempt of every live trajectory (no host sync)."""
+        self.derivs(mask=self.fresh)
+        self.backward(active=self.active)
+        self.line_search(active=self.active)
+        self.n_live.zero_()
+        self.accept(tol, max_reg, n_iterations)
+
+    def fit(self, n_iterations=50, tol=5e-6, max_reg=1e10, on_round=None,
+            max_rounds=None):
+        """Runs rounds until every trajectory left the fit loop
+        (ilqr.py:298-314). Returns the number of rounds."""
+        rounds = 0
+        while True:
+            self.round(tol, max_reg, n_iterations)
+            rounds += 1
+            if on_round is not None:
+                on_round(rounds, self)
+            if int(self.n_live.item()) == 0:
+                break
+            if max_rounds is not None and rounds >= max_rounds:
+                break
+        return rounds

@@ -1,0 +1,293 @@
+// controller.hip - per-trajectory controller state machine on the device,
+// record packing and the host-side probes / timing helpers of the C ABI.
+//
+//   accept / reject + mu schedule   pddp/controllers/ilqr.py:102-181,364-390
+//   fit() loop bookkeeping          pddp/controllers/ilqr.py:298-314
+#include "pddp_common.hpp"
+
+namespace pddp {
+
+template <typename T>
+struct AcceptArgs {
+  int B, N, n, m, A;
+  const T* Zc;
+  const T* Uc;
+  const T* Jc;
+  const T* gains;
+  const int32_t* bwd_status;
+  double tol, max_reg;
+  int n_iterations;
+  T* Z;
+  T* U;
+  T* gains_acc;
+  T* J_opt;
+  double* mu;
+  double* delta;
+  int32_t* state;
+  int32_t* iter;
+  uint8_t* active;
+  uint8_t* fresh;
+  int32_t* n_live;
+};
+
+constexpr double kMuMin = 1e-6;   // ilqr.py:94
+constexpr double kDelta0 = 2.0;   // ilqr.py:95
+
+template <typename T>
+__global__ __launch_bounds__(kWave) void accept_kernel(AcceptArgs<T> a) {
+  __shared__ int sh_amin;  // >= 0: accepted candidate, -1: nothing to copy
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const bool attempted = a.active[b] != 0;
+  if (!attempted) return;  // masks of finished trajectories stay 0
+
+  if (tid == 0) {
+    int amin_out = -1;
+    double mu = a.mu[b], delta = a.delta[b];
+    int st;
+    bool increase = false;
+    if (a.bwd_status[b] != 0) {
+      increase = true;  // RuntimeError path                    (ilqr.py:140-145)
+      st = PDDP_STATE_NOT_PD;
+    } else {
+      const T* J = a.Jc + (size_t)b * a.A;
+      int amin = 0;  // torch argmin: first minimum, a NaN wins     (ilqr.py:161)
+      for (int i = 1; i < a.A && J[amin] == J[amin]; ++i)
+        if (J[i] < J[amin] || J[i] != J[i]) amin = i;
+      const T J_new = J[amin];
+      const T J_opt = a.J_opt[b];
+      if (J_new < J_opt) {  // ilqr.py:166
+        amin_out = amin;
+        delta = (delta < 1.0 ? delta : 1.0) / kDelta0;  // _decrease_reg :369-374
+        mu *= delta;
+        if (mu <= kMuMin) mu = 0.0;
+        const T rel = abs_(J_opt - J_new) / J_opt;
+        st = (rel < (T)a.tol) ? PDDP_STATE_CONVERGED : PDDP_STATE_ACCEPTED;
+        a.J_opt[b] = J_new;
+      } else {
+        increase = true;
+        st = PDDP_STATE_REJECTED;
+      }
+    }
+    if (increase) {  // _increase_reg                            (ilqr.py:376-390)
+      delta = (delta > 1.0 ? delta : 1.0) * kDelta0;
+      mu = (kMuMin > mu * delta) ? kMuMin : mu * delta;
+      if (mu >= a.max_reg) st = PDDP_STATE_MAX_REG;
+    }
+    a.mu[b] = mu;
+    a.delta[b] = delta;
+    a.state[b] = st;
+    // masks of the next round (fit loop, ilqr.py:298-314)
+    uint8_t act = 0, fr = 0;
+    if (st == PDDP_STATE_NOT_PD || st == PDDP_STATE_REJECTED) {
+      act = 1;
+    } else if (st == PDDP_STATE_ACCEPTED) {
+      if (a.iter[b] < a.n_iterations) {
+        a.iter[b] += 1;
+        act = 1;
+        fr = 1;
+      }
+    }
+    a.active[b] = act;
+    a.fresh[b] = fr;
+    if (act && a.n_live != nullptr) atomicAdd(a.n_live, 1);
+    sh_amin = amin_out;
+  }
+  __syncthreads();
+  const int amin = sh_amin;
+  if (amin < 0) return;
+  // nominal <- winning candidate; self._K <- K                (ilqr.py:167-169)
+  const int n = a.n, m = a.m, N = a.N;
+  const size_t total = (size_t)a.B * a.A;
+  const size_t cidx = (size_t)b * a.A + amin;
+  T* Zb = a.Z + (size_t)b * (N + 1) * n;
+  T* Ub = a.U + (size_t)b * N * m;
+  for (int o = tid; o < (N + 1) * n; o += kWave) {
+    const int t = o / n, j = o - t * n;
+    Zb[o] = a.Zc[((size_t)t * total + cidx) * n + j];
+  }
+  for (int o = tid; o < N * m; o += kWave) {
+    const int t = o / m, j = o - t * m;
+    Ub[o] = a.Uc[((size_t)t * total + cidx) * m + j];
+  }
+  const int gs = m + m * n;
+  const T* G = a.gains + (size_t)b * N * gs;
+  T* Ga = a.gains_acc + (size_t)b * N * gs;
+  for (int o = tid; o < N * gs; o += kWave) Ga[o] = G[o];
+}
+
+template <typename T>
+static int accept_impl(int B, int N, int n, int m, int A, const T* Zc,
+                       const T* Uc, const T* Jc, const T* gains,
+                       const int32_t* bwd_status, double tol, double max_reg,
+                       int n_iterations, T* Z, T* U, T* gains_acc, T* J_opt,
+                       double* mu, double* delta, int32_t* state,
+                       int32_t* iter, uint8_t* active, uint8_t* fresh,
+                       int32_t* n_live, void* stream) {
+  if (B <= 0 || N <= 0 || n <= 0 || m <= 0 || A <= 0 || !Zc || !Uc || !Jc ||
+      !gains || !bwd_status || !Z || !U || !gains_acc || !J_opt || !mu ||
+      !delta || !state || !iter || !active || !fresh)
+    return PDDP_E_BADARG;
+  AcceptArgs<T> a{B, N, n, m, A, Zc, Uc, Jc, gains, bwd_status, tol, max_reg,
+                  n_iterations, Z, U, gains_acc, J_opt, mu, delta, state, iter,
+                  active, fresh, n_live};
+  hipLaunchKernelGGL((accept_kernel<T>), dim3(B), dim3(kWave), 0,
+                     (hipStream_t)stream, a);
+  return launch_status();
+}
+
+// --------------------------------------------------------------------------
+// reference layout -> records
+// --------------------------------------------------------------------------
+template <typename T>
+struct PackArgs {
+  int B, N, n, m;
+  const T *F_z, *F_u, *L_z, *L_u, *L_zz, *L_uz, *L_uu, *U;
+  T* rec;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kernel(PackArgs<T> a) {
+  const RecLayout lay(a.n, a.m);
+  const int n = a.n, m = a.m, N = a.N, S = lay.stride;
+  const size_t total = (size_t)a.B * (N + 1) * S;
+  for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+       o += (size_t)gridDim.x * blockDim.x) {
+    const size_t bt = o / S;
+    const int w = (int)(o - bt * S);
+    const size_t b = bt / (N + 1);
+    const int t = (int)(bt - b * (N + 1));
+    const bool term = (t == N);
+    T v = T(0);
+    if (w < lay.oLzz) {
+      if (!term) v = a.F_z[(b * N + t) * n * n + (w - lay.oFz)];
+    } else if (w < lay.oFu) {
+      v = a.L_zz[(b * (N + 1) + t) * n * n + (w - lay.oLzz)];
+    } else if (w < lay.oLuz) {
+      if (!term) v = a.F_u[(b * N + t) * n * m + (w - lay.oFu)];
+    } else if (w < lay.oLz) {
+      if (!term) v = a.L_uz[(b * N + t) * m * n + (w - lay.oLuz)];
+    } else if (w < lay.oLuu) {
+      v = a.L_z[(b * (N + 1) + t) * n + (w - lay.oLz)];
+    } else if (w < lay.oLu) {
+      if (!term) v = a.L_uu[(b * N + t) * m * m + (w - lay.oLuu)];
+    } else if (w < lay.oU) {
+      if (!term) v = a.L_u[(b * N + t) * m + (w - lay.oLu)];
+    } else if (w < lay.oU + m) {
+      if (!term && a.U != nullptr) v = a.U[(b * N + t) * m + (w - lay.oU)];
+    }
+    a.rec[o] = v;
+  }
+}
+
+template <typename T>
+static int pack_impl(int B, int N, int n, int m, const T* F_z, const T* F_u,
+                     const T* L_z, const T* L_u, const T* L_zz, const T* L_uz,
+                     const T* L_uu, const T* U, T* rec, void* stream) {
+  if (B <= 0 || N <= 0 || n <= 0 || m <= 0 || !F_z || !F_u || !L_z || !L_u ||
+      !L_zz || !L_uz || !L_uu || !rec)
+    return PDDP_E_BADARG;
+  PackArgs<T> a{B, N, n, m, F_z, F_u, L_z, L_u, L_zz, L_uz, L_uu, U, rec};
+  const RecLayout lay(n, m);
+  const size_t total = (size_t)B * (N + 1) * lay.stride;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((pack_kernel<T>), dim3(blocks), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return launch_status();
+}
+
+}  // namespace pddp
+
+extern "C" {
+
+int pddp_hip_abi_version(void) { return 1; }
+
+int pddp_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* pddp_hip_arch(void) { return "gfx950"; }
+
+int pddp_record_layout_of(int n, int m, pddp_record_layout* out) {
+  if (n <= 0 || m <= 0 || out == nullptr) return PDDP_E_BADARG;
+  const pddp::RecLayout l(n, m);
+  out->n = n;
+  out->m = m;
+  out->o_Fz = l.oFz;
+  out->o_Lzz = l.oLzz;
+  out->o_Fu = l.oFu;
+  out->o_Luz = l.oLuz;
+  out->o_Lz = l.oLz;
+  out->o_Luu = l.oLuu;
+  out->o_Lu = l.oLu;
+  out->o_U = l.oU;
+  out->stride = l.stride;
+  out->gain_stride = l.gstride;
+  return 0;
+}
+
+int pddp_accept_f32(int B, int N, int n, int m, int A, const float* Zc,
+                    const float* Uc, const float* Jc, const float* gains,
+                    const int32_t* bwd_status, double tol, double max_reg,
+                    int n_iterations, float* Z, float* U, float* gains_acc,
+                    float* J_opt, double* mu, double* delta, int32_t* state,
+                    int32_t* iter, uint8_t* active, uint8_t* fresh,
+                    int32_t* n_live, void* stream) {
+  return pddp::accept_impl<float>(B, N, n, m, A, Zc, Uc, Jc, gains, bwd_status,
+                                  tol, max_reg, n_iterations, Z, U, gains_acc,
+                                  J_opt, mu, delta, state, iter, active, fresh,
+                                  n_live, stream);
+}
+int pddp_accept_f64(int B, int N, int n, int m, int A, const double* Zc,
+                    const double* Uc, const double* Jc, const double* gains,
+                    const int32_t* bwd_status, double tol, double max_reg,
+                    int n_iterations, double* Z, double* U, double* gains_acc,
+                    double* J_opt, double* mu, double* delta, int32_t* state,
+                    int32_t* iter, uint8_t* active, uint8_t* fresh,
+                    int32_t* n_live, void* stream) {
+  return pddp::accept_impl<double>(B, N, n, m, A, Zc, Uc, Jc, gains,
+                                   bwd_status, tol, max_reg, n_iterations, Z,
+                                   U, gains_acc, J_opt, mu, delta, state, iter,
+                                   active, fresh, n_live, stream);
+}
+
+int pddp_pack_records_f32(int B, int N, int n, int m, const float* F_z,
+                          const float* F_u, const float* L_z, const float* L_u,
+                          const float* L_zz, const float* L_uz,
+                          const float* L_uu, const float* U, float* rec,
+                          void* stream) {
+  return pddp::pack_impl<float>(B, N, n, m, F_z, F_u, L_z, L_u, L_zz, L_uz,
+                                L_uu, U, rec, stream);
+}
+int pddp_pack_records_f64(int B, int N, int n, int m, const double* F_z,
+                          const double* F_u, const double* L_z,
+                          const double* L_u, const double* L_zz,
+                          const double* L_uz, const double* L_uu,
+                          const double* U, double* rec, void* stream) {
+  return pddp::pack_impl<double>(B, N, n, m, F_z, F_u, L_z, L_u, L_zz, L_uz,
+                                 L_uu, U, rec, stream);
+}
+
+int pddp_event_create(void** ev) {
+  hipEvent_t e;
+  hipError_t rc = hipEventCreate(&e);
+  if (rc != hipSuccess) return (int)rc;
+  *ev = (void*)e;
+  return 0;
+}
+int pddp_event_record(void* ev, void* stream) {
+  return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+}
+int pddp_event_elapsed_ms(void* start, void* stop, float* ms) {
+  hipError_t rc = hipEventSynchronize((hipEvent_t)stop);
+  if (rc != hipSuccess) return (int)rc;
+  return (int)hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
+int pddp_event_destroy(void* ev) {
+  return (int)hipEventDestroy((hipEvent_t)ev);
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// riccati.hip - C-ABI entry points of the backward Riccati sweep
+// (pddp/controllers/ilqr.py:529-674) and their dispatch.
+#include "riccati_generic.hpp"
+#include "riccati_n4.hpp"
+
+namespace pddp {
+
+template <typename T, int NMAX, int M>
+static int launch_generic(const RiccatiArgs<T>& a, hipStream_t st) {
+  hipLaunchKernelGGL((riccati_generic_kernel<T, NMAX, M>), dim3(a.B),
+                     dim3(kWave), 0, st, a);
+  return launch_status();
+}
+
+template <typename T, int M>
+static int dispatch_nmax(const RiccatiArgs<T>& a, hipStream_t st) {
+  if (a.n <= 8) return launch_generic<T, 8, M>(a, st);
+  if (a.n <= 16) return launch_generic<T, 16, M>(a, st);
+  if (a.n <= 32) return launch_generic<T, 32, M>(a, st);
+  return PDDP_E_UNSUPPORTED;
+}
+
+template <typename T>
+static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
+                                 const T* u_min, const T* u_max,
+                                 const double* reg, int branch,
+                                 const uint8_t* active, T* gains,
+                                 int32_t* status, void* stream, int variant) {
+  if (B <= 0 || N <= 0 || n <= 0 || m <= 0 || !rec || !reg || !gains ||
+      !status)
+    return PDDP_E_BADARG;
+  if ((u_min == nullptr) != (u_max == nullptr)) return PDDP_E_BADARG;
+  if (branch != PDDP_BRANCH_EIG && branch != PDDP_BRANCH_CHOLESKY)
+    return PDDP_E_BADARG;
+  RiccatiArgs<T> a{B, N, n, rec, u_min, u_max, reg, branch, active, gains,
+                   status};
+  hipStream_t st = (hipStream_t)stream;
+  if (variant != 1 && n == 4 && m == 1) return launch_n4<T>(a, st);
+  switch (m) {
+    case 1: return dispatch_nmax<T, 1>(a, st);
+    case 2: return dispatch_nmax<T, 2>(a, st);
+    case 3: return dispatch_nmax<T, 3>(a, st);
+    case 4: return dispatch_nmax<T, 4>(a, st);
+  }
+  return PDDP_E_UNSUPPORTED;
+}
+
+}  // namespace pddp
+
+extern "C" {
+
+int pddp_riccati_backward_f32(int B, int N, int n, int m, const float* rec,
+                              const float* u_min, const float* u_max,
+                              const double* reg, int branch,
+                              const uint8_t* active, float* gains,
+                              int32_t* status, void* stream) {
+  return pddp::riccati_backward_impl<float>(B, N, n, m, rec, u_min, u_max, reg,
+                                            branch, active, gains, status,
+                                            stream, 0);
+}
+int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
+                              const double* u_min, const double* u_max,
+                              const double* reg, int branch,
+                              const uint8_t* active, double* gains,
+                              int32_t* status, void* stream) {
+  return pddp::riccati_backward_impl<double>(B, N, n, m, rec, u_min, u_max,
+                                             reg, branch, active, gains,
+                                             status, stream, 0);
+}
+/* Same sweep forced through the generic one-wavefront-per-trajectory kernel
+ * (A/B testing of the specialised n=4 kernel). */
+int pddp_riccati_backward_generic_f32(int B, int N, int n, int m,
+                                      const float* rec, const float* u_min,
+                                      const float* u_max, const double* reg,
+                                      int branch, const uint8_t* active,
+                                      float* gains, int32_t* status,
+                                      void* stream) {
+  return pddp::riccati_backward_impl<float>(B, N, n, m, rec, u_min, u_max, reg,
+                                            branch, active, gains, status,
+                                            stream, 1);
+}
+int pddp_riccati_backward_generic_f64(int B, int N, int n, int m,
+                                      const double* rec, const double* u_min,
+                                      const double* u_max, const double* reg,
+                                      int branch, const uint8_t* active,
+                                      double* gains, int32_t* status,
+                                      void* stream) {
+  return pddp::riccati_backward_impl<double>(B, N, n, m, rec, u_min, u_max,
+                                             reg, branch, active, gains,
+                                             status, stream, 1);
+}
+
+}  // extern "C"

@@ -1,0 +1,214 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol,
+host-side plugin API (encodings, costs, models vs the oracle / goldens), the
+loud failure without a GPU, and the multi-rank best-rollout exchange over
+gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as orc
+from golden_util import DT, load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from pddp_amd import _native
+    hdr = open(os.path.join(ROOT, "include", "pddp_hip.h")).read()
+    declared = set(re.findall(r"\b(pddp_[a-z0-9_]+)\s*\(", hdr))
+    declared = {d for d in declared if not d.startswith("pddp_record_layout")
+                or d == "pddp_record_layout_of"}
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert set(_native.exported_symbols()) >= declared
+    assert _native.lib().pddp_hip_abi_version() == 1
+    lay = _native.record_layout(4, 1)
+    assert (lay.stride, lay.gain_stride, lay.o_U) == (48, 5, 46)
+    lay = _native.record_layout(27, 1)
+    assert lay.stride % 4 == 0 and lay.stride >= 2 * 27 * 27 + 3 * 27 + 3
+
+
+def test_no_cpu_fallback():
+    """The product path refuses CPU tensors instead of silently computing."""
+    import pddp_amd
+    from pddp_amd import _native
+    from pddp_amd.examples import cartpole
+    env = cartpole.CartpoleEnv()
+    ctrl = pddp_amd.controllers.iLQRController(
+        env, cartpole.CartpoleDynamicsModel(0.1), cartpole.CartpoleCost())
+    with pytest.raises(_native.NativeError):
+        ctrl.fit(torch.zeros(5, 1),
+                 encoding=pddp_amd.StateEncoding.IGNORE_UNCERTAINTY)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under pddp_amd/ may mention it."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pddp_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in text and \
+                    "from oracle" not in text and \
+                    "pddp_oracle" not in text, f
+
+
+@pytest.mark.parametrize("problem", ["cartpole", "pendulum",
+                                     "double_cartpole", "rendezvous"])
+def test_host_models_and_costs_match_oracle(problem):
+    """The torch plugin classes (used by envs / user scripts) agree with the
+    oracle on dynamics and cost values, and carry the reference's constants."""
+    import pddp_amd
+    from pddp_amd.utils.encoding import StateEncoding
+    enc = StateEncoding.IGNORE_UNCERTAINTY
+    mod = getattr(pddp_amd.examples, problem)
+    model = [getattr(mod, n) for n in dir(mod) if n.endswith("DynamicsModel")
+             and n != "DynamicsModel"][0](DT[problem]).double()
+    cost = [getattr(mod, n) for n in dir(mod) if n.endswith("Cost")
+            and n != "AugmentedQRCost"][0]().double()
+    prob = model.native_problem(enc, cost)
+    op = orc.make_problem(problem, DT[problem])
+    for f in ("params", "Q", "Q_term", "R", "x_goal", "u_goal"):
+        assert list(getattr(prob, f)) == list(getattr(op, f)), f
+    o = orc.load(np.float64)
+    rng = np.random.RandomState(0)
+    n, m = op.encoded_size, op.action_size
+    for _ in range(5):
+        z, u = rng.randn(n), rng.randn(m)
+        zn, _, _ = o.dynamics(op, z, u)
+        got = model(torch.from_numpy(z), torch.from_numpy(u), 0, enc)
+        assert np.allclose(got.detach().numpy(), zn, rtol=1e-12, atol=1e-12)
+        l = o.cost(op, z, u)[0]
+        gl = cost(torch.from_numpy(z), torch.from_numpy(u), 0, False, enc)
+        assert np.allclose(float(gl), l, rtol=1e-12)
+        lt = o.cost(op, z, None, terminal=True)[0]
+        glt = cost(torch.from_numpy(z), None, 0, True, enc)
+        assert np.allclose(float(glt), lt, rtol=1e-12)
+    # batched evaluation == row-wise evaluation (reference test strategy:
+    # tests/utils/test_evaluation.py loop-vs-batch)
+    Zb, Ub = torch.randn(7, n).double(), torch.randn(7, m).double()
+    out = model(Zb, Ub, 0, enc)
+    for r in range(7):
+        assert torch.allclose(out[r], model(Zb[r], Ub[r], 0, enc))
+
+
+def test_encoding_sizes_and_round_trip():
+    """tests/utils/test_encoding.py of the reference: sizes 30/20/10/10/5 for
+    D = 5 and encode . decode round trips."""
+    from pddp_amd.utils import encoding as E
+    from pddp_amd import GaussianVariable, StateEncoding
+    sizes = {StateEncoding.FULL_COVARIANCE_MATRIX: 30,
+             StateEncoding.UPPER_TRIANGULAR_CHOLESKY: 20,
+             StateEncoding.VARIANCE_ONLY: 10,
+             StateEncoding.STANDARD_DEVIATION_ONLY: 10,
+             StateEncoding.IGNORE_UNCERTAINTY: 5}
+    torch.manual_seed(0)
+    for enc, size in sizes.items():
+        assert E.infer_encoded_state_size(5, enc) == size
+        assert E.infer_state_size(size, enc) == 5
+        x = GaussianVariable.random(5, dtype=torch.float64)
+        z = x.encode(enc)
+        assert z.shape == (size,)
+        assert torch.allclose(E.decode_mean(z, enc), x.mean())
+        if enc in (StateEncoding.FULL_COVARIANCE_MATRIX,
+                   StateEncoding.UPPER_TRIANGULAR_CHOLESKY):
+            assert torch.allclose(E.decode_covar(z, enc), x.covar(),
+                                  atol=1e-9)
+            L = E.decode_covar_sqrt(z, enc)
+            assert torch.allclose(L.t() @ L, x.covar(), atol=1e-9)
+        if enc != StateEncoding.IGNORE_UNCERTAINTY:
+            assert torch.allclose(E.decode_var(z, enc), x.var(), atol=1e-9)
+            assert torch.allclose(E.decode_std(z, enc), x.std(), atol=1e-9)
+        # batched
+        zb = torch.stack([z, z])
+        assert E.decode_mean(zb, enc).shape == (2, 5)
+        assert E.decode_covar(zb, enc).shape == (2, 5, 5)
+
+
+def test_default_encoding_matches_reference_golden():
+    """z0 under the DEFAULT (upper-triangular Cholesky) encoding equals the
+    reference's (golden)."""
+    from pddp_amd import GaussianVariable, StateEncoding
+    g = load("cartpole", encoding="default")
+    mean = torch.tensor([0.01, -0.02, 0.015, 0.0], dtype=torch.float64)
+    z0 = GaussianVariable(mean, var=1e-2 * torch.ones_like(mean)).encode(
+        StateEncoding.DEFAULT)
+    assert np.allclose(z0.numpy(), g["z0"], rtol=1e-12, atol=1e-15)
+
+
+def test_augment_reduce_round_trip():
+    from pddp_amd.utils.angular import augment_state, reduce_state
+    from pddp_amd.examples.double_cartpole import DoubleCartpoleDynamicsModel \
+        as M
+    x = torch.randn(9, 6).double()
+    xa = augment_state(x, M.angular_indices, M.non_angular_indices)
+    assert xa.shape == (9, 8)
+    xr = reduce_state(xa, M.angular_indices, M.non_angular_indices)
+    d = (xr - x)
+    d[:, M.angular_indices] = torch.remainder(
+        d[:, M.angular_indices] + np.pi, 2 * np.pi) - np.pi
+    assert d.abs().max() < 1e-12
+
+
+def test_shard_bounds_cover_batch():
+    from pddp_amd.parallel import shard_bounds
+    for total in (1, 7, 4096, 8192, 8191):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from pddp_amd.parallel import gather_best_rollout, shard_bounds
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+B, N, n, m = 10, 4, 3, 2
+g = torch.Generator().manual_seed(5)
+J = torch.rand(B, generator=g, dtype=torch.float64) + 1.0
+J[3] = float("nan")          # a diverged trajectory never wins
+J[7] = 0.25                  # global best lives on the last rank
+Z = torch.arange(B * (N + 1) * n, dtype=torch.float64).view(B, N + 1, n)
+U = -torch.arange(B * N * m, dtype=torch.float64).view(B, N, m)
+lo, hi = shard_bounds(B, rank, world)
+Jb, idx, Zb, Ub = gather_best_rollout(J[lo:hi], Z[lo:hi], U[lo:hi], offset=lo)
+assert idx == 7 and float(Jb) == 0.25, (idx, float(Jb))
+assert torch.equal(Zb, Z[7]) and torch.equal(Ub, U[7])
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_best_rollout_all_gather_two_ranks(tmp_path):
+    """world_size-2 gloo run of the one collective on the path."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port",
+         "29561", str(script)], capture_output=True, text=True, env=env,
+        timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2
+
+
+def test_best_rollout_single_process():
+    from pddp_amd.parallel import gather_best_rollout
+    J = torch.tensor([3.0, float("inf"), 1.5])
+    Z = torch.randn(3, 5, 2)
+    U = torch.randn(3, 4, 1)
+    Jb, idx, Zb, Ub = gather_best_rollout(J, Z, U, offset=100)
+    assert idx == 102 and float(Jb) == 1.5
+    assert torch.allclose(Zb, Z[2]) and torch.allclose(Ub, U[2])
