@@ -79,8 +79,8 @@ def main():
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--generic-kernel", action="store_true",
-                    help="force the generic backward kernel (A/B)")
+    ap.add_argument("--kernel-variant", type=int, default=0,
+                    help="backward kernel: 0 auto, 1 generic, 2 n4, 3 n4 fast")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,7 +123,7 @@ def main():
         s.derivs(mask=s.fresh)
         if ev is not None:
             lib.pddp_event_record(ev[0], s._s())
-        s.backward(active=s.active, generic=args.generic_kernel)
+        s.backward(active=s.active, variant=args.kernel_variant)
         if ev is not None:
             lib.pddp_event_record(ev[1], s._s())
         s.line_search(active=s.active)
@@ -209,8 +209,7 @@ def main():
                 "batched_iterations_per_s": K / elapsed,
                 "trajectory_timesteps_per_s": total_attempted * N / elapsed,
                 "live_trajectories_start_end": [live0, liveK],
-                "backward_kernel": "generic" if args.generic_kernel
-                                   else "specialised",
+                "backward_kernel_variant": args.kernel_variant,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "backward Riccati sweep",

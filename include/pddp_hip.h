@@ -72,8 +72,10 @@ int pddp_record_layout_of(int n, int m, pddp_record_layout* out /* host */);
  * reg    [B] per-trajectory mu (ilqr.py:135 passes self._mu), host-side type
  *        double like the reference's python float
  * branch PDDP_BRANCH_EIG (controller default, V_zz_reg=False) or _CHOLESKY
- * active [B] nullable; trajectories with active[b]==0 are skipped untouched
- * gains  [B][N][m + m*n] out
+ * active [B] nullable; trajectories with active[b]==0 are skipped: their
+ *        status is left untouched, their gains rows are unspecified
+ * gains  [B][N][m + m*n] out (unspecified from the failing step on when
+ *        status[b] != 0, like the reference which raises)
  * status [B] out (PDDP_BWD_*) */
 int pddp_riccati_backward_f32(int B, int N, int n, int m, const float* rec,
                               const float* u_min, const float* u_max,
@@ -85,6 +87,38 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
                               const double* reg, int branch,
                               const uint8_t* active, double* gains,
                               int32_t* status, void* stream);
+
+/* The same sweep through a chosen kernel variant (A/B measurements):
+ * 0 auto (what the entry points above use), 1 generic kernel (one wavefront
+ * per trajectory, any n <= 32, m <= 4), 2 specialised n=4/m=1 kernel
+ * (16 lanes per trajectory), 3 variant 2 with v_rcp/v_sqrt approximations
+ * instead of IEEE division / square root (f32 only). */
+int pddp_riccati_backward_variant_f32(int B, int N, int n, int m,
+                                      const float* rec, const float* u_min,
+                                      const float* u_max, const double* reg,
+                                      int branch, const uint8_t* active,
+                                      float* gains, int32_t* status,
+                                      void* stream, int variant);
+int pddp_riccati_backward_variant_f64(int B, int N, int n, int m,
+                                      const double* rec, const double* u_min,
+                                      const double* u_max, const double* reg,
+                                      int branch, const uint8_t* active,
+                                      double* gains, int32_t* status,
+                                      void* stream, int variant);
+
+/* ---- utils/constraint.py:150-266 boxqp() for one action dimension -------- */
+/* `count` independent scalar QPs  min 0.5 Q x^2 + c x  s.t. lower <= x <= upper,
+ * warm-started at x0: the projected-Newton loop of the reference with its
+ * exit codes (`result`, constraint.py:23-32) and its `free` flag, exactly the
+ * device routine the sweep calls.  All arrays [count]. */
+int pddp_boxqp_m1_f32(int count, const float* x0, const float* Q,
+                      const float* c, const float* lower, const float* upper,
+                      float* x, int32_t* result, uint8_t* free_mask,
+                      void* stream);
+int pddp_boxqp_m1_f64(int count, const double* x0, const double* Q,
+                      const double* c, const double* lower,
+                      const double* upper, double* x, int32_t* result,
+                      uint8_t* free_mask, void* stream);
 
 /* Packs reference-layout tensors (what ilqr.py:393-486 forward() returns,
  * with a leading batch axis) into records, for plugin models whose

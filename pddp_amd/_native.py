@@ -58,7 +58,9 @@ _SIGS = {
     "pddp_hip_device_count": [],
     "pddp_record_layout_of": [c_int, c_int, _P],
     "pddp_riccati_backward": [c_int] * 4 + [_P] * 4 + [c_int] + [_P] * 4,
-    "pddp_riccati_backward_generic": [c_int] * 4 + [_P] * 4 + [c_int] + [_P] * 4,
+    "pddp_riccati_backward_variant": [c_int] * 4 + [_P] * 4 + [c_int] +
+                                     [_P] * 4 + [c_int],
+    "pddp_boxqp_m1": [c_int] + [_P] * 9,
     "pddp_pack_records": [c_int] * 4 + [_P] * 10,
     "pddp_nominal_rollout": [_P, c_int, c_int] + [_P] * 7,
     "pddp_derivs": [_P, c_int, c_int] + [_P] * 10,
@@ -70,8 +72,9 @@ _SIGS = {
     "pddp_event_elapsed_ms": [_P, _P, _P],
     "pddp_event_destroy": [_P],
 }
-_TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_generic",
-          "pddp_pack_records", "pddp_nominal_rollout", "pddp_derivs",
+_TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
+          "pddp_boxqp_m1", "pddp_pack_records", "pddp_nominal_rollout",
+          "pddp_derivs",
           "pddp_line_search", "pddp_accept")
 
 _lib = None

@@ -252,7 +252,7 @@ _STATUS_MSG = {1: "non-positive definite matrix",
 @torch.no_grad()
 def backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu, reg=0.0,
              V_zz_reg=False, u_min=None, u_max=None, U=None, quiet=False,
-             return_status=False, generic_kernel=False):
+             return_status=False, kernel_variant=0):
     """ilqr.py:529-674: the backward Riccati sweep -> (k, K).
 
     Un-batched inputs raise RuntimeError on failure like the reference;
@@ -300,13 +300,12 @@ def backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu, reg=0.0,
         regv = torch.full((B,), float(reg), dtype=torch.float64, device=device)
     gains = torch.zeros(B, N, lay.gain_stride, **opts)
     status = torch.zeros(B, dtype=torch.int32, device=device)
-    name = "pddp_riccati_backward_generic" if generic_kernel else \
-        "pddp_riccati_backward"
-    _native.call(name, dtype, B, N, n, m, _native.ptr(rec), _native.ptr(umin),
-                 _native.ptr(umax), _native.ptr(regv),
+    _native.call("pddp_riccati_backward_variant", dtype, B, N, n, m,
+                 _native.ptr(rec), _native.ptr(umin), _native.ptr(umax),
+                 _native.ptr(regv),
                  BRANCH_CHOLESKY if V_zz_reg else BRANCH_EIG, None,
                  _native.ptr(gains), _native.ptr(status),
-                 _native.stream_handle(device))
+                 _native.stream_handle(device), int(kernel_variant))
     k = gains[..., :m]
     K = gains[..., m:].unflatten(-1, (m, n))
     if not batched:

@@ -136,17 +136,18 @@ class ILQRSolver(object):
                      p(self.state) if set_state else None, self._s())
 
     def backward(self, active=None, reg=None, branch=None, bounded=True,
-                 generic=False):
+                 variant=0):
+        """variant: 0 auto, 1 generic kernel, 2 / 3 specialised n=4 kernel
+        (IEEE / approximate division), see include/pddp_hip.h."""
         p = _native.ptr
         reg = self.mu if reg is None else reg
         branch = self.branch if branch is None else branch
         umin = self.u_min if bounded else None
         umax = self.u_max if bounded else None
-        name = "pddp_riccati_backward_generic" if generic else \
-            "pddp_riccati_backward"
-        _native.call(name, self.dtype, self.B, self.N, self.n, self.m,
-                     p(self.rec), p(umin), p(umax), p(reg), int(branch),
-                     p(active), p(self.gains), p(self.bwd_status), self._s())
+        _native.call("pddp_riccati_backward_variant", self.dtype, self.B,
+                     self.N, self.n, self.m, p(self.rec), p(umin), p(umax),
+                     p(reg), int(branch), p(active), p(self.gains),
+                     p(self.bwd_status), self._s(), int(variant))
 
     def line_search(self, active=None, use_status=True):
         p = _native.ptr

@@ -35,7 +35,11 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   RiccatiArgs<T> a{B, N, n, rec, u_min, u_max, reg, branch, active, gains,
                    status};
   hipStream_t st = (hipStream_t)stream;
-  if (variant != 1 && n == 4 && m == 1) return launch_n4<T>(a, st);
+  // variant: 0 auto, 1 generic, 2 specialised n=4 (IEEE div/sqrt),
+  //          3 specialised n=4 with rcp / sqrt approximations (f32 only)
+  if (variant >= 2 && !(n == 4 && m == 1)) return PDDP_E_UNSUPPORTED;
+  if (variant != 1 && n == 4 && m == 1)
+    return launch_n4<T>(a, st, variant == 3 && sizeof(T) == 4);
   switch (m) {
     case 1: return dispatch_nmax<T, 1>(a, st);
     case 2: return dispatch_nmax<T, 2>(a, st);
@@ -67,27 +71,55 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
                                              reg, branch, active, gains,
                                              status, stream, 0);
 }
-/* Same sweep forced through the generic one-wavefront-per-trajectory kernel
- * (A/B testing of the specialised n=4 kernel). */
-int pddp_riccati_backward_generic_f32(int B, int N, int n, int m,
+/* Same sweep through a chosen kernel variant (A/B tests):
+ * 0 auto, 1 generic one-wavefront-per-trajectory kernel, 2 specialised n=4/m=1
+ * kernel, 3 the same with rcp/sqrt approximations (f32). */
+int pddp_riccati_backward_variant_f32(int B, int N, int n, int m,
                                       const float* rec, const float* u_min,
                                       const float* u_max, const double* reg,
                                       int branch, const uint8_t* active,
                                       float* gains, int32_t* status,
-                                      void* stream) {
+                                      void* stream, int variant) {
   return pddp::riccati_backward_impl<float>(B, N, n, m, rec, u_min, u_max, reg,
                                             branch, active, gains, status,
-                                            stream, 1);
+                                            stream, variant);
 }
-int pddp_riccati_backward_generic_f64(int B, int N, int n, int m,
+int pddp_riccati_backward_variant_f64(int B, int N, int n, int m,
                                       const double* rec, const double* u_min,
                                       const double* u_max, const double* reg,
                                       int branch, const uint8_t* active,
                                       double* gains, int32_t* status,
-                                      void* stream) {
+                                      void* stream, int variant) {
   return pddp::riccati_backward_impl<double>(B, N, n, m, rec, u_min, u_max,
                                              reg, branch, active, gains,
-                                             status, stream, 1);
+                                             status, stream, variant);
+}
+
+int pddp_boxqp_m1_f32(int count, const float* x0, const float* Q,
+                      const float* c, const float* lower, const float* upper,
+                      float* x, int32_t* result, uint8_t* free_mask,
+                      void* stream) {
+  if (count <= 0 || !x0 || !Q || !c || !lower || !upper || !x || !result ||
+      !free_mask)
+    return PDDP_E_BADARG;
+  hipLaunchKernelGGL((pddp::n4::boxqp1_kernel<float, false>),
+                     dim3((count + 3) / 4), dim3(pddp::kWave), 0,
+                     (hipStream_t)stream, count, x0, Q, c, lower, upper, x,
+                     result, free_mask);
+  return pddp::launch_status();
+}
+int pddp_boxqp_m1_f64(int count, const double* x0, const double* Q,
+                      const double* c, const double* lower,
+                      const double* upper, double* x, int32_t* result,
+                      uint8_t* free_mask, void* stream) {
+  if (count <= 0 || !x0 || !Q || !c || !lower || !upper || !x || !result ||
+      !free_mask)
+    return PDDP_E_BADARG;
+  hipLaunchKernelGGL((pddp::n4::boxqp1_kernel<double, false>),
+                     dim3((count + 3) / 4), dim3(pddp::kWave), 0,
+                     (hipStream_t)stream, count, x0, Q, c, lower, upper, x,
+                     result, free_mask);
+  return pddp::launch_status();
 }
 
 }  // extern "C"

@@ -1,16 +1,567 @@
-// riccati_n4.hpp - specialised backward sweep for n = 4, m = 1 (cartpole).
-// Placeholder dispatch: routed to the generic kernel until the specialised
-// kernel lands.
+// riccati_n4.hpp - backward Riccati sweep specialised for n = 4, m = 1
+// (cartpole; BASELINE.json configs[1]).
+//
+// Mapping: 16 lanes per trajectory, lane (i, j) = (row, column) of the 4x4
+// matrices, FOUR trajectories per 64-lane wavefront, one wavefront per
+// workgroup -> B/4 workgroups (1024 at B = 4096: one wave per SIMD on all 256
+// CUs).  V_zz lives in ONE register per lane, V_z in one more.  The sweep is a
+// chain of N dependent steps, so what bounds it is the per-step instruction
+// count of one wave, not bandwidth: every product is a single FMA whose moving
+// operand arrives through a DPP modifier (row rotation / quad permutation -
+// no LDS traffic, no shuffles on the critical path), and every reduction is a
+// two-step butterfly whose result is bit-identical in all participating lanes
+// (a + b == b + a), which keeps replicated quantities consistent.
+//
+// Records stream HBM -> LDS by `global_load_lds` DMA (no VGPR round trip) into
+// a ring of R slots per wave, R steps ahead of the dependent chain; each lane
+// then gathers the ~17 record words it needs (skewed copies of F_z for the
+// rotation-based products, row/column forms of the vectors) with ds_read.
+//
+// Restates pddp/controllers/ilqr.py:489-526 (Q) and :529-674 (backward) for
+// m = 1, all four gain branches.  Summation order differs from the reference's
+// left-to-right dot products (butterflies), i.e. results agree to rounding.
 #pragma once
 
+#include "gains.hpp"
 #include "riccati_generic.hpp"
 
 namespace pddp {
 
+#ifndef PDDP_N4_LS_MODE
+#define PDDP_N4_LS_MODE 0  // 0: 16 candidates per round; else sequential scan
+#endif
+
+namespace n4 {
+
+constexpr int kRec = 48;   // scalars per record (RecLayout(4,1).stride)
+constexpr int kGain = 5;   // k, K[0..3]
+constexpr int kRing = 8;   // record slots in flight per wave
+
+template <int CTRL>
+PDDP_DEV float dpp(float v) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+PDDP_DEV int dppi(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+template <int CTRL>
+PDDP_DEV double dpp(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL,
+                                             0xf, 0xf, true);
+  const int hi =
+      __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+  return __longlong_as_double(((long long)hi << 32) |
+                              (long long)(unsigned int)lo);
+}
+
+// value of lane (i + D, j): DPP row_ror reads lane (l - n) mod 16 (probed on
+// gfx950, tools/dpp_probe.hip), so "+4D lanes" is a rotation by 16 - 4D.
+template <int D, typename T>
+PDDP_DEV T from_row_plus(T v) {
+  static_assert(D >= 1 && D <= 3, "");
+  return dpp<0x120 + (16 - 4 * D)>(v);
+}
+// value of lane (i, j + D): quad_perm [D, D+1, D+2, D+3] (mod 4)
+template <int D, typename T>
+PDDP_DEV T from_col_plus(T v) {
+  static_assert(D >= 1 && D <= 3, "");
+  constexpr int P = ((0 + D) & 3) | (((1 + D) & 3) << 2) |
+                    (((2 + D) & 3) << 4) | (((3 + D) & 3) << 6);
+  return dpp<P>(v);
+}
+// A product that is never fused into a following add.  Replicated
+// quantities must come out bit-identical in every lane that holds a copy, and
+// x + y == y + x only holds when BOTH terms are already rounded: a contracted
+// fma(a, b, y) on one lane against fma(c, d, x) on its partner would differ in
+// the last bit and let the lanes of one trajectory disagree on branches.
+// (The empty asm makes the rounded product opaque to the optimiser: LLVM
+// otherwise distributes the lane permutation over the multiply,
+// dpp(a * b) -> dpp(a) * dpp(b), and fuses THAT product into the add.)
+PDDP_DEV float opaque(float x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+PDDP_DEV double opaque(double x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
 template <typename T>
-static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st) {
-  hipLaunchKernelGGL((riccati_generic_kernel<T, 8, 1>), dim3(a.B), dim3(kWave),
-                     0, st, a);
+PDDP_DEV T mul_nc(T a, T b) {
+#pragma clang fp contract(off)
+  return opaque(a * b);
+}
+PDDP_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PDDP_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// sum over the four rows (same column) of a * b; identical bits in all rows
+template <typename T>
+PDDP_DEV T dot_rows(T a, T b) {
+#pragma clang fp contract(off)
+  const T x = opaque(a * b);
+  const T y = x + from_row_plus<2>(x);
+  return y + from_row_plus<1>(y);
+}
+// sum over the four columns of a row (a quad) of a * b; identical in the quad
+template <typename T>
+PDDP_DEV T dot_cols(T a, T b) {
+#pragma clang fp contract(off)
+  const T x = opaque(a * b);
+  const T y = x + from_col_plus<2>(x);
+  return y + dpp<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(y);
+}
+template <typename T>
+PDDP_DEV T sum_cols(T x) {
+#pragma clang fp contract(off)
+  const T y = x + from_col_plus<2>(x);
+  return y + dpp<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(y);
+}
+PDDP_DEV float bperm(int addr, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
+}
+PDDP_DEV double bperm(int addr, double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_ds_bpermute(addr, (int)(b & 0xffffffffll));
+  const int hi = __builtin_amdgcn_ds_bpermute(addr, (int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) |
+                              (long long)(unsigned int)lo);
+}
+
+template <bool FAST>
+PDDP_DEV float div_(float a, float b) {
+  if constexpr (FAST) return a * __builtin_amdgcn_rcpf(b);
+  else return a / b;
+}
+template <bool FAST>
+PDDP_DEV double div_(double a, double b) { return a / b; }
+template <bool FAST>
+PDDP_DEV float sqrtx(float a) {
+  if constexpr (FAST) return __builtin_amdgcn_sqrtf(a);
+  else return sqrt_(a);
+}
+template <bool FAST>
+PDDP_DEV double sqrtx(double a) { return sqrt_(a); }
+
+template <int N>
+PDDP_DEV void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Step sizes of the reference's backtracking line search: python
+// `step *= step_dec` in double, rounded to T when it multiplies a tensor
+// (utils/constraint.py:248-259).  kLsFail = first n with step < min_step.
+constexpr int kLsSteps = 112;
+struct LsTable {
+  double v[kLsSteps];
+  int n_fail;
+  constexpr LsTable() : v(), n_fail(kLsSteps) {
+    double s = 1.0;
+    for (int n = 0; n < kLsSteps; ++n) {
+      v[n] = s;
+      if (s < 1e-22 && n < n_fail) n_fail = n;
+      s *= 0.6;
+    }
+  }
+};
+__device__ constexpr LsTable kLs{};
+
+// clamp for the hot loop: v_med3 when the operands are known finite
+template <bool FAST>
+PDDP_DEV float clampq(float v, float lo, float hi) {
+  if constexpr (FAST) return __builtin_amdgcn_fmed3f(v, lo, hi);
+  else return clamp1(v, lo, hi);
+}
+template <bool FAST>
+PDDP_DEV double clampq(double v, double lo, double hi) {
+  return clamp1(v, lo, hi);
+}
+
+// Scalar BoxQP (m = 1): the reference's projected-Newton loop
+// (utils/constraint.py:150-266) with its exit codes and its possibly stale
+// `free` flag.  Every lane of the 16-lane group holds the same scalars; the
+// backtracking line search (:248-259), a sequential scan for the first step
+// 0.6^n that passes the Armijo test, evaluates 16 candidate n per round, one
+// per lane, and takes the first passing lane - the same n the sequential scan
+// stops at, for 1/16 of the dependent instructions.
+// `lstep[0]` = T(0.6^l) for this lane (l = lane % 16); later rounds read LDS.
+template <typename T, bool FAST>
+PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, const T (&lstep)[1],
+                    const T* ls_tail, int lane, T& x_out, T& U_out,
+                    bool& free_out) {
+  const T min_grad = T(1e-8), tol = T(1e-8), armijo = T(0.1);
+  const int l = lane & 15, gsh = lane & 48;
+  int result = 0;
+  bool clamped = false, free_ = true;
+  T U = T(0);
+  T x = clamp1(x0, lo, hi);
+  x = ((x - x != T(0)) && (x == x)) ? T(0) : x;
+  T f = T(0.5) * ((x * Q) * x) + x * c;
+  T old_f = T(0);
+  for (int it = 0; it < 100; ++it) {
+    if (it > 0 && (old_f - f) < tol * abs_(old_f)) {
+      result = 4;
+      break;
+    }
+    old_f = f;
+    const T g = Q * x + c;
+    const bool ncl = ((x == lo) && (g > T(0))) || ((x == hi) && (g < T(0)));
+    const bool changed = (ncl != clamped);
+    clamped = ncl;
+    free_ = !clamped;
+    if (clamped) {
+      result = 6;
+      break;
+    }
+    if (it == 0 || changed) {
+      if (!(Q > T(0)) || !is_finite(Q)) {
+        result = -1;
+        break;
+      }
+      U = sqrtx<FAST>(Q);
+    }
+    if (abs_(g) < min_grad) {  // ||g[free]||
+      result = 5;
+      break;
+    }
+    // g_clamped = Q (x * 0) + c; search = -potrs(g_clamped, U) - x
+    const T gc = Q * (x * T(0)) + c;
+    const T search = -div_<FAST>(div_<FAST>(gc, U), U) - x;
+    const T sdotg = search * g;
+    // line search: candidate n = 16 r + l in lane l
+    T xc = x, fc = f;
+    int nsel = 0;
+#if PDDP_N4_LS_MODE == 0
+    // 16 candidates per round; the first passing n is a group-wide integer
+    // min by DPP butterflies (a ballot-based pick proved fragile here)
+    for (int nb = 0;; nb += 16) {
+      const int n = nb + l;
+      const T st = (nb == 0) ? lstep[0] : ls_tail[n];
+      const T xn = clampq<FAST>(x + st * search, lo, hi);
+      const T fn = T(0.5) * ((xn * Q) * xn) + xn * c;
+      const bool ok = !(div_<FAST>(fn - old_f, st * sdotg) < armijo) ||
+                      (n >= kLs.n_fail);
+      int m = ok ? n : 0x7fffffff;
+      m = min(m, dppi<0x128>(m));
+      m = min(m, dppi<0x12C>(m));
+      m = min(m, dppi<(2 | (3 << 2) | (0 << 4) | (1 << 6))>(m));
+      m = min(m, dppi<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(m));
+      if (m != 0x7fffffff) {
+        nsel = m;
+        const int src = (gsh + (m & 15)) * 4;
+        xc = bperm(src, xn);
+        fc = bperm(src, fn);
+        break;
+      }
+    }
+#else
+    for (nsel = 0;; ++nsel) {
+      const T st = ls_tail[nsel];
+      xc = clampq<FAST>(x + st * search, lo, hi);
+      fc = T(0.5) * ((xc * Q) * xc) + xc * c;
+      if (nsel >= kLs.n_fail) break;
+      if (!(div_<FAST>(fc - old_f, st * sdotg) < armijo)) break;
+    }
+#endif
+    x = xc;
+    f = fc;
+    if (nsel >= kLs.n_fail) {  // step < min_step                 (:257-259)
+      result = 2;
+      break;
+    }
+  }
+  x_out = x;
+  U_out = U;
+  free_out = free_;
+  return result;
+}
+
+template <typename T, bool CHOL, bool BOUNDED, bool FAST>
+__global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
+  constexpr int CH = kRec * (int)sizeof(T) / 16;  // 16-B chunks per record
+  constexpr int NI = (4 * CH + kWave - 1) / kWave;  // DMA instructions / step
+  constexpr int R = kRing;
+  __shared__ __attribute__((aligned(16))) T ring[R][4 * kRec];
+  __shared__ T ls_tail[kLsSteps];  // T(0.6^n), read only past n = 31
+
+  const int lane = threadIdx.x;
+  T lstep[1] = {T(0)};
+  if constexpr (BOUNDED) {
+    for (int q = lane; q < kLsSteps; q += kWave) ls_tail[q] = (T)kLs.v[q];
+    lstep[0] = (T)kLs.v[lane & 15];
+    __syncthreads();
+  }
+  const int grp = lane >> 4, l = lane & 15, i = l >> 2, j = l & 3;
+  const int N = a.N;
+  const int b0 = blockIdx.x * 4;
+  const int b = b0 + grp;
+  const bool exists = b < a.B;
+  const int bc = exists ? b : a.B - 1;
+  bool alive = exists && (a.active == nullptr || a.active[bc] != 0);
+  const bool counted = alive;  // writes its status at the end
+  if (!__any(alive)) return;
+
+  const T reg = (T)a.reg[bc];
+  T umin = T(0), umax = T(0);
+  if constexpr (BOUNDED) {
+    umin = a.u_min[0];
+    umax = a.u_max[0];
+  }
+
+  // ---- DMA source addressing: chunk q of the wave's 4 records -> lane
+  const T* src[NI];
+  bool dma_on[NI];
+#pragma unroll
+  for (int r = 0; r < NI; ++r) {
+    const int q = lane + kWave * r;
+    const int tg = q / CH, c = q - tg * CH;
+    dma_on[r] = q < 4 * CH;
+    int tb = b0 + (dma_on[r] ? tg : 0);
+    tb = tb < a.B ? tb : a.B - 1;
+    src[r] = a.rec + (size_t)tb * (size_t)(N + 1) * kRec + c * (16 / sizeof(T));
+  }
+  auto dma = [&](int slot, int t) {
+    const int tt = t < 0 ? 0 : t;  // tail: harmless reload keeps vmcnt exact
+#pragma unroll
+    for (int r = 0; r < NI; ++r)
+      if (dma_on[r])
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src[r] +
+                                                            (size_t)tt * kRec),
+            (__attribute__((address_space(3))) void*)((char*)&ring[slot][0] +
+                                                      r * kWave * 16),
+            16, 0, 0);
+  };
+
+  // ---- LDS gather offsets (words inside this group's record)
+  const int gb = grp * kRec;
+  int oFs[4], oFq[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    oFs[d] = gb + ((i + d) & 3) * 4 + i;  // F_z[(i+d)%4][i]
+    oFq[d] = gb + ((j + d) & 3) * 4 + j;  // F_z[(j+d)%4][j]
+  }
+  const int oFt = gb + j * 4 + i;         // F_z[j][i]
+  const int oLzz = gb + 16 + i * 4 + j;   // L_zz[i][j]
+  const int oFur = gb + 32 + i, oFuc = gb + 32 + j;
+  const int oLuzr = gb + 36 + i;
+  const int oLzr = gb + 40 + i;
+  const int oLuu = gb + 44, oLu = gb + 45, oU = gb + 46;
+  const int tr_addr = ((lane & 48) | (j * 4 + i)) * 4;  // lane (j, i)
+
+  // ---- terminal value function: V = L_zz[N], V_z = L_z[N] (column form)
+  const T* term = a.rec + ((size_t)bc * (size_t)(N + 1) + N) * kRec;
+  T V = term[16 + i * 4 + j];
+  T Vzc = term[40 + j];
+
+  // ---- prologue: fill the ring
+#pragma unroll
+  for (int s = 0; s < R; ++s) dma(s, N - 1 - s);
+  wait_vmcnt<0>();
+
+  T kprev = T(0);
+  int status = PDDP_BWD_OK;
+  T* gout = a.gains + (size_t)bc * (size_t)N * kGain;
+
+  int t = N - 1;
+  while (t >= 0) {
+#pragma unroll
+    for (int s = 0; s < R; ++s) {
+      if (t < 0) break;
+      // DMA(t) retired when at most (R-1) younger {store, DMA} pairs remain
+      wait_vmcnt<(R - 1) * (1 + NI)>();
+      const T* rc = &ring[s][0];
+      const T Fs0 = rc[oFs[0]], Fs1 = rc[oFs[1]], Fs2 = rc[oFs[2]],
+              Fs3 = rc[oFs[3]];
+      const T Fq0 = rc[oFq[0]], Fq1 = rc[oFq[1]], Fq2 = rc[oFq[2]],
+              Fq3 = rc[oFq[3]];
+      const T Ft = rc[oFt], Lzz = rc[oLzz];
+      const T fr = rc[oFur], fc = rc[oFuc];
+      const T Luzr = rc[oLuzr], Lzr = rc[oLzr];
+      const T Luu = rc[oLuu], Lu = rc[oLu];
+      const T Un = BOUNDED ? rc[oU] : T(0);
+
+      // A = F^T V : A[i][j] = sum_k F[k][i] V[k][j], k = (i + d) % 4
+      T A = Fs0 * V;
+      A += Fs1 * from_row_plus<1>(V);
+      A += Fs2 * from_row_plus<2>(V);
+      A += Fs3 * from_row_plus<3>(V);
+      // (f^T V)[j], column form
+      const T bTc = dot_rows(fr, V);
+      // Q_zz (raw) = L_zz + A F : sum_k A[i][k] F[k][j], k = (j + d) % 4
+      T Qzz = Lzz + A * Fq0;
+      Qzz += from_col_plus<1>(A) * Fq1;
+      Qzz += from_col_plus<2>(A) * Fq2;
+      Qzz += from_col_plus<3>(A) * Fq3;
+      // Q_uz (row form) = L_uz + A f ; Q_uu ; Q_u ; Q_z (row form)
+      const T Quzr = Luzr + dot_cols(A, fc);
+      const T Quu = Luu + dot_cols(bTc, fc);
+      const T Qu = Lu + dot_cols(fc, Vzc);
+      const T Qzr = Lzr + dot_cols(Ft, Vzc);
+
+      T Quzgr = Quzr, Quug = Quu;  // operands of the gain solve
+      if constexpr (CHOL) {
+        // second Q() with V + reg I                           (ilqr.py:590-592)
+        const T Vr = (i == j) ? V + reg : V;
+        T Ar = Fs0 * Vr;
+        Ar += Fs1 * from_row_plus<1>(Vr);
+        Ar += Fs2 * from_row_plus<2>(Vr);
+        Ar += Fs3 * from_row_plus<3>(Vr);
+        const T bTrc = dot_rows(fr, Vr);
+        Quzgr = Luzr + dot_cols(Ar, fc);
+        Quug = Luu + dot_cols(bTrc, fc);
+      }
+
+      // transposes (lane (i,j) <- lane (j,i)); latency hidden by the gains
+      const T QzzT = bperm(tr_addr, Qzz);
+      const T Quzc = bperm(tr_addr, Quzr);
+      const T Qzc = bperm(tr_addr, Qzr);
+      T Quzgc = Quzc;
+      if constexpr (CHOL) Quzgc = bperm(tr_addr, Quzgr);
+
+      // ---- gains (every lane of the group computes the same scalars)
+      T kt;
+      T Uch = T(1);
+      bool Kzero = false, by_inv = false;
+      T inv = T(0);
+      int st = PDDP_BWD_OK;
+      // dead groups get a trivial QP so that their BoxQP loop exits at once
+      const T Quu_s = alive ? Quu : T(1);
+      const T Quug_s = alive ? Quug : T(1);
+      const T Qu_s = alive ? Qu : T(0);
+      const T x0_s = alive ? kprev : T(0);
+      const T Un_s = alive ? Un : T(0);
+      if constexpr (!CHOL) {
+        if (!is_finite(Quu_s)) st = PDDP_BWD_NAN;  // eig raises (ilqr.py:631)
+        T e = (Quu_s < T(0)) ? T(1e-12) : Quu_s;   // ilqr.py:633
+        e += reg;                                  // ilqr.py:634
+        if constexpr (!BOUNDED) {
+          inv = div_<FAST>(T(1), e) * T(1);        // (E / e) E^T
+          kt = -(inv * Qu_s);
+          by_inv = true;
+          if (kt != kt) st = PDDP_BWD_NAN;
+        } else {
+          const T Qg = (T(1) * e) * T(1);          // (E * e) E^T
+          bool fr_;
+          const int res = boxqp1<T, FAST>(x0_s, Qg, Qu_s, umin - Un_s,
+                                          umax - Un_s, lstep, ls_tail,
+                                          lane, kt, Uch, fr_);
+          if (res < 1) st = PDDP_BWD_BOXQP_FAILED;
+          Kzero = !fr_;
+        }
+      } else {
+        if constexpr (!BOUNDED) {
+          if (!(Quug_s > T(0)) || !is_finite(Quug_s)) st = PDDP_BWD_NOT_PD;
+          Uch = sqrtx<FAST>(Quug_s);
+          kt = -div_<FAST>(div_<FAST>(Qu_s, Uch), Uch);
+        } else {
+          bool fr_;
+          const int res = boxqp1<T, FAST>(x0_s, Quug_s, Qu_s, umin - Un_s,
+                                          umax - Un_s, lstep, ls_tail,
+                                          lane, kt, Uch, fr_);
+          if (res < 1) st = PDDP_BWD_BOXQP_FAILED;
+          Kzero = !fr_;
+        }
+      }
+      // K in row and column form, same arithmetic on transposed copies
+      T Kr, Kc;
+      if (by_inv) {
+        Kr = -(inv * Quzgr);
+        Kc = -(inv * Quzgc);
+      } else {
+        Kr = Kzero ? T(0) : -div_<FAST>(div_<FAST>(Quzgr, Uch), Uch);
+        Kc = Kzero ? T(0) : -div_<FAST>(div_<FAST>(Quzgc, Uch), Uch);
+      }
+      if constexpr (!CHOL && !BOUNDED) {
+        // NaN anywhere in K raises too (ilqr.py:639-640)
+        const bool nanK = (Kc != Kc);
+        const bool any4 = sum_cols(nanK ? T(1) : T(0)) != T(0);
+        if (any4 && st == PDDP_BWD_OK) st = PDDP_BWD_NAN;
+      }
+      if (st != PDDP_BWD_OK && alive) {
+        status = st;
+        alive = false;
+      }
+
+      // ---- store k, K (lanes l < 5 of each group; dead groups write junk)
+      {
+        const T val = (l < 4) ? Kc : kt;
+        T* dst = gout + (size_t)t * kGain + ((l < 4) ? 1 + l : 0);
+        if (exists && l < 5) *dst = val;
+      }
+      kprev = kt;
+
+      // ---- value update with the un-regularised Q_uu, Q_uz  (ilqr.py:664-672)
+      // on the diagonal QzzT == Qzz and 0.5 (q + q) == q exactly
+      const T Qzzs = mul_nc(T(0.5), Qzz + QzzT);
+      {
+        T v = Qzc + Kc * Qu;
+        v += (Kc * Quu) * kt;
+        v += Quzc * kt;
+        Vzc = v;
+      }
+      {
+        // lane (i,j) forms V'[i][j] AND V'[j][i] from the row / column copies
+        // with mirrored operation trees, so that its partner lane (j,i)
+        // computes bit-identical values and 0.5 (a + b) is exactly symmetric
+        const T va = fma_(mul_nc(Kr, Quu), Kc, Qzzs) +
+                     fma_(Kr, Quzc, mul_nc(Quzr, Kc));
+        const T vb = fma_(mul_nc(Kc, Quu), Kr, Qzzs) +
+                     fma_(Kc, Quzr, mul_nc(Quzc, Kr));
+        V = T(0.5) * (va + vb);
+      }
+
+      // refill this slot with the record R steps further down the sweep
+      dma(s, t - R);
+      --t;
+    }
+  }
+  wait_vmcnt<0>();
+  if (counted && l == 0) a.status[bc] = status;
+}
+
+// Stand-alone batched scalar BoxQP (utils/constraint.py:150-266 for m = 1):
+// one 16-lane group per problem, the code path of the sweep kernel.
+template <typename T, bool FAST>
+__global__ __launch_bounds__(kWave) void boxqp1_kernel(
+    int count, const T* x0, const T* Q, const T* c, const T* lo, const T* hi,
+    T* x, int32_t* result, uint8_t* free_mask) {
+  __shared__ T ls_tail[kLsSteps];
+  const int lane = threadIdx.x;
+  for (int q = lane; q < kLsSteps; q += kWave) ls_tail[q] = (T)kLs.v[q];
+  T lstep[1] = {(T)kLs.v[lane & 15]};
+  __syncthreads();
+  const int p = blockIdx.x * 4 + (lane >> 4);
+  const int pc = p < count ? p : count - 1;
+  T xo, U;
+  bool fr;
+  const int res = boxqp1<T, FAST>(x0[pc], Q[pc], c[pc], lo[pc], hi[pc], lstep,
+                                  ls_tail, lane, xo, U, fr);
+  if (p < count && (lane & 15) == 0) {
+    x[p] = xo;
+    result[p] = res;
+    free_mask[p] = fr ? 1 : 0;
+  }
+}
+
+}  // namespace n4
+
+template <typename T>
+static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st, bool fast_math) {
+  const bool bounded = a.u_min != nullptr;
+  const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
+  const dim3 grid((a.B + 3) / 4), block(kWave);
+#define PDDP_N4_LAUNCH(C, Bd, F)                                             \
+  hipLaunchKernelGGL((n4::riccati_n4_kernel<T, C, Bd, F>), grid, block, 0,   \
+                     st, a)
+  if (fast_math) {
+    if (chol) { if (bounded) PDDP_N4_LAUNCH(true, true, true); else PDDP_N4_LAUNCH(true, false, true); }
+    else { if (bounded) PDDP_N4_LAUNCH(false, true, true); else PDDP_N4_LAUNCH(false, false, true); }
+  } else {
+    if (chol) { if (bounded) PDDP_N4_LAUNCH(true, true, false); else PDDP_N4_LAUNCH(true, false, false); }
+    else { if (bounded) PDDP_N4_LAUNCH(false, true, false); else PDDP_N4_LAUNCH(false, false, false); }
+  }
+#undef PDDP_N4_LAUNCH
   return launch_status();
 }
 

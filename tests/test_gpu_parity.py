@@ -21,7 +21,7 @@ MEAN0 = {"cartpole": [0, 0, 0, 0], "pendulum": [0, 0],
 TDT = {"f64": torch.float64, "f32": torch.float32}
 # fp32 tolerance: parity is graded in fp64; fp32 drift over a
 # horizon is ~1e-5 on K (eig + BoxQP branch) in the reference itself.
-TOL = {"f64": 1e-9, "f32": 2e-3}
+TOL = {"f64": 1e-9, "f32": 5e-3}
 
 
 def _setup(problem, dtype, B, N, seed=0):
@@ -98,11 +98,13 @@ def test_derivative_records_vs_oracle(problem, dtype):
         assert np.array_equal(got_U, U[b])
 
 
-@pytest.mark.parametrize("generic", [False, True])
+@pytest.mark.parametrize("variant", [0, 1, 3])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", PROBLEMS)
-def test_backward_vs_oracle(problem, dtype, generic):
+def test_backward_vs_oracle(problem, dtype, variant):
     """All four gain branches x regularisations, native record path."""
+    if variant == 3 and not (problem == "cartpole" and dtype == "f32"):
+        pytest.skip("variant 3 = n=4/m=1 f32 kernel with approximate division")
     B, N = 5, 40
     s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N)
     s.nominal_rollout()
@@ -115,7 +117,7 @@ def test_backward_vs_oracle(problem, dtype, generic):
             regv = torch.full((B,), reg, dtype=torch.float64, device="cuda")
             s.gains.zero_()
             s.backward(reg=regv, branch=branch, bounded=bounded,
-                       generic=generic)
+                       variant=variant)
             k, K = s.gain_views()
             status = s.bwd_status.cpu().numpy()
             for b in range(B):
@@ -333,3 +335,45 @@ def test_full_size_batch_invariance(dtype):
         if J_prev is not None:
             assert np.all(J <= J_prev)
         J_prev = J
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_boxqp_m1_vs_oracle(dtype):
+    """The device BoxQP (one action dimension) against the oracle's
+    restatement of utils/constraint.py:150-266 on random scalar problems,
+    including problems whose Newton step overshoots the box by orders of
+    magnitude (long back-tracking), pinned, warm-started-at-bound and
+    indefinite ones."""
+    from pddp_amd.utils.constraint import boxqp
+    rng = np.random.RandomState(5)
+    n = 4000
+    nd = np_dtype(dtype)
+    Q = np.exp(rng.uniform(-6, 6, n))
+    c = rng.randn(n) * np.exp(rng.uniform(-3, 6, n))
+    lo = -np.exp(rng.uniform(-3, 3, n))
+    hi = np.exp(rng.uniform(-3, 3, n))
+    x0 = rng.randn(n) * 3
+    x0[:200] = hi[:200]            # warm start on the bound
+    hi[200:300] = lo[200:300]      # pinned
+    Q[300:350] *= -1               # not positive definite
+    c[350:400] = 0.0
+    arrs = [a.astype(nd) for a in (x0, Q, c, lo, hi)]
+    x, result, U, free = boxqp(*[torch.from_numpy(a).cuda() for a in arrs])
+    x, result, free = x.cpu().numpy(), result.cpu().numpy(), free.cpu().numpy()
+    o = orc.load(nd)
+    n_exact = 0
+    for i in range(n):
+        xr, rr, _, fr = o.boxqp(arrs[0][i:i + 1], arrs[1][i:i + 1],
+                                arrs[2][i:i + 1], arrs[3][i:i + 1],
+                                arrs[4][i:i + 1])
+        if dtype == "f64":
+            assert result[i] == rr, i
+        else:
+            assert (result[i] >= 1) == (rr >= 1), i
+        if rr >= 1:
+            tol = 1e-10 if dtype == "f64" else 1e-4
+            assert abs(x[i] - xr[0]) <= tol * max(1.0, abs(xr[0])), (
+                i, x[i], xr[0], result[i], rr)
+            n_exact += int(free[i] == fr[0])
+    # the (possibly stale) free flag agrees except on float knife edges
+    assert n_exact >= (n - 50 if dtype == "f64" else int(0.97 * n))
