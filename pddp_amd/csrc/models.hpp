@@ -79,6 +79,30 @@ struct ModelDims<PDDP_MODEL_RENDEZVOUS> {
   static constexpr int kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+PDDP_DEV void sincos_(float x, float& s, float& c) { sincosf(x, &s, &c); }
+PDDP_DEV void sincos_(double x, double& s, double& c) { sincos(x, &s, &c); }
+
+// sin / cos of a state's angles, evaluated once per state and shared by the
+// dynamics and the cost (both need them; each costs a range reduction).
+template <typename T, int MODEL>
+struct Trig {
+  T s[ModelDims<MODEL>::n_ang > 0 ? ModelDims<MODEL>::n_ang : 1];
+  T c[ModelDims<MODEL>::n_ang > 0 ? ModelDims<MODEL>::n_ang : 1];
+};
+template <typename T, int MODEL>
+PDDP_DEV Trig<T, MODEL> trig_of(const T* z) {
+  Trig<T, MODEL> tr;
+  tr.s[0] = T(0);
+  tr.c[0] = T(1);
+  if constexpr (MODEL == PDDP_MODEL_CARTPOLE) sincos_(z[2], tr.s[0], tr.c[0]);
+  if constexpr (MODEL == PDDP_MODEL_PENDULUM) sincos_(z[0], tr.s[0], tr.c[0]);
+  if constexpr (MODEL == PDDP_MODEL_DOUBLE_CARTPOLE) {
+    sincos_(z[2], tr.s[0], tr.c[0]);
+    sincos_(z[4], tr.s[1], tr.c[1]);
+  }
+  return tr;
+}
+
 // 3x3 solve with partial pivoting, NR right-hand sides (B[3][NR]).
 template <typename T, int NR>
 PDDP_DEV void solve3(const T (&A)[3][3], T (&B)[3][NR]) {
@@ -128,8 +152,8 @@ PDDP_DEV void solve3(const T (&A)[3][3], T (&B)[3][NR]) {
 
 // z_next = model(z, u); if JAC also F_z [n][n] and F_u [n][m] (row-major).
 template <typename T, int MODEL, bool JAC>
-PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u, T* zn,
-                       T* Fz, T* Fu) {
+PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
+                       const Trig<T, MODEL>& tr, T* zn, T* Fz, T* Fu) {
   using D = ModelDims<MODEL>;
   constexpr int n = D::n, m = D::m;
   const T dt = P.dt;
@@ -143,7 +167,7 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u, T* zn,
   if constexpr (MODEL == PDDP_MODEL_CARTPOLE) {
     const T mc = P.p[0], mp = P.p[1], l = P.p[2], mu = P.p[3], g = P.p[4];
     const T x = z[0], xd = z[1], th = z[2], thd = z[3], F = u[0];
-    const T s = sin_(th), c = cos_(th);
+    const T s = tr.s[0], c = tr.c[0];
     const T a0 = mp * l * thd * thd * s;
     const T a1 = g * s;
     const T a2 = F - mu * xd;
@@ -203,7 +227,7 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u, T* zn,
     const T mm = P.p[0], l = P.p[1], mu = P.p[2], g = P.p[3];
     const T th = z[0], thd = z[1], tq = u[0];
     const T temp = mm * l;
-    const T s = sin_(th), c = cos_(th);
+    const T s = tr.s[0], c = tr.c[0];
     T acc = tq - mu * thd - T(0.5) * temp * g * s;
     const T sc = T(3) / (temp * l);
     acc = T(3) * acc / (temp * l);
@@ -222,8 +246,9 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u, T* zn,
             mu = P.p[5], g = P.p[6];
     const T x = z[0], xd = z[1], t1 = z[2], t1d = z[3], t2 = z[4], t2d = z[5],
             F = u[0];
-    const T s1 = sin_(t1), c1 = cos_(t1), s2 = sin_(t2), c2 = cos_(t2);
-    const T sd = sin_(t1 - t2), cd = cos_(t1 - t2);
+    const T s1 = tr.s[0], c1 = tr.c[0], s2 = tr.s[1], c2 = tr.c[1];
+    T sd, cd;
+    sincos_(t1 - t2, sd, cd);
     const T a0 = mp2 + T(2) * mc;
     const T a1 = mc * l2;
     const T a2 = l1 * t1d * t1d;
@@ -297,20 +322,21 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u, T* zn,
 
 // Augmented state a = augment_state(z), and d a_i / d z_{col_i}.
 template <typename T, int MODEL>
-PDDP_DEV void augment(const T* z, T* a, T* d) {
+PDDP_DEV void augment(const T* z, const Trig<T, MODEL>& tr, T* a, T* d) {
   using D = ModelDims<MODEL>;
+  int q = 0;  // angle counter: rows come as (sin a_q, cos a_q) pairs
 #pragma unroll
   for (int i = 0; i < D::na; ++i) {
-    const T v = z[D::col[i]];
     if (D::kind[i] == 0) {
-      a[i] = v;
+      a[i] = z[D::col[i]];
       d[i] = T(1);
     } else if (D::kind[i] == 1) {
-      a[i] = sin_(v);
-      d[i] = cos_(v);
+      a[i] = tr.s[q];
+      d[i] = tr.c[q];
     } else {
-      a[i] = cos_(v);
-      d[i] = -sin_(v);
+      a[i] = tr.c[q];
+      d[i] = -tr.s[q];
+      ++q;
     }
   }
 }
@@ -318,12 +344,12 @@ PDDP_DEV void augment(const T* z, T* a, T* d) {
 // Cost value only (line search, ilqr.py:764-791). u == nullptr <=> terminal.
 template <typename T, int MODEL>
 PDDP_DEV T cost_value(const ProblemT<T>& P, const T* z, const T* u,
-                      bool terminal) {
+                      const Trig<T, MODEL>& tr, bool terminal) {
   using D = ModelDims<MODEL>;
   constexpr int na = D::na, m = D::m;
   const T* Q = terminal ? P.Qt : P.Q;
   T a[na], d[na], dx[na];
-  augment<T, MODEL>(z, a, d);
+  augment<T, MODEL>(z, tr, a, d);
 #pragma unroll
   for (int i = 0; i < na; ++i) dx[i] = a[i] - P.goal[i];
   T cost = T(0);
@@ -353,12 +379,13 @@ PDDP_DEV T cost_value(const ProblemT<T>& P, const T* z, const T* u,
 // l_uz is identically zero for QRCost and is not returned.
 template <typename T, int MODEL>
 PDDP_DEV T cost_derivs(const ProblemT<T>& P, const T* z, const T* u,
-                       bool terminal, T* l_z, T* l_zz, T* l_u, T* l_uu) {
+                       const Trig<T, MODEL>& tr, bool terminal, T* l_z,
+                       T* l_zz, T* l_u, T* l_uu) {
   using D = ModelDims<MODEL>;
   constexpr int na = D::na, n = D::n, m = D::m;
   const T* Q = terminal ? P.Qt : P.Q;
   T a[na], d[na], dx[na], g[na];
-  augment<T, MODEL>(z, a, d);
+  augment<T, MODEL>(z, tr, a, d);
 #pragma unroll
   for (int i = 0; i < na; ++i) dx[i] = a[i] - P.goal[i];
   T cost = T(0);

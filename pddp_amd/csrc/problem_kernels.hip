@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kWave) void nominal_rollout_kernel(
       u[j] = Ub[t * m + j];
       if (bounded) u[j] = clamp1(u[j], a.u_min[j], a.u_max[j]);
     }
-    dynamics<T, MODEL, false>(P, z, u, zn, nullptr, nullptr);
+    const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
+    dynamics<T, MODEL, false>(P, z, u, tr, zn, nullptr, nullptr);
 #pragma unroll
     for (int j = 0; j < n; ++j) {
       z[j] = zn[j];
@@ -113,9 +114,10 @@ __global__ __launch_bounds__(kDerivThreads) void derivs_kernel(
       }
 #pragma unroll
       for (int j = 0; j < m * m; ++j) luu[j] = T(0);
-      l = cost_derivs<T, MODEL>(P, z, u, terminal, lz, lzz, lu, luu);
+      const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
+      l = cost_derivs<T, MODEL>(P, z, u, tr, terminal, lz, lzz, lu, luu);
       if (!terminal) {
-        dynamics<T, MODEL, true>(P, z, u, zn, Fz, Fu);
+        dynamics<T, MODEL, true>(P, z, u, tr, zn, Fz, Fu);
       } else {
 #pragma unroll
         for (int j = 0; j < n * n; ++j) Fz[j] = T(0);
@@ -238,8 +240,9 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
     for (int j = 0; j < n; ++j) a.Zc[((size_t)t * total + idx) * n + j] = z[j];
 #pragma unroll
     for (int j = 0; j < m; ++j) a.Uc[((size_t)t * total + idx) * m + j] = un[j];
-    J += cost_value<T, MODEL>(P, z, un, false);
-    dynamics<T, MODEL, false>(P, z, un, zn, nullptr, nullptr);
+    const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
+    J += cost_value<T, MODEL>(P, z, un, tr, false);
+    dynamics<T, MODEL, false>(P, z, un, tr, zn, nullptr, nullptr);
 #pragma unroll
     for (int j = 0; j < n; ++j) {
       z[j] = zn[j];
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
   }
 #pragma unroll
   for (int j = 0; j < n; ++j) a.Zc[((size_t)N * total + idx) * n + j] = z[j];
-  const T lf = cost_value<T, MODEL>(P, z, nullptr, true);
+  const T lf = cost_value<T, MODEL>(P, z, nullptr, trig_of<T, MODEL>(z), true);
   a.Jc[idx] = J + lf;  // L.sum(0) + l_f                           (ilqr.py:789)
 }
 

@@ -111,6 +111,16 @@ PDDP_DEV T dot_cols(T a, T b) {
   const T y = x + from_col_plus<2>(x);
   return y + dpp<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(y);
 }
+// sum over all 16 lanes of a trajectory's group (identical in all of them)
+template <typename T>
+PDDP_DEV T group_sum(T x) {
+#pragma clang fp contract(off)
+  x = opaque(x);
+  T y = x + from_row_plus<2>(x);
+  y = y + from_row_plus<1>(y);
+  y = y + from_col_plus<2>(y);
+  return y + dpp<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(y);
+}
 template <typename T>
 PDDP_DEV T sum_cols(T x) {
 #pragma clang fp contract(off)
@@ -248,9 +258,10 @@ PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, const T (&lstep)[1],
       m = min(m, dppi<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(m));
       if (m != 0x7fffffff) {
         nsel = m;
-        const int src = (gsh + (m & 15)) * 4;
-        xc = bperm(src, xn);
-        fc = bperm(src, fn);
+        // broadcast the winner's (xn, fn): exactly one lane contributes,
+        // the others add zeros, so the butterfly sums are exact
+        xc = group_sum((n == m) ? xn : T(0));
+        fc = group_sum((n == m) ? fn : T(0));
         break;
       }
     }
@@ -363,23 +374,40 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
   int status = PDDP_BWD_OK;
   T* gout = a.gains + (size_t)bc * (size_t)N * kGain;
 
+  // The words a lane needs from one record, gathered from LDS one step ahead
+  // of their use so that the ds_read latency overlaps the previous step.
+  struct Words {
+    T Fs0, Fs1, Fs2, Fs3, Fq0, Fq1, Fq2, Fq3, Ft, Lzz, fr, fc, Luzr, Lzr, Luu,
+        Lu, Un;
+  };
+  auto gather = [&](int slot) {
+    const T* rc = &ring[slot][0];
+    Words w;
+    w.Fs0 = rc[oFs[0]]; w.Fs1 = rc[oFs[1]]; w.Fs2 = rc[oFs[2]]; w.Fs3 = rc[oFs[3]];
+    w.Fq0 = rc[oFq[0]]; w.Fq1 = rc[oFq[1]]; w.Fq2 = rc[oFq[2]]; w.Fq3 = rc[oFq[3]];
+    w.Ft = rc[oFt]; w.Lzz = rc[oLzz];
+    w.fr = rc[oFur]; w.fc = rc[oFuc];
+    w.Luzr = rc[oLuzr]; w.Lzr = rc[oLzr];
+    w.Luu = rc[oLuu]; w.Lu = rc[oLu];
+    w.Un = BOUNDED ? rc[oU] : T(0);
+    return w;
+  };
+  Words nxt = gather(0);
+
   int t = N - 1;
   while (t >= 0) {
 #pragma unroll
     for (int s = 0; s < R; ++s) {
       if (t < 0) break;
-      // DMA(t) retired when at most (R-1) younger {store, DMA} pairs remain
-      wait_vmcnt<(R - 1) * (1 + NI)>();
-      const T* rc = &ring[s][0];
-      const T Fs0 = rc[oFs[0]], Fs1 = rc[oFs[1]], Fs2 = rc[oFs[2]],
-              Fs3 = rc[oFs[3]];
-      const T Fq0 = rc[oFq[0]], Fq1 = rc[oFq[1]], Fq2 = rc[oFq[2]],
-              Fq3 = rc[oFq[3]];
-      const T Ft = rc[oFt], Lzz = rc[oLzz];
-      const T fr = rc[oFur], fc = rc[oFuc];
-      const T Luzr = rc[oLuzr], Lzr = rc[oLzr];
-      const T Luu = rc[oLuu], Lu = rc[oLu];
-      const T Un = BOUNDED ? rc[oU] : T(0);
+      const Words w = nxt;
+      // DMA(t-1) has landed once at most (R-2) younger {store, DMA} pairs
+      // are outstanding; gather it now, use it in the next step
+      wait_vmcnt<(R - 2) * (1 + NI)>();
+      if (t > 0) nxt = gather((s + 1) % R);
+      const T Fs0 = w.Fs0, Fs1 = w.Fs1, Fs2 = w.Fs2, Fs3 = w.Fs3;
+      const T Fq0 = w.Fq0, Fq1 = w.Fq1, Fq2 = w.Fq2, Fq3 = w.Fq3;
+      const T Ft = w.Ft, Lzz = w.Lzz, fr = w.fr, fc = w.fc;
+      const T Luzr = w.Luzr, Lzr = w.Lzr, Luu = w.Luu, Lu = w.Lu, Un = w.Un;
 
       // A = F^T V : A[i][j] = sum_k F[k][i] V[k][j], k = (i + d) % 4
       T A = Fs0 * V;
