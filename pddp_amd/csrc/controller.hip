@@ -33,8 +33,11 @@ struct AcceptArgs {
 constexpr double kMuMin = 1e-6;   // ilqr.py:94
 constexpr double kDelta0 = 2.0;   // ilqr.py:95
 
+constexpr int kAcceptThreads = 256;
+constexpr int kMaxAlphas = 16;
+
 template <typename T>
-__global__ __launch_bounds__(kWave) void accept_kernel(AcceptArgs<T> a) {
+__global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a) {
   __shared__ int sh_amin;  // >= 0: accepted candidate, -1: nothing to copy
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -50,11 +53,19 @@ __global__ __launch_bounds__(kWave) void accept_kernel(AcceptArgs<T> a) {
       increase = true;  // RuntimeError path                    (ilqr.py:140-145)
       st = PDDP_STATE_NOT_PD;
     } else {
-      const T* J = a.Jc + (size_t)b * a.A;
+      const T* Jg = a.Jc + (size_t)b * a.A;
+      T J[kMaxAlphas];  // independent loads first, then the dependent scan
+#pragma unroll
+      for (int i = 0; i < kMaxAlphas; ++i) J[i] = Jg[i < a.A ? i : 0];
       int amin = 0;  // torch argmin: first minimum, a NaN wins     (ilqr.py:161)
-      for (int i = 1; i < a.A && J[amin] == J[amin]; ++i)
-        if (J[i] < J[amin] || J[i] != J[i]) amin = i;
-      const T J_new = J[amin];
+      T Jm = J[0];
+#pragma unroll
+      for (int i = 1; i < kMaxAlphas; ++i) {
+        const bool take = (i < a.A) && (Jm == Jm) && (J[i] < Jm || J[i] != J[i]);
+        amin = take ? i : amin;
+        Jm = take ? J[i] : Jm;
+      }
+      const T J_new = Jm;
       const T J_opt = a.J_opt[b];
       if (J_new < J_opt) {  // ilqr.py:166
         amin_out = amin;
@@ -102,18 +113,20 @@ __global__ __launch_bounds__(kWave) void accept_kernel(AcceptArgs<T> a) {
   const size_t cidx = (size_t)b * a.A + amin;
   T* Zb = a.Z + (size_t)b * (N + 1) * n;
   T* Ub = a.U + (size_t)b * N * m;
-  for (int o = tid; o < (N + 1) * n; o += kWave) {
-    const int t = o / n, j = o - t * n;
-    Zb[o] = a.Zc[((size_t)t * total + cidx) * n + j];
+  // one lane per time step: each reads its n (resp. m) contiguous scalars of
+  // the time-major candidate buffers, so a wavefront has 64 rows in flight
+  for (int t = tid; t <= N; t += kAcceptThreads) {
+    const T* srcz = a.Zc + ((size_t)t * total + cidx) * n;
+    for (int j = 0; j < n; ++j) Zb[t * n + j] = srcz[j];
   }
-  for (int o = tid; o < N * m; o += kWave) {
-    const int t = o / m, j = o - t * m;
-    Ub[o] = a.Uc[((size_t)t * total + cidx) * m + j];
+  for (int t = tid; t < N; t += kAcceptThreads) {
+    const T* srcu = a.Uc + ((size_t)t * total + cidx) * m;
+    for (int j = 0; j < m; ++j) Ub[t * m + j] = srcu[j];
   }
   const int gs = m + m * n;
   const T* G = a.gains + (size_t)b * N * gs;
   T* Ga = a.gains_acc + (size_t)b * N * gs;
-  for (int o = tid; o < N * gs; o += kWave) Ga[o] = G[o];
+  for (int o = tid; o < N * gs; o += kAcceptThreads) Ga[o] = G[o];
 }
 
 template <typename T>
@@ -124,6 +137,7 @@ static int accept_impl(int B, int N, int n, int m, int A, const T* Zc,
                        double* mu, double* delta, int32_t* state,
                        int32_t* iter, uint8_t* active, uint8_t* fresh,
                        int32_t* n_live, void* stream) {
+  if (A > kMaxAlphas) return PDDP_E_UNSUPPORTED;
   if (B <= 0 || N <= 0 || n <= 0 || m <= 0 || A <= 0 || !Zc || !Uc || !Jc ||
       !gains || !bwd_status || !Z || !U || !gains_acc || !J_opt || !mu ||
       !delta || !state || !iter || !active || !fresh)
@@ -131,7 +145,7 @@ static int accept_impl(int B, int N, int n, int m, int A, const T* Zc,
   AcceptArgs<T> a{B, N, n, m, A, Zc, Uc, Jc, gains, bwd_status, tol, max_reg,
                   n_iterations, Z, U, gains_acc, J_opt, mu, delta, state, iter,
                   active, fresh, n_live};
-  hipLaunchKernelGGL((accept_kernel<T>), dim3(B), dim3(kWave), 0,
+  hipLaunchKernelGGL((accept_kernel<T>), dim3(B), dim3(kAcceptThreads), 0,
                      (hipStream_t)stream, a);
   return launch_status();
 }

@@ -36,10 +36,14 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
                    status};
   hipStream_t st = (hipStream_t)stream;
   // variant: 0 auto, 1 generic, 2 specialised n=4 (IEEE div/sqrt),
-  //          3 specialised n=4 with rcp / sqrt approximations (f32 only)
+  //          3 specialised n=4 with rcp / sqrt approximations (f32 only),
+  //          4 / 5 = 2 / 3 with two trajectories per wavefront instead of four
   if (variant >= 2 && !(n == 4 && m == 1)) return PDDP_E_UNSUPPORTED;
-  if (variant != 1 && n == 4 && m == 1)
-    return launch_n4<T>(a, st, variant == 3 && sizeof(T) == 4);
+  if (variant != 1 && n == 4 && m == 1) {
+    const bool fast = (variant == 0 || variant == 3 || variant == 5) &&
+                      sizeof(T) == 4;
+    return launch_n4<T>(a, st, fast, (variant == 4 || variant == 5) ? 2 : 4);
+  }
   switch (m) {
     case 1: return dispatch_nmax<T, 1>(a, st);
     case 2: return dispatch_nmax<T, 2>(a, st);

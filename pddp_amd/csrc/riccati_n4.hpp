@@ -187,108 +187,136 @@ PDDP_DEV double clampq(double v, double lo, double hi) {
   return clamp1(v, lo, hi);
 }
 
+// group-wide integer min (identical in all 16 lanes)
+PDDP_DEV int group_min(int m) {
+  m = min(m, dppi<0x128>(m));
+  m = min(m, dppi<0x12C>(m));
+  m = min(m, dppi<(2 | (3 << 2) | (0 << 4) | (1 << 6))>(m));
+  return min(m, dppi<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(m));
+}
+
 // Scalar BoxQP (m = 1): the reference's projected-Newton loop
 // (utils/constraint.py:150-266) with its exit codes and its possibly stale
-// `free` flag.  Every lane of the 16-lane group holds the same scalars; the
-// backtracking line search (:248-259), a sequential scan for the first step
-// 0.6^n that passes the Armijo test, evaluates 16 candidate n per round, one
-// per lane, and takes the first passing lane - the same n the sequential scan
-// stops at, for 1/16 of the dependent instructions.
-// `lstep[0]` = T(0.6^l) for this lane (l = lane % 16); later rounds read LDS.
+// `free` flag.  Every lane of the 16-lane group holds the same scalars.
+//
+// Two things keep it short on a wavefront that carries four trajectories:
+//  * the back-tracking line search (:248-259), a sequential scan for the
+//    first step 0.6^n that passes the Armijo test, evaluates 16 candidate n
+//    per round, one per lane; the first passing n is a DPP integer-min
+//    butterfly - the same n the sequential scan stops at;
+//  * iterations are PREDICATED, not branched: a trajectory that has left the
+//    loop keeps executing with its commits masked (`live`), so the whole
+//    wavefront has one loop back-edge instead of six divergent exits.
+// For one action dimension Q never changes, so the factorisation U = sqrt(Q)
+// (:212-228) happens exactly once, and the Newton point -potrs(c, U) is
+// loop-invariant.
+// `lstep0` = T(0.6^l) for this lane (l = lane % 16); later rounds read LDS.
 template <typename T, bool FAST>
-PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, const T (&lstep)[1],
-                    const T* ls_tail, int lane, T& x_out, T& U_out,
-                    bool& free_out) {
+PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, T lstep0, const T* ls_tail,
+                    int lane, T& x_out, T& U_out, bool& free_out) {
   const T min_grad = T(1e-8), tol = T(1e-8), armijo = T(0.1);
-  const int l = lane & 15, gsh = lane & 48;
-  int result = 0;
-  bool clamped = false, free_ = true;
-  T U = T(0);
+  const int l = lane & 15;
+  auto obj = [&](T v) { return T(0.5) * ((v * Q) * v) + v * c; };
+
   T x = clamp1(x0, lo, hi);
-  x = ((x - x != T(0)) && (x == x)) ? T(0) : x;
-  T f = T(0.5) * ((x * Q) * x) + x * c;
+  x = ((x - x != T(0)) && (x == x)) ? T(0) : x;  // x[isinf(x)] = 0   (:179)
+  T f = obj(x);
   T old_f = T(0);
+  bool free_ = true;
+  int result = 0;
+  const T U = sqrtx<FAST>(Q);
+  const T newton = -div_<FAST>(div_<FAST>(c, U), U);  // -potrs(g_clamped, U)
+  const bool not_pd = !(Q > T(0)) || !is_finite(Q);
+
+#if PDDP_N4_LS_MODE == 0
   for (int it = 0; it < 100; ++it) {
-    if (it > 0 && (old_f - f) < tol * abs_(old_f)) {
-      result = 4;
-      break;
+    bool live = (result == 0);
+    if (!__any(live)) break;
+    if (it > 0) {  // convergence on the objective decrease       (:191-193)
+      const bool conv = (old_f - f) < tol * abs_(old_f);
+      result = (live && conv) ? 4 : result;
+      live = live && !conv;
     }
-    old_f = f;
+    old_f = live ? f : old_f;
     const T g = Q * x + c;
     const bool ncl = ((x == lo) && (g > T(0))) || ((x == hi) && (g < T(0)));
-    const bool changed = (ncl != clamped);
-    clamped = ncl;
-    free_ = !clamped;
-    if (clamped) {
-      result = 6;
-      break;
+    free_ = live ? !ncl : free_;                      // (:200-204)
+    result = (live && ncl) ? 6 : result;              // all clamped (:207-209)
+    live = live && !ncl;
+    if (it == 0) {                                    // factorise (:212-228)
+      result = (live && not_pd) ? -1 : result;
+      live = live && !not_pd;
     }
-    if (it == 0 || changed) {
-      if (!(Q > T(0)) || !is_finite(Q)) {
-        result = -1;
-        break;
-      }
-      U = sqrtx<FAST>(Q);
-    }
-    if (abs_(g) < min_grad) {  // ||g[free]||
-      result = 5;
-      break;
-    }
-    // g_clamped = Q (x * 0) + c; search = -potrs(g_clamped, U) - x
-    const T gc = Q * (x * T(0)) + c;
-    const T search = -div_<FAST>(div_<FAST>(gc, U), U) - x;
+    const bool gsmall = abs_(g) < min_grad;           // (:231-234)
+    result = (live && gsmall) ? 5 : result;
+    live = live && !gsmall;
+
+    const T search = newton - x;                      // (:237-239)
     const T sdotg = search * g;
-    // line search: candidate n = 16 r + l in lane l
+    // line search (:248-259): candidate n = nb + l in lane l
     T xc = x, fc = f;
     int nsel = 0;
-#if PDDP_N4_LS_MODE == 0
-    // 16 candidates per round; the first passing n is a group-wide integer
-    // min by DPP butterflies (a ballot-based pick proved fragile here)
+    bool found = !live;
     for (int nb = 0;; nb += 16) {
       const int n = nb + l;
-      const T st = (nb == 0) ? lstep[0] : ls_tail[n];
+      const T st = (nb == 0) ? lstep0 : ls_tail[n];
       const T xn = clampq<FAST>(x + st * search, lo, hi);
-      const T fn = T(0.5) * ((xn * Q) * xn) + xn * c;
+      const T fn = obj(xn);
       const bool ok = !(div_<FAST>(fn - old_f, st * sdotg) < armijo) ||
                       (n >= kLs.n_fail);
-      int m = ok ? n : 0x7fffffff;
-      m = min(m, dppi<0x128>(m));
-      m = min(m, dppi<0x12C>(m));
-      m = min(m, dppi<(2 | (3 << 2) | (0 << 4) | (1 << 6))>(m));
-      m = min(m, dppi<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(m));
-      if (m != 0x7fffffff) {
-        nsel = m;
-        // broadcast the winner's (xn, fn): exactly one lane contributes,
-        // the others add zeros, so the butterfly sums are exact
-        xc = group_sum((n == m) ? xn : T(0));
-        fc = group_sum((n == m) ? fn : T(0));
-        break;
-      }
+      const int m = group_min(ok ? n : 0x7fffffff);
+      const bool hit = (m != 0x7fffffff) && !found;
+      // broadcast the winner's (xn, fn): exactly one lane contributes, the
+      // others add zeros, so the butterfly sums are exact
+      const T xw = group_sum((n == m) ? xn : T(0));
+      const T fw = group_sum((n == m) ? fn : T(0));
+      xc = hit ? xw : xc;
+      fc = hit ? fw : fc;
+      nsel = hit ? m : nsel;
+      found = found || (m != 0x7fffffff);
+      if (!__any(!found)) break;
     }
+    x = live ? xc : x;
+    f = live ? fc : f;
+    result = (live && nsel >= kLs.n_fail) ? 2 : result;  // step < min_step
+  }
 #else
-    for (nsel = 0;; ++nsel) {
+  bool clamped = false;
+  for (int it = 0; it < 100; ++it) {
+    if (it > 0 && (old_f - f) < tol * abs_(old_f)) { result = 4; break; }
+    old_f = f;
+    const T g = Q * x + c;
+    clamped = ((x == lo) && (g > T(0))) || ((x == hi) && (g < T(0)));
+    free_ = !clamped;
+    if (clamped) { result = 6; break; }
+    if (it == 0 && not_pd) { result = -1; break; }
+    if (abs_(g) < min_grad) { result = 5; break; }
+    const T search = newton - x;
+    const T sdotg = search * g;
+    T xc = x, fc = f;
+    int nsel = 0;
+    for (;; ++nsel) {  // sequential reference scan
       const T st = ls_tail[nsel];
       xc = clampq<FAST>(x + st * search, lo, hi);
-      fc = T(0.5) * ((xc * Q) * xc) + xc * c;
+      fc = obj(xc);
       if (nsel >= kLs.n_fail) break;
       if (!(div_<FAST>(fc - old_f, st * sdotg) < armijo)) break;
     }
-#endif
     x = xc;
     f = fc;
-    if (nsel >= kLs.n_fail) {  // step < min_step                 (:257-259)
-      result = 2;
-      break;
-    }
+    if (nsel >= kLs.n_fail) { result = 2; break; }
   }
+#endif
   x_out = x;
   U_out = U;
   free_out = free_;
   return result;
 }
 
-template <typename T, bool CHOL, bool BOUNDED, bool FAST>
+template <typename T, bool CHOL, bool BOUNDED, bool FAST, int G>
 __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
+  // G = trajectories per wavefront (4: all lanes busy; 2: half the lanes idle
+  // but twice the wavefronts and less BoxQP divergence per wavefront)
   constexpr int CH = kRec * (int)sizeof(T) / 16;  // 16-B chunks per record
   constexpr int NI = (4 * CH + kWave - 1) / kWave;  // DMA instructions / step
   constexpr int R = kRing;
@@ -304,9 +332,9 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
   }
   const int grp = lane >> 4, l = lane & 15, i = l >> 2, j = l & 3;
   const int N = a.N;
-  const int b0 = blockIdx.x * 4;
+  const int b0 = blockIdx.x * G;
   const int b = b0 + grp;
-  const bool exists = b < a.B;
+  const bool exists = (grp < G) && (b < a.B);
   const int bc = exists ? b : a.B - 1;
   bool alive = exists && (a.active == nullptr || a.active[bc] != 0);
   const bool counted = alive;  // writes its status at the end
@@ -326,7 +354,7 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
   for (int r = 0; r < NI; ++r) {
     const int q = lane + kWave * r;
     const int tg = q / CH, c = q - tg * CH;
-    dma_on[r] = q < 4 * CH;
+    dma_on[r] = q < G * CH;
     int tb = b0 + (dma_on[r] ? tg : 0);
     tb = tb < a.B ? tb : a.B - 1;
     src[r] = a.rec + (size_t)tb * (size_t)(N + 1) * kRec + c * (16 / sizeof(T));
@@ -472,7 +500,7 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
           const T Qg = (T(1) * e) * T(1);          // (E * e) E^T
           bool fr_;
           const int res = boxqp1<T, FAST>(x0_s, Qg, Qu_s, umin - Un_s,
-                                          umax - Un_s, lstep, ls_tail,
+                                          umax - Un_s, lstep[0], ls_tail,
                                           lane, kt, Uch, fr_);
           if (res < 1) st = PDDP_BWD_BOXQP_FAILED;
           Kzero = !fr_;
@@ -485,7 +513,7 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
         } else {
           bool fr_;
           const int res = boxqp1<T, FAST>(x0_s, Quug_s, Qu_s, umin - Un_s,
-                                          umax - Un_s, lstep, ls_tail,
+                                          umax - Un_s, lstep[0], ls_tail,
                                           lane, kt, Uch, fr_);
           if (res < 1) st = PDDP_BWD_BOXQP_FAILED;
           Kzero = !fr_;
@@ -563,8 +591,8 @@ __global__ __launch_bounds__(kWave) void boxqp1_kernel(
   const int pc = p < count ? p : count - 1;
   T xo, U;
   bool fr;
-  const int res = boxqp1<T, FAST>(x0[pc], Q[pc], c[pc], lo[pc], hi[pc], lstep,
-                                  ls_tail, lane, xo, U, fr);
+  const int res = boxqp1<T, FAST>(x0[pc], Q[pc], c[pc], lo[pc], hi[pc],
+                                  lstep[0], ls_tail, lane, xo, U, fr);
   if (p < count && (lane & 15) == 0) {
     x[p] = xo;
     result[p] = res;
@@ -575,13 +603,21 @@ __global__ __launch_bounds__(kWave) void boxqp1_kernel(
 }  // namespace n4
 
 template <typename T>
-static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st, bool fast_math) {
+static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st, bool fast_math,
+                     int groups_per_wave) {
   const bool bounded = a.u_min != nullptr;
   const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
-  const dim3 grid((a.B + 3) / 4), block(kWave);
+  const int G = (groups_per_wave == 2) ? 2 : 4;
+  const dim3 grid((a.B + G - 1) / G), block(kWave);
 #define PDDP_N4_LAUNCH(C, Bd, F)                                             \
-  hipLaunchKernelGGL((n4::riccati_n4_kernel<T, C, Bd, F>), grid, block, 0,   \
-                     st, a)
+  do {                                                                       \
+    if (G == 2)                                                              \
+      hipLaunchKernelGGL((n4::riccati_n4_kernel<T, C, Bd, F, 2>), grid,      \
+                         block, 0, st, a);                                   \
+    else                                                                     \
+      hipLaunchKernelGGL((n4::riccati_n4_kernel<T, C, Bd, F, 4>), grid,      \
+                         block, 0, st, a);                                   \
+  } while (0)
   if (fast_math) {
     if (chol) { if (bounded) PDDP_N4_LAUNCH(true, true, true); else PDDP_N4_LAUNCH(true, false, true); }
     else { if (bounded) PDDP_N4_LAUNCH(false, true, true); else PDDP_N4_LAUNCH(false, false, true); }
