@@ -160,7 +160,7 @@ def main():
 
     # units processed: attempts actually made (live trajectories per round)
     liveK = int(s.active.sum().item())
-    cum_live = int(s.n_live.item())          # sum over rounds of live-after
+    cum_live = int(s.n_live.sum().item())    # sum over rounds of live-after
     attempted = live0 + cum_live - liveK     # sum over rounds of live-before
     total_attempted = attempted
     if world > 1:

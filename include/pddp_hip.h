@@ -169,8 +169,9 @@ int pddp_derivs_f64(const pddp_problem* problem, int B, int N, const double* Z,
 /* A candidate step sizes per trajectory.  Z [B][N+1][n], U [B][N][m] nominal;
  * gains [B][N][m+m*n]; alphas [A]; bwd_status [B] nullable (non-zero ->
  * skipped, the reference never reaches the line search then, ilqr.py:140-145);
- * Zc [N+1][B*A][n], Uc [N][B*A][m] candidates out (time-major so that a
- * wavefront's stores coalesce), Jc [B][A] out. */
+ * Zc [B][A][N+1][n], Uc [B][A][N][m] candidates out (candidate-major: each
+ * rollout is contiguous, so the accepted one is copied with full cache lines),
+ * Jc [B][A] out. */
 int pddp_line_search_f32(const pddp_problem* problem, int B, int N, int A,
                          const float* Z, const float* U, const float* gains,
                          const float* alphas, const float* u_min,
@@ -198,8 +199,11 @@ int pddp_line_search_f64(const pddp_problem* problem, int B, int N, int A,
  *     reject: _increase_reg, REJECTED / MAX_REG                  (:178-181)
  * then the masks of the NEXT round: retry states keep active=1, fresh=0;
  * ACCEPTED starts the next step() (iter+1, fresh=1) unless iter == n_iterations;
- * CONVERGED / MAX_REG leave the loop (:313).  n_live (device int32, nullable)
- * accumulates the number of trajectories still active after this round. */
+ * CONVERGED / MAX_REG leave the loop (:313).  n_live (device
+ * int32[PDDP_LIVE_SHARDS], nullable) accumulates, sharded by b mod
+ * PDDP_LIVE_SHARDS, the number of trajectories still active after this round
+ * (sum the shards; one word would serialise 4096 atomics). */
+#define PDDP_LIVE_SHARDS 256
 int pddp_accept_f32(int B, int N, int n, int m, int A, const float* Zc,
                     const float* Uc, const float* Jc, const float* gains,
                     const int32_t* bwd_status, double tol, double max_reg,

@@ -66,8 +66,8 @@ class ILQRSolver(object):
         self.J_opt = torch.zeros(B, **opts)
         self.gains = torch.zeros(B, N, gs, **opts)
         self.gains_acc = torch.zeros(B, N, gs, **opts)
-        self.Zc = torch.zeros(N + 1, B * A, n, **opts)
-        self.Uc = torch.zeros(N, B * A, m, **opts)
+        self.Zc = torch.zeros(B, A, N + 1, n, **opts)
+        self.Uc = torch.zeros(B, A, N, m, **opts)
         self.Jc = torch.zeros(B, A, **opts)
         i32 = dict(dtype=torch.int32, device=self.device)
         u8 = dict(dtype=torch.uint8, device=self.device)
@@ -79,7 +79,7 @@ class ILQRSolver(object):
         self.delta = torch.full((B,), 2.0, **f64)
         self.active = torch.zeros(B, **u8)
         self.fresh = torch.zeros(B, **u8)
-        self.n_live = torch.zeros(1, **i32)
+        self.n_live = torch.zeros(256, **i32)  # PDDP_LIVE_SHARDS
         self._pp = ctypes.addressof(self.problem)
 
     # -- views in the reference's tensor layout -----------------------------
@@ -185,7 +185,7 @@ class ILQRSolver(object):
             rounds += 1
             if on_round is not None:
                 on_round(rounds, self)
-            if int(self.n_live.item()) == 0:
+            if int(self.n_live.sum().item()) == 0:
                 break
             if max_rounds is not None and rounds >= max_rounds:
                 break

@@ -35,6 +35,7 @@ constexpr double kDelta0 = 2.0;   // ilqr.py:95
 
 constexpr int kAcceptThreads = 256;
 constexpr int kMaxAlphas = 16;
+constexpr int kLiveShards = 256;  // PDDP_LIVE_SHARDS of include/pddp_hip.h
 
 template <typename T>
 __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a) {
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a)
     }
     a.active[b] = act;
     a.fresh[b] = fr;
-    if (act && a.n_live != nullptr) atomicAdd(a.n_live, 1);
+    // sharded counter: 4096 adds on ONE word serialise at ~12 ns each (= 50 us)
+    if (act && a.n_live != nullptr) atomicAdd(a.n_live + (b & (kLiveShards - 1)), 1);
     sh_amin = amin_out;
   }
   __syncthreads();
@@ -109,20 +111,13 @@ __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a)
   if (amin < 0) return;
   // nominal <- winning candidate; self._K <- K                (ilqr.py:167-169)
   const int n = a.n, m = a.m, N = a.N;
-  const size_t total = (size_t)a.B * a.A;
   const size_t cidx = (size_t)b * a.A + amin;
   T* Zb = a.Z + (size_t)b * (N + 1) * n;
   T* Ub = a.U + (size_t)b * N * m;
-  // one lane per time step: each reads its n (resp. m) contiguous scalars of
-  // the time-major candidate buffers, so a wavefront has 64 rows in flight
-  for (int t = tid; t <= N; t += kAcceptThreads) {
-    const T* srcz = a.Zc + ((size_t)t * total + cidx) * n;
-    for (int j = 0; j < n; ++j) Zb[t * n + j] = srcz[j];
-  }
-  for (int t = tid; t < N; t += kAcceptThreads) {
-    const T* srcu = a.Uc + ((size_t)t * total + cidx) * m;
-    for (int j = 0; j < m; ++j) Ub[t * m + j] = srcu[j];
-  }
+  const T* srcz = a.Zc + cidx * (size_t)(N + 1) * n;  // contiguous rollout
+  const T* srcu = a.Uc + cidx * (size_t)N * m;
+  for (int o = tid; o < (N + 1) * n; o += kAcceptThreads) Zb[o] = srcz[o];
+  for (int o = tid; o < N * m; o += kAcceptThreads) Ub[o] = srcu[o];
   const int gs = m + m * n;
   const T* G = a.gains + (size_t)b * N * gs;
   T* Ga = a.gains_acc + (size_t)b * N * gs;

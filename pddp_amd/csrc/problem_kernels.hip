@@ -214,6 +214,11 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
 #pragma unroll
   for (int j = 0; j < GS; ++j) gr[j] = Gb[j];
 
+  // candidate-major output: this lane's rollout is contiguous in memory (the
+  // winner is then copied with full cache lines; the per-step 16-B stores of
+  // a lane fill one 128-B line every 8 steps and merge in L2)
+  T* Zci = a.Zc + (size_t)idx * (N + 1) * n;
+  T* Uci = a.Uc + (size_t)idx * N * m;
   T J = T(0);
   for (int t = 0; t < N; ++t) {
     // prefetch the next step's nominal data before the dependent chain
@@ -237,9 +242,9 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
       un[r] = bounded ? clamp1(v, a.u_min[r], a.u_max[r]) : v;
     }
 #pragma unroll
-    for (int j = 0; j < n; ++j) a.Zc[((size_t)t * total + idx) * n + j] = z[j];
+    for (int j = 0; j < n; ++j) Zci[(size_t)t * n + j] = z[j];
 #pragma unroll
-    for (int j = 0; j < m; ++j) a.Uc[((size_t)t * total + idx) * m + j] = un[j];
+    for (int j = 0; j < m; ++j) Uci[(size_t)t * m + j] = un[j];
     const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
     J += cost_value<T, MODEL>(P, z, un, tr, false);
     dynamics<T, MODEL, false>(P, z, un, tr, zn, nullptr, nullptr);
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
     for (int j = 0; j < GS; ++j) gr[j] = gr2[j];
   }
 #pragma unroll
-  for (int j = 0; j < n; ++j) a.Zc[((size_t)N * total + idx) * n + j] = z[j];
+  for (int j = 0; j < n; ++j) Zci[(size_t)N * n + j] = z[j];
   const T lf = cost_value<T, MODEL>(P, z, nullptr, trig_of<T, MODEL>(z), true);
   a.Jc[idx] = J + lf;  // L.sum(0) + l_f                           (ilqr.py:789)
 }
