@@ -181,6 +181,25 @@ def main():
     # every timed launch swept `attempted / K` trajectories on average
     achieved = (attempted / K) * per_traj / avg_dur / 1e9
 
+    # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE and
+    # WRITE_SIZE cannot share a pass, and counters cannot be read from inside
+    # this process): taken from the committed summary of the profiled run of
+    # this very command, see profiles/.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath) and B == 4096 and N == 100 and args.dtype == "f32":
+        try:
+            with open(tpath) as fh:
+                for kname, v in json.load(fh)["kernels"].items():
+                    if "riccati" in kname:
+                        traffic = {"hbm_bytes_per_launch":
+                                   v["hbm_bytes_per_launch"],
+                                   "source": "profiles/r01_pmc_traffic.json "
+                                             "(rocprofv3 --pmc FETCH_SIZE / "
+                                             "WRITE_SIZE, 2*FETCH+WRITE)"}
+        except (OSError, KeyError, ValueError):
+            traffic = None
+
     out = None
     if rank == 0:
         out = {
@@ -218,7 +237,7 @@ def main():
                 "avg_launch_us": avg_dur * 1e6,
                 "min_launch_us": float(np.min(durs)) * 1e6,
                 "algorithmic_bytes_per_launch": (attempted / K) * per_traj,
-                "traffic": None,
+                "traffic": traffic,
             },
         }
         if not args.no_cpu_baseline and world == 1:

@@ -377,3 +377,40 @@ def test_boxqp_m1_vs_oracle(dtype):
             n_exact += int(free[i] == fr[0])
     # the (possibly stale) free flag agrees except on float knife edges
     assert n_exact >= (n - 50 if dtype == "f64" else int(0.97 * n))
+
+
+def test_mpc_steps_vs_oracle():
+    """iLQRController.forward(mpc=True) (ilqr.py:355-362): regularisation
+    reset, ONE step() with the 11-alpha default schedule from the current
+    state, emit U[0], shift the nominal - against the same loop driven by the
+    oracle (fp64, cartpole with bounds, a deterministic plant)."""
+    import pddp_amd
+    from pddp_amd.examples import cartpole
+    enc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
+    model = cartpole.CartpoleDynamicsModel(0.1).double()
+    cost = cartpole.CartpoleCost().double()
+    env = cartpole.CartpoleEnv(dt=0.1)
+    ctrl = pddp_amd.controllers.iLQRController(env, model, cost)
+    N, steps = 20, 6
+    rng = np.random.RandomState(4)
+    U0 = 0.1 * rng.randn(N, 1)
+    z = np.array([0.01, -0.02, 0.015, 0.0])
+    u_min, u_max = np.array([-10.0]), np.array([10.0])
+    o = orc.load(np.float64)
+    op = orc.make_problem("cartpole", 0.1)
+    alphas = 10.0 ** np.linspace(0, -3, 11)
+    alphas = (10.0 ** torch.linspace(0, -3, 11)).double().numpy()
+    ctrl._U_nominal = torch.from_numpy(U0).cuda()
+    Uo = U0.copy()
+    for i in range(steps):
+        u = ctrl(torch.from_numpy(z).cuda(), i, encoding=enc, mpc=True,
+                 u_min=torch.from_numpy(u_min), u_max=torch.from_numpy(u_max))
+        _, Uo, _, st, _ = o.fit(op, z, Uo, alphas, n_iterations=1,
+                                u_min=u_min, u_max=u_max)
+        u_ref = Uo[0].copy()
+        Uo = np.concatenate([Uo[1:], Uo[-1:]], 0)
+        assert np.allclose(u.cpu().numpy(), u_ref, rtol=1e-8, atol=1e-10), i
+        assert np.allclose(ctrl._U_nominal.cpu().numpy(), Uo, rtol=1e-8,
+                           atol=1e-10)
+        # deterministic plant: the oracle's model
+        z, _, _ = o.dynamics(op, z, np.clip(u_ref, u_min, u_max), jac=False)
