@@ -14,6 +14,7 @@ from enum import IntEnum
 import torch
 
 from .base import Controller
+from .plugin import TorchProblem
 from .solver import (BRANCH_CHOLESKY, BRANCH_EIG, ILQRSolver, fit_alphas,
                      mpc_alphas)
 from .. import _native
@@ -38,16 +39,21 @@ class iLQRState(IntEnum):
 
 
 def _native_problem(model, cost, encoding):
-    problem = None
+    """ctypes PddpProblem when (model, cost, encoding) is a sample problem the
+    HIP kernels evaluate in closed form, else None (plugin path)."""
     if hasattr(model, "native_problem"):
-        problem = model.native_problem(encoding, cost)
-    if problem is None:
-        raise NotImplementedError(
-            "this build runs the sample problems (pddp_amd.examples.*) under "
-            "StateEncoding.IGNORE_UNCERTAINTY natively; arbitrary plugin "
-            "models / costs and the other encodings are the next rows of "
-            "SURVEY.md 8(f)")
-    return problem
+        return model.native_problem(encoding, cost)
+    return None
+
+
+def _make_solver(model, cost, encoding, B, N, n, dtype, device, u_min, u_max,
+                 alphas, model_opts=None, cost_opts=None, force_plugin=False):
+    problem = None if force_plugin else _native_problem(model, cost, encoding)
+    if problem is not None:
+        return ILQRSolver(problem, B, N, dtype, device, u_min, u_max, alphas)
+    plugin = TorchProblem(model, cost, encoding, model_opts, cost_opts)
+    return ILQRSolver(None, B, N, dtype, device, u_min, u_max, alphas,
+                      plugin=plugin, n=n, m=model.action_size)
 
 
 def _as_batch(t, ndim_single):
@@ -64,8 +70,9 @@ class iLQRController(Controller):
     `env.get_state()`)."""
 
     def __init__(self, env, model, cost, model_opts={}, cost_opts={},
-                 **kwargs):
+                 force_plugin=False, **kwargs):
         super(iLQRController, self).__init__()
+        self._force_plugin = force_plugin
         self.env = env
         self.cost = cost
         self.model = model
@@ -82,17 +89,19 @@ class iLQRController(Controller):
         self._batched = False
 
     # -- solver plumbing ------------------------------------------------------
-    def _get_solver(self, B, N, dtype, device, encoding, u_min, u_max, alphas):
-        problem = _native_problem(self.model, self.cost, encoding)
+    def _get_solver(self, B, N, n, dtype, device, encoding, u_min, u_max,
+                    alphas):
         s = self._solver
-        key = (B, N, dtype, torch.device(device), int(encoding),
+        key = (B, N, n, dtype, torch.device(device), int(encoding),
                None if u_min is None else tuple(
                    torch.as_tensor(u_min).flatten().tolist()),
                None if u_max is None else tuple(
                    torch.as_tensor(u_max).flatten().tolist()),
                tuple(alphas.flatten().tolist()))
         if s is None or getattr(s, "_key", None) != key:
-            s = ILQRSolver(problem, B, N, dtype, device, u_min, u_max, alphas)
+            s = _make_solver(self.model, self.cost, encoding, B, N, n, dtype,
+                             device, u_min, u_max, alphas, self._model_opts,
+                             self._cost_opts, self._force_plugin)
             s._key = key
             self._solver = s
         return s
@@ -143,8 +152,8 @@ class iLQRController(Controller):
         z0 = z0.to(**opts)
         if z0.dim() == 1:
             z0 = z0.unsqueeze(0).expand(B, -1)
-        s = self._get_solver(B, N, U.dtype, U.device, encoding, u_min, u_max,
-                             fit_alphas(U.dtype, U.device))
+        s = self._get_solver(B, N, z0.shape[-1], U.dtype, U.device, encoding,
+                             u_min, u_max, fit_alphas(U.dtype, U.device))
         s.set_nominal(z0.contiguous(), Ub.contiguous())
         self._mu, self._delta = 0.0, self._delta_0
         self._run(s, n_iterations, tol, max_reg, on_iteration)
@@ -178,11 +187,11 @@ class iLQRController(Controller):
         _native.require_gpu(U)
         Ub, self._batched = _as_batch(U, 2)
         B, N, m = Ub.shape
-        s = self._get_solver(B, N, U.dtype, U.device, encoding, u_min, u_max,
-                             mpc_alphas(U.dtype, U.device))
         z = z.to(dtype=U.dtype, device=U.device)
         if z.dim() == 1:
             z = z.unsqueeze(0).expand(B, -1)
+        s = self._get_solver(B, N, z.shape[-1], U.dtype, U.device, encoding,
+                             u_min, u_max, mpc_alphas(U.dtype, U.device))
         s.set_nominal(z.contiguous(), Ub.contiguous())
         self._run(s, 1, kwargs.get("tol", 5e-6), kwargs.get("max_reg", 1e10),
                   kwargs.get("on_iteration"))
@@ -214,8 +223,8 @@ def forward(z0, U, model, cost, encoding=StateEncoding.DEFAULT,
     z0b = z0.detach().to(dtype=U.dtype, device=U.device)
     if z0b.dim() == 1:
         z0b = z0b.unsqueeze(0).expand(B, -1)
-    problem = _native_problem(model, cost, encoding)
-    s = ILQRSolver(problem, B, N, U.dtype, U.device, u_min, u_max)
+    s = _make_solver(model, cost, encoding, B, N, z0b.shape[-1], U.dtype,
+                     U.device, u_min, u_max, None, model_opts, cost_opts)
     s.z0.copy_(z0b)
     s.U.copy_(Ub)
     s.nominal_rollout()
@@ -334,9 +343,11 @@ def _control_law(model, Z, U, k, K, alpha, encoding=StateEncoding.DEFAULT,
     Ub, batched = _as_batch(U, 2)
     B, N, m = Ub.shape
     n = Z.shape[-1]
-    problem = _native_problem(model, cost, encoding)
     alpha = torch.as_tensor(alpha).flatten()
-    s = ILQRSolver(problem, B, N, U.dtype, U.device, u_min, u_max, alpha)
+    if cost is None:  # candidates only: the plugin line search needs a cost
+        cost = _ZeroCost()
+    s = _make_solver(model, cost, encoding, B, N, n, U.dtype, U.device, u_min,
+                     u_max, alpha, model_opts)
     s.Z.copy_(Z.reshape(B, N + 1, n))
     s.U.copy_(Ub)
     s.gains[..., :m] = k.reshape(B, N, m)
@@ -353,6 +364,13 @@ def _control_law(model, Z, U, k, K, alpha, encoding=StateEncoding.DEFAULT,
     if return_cost:
         return Zn, Un, J
     return Zn, Un
+
+
+class _ZeroCost(torch.nn.Module):
+    """Stand-in when `_control_law` is asked for rollouts only."""
+
+    def forward(self, z, u, i, terminal=False, encoding=None, **kwargs):
+        return z.new_zeros(z.shape[:-1])
 
 
 @torch.no_grad()

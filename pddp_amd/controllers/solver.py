@@ -38,10 +38,18 @@ def mpc_alphas(dtype, device):
 class ILQRSolver(object):
 
     def __init__(self, problem, B, N, dtype, device, u_min=None, u_max=None,
-                 alphas=None, branch=BRANCH_EIG):
+                 alphas=None, branch=BRANCH_EIG, plugin=None, n=None, m=None):
+        """`problem`: ctypes PddpProblem of a sample problem (everything in
+        HIP), or None together with `plugin` (plugin.TorchProblem) and the
+        encoded state / action sizes `n`, `m`: derivatives and the line search
+        then come from the plugin modules, the sweep / accept stay HIP."""
         self.problem = problem
+        self.plugin = plugin
         self.B, self.N = int(B), int(N)
-        self.n, self.m = problem.encoded_size, problem.action_size
+        if problem is not None:
+            self.n, self.m = problem.encoded_size, problem.action_size
+        else:
+            self.n, self.m = int(n), int(m)
         self.dtype, self.device = dtype, torch.device(device)
         if self.device.type != "cuda":
             raise _native.NativeError(
@@ -80,7 +88,7 @@ class ILQRSolver(object):
         self.active = torch.zeros(B, **u8)
         self.fresh = torch.zeros(B, **u8)
         self.n_live = torch.zeros(256, **i32)  # PDDP_LIVE_SHARDS
-        self._pp = ctypes.addressof(self.problem)
+        self._pp = None if problem is None else ctypes.addressof(problem)
 
     # -- views in the reference's tensor layout -----------------------------
     def record_views(self):
@@ -123,12 +131,16 @@ class ILQRSolver(object):
         self.fresh.fill_(1)
 
     def nominal_rollout(self, mask=None):
+        if self.plugin is not None:
+            return self.plugin.rollout(self)
         p = _native.ptr
         _native.call("pddp_nominal_rollout", self.dtype, self._pp, self.B,
                      self.N, p(self.z0), p(self.U), p(self.u_min),
                      p(self.u_max), p(mask), p(self.Z), self._s())
 
     def derivs(self, mask=None, set_state=True):
+        if self.plugin is not None:
+            return self.plugin.derivs(self, mask, set_state)
         p = _native.ptr
         _native.call("pddp_derivs", self.dtype, self._pp, self.B, self.N,
                      p(self.Z), p(self.U), p(self.u_min), p(self.u_max),
@@ -150,6 +162,8 @@ class ILQRSolver(object):
                      p(self.bwd_status), self._s(), int(variant))
 
     def line_search(self, active=None, use_status=True):
+        if self.plugin is not None:
+            return self.plugin.line_search(self, active, use_status)
         p = _native.ptr
         _native.call("pddp_line_search", self.dtype, self._pp, self.B, self.N,
                      self.A, p(self.Z), p(self.U), p(self.gains),

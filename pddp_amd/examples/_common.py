@@ -3,7 +3,7 @@ import torch
 
 from .. import _native
 from ..costs.quadratic import QRCost
-from ..utils.angular import augment_state
+from ..utils.angular import augment_encoded_state
 from ..utils.encoding import (StateEncoding, decode_mean,
                               infer_encoded_state_size)
 
@@ -19,13 +19,10 @@ class AugmentedQRCost(QRCost):
 
     def forward(self, z, u, i, terminal=False,
                 encoding=StateEncoding.DEFAULT, **kwargs):
-        if encoding != StateEncoding.IGNORE_UNCERTAINTY:
-            raise NotImplementedError(
-                "sample costs implement StateEncoding.IGNORE_UNCERTAINTY on "
-                "this build (SURVEY.md 8(f).3 lists the other encodings next)")
         mc = self.model_class
-        za = augment_state(decode_mean(z, encoding), mc.angular_indices,
-                           mc.non_angular_indices)
+        za = augment_encoded_state(z, mc.angular_indices,
+                                   mc.non_angular_indices, encoding,
+                                   mc.state_size)
         return super(AugmentedQRCost, self).forward(za, u, i, terminal,
                                                     encoding, **kwargs)
 

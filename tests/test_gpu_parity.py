@@ -414,3 +414,109 @@ def test_mpc_steps_vs_oracle():
                            atol=1e-10)
         # deterministic plant: the oracle's model
         z, _, _ = o.dynamics(op, z, np.clip(u_ref, u_min, u_max), jac=False)
+
+
+def test_plugin_path_equals_native_path():
+    """The same cartpole problem through the plugin path (torch autograd
+    derivatives + torch line search around the HIP sweep / accept kernels)
+    and through the all-HIP path: same state sequence and costs, fp64."""
+    import pddp_amd
+    from pddp_amd.examples import cartpole
+    enc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
+    model = cartpole.CartpoleDynamicsModel(0.1).double()
+    cost = cartpole.CartpoleCost().double()
+    env = cartpole.CartpoleEnv(dt=0.1)
+    rng = np.random.RandomState(8)
+    B, N = 3, 20
+    U0 = torch.from_numpy(0.1 * rng.randn(B, N, 1)).cuda()
+    z0 = torch.from_numpy(1e-2 * rng.randn(B, 4)).cuda()
+    bounds = dict(u_min=torch.tensor([-10.0]).double(),
+                  u_max=torch.tensor([10.0]).double())
+    out = []
+    for force in (False, True):
+        ctrl = pddp_amd.controllers.iLQRController(env, model.cuda(),
+                                                   cost.cuda(),
+                                                   force_plugin=force)
+        tr = []
+        Z, U, st = ctrl.fit(U0.clone(), encoding=enc, n_iterations=6, z0=z0,
+                            on_iteration=lambda i, s, Z, U, J: tr.append(
+                                (s.clone(), J.cpu().clone())), **bounds)
+        assert (ctrl._solver.plugin is not None) == force
+        out.append((Z.cpu(), U.cpu(), st, tr, ctrl._K.cpu()))
+    (Za, Ua, sa, tra, Ka), (Zb, Ub, sb, trb, Kb) = out
+    assert torch.equal(sa, sb)
+    assert len(tra) == len(trb)
+    for (s1, J1), (s2, J2) in zip(tra, trb):
+        assert torch.equal(s1, s2)
+        assert torch.allclose(J1, J2, rtol=1e-9)
+    assert torch.allclose(Ua, Ub, rtol=1e-7, atol=1e-9)
+    assert torch.allclose(Za, Zb, rtol=1e-7, atol=1e-9)
+    assert torch.allclose(Ka, Kb, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("problem", ["cartpole", "pendulum"])
+def test_default_encoding_vs_reference_golden(problem):
+    """StateEncoding.DEFAULT (upper-triangular Cholesky, n = 14 / 5) through
+    the reference-signature API - forward, backward (zero-copy records, generic
+    HIP sweep), _control_law + costs, and a full fit - against the reference's
+    own outputs (fp64 goldens)."""
+    import pddp_amd
+    from pddp_amd import StateEncoding
+    from pddp_amd.controllers.ilqr import _control_law, backward, forward
+    mod = getattr(pddp_amd.examples, problem)
+    model = [getattr(mod, n) for n in dir(mod) if n.endswith("DynamicsModel")
+             and n != "DynamicsModel"][0](DT[problem]).double().cuda()
+    cost = [getattr(mod, n) for n in dir(mod) if n.endswith("Cost")
+            and n != "AugmentedQRCost"][0]().double().cuda()
+    env_cls = [getattr(mod, n) for n in dir(mod) if n.endswith("Env")
+               and n != "ModelEnv"][0]
+    g = load(problem, encoding="default")
+    enc = StateEncoding.DEFAULT
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u_min, u_max = cu(g["u_min"]), cu(g["u_max"])
+    for tag in ("N5_cos", "N25_cos"):
+        U = cu(g[tag + "/U"])
+        out = forward(cu(g["z0"]), U, model, cost, enc, u_min=u_min,
+                      u_max=u_max)
+        for nm, t in zip(FWD_NAMES, out):
+            ref = g["%s/fwd_bounded/%s" % (tag, nm)]
+            assert rel_err(t.cpu().numpy(), ref) < 1e-9, (tag, nm)
+        for branch, reg in (("B", 1.0), ("A", 1.0), ("C", 100.0), ("D", 1.0)):
+            key = "%s/bwd/%s/%g" % (tag, branch, reg)
+            kw = dict(reg=reg, V_zz_reg=branch in "CD")
+            if branch in "BD":
+                kw.update(u_min=u_min, u_max=u_max, U=U)
+            k, K, st = backward(*out, return_status=True, **kw)
+            assert (st == 0) == bool(int(g[key + "/ok"])), key
+            if st == 0:
+                assert rel_err(k.cpu().numpy(), g[key + "/k"]) < 1e-7, key
+                assert rel_err(K.cpu().numpy(), g[key + "/K"]) < 1e-7, key
+        k, K = cu(g[tag + "/bwd/B/1/k"]), cu(g[tag + "/bwd/B/1/K"])
+        Zn, Un, J = _control_law(model, out[0], U, k, K,
+                                 cu(g[tag + "/ls_fit/alphas"]), enc,
+                                 u_min=u_min, u_max=u_max, cost=cost,
+                                 return_cost=True)
+        T = 6  # stable prefix of possibly diverging candidates
+        assert rel_err(Zn[:T].cpu().numpy(), g[tag + "/ls_fit/Z_new"][:T]) < 1e-8
+        assert rel_err(Un[:T].cpu().numpy(), g[tag + "/ls_fit/U_new"][:T]) < 1e-8
+        Jr = g[tag + "/ls_fit/J"]
+        fin = np.isfinite(Jr)
+        assert np.allclose(J.cpu().numpy()[fin], Jr[fin], rtol=1e-6)
+    # whole controller
+    env = env_cls(dt=DT[problem])
+    ctrl = pddp_amd.controllers.iLQRController(env, model, cost)
+    trace = []
+    Z, U, state = ctrl.fit(
+        cu(g["fit_bounded/U0"]), encoding=enc,
+        n_iterations=int(g["fit_bounded/n_iterations"]), u_min=u_min,
+        u_max=u_max, z0=cu(g["z0"]),
+        on_iteration=lambda i, st, Z, U, J: trace.append((i, int(st),
+                                                          float(J))))
+    ref = g["fit_bounded/trace"]
+    got = np.array(trace)
+    assert got.shape[0] == ref.shape[0]
+    assert np.array_equal(got[:, :2], ref[:, :2])
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-7)
+    assert int(state) == int(g["fit_bounded/state"])
+    assert rel_err(U.cpu().numpy(), g["fit_bounded/U"]) < 1e-5
+    assert rel_err(ctrl._K.cpu().numpy(), g["fit_bounded/K"]) < 1e-5

@@ -212,3 +212,43 @@ def test_best_rollout_single_process():
     Jb, idx, Zb, Ub = gather_best_rollout(J, Z, U, offset=100)
     assert idx == 102 and float(Jb) == 1.5
     assert torch.allclose(Zb, Z[2]) and torch.allclose(Ub, U[2])
+
+
+@pytest.mark.parametrize("problem", ["cartpole", "pendulum"])
+def test_plugin_derivatives_match_reference_default_encoding(problem):
+    """DEFAULT (upper-triangular Cholesky) encoding, n = 14 / 5: the plugin
+    path's autograd derivatives (replicated-input trick) of OUR models / costs
+    (moment-matched angle augmentation, tr(Q Sigma) term) against the
+    reference's own forward() outputs (golden, fp64).  Device-agnostic code,
+    checked here on CPU tensors."""
+    import pddp_amd
+    from pddp_amd import StateEncoding
+    from pddp_amd.controllers.plugin import TorchProblem
+    mod = getattr(pddp_amd.examples, problem)
+    model = [getattr(mod, n) for n in dir(mod) if n.endswith("DynamicsModel")
+             and n != "DynamicsModel"][0](DT[problem]).double()
+    cost = [getattr(mod, n) for n in dir(mod) if n.endswith("Cost")
+            and n != "AugmentedQRCost"][0]().double()
+    g = load(problem, encoding="default")
+    tp = TorchProblem(model, cost, StateEncoding.DEFAULT)
+    for tag in ("N5_cos", "N25_cos"):
+        U = torch.from_numpy(g[tag + "/U"])
+        Z = torch.from_numpy(g[tag + "/fwd/Z"])
+        N = U.shape[0]
+        # batched over time: every (z_t, u_t) pair is one row
+        l, lz, lu, lzz, luz, luu = tp._cost_derivs(Z[:N], U, 0, False)
+        Fz, Fu = tp._dyn_derivs(Z[:N], U, 0)
+        zn = model(Z[:N], U, 0, StateEncoding.DEFAULT)
+        for got, nm in ((l, "L"), (lz, "L_z"), (lu, "L_u"), (lzz, "L_zz"),
+                        (luz, "L_uz"), (luu, "L_uu"), (Fz, "F_z"),
+                        (Fu, "F_u")):
+            ref = g["%s/fwd/%s" % (tag, nm)][:N]
+            assert np.allclose(got.detach().numpy(), ref, rtol=1e-9,
+                               atol=1e-11), (tag, nm)
+        assert np.allclose(zn.detach().numpy(), g[tag + "/fwd/Z"][1:],
+                           rtol=1e-10, atol=1e-12)
+        lt, lzt, _, lzzt, _, _ = tp._cost_derivs(Z[N:], None, N - 1, True)
+        assert np.allclose(lzzt[0].numpy(), g[tag + "/fwd/L_zz"][N],
+                           rtol=1e-9, atol=1e-11)
+        assert np.allclose(lzt[0].numpy(), g[tag + "/fwd/L_z"][N], rtol=1e-9,
+                           atol=1e-11)

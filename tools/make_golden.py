@@ -171,7 +171,8 @@ def capture_problem(name, enc_name, dtype, Ns, with_fit):
 
     if with_fit:
         N = with_fit
-        for n_iter, bounded in ((25, True), (8, False)):
+        for n_iter, bounded in (((25, True), (8, False))
+                                if enc_name == "ignore" else ((6, True),)):
             env = env_cls(dt=dt, model=model_cls(dt))
             env._state = mean.clone()
             ctrl = iLQRController(env, model, cost)
@@ -250,6 +251,12 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
+    if "--default-only" in sys.argv:
+        capture_problem("cartpole", "default", torch.float64, [5, 25],
+                        with_fit=12)
+        capture_problem("pendulum", "default", torch.float64, [5, 25],
+                        with_fit=12)
+        return
     capture_boxqp()
     for dtype in (torch.float64, torch.float32):
         capture_problem("cartpole", "ignore", dtype, [5, 100], with_fit=30)
@@ -259,8 +266,8 @@ def main():
         capture_problem("rendezvous", "ignore", dtype, [5, 40], with_fit=20)
     # DEFAULT (upper-triangular Cholesky) encoding: captured for the next
     # rows of SURVEY 8(f); fp64 only, short horizons (n = 14 / 5).
-    capture_problem("cartpole", "default", torch.float64, [5, 25], with_fit=0)
-    capture_problem("pendulum", "default", torch.float64, [5, 25], with_fit=0)
+    capture_problem("cartpole", "default", torch.float64, [5, 25], with_fit=12)
+    capture_problem("pendulum", "default", torch.float64, [5, 25], with_fit=12)
 
 
 if __name__ == "__main__":
