@@ -520,3 +520,93 @@ def test_default_encoding_vs_reference_golden(problem):
     assert int(state) == int(g["fit_bounded/state"])
     assert rel_err(U.cpu().numpy(), g["fit_bounded/U"]) < 1e-5
     assert rel_err(ctrl._K.cpu().numpy(), g["fit_bounded/K"]) < 1e-5
+
+
+def test_bnn_ilqr_fit_vs_reference_golden():
+    """BASELINE configs[2] in miniature: iLQR on a BNN dynamics model
+    (particle moment matching, DEFAULT encoding, n = 14) - plugin derivatives
+    and line search on the GPU, HIP backward sweep (generic kernel, eig-clamp +
+    BoxQP) and HIP accept - against the reference's own fit with identical
+    weights, dropout noise and particle noise: same sequence of rejections /
+    accepts, mu / delta, costs, and the same controls."""
+    import os
+    import pddp_amd
+    from golden_util import GOLDEN_DIR
+    from pddp_amd.examples import cartpole
+    from pddp_amd.models.bnn import (bnn_dynamics_model_factory,
+                                     load_reference_state)
+    g = np.load(os.path.join(GOLDEN_DIR, "bnn_cartpole_default_f64.npz"))
+    CM = cartpole.CartpoleDynamicsModel
+    cls = bnn_dynamics_model_factory(4, 1, [32, 24], CM.angular_indices,
+                                     CM.non_angular_indices)
+    model = cls(n_particles=int(g["P"])).double().eval()
+    load_reference_state(model, {k[len("state/"):]: g[k] for k in g.files
+                                 if k.startswith("state/")})
+    model = model.cuda()
+    model.eps_in = {k: v.cuda() for k, v in model.eps_in.items()}
+    for d in model.model.drops:
+        d.noise = d.noise.cuda()
+    cost = cartpole.CartpoleCost().double().cuda()
+    opts = {"use_predicted_std": False, "infer_noise_variables": True}
+    ctrl = pddp_amd.controllers.iLQRController(None, model, cost,
+                                               model_opts=opts)
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    trace = []
+
+    def on_iteration(i, st, Z, U, J):
+        trace.append((i, int(st), float(J), ctrl._solver.mu[0].item(),
+                      ctrl._solver.delta[0].item()))
+
+    Z, U, state = ctrl.fit(cu(g["U"]), encoding=pddp_amd.StateEncoding.DEFAULT,
+                           n_iterations=5, z0=cu(g["z0"]),
+                           u_min=torch.tensor([-10.0]).double(),
+                           u_max=torch.tensor([10.0]).double(),
+                           on_iteration=on_iteration)
+    assert ctrl._solver.plugin is not None and ctrl._solver.n == 14
+    ref = g["fit/trace"]
+    got = np.array(trace)
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, :2], ref[:, :2])        # iteration, state
+    assert np.allclose(got[:, 3:], ref[:, 3:], rtol=1e-12)  # mu, delta
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-7)  # J_opt
+    assert int(state) == int(g["fit/state"])
+    assert rel_err(U.cpu().numpy(), g["fit/U"]) < 1e-5
+    assert rel_err(Z.cpu().numpy(), g["fit/Z"]) < 1e-5
+    assert rel_err(ctrl._K.cpu().numpy(), g["fit/K"]) < 1e-5
+
+
+def test_pddp_controller_runs_on_gpu():
+    """PDDPController.fit (pddp.py:61-206) end to end on the GPU, the way the
+    reference's tests/controllers/test_pddp.py checks it: exploration trials,
+    BNN training, iLQR on the learned model, an MPC trial, re-training - ends
+    with a valid state in eval and train mode."""
+    import pddp_amd
+    from pddp_amd.examples import pendulum
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    torch.manual_seed(0)
+    np.random.seed(0)
+    PM = pendulum.PendulumDynamicsModel
+    env = pendulum.PendulumEnv(dt=0.1)
+    cost = pendulum.PendulumCost().cuda()
+    cls = bnn_dynamics_model_factory(2, 1, [16, 16], PM.angular_indices,
+                                     PM.non_angular_indices)
+    model = cls(n_particles=12).cuda()
+    ctrl = pddp_amd.controllers.PDDPController(
+        env, model, cost, model_opts={"use_predicted_std": False},
+        training_opts={"n_iter": 30, "learning_rate": 1e-2})
+    N = 4
+    U0 = 0.1 * torch.randn(N, 1, device="cuda")
+    trials = []
+    kw = dict(encoding=pddp_amd.StateEncoding.DEFAULT, quiet=True,
+              n_iterations=3, u_min=torch.tensor([-2.5]),
+              u_max=torch.tensor([2.5]),
+              on_trial=lambda t, X, U: trials.append((t, X.shape, U.shape)))
+    ctrl.eval()
+    Z, U, state = ctrl.fit(U0, **kw)
+    assert Z.shape == (N + 1, 5) and U.shape == (N, 1)
+    assert isinstance(state, pddp_amd.controllers.iLQRState)
+    assert [t[0] for t in trials] == [0, 1]        # the two exploration trials
+    ctrl.train()
+    Z, U, state = ctrl.fit(U0, max_trials=3, **kw)
+    assert trials[-1][1] == (2 * N, 2)             # MPC trial of horizon 2N
+    assert torch.isfinite(U).all()

@@ -247,10 +247,130 @@ def capture_boxqp():
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
 
 
+def capture_bnn():
+    """BNN moment-matched dynamics (pddp/models/bnn/modules.py): fixed weights,
+    dropout noise and particle noise are stored with the outputs, so that an
+    independent implementation can be fed the same randomness."""
+    from pddp.models.bnn import bnn_dynamics_model_factory
+    from pddp.utils.evaluation import batch_eval_dynamics
+    from pddp.examples.cartpole import CartpoleDynamicsModel as CM
+    torch.manual_seed(3)
+    dtype = torch.float64
+    P, D, m = 24, 4, 1
+    enc = StateEncoding.DEFAULT
+    cls = bnn_dynamics_model_factory(D, m, [32, 24], CM.angular_indices,
+                                     CM.non_angular_indices)
+    model = cls(n_particles=P).to(dtype).eval()
+    model.X_mean.data = 0.1 * torch.randn(6, dtype=dtype)
+    model.X_std.data = 0.5 + torch.rand(6, dtype=dtype)
+    model.X_std_inv.data = model.X_std.reciprocal()
+    model.dX_mean.data = 0.05 * torch.randn(D, dtype=dtype)
+    model.dX_std.data = 0.2 + 0.3 * torch.rand(D, dtype=dtype)
+    model.dX_std_inv.data = model.dX_std.reciprocal()
+    store = {}
+    mean = torch.tensor([0.1, -0.2, 0.3, 0.05], dtype=dtype)
+    A_ = 0.2 * torch.randn(D, D, dtype=dtype)
+    covar = A_.t().mm(A_) + 0.01 * torch.eye(D, dtype=dtype)
+    z0 = GaussianVariable(mean, covar=covar).encode(enc).detach()
+    store["z0"] = np_(z0)
+    T = 6
+    U = 0.3 * torch.randn(T, m, dtype=dtype)
+    store["U"] = np_(U)
+    opts = {"use_predicted_std": False, "infer_noise_variables": True}
+    # 1. single-state moment-matched rollout i = 0..T-1 (fills the caches)
+    z = z0
+    Zs = [np_(z)]
+    for i in range(T):
+        z = model(z, U[i], i, enc, **opts).detach()
+        Zs.append(np_(z))
+    store["single/Z"] = np.stack(Zs)
+    # everything random the model drew
+    for name, mod in model.model.named_children():
+        if hasattr(mod, "noise") and name.startswith("drop"):
+            store["state/%s.noise" % name] = np_(mod.noise)
+            store["state/%s.logit_p" % name] = np_(mod.logit_p)
+            store["state/%s.temperature" % name] = np_(mod.temperature)
+        if hasattr(mod, "weight"):
+            store["state/%s.weight" % name] = np_(mod.weight)
+            store["state/%s.bias" % name] = np_(mod.bias)
+    for nm in ("X_mean", "X_std", "X_std_inv", "dX_mean", "dX_std",
+               "dX_std_inv"):
+        store["state/" + nm] = np_(getattr(model, nm))
+    for i, e in model.eps_in.items():
+        store["state/eps_in/%d" % i] = np_(e)
+    # 2. Jacobians by the reference's replicated-input trick along that
+    #    rollout (ilqr.py:467 calls it in time order, so output[i-1] is the
+    #    cache of the previous call with the same row count)
+    model.output = {}
+    z = z0
+    Fz, Fu, Zb = [], [], [np_(z0)]
+    for i in range(T):
+        zi = z.detach().requires_grad_()
+        ui = U[i].detach().requires_grad_()
+        zn, fz, fu = batch_eval_dynamics(model, zi, ui, i, encoding=enc,
+                                         **opts)
+        Fz.append(np_(fz)); Fu.append(np_(fu)); Zb.append(np_(zn))
+        z = zn.detach()
+    store["jac/Z"] = np.stack(Zb)
+    store["jac/F_z"] = np.stack(Fz)
+    store["jac/F_u"] = np.stack(Fu)
+    # 3. a batch of DIFFERENT rows (what the line search feeds), time order
+    model.output = {}
+    rows = 5
+    Zr = z0.unsqueeze(0) + 0.01 * torch.randn(rows, z0.shape[0], dtype=dtype)
+    # keep the Cholesky block valid: only perturb the mean part
+    Zr[:, D:] = z0[D:]
+    store["rows/Z0"] = np_(Zr)
+    Ur = 0.3 * torch.randn(T, rows, m, dtype=dtype)
+    store["rows/U"] = np_(Ur)
+    outs = []
+    z = Zr
+    for i in range(T):
+        z = model(z, Ur[i], i, enc, **opts).detach()
+        outs.append(np_(z))
+    store["rows/Z"] = np.stack(outs)
+    store["P"] = np.array(P)
+    # 4. a whole iLQR fit on the learned model (same cached noise: eps_in and
+    #    the dropout masks are reused as long as nobody calls resample())
+    from pddp.examples.cartpole import CartpoleCost, CartpoleEnv
+    model.output = {}
+    cost = CartpoleCost().to(dtype)
+    env = CartpoleEnv(dt=0.1)
+    ctrl = iLQRController(env, model, cost, model_opts=opts)
+    u_min = torch.tensor([-10.0], dtype=dtype)
+    u_max = torch.tensor([10.0], dtype=dtype)
+    trace = []
+
+    def on_iteration(i, state, Z, U_, J):
+        trace.append((i, int(state), float(J), ctrl._mu, ctrl._delta))
+
+    class _E(object):  # env.get_state() with the stored z0
+        def get_state(self_inner):
+            class G(object):
+                def encode(s2, enc_):
+                    return z0
+            return G()
+    ctrl.env = _E()
+    Zf, Uf, state = ctrl.fit(U.clone(), encoding=enc, n_iterations=5,
+                             quiet=True, on_iteration=on_iteration,
+                             u_min=u_min, u_max=u_max)
+    store["fit/trace"] = np.array(trace, dtype=np.float64)
+    store["fit/Z"] = np_(Zf)
+    store["fit/U"] = np_(Uf)
+    store["fit/K"] = np_(ctrl._K)
+    store["fit/state"] = np.array(int(state))
+    path = os.path.join(OUT, "bnn_cartpole_default_f64.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
+    if "--bnn-only" in sys.argv:
+        capture_bnn()
+        return
     if "--default-only" in sys.argv:
         capture_problem("cartpole", "default", torch.float64, [5, 25],
                         with_fit=12)
@@ -268,6 +388,7 @@ def main():
     # rows of SURVEY 8(f); fp64 only, short horizons (n = 14 / 5).
     capture_problem("cartpole", "default", torch.float64, [5, 25], with_fit=12)
     capture_problem("pendulum", "default", torch.float64, [5, 25], with_fit=12)
+    capture_bnn()
 
 
 if __name__ == "__main__":
