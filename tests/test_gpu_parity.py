@@ -610,3 +610,46 @@ def test_pddp_controller_runs_on_gpu():
     Z, U, state = ctrl.fit(U0, max_trials=3, **kw)
     assert trials[-1][1] == (2 * N, 2)             # MPC trial of horizon 2N
     assert torch.isfinite(U).all()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("B,N", [(1, 1), (1, 3), (2, 7), (5, 8), (7, 9),
+                                 (3, 17), (6, 1)])
+def test_backward_ragged_shapes(B, N, dtype):
+    """Edge shapes of the reference's own tests (N in {1, 3},
+    tests/controllers/test_ilqr.py:49) and ragged ones: horizons shorter than
+    the specialised kernel's 8-slot record ring, batches that do not fill a
+    wavefront's four trajectory groups, inactive trajectories - both kernels,
+    all branches, against the oracle."""
+    s, op, z0, U, u_min, u_max = _setup("cartpole", dtype, B, N, seed=B * 31 + N)
+    s.nominal_rollout()
+    s.derivs(set_state=False)
+    o = orc.load(np_dtype(dtype))
+    active = torch.ones(B, dtype=torch.uint8, device="cuda")
+    if B > 2:
+        active[1] = 0
+    for variant in (0, 1):
+        for branch, bounded in ((0, True), (0, False), (1, True), (1, False)):
+            regv = torch.full((B,), 1.0, dtype=torch.float64, device="cuda")
+            s.gains.fill_(float("nan"))
+            s.bwd_status.fill_(-7)
+            s.backward(active=active, reg=regv, branch=branch, bounded=bounded,
+                       variant=variant)
+            k, K = s.gain_views()
+            st = s.bwd_status.cpu().numpy()
+            for b in range(B):
+                if not int(active[b]):
+                    assert st[b] == -7  # untouched
+                    continue
+                f = o.forward(op, z0[b], U[b], u_min, u_max)
+                kw = dict(reg=1.0, V_zz_reg=bool(branch))
+                if bounded:
+                    kw.update(u_min=u_min, u_max=u_max, U=U[b])
+                kr, Kr, sr = o.backward(f["F_z"], f["F_u"], f["L_z"], f["L_u"],
+                                        f["L_zz"], f["L_uz"], f["L_uu"], **kw)
+                if dtype == "f32" and (sr == 0) != (st[b] == 0):
+                    continue
+                assert (sr == 0) == (st[b] == 0), (variant, branch, bounded, b)
+                if sr == 0:
+                    assert rel_err(k[b].cpu().numpy(), kr) < TOL[dtype]
+                    assert rel_err(K[b].cpu().numpy(), Kr) < TOL[dtype]
