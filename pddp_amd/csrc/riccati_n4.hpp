@@ -253,28 +253,35 @@ PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, T lstep0, const T* ls_tail,
 
     const T search = newton - x;                      // (:237-239)
     const T sdotg = search * g;
-    // line search (:248-259): candidate n = nb + l in lane l
-    T xc = x, fc = f;
+    // line search (:248-259).  The full step (n = 0) is what the scan tests
+    // first, and it passes whenever the Newton point is inside the box; every
+    // lane evaluates it (no cross-lane traffic).  Only trajectories that fail
+    // it enter the 16-candidates-per-round scan (candidate n = nb + l in
+    // lane l), which starts over from n = 0 so that the same n is found.
+    T xc = clampq<FAST>(x + search, lo, hi);
+    T fc = obj(xc);
     int nsel = 0;
-    bool found = !live;
-    for (int nb = 0;; nb += 16) {
-      const int n = nb + l;
-      const T st = (nb == 0) ? lstep0 : ls_tail[n];
-      const T xn = clampq<FAST>(x + st * search, lo, hi);
-      const T fn = obj(xn);
-      const bool ok = !(div_<FAST>(fn - old_f, st * sdotg) < armijo) ||
-                      (n >= kLs.n_fail);
-      const int m = group_min(ok ? n : 0x7fffffff);
-      const bool hit = (m != 0x7fffffff) && !found;
-      // broadcast the winner's (xn, fn): exactly one lane contributes, the
-      // others add zeros, so the butterfly sums are exact
-      const T xw = group_sum((n == m) ? xn : T(0));
-      const T fw = group_sum((n == m) ? fn : T(0));
-      xc = hit ? xw : xc;
-      fc = hit ? fw : fc;
-      nsel = hit ? m : nsel;
-      found = found || (m != 0x7fffffff);
-      if (!__any(!found)) break;
+    bool found = !live || !(div_<FAST>(fc - old_f, sdotg) < armijo);
+    if (__any(!found)) {
+      for (int nb = 0;; nb += 16) {
+        const int n = nb + l;
+        const T st = (nb == 0) ? lstep0 : ls_tail[n];
+        const T xn = clampq<FAST>(x + st * search, lo, hi);
+        const T fn = obj(xn);
+        const bool ok = !(div_<FAST>(fn - old_f, st * sdotg) < armijo) ||
+                        (n >= kLs.n_fail);
+        const int m = group_min(ok ? n : 0x7fffffff);
+        const bool hit = (m != 0x7fffffff) && !found;
+        // broadcast the winner's (xn, fn): exactly one lane contributes, the
+        // others add zeros, so the butterfly sums are exact
+        const T xw = group_sum((n == m) ? xn : T(0));
+        const T fw = group_sum((n == m) ? fn : T(0));
+        xc = hit ? xw : xc;
+        fc = hit ? fw : fc;
+        nsel = hit ? m : nsel;
+        found = found || (m != 0x7fffffff);
+        if (!__any(!found)) break;
+      }
     }
     x = live ? xc : x;
     f = live ? fc : f;
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
       // DMA(t-1) has landed once at most (R-2) younger {store, DMA} pairs
       // are outstanding; gather it now, use it in the next step
       wait_vmcnt<(R - 2) * (1 + NI)>();
-      if (t > 0) nxt = gather((s + 1) % R);
+      nxt = gather((s + 1) % R);  // (at t == 0 this reads a stale slot, unused)
       const T Fs0 = w.Fs0, Fs1 = w.Fs1, Fs2 = w.Fs2, Fs3 = w.Fs3;
       const T Fq0 = w.Fq0, Fq1 = w.Fq1, Fq2 = w.Fq2, Fq3 = w.Fq3;
       const T Ft = w.Ft, Lzz = w.Lzz, fr = w.fr, fc = w.fc;
