@@ -264,6 +264,87 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
   a.Jc[idx] = J + lf;  // L.sum(0) + l_f                           (ilqr.py:789)
 }
 
+// Same line search with the trajectory's nominal data staged in LDS: 16 lanes
+// per trajectory (one per alpha, A <= 16), four trajectories per wavefront.
+// Z, U and the gains of a trajectory (4 KB for cartpole at N = 100) are copied
+// into LDS once, coalesced, and every step then reads them as LDS broadcasts:
+// the dependent chain never waits on a global load.
+template <typename T, int MODEL>
+__global__ __launch_bounds__(kWave) void line_search_lds_kernel(
+    ProblemT<T> P, LineSearchArgs<T> a) {
+  using D = ModelDims<MODEL>;
+  constexpr int n = D::n, m = D::m;
+  constexpr int GS = m + m * n;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+  const int lane = threadIdx.x;
+  const int grp = lane >> 4, ai = lane & 15;
+  const int N = a.N;
+  const int per = (N + 1) * n + N * m + N * GS;  // scalars per trajectory
+  const int b0 = blockIdx.x * 4;
+
+  // cooperative, coalesced staging of up to four trajectories
+  for (int g = 0; g < 4; ++g) {
+    const int bg = b0 + g;
+    if (bg >= a.B) break;
+    if (a.active != nullptr && a.active[bg] == 0) continue;
+    T* dst = smem + (size_t)g * per;
+    const T* zs = a.Z + (size_t)bg * (N + 1) * n;
+    const T* us = a.U + (size_t)bg * N * m;
+    const T* gs = a.gains + (size_t)bg * N * GS;
+    for (int o = lane; o < (N + 1) * n; o += kWave) dst[o] = zs[o];
+    for (int o = lane; o < N * m; o += kWave) dst[(N + 1) * n + o] = us[o];
+    for (int o = lane; o < N * GS; o += kWave)
+      dst[(N + 1) * n + N * m + o] = gs[o];
+  }
+  __syncthreads();
+
+  const int b = b0 + grp;
+  if (b >= a.B || ai >= a.A) return;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  if (a.bwd_status != nullptr && a.bwd_status[b] != 0) return;
+  const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
+  const T alpha = a.alphas[ai];
+  const T* Zs = smem + (size_t)grp * per;
+  const T* Us = Zs + (N + 1) * n;
+  const T* Gs = Us + N * m;
+  const int idx = b * a.A + ai;
+  T* Zci = a.Zc + (size_t)idx * (N + 1) * n;
+  T* Uci = a.Uc + (size_t)idx * N * m;
+
+  T z[n], zn[n], un[m];
+#pragma unroll
+  for (int j = 0; j < n; ++j) z[j] = Zs[j];  // Z_new[0] = Z[0]    (ilqr.py:690)
+  T J = T(0);
+  for (int t = 0; t < N; ++t) {
+    const T* zr = Zs + t * n;
+    const T* gr = Gs + t * GS;
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+      T du = alpha * gr[r];  // alpha * k[i]                      (ilqr.py:708)
+      T s = T(0);
+#pragma unroll
+      for (int c = 0; c < n; ++c) s += (z[c] - zr[c]) * gr[m + r * n + c];
+      du = du + s;  // + dz K^T                                   (ilqr.py:710)
+      const T v = Us[t * m + r] + du;
+      un[r] = bounded ? clamp1(v, a.u_min[r], a.u_max[r]) : v;
+    }
+#pragma unroll
+    for (int j = 0; j < n; ++j) Zci[(size_t)t * n + j] = z[j];
+#pragma unroll
+    for (int j = 0; j < m; ++j) Uci[(size_t)t * m + j] = un[j];
+    const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
+    J += cost_value<T, MODEL>(P, z, un, tr, false);
+    dynamics<T, MODEL, false>(P, z, un, tr, zn, nullptr, nullptr);
+#pragma unroll
+    for (int j = 0; j < n; ++j) z[j] = zn[j];
+  }
+#pragma unroll
+  for (int j = 0; j < n; ++j) Zci[(size_t)N * n + j] = z[j];
+  const T lf = cost_value<T, MODEL>(P, z, nullptr, trig_of<T, MODEL>(z), true);
+  a.Jc[idx] = J + lf;  // L.sum(0) + l_f                           (ilqr.py:789)
+}
+
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
@@ -287,6 +368,15 @@ template <typename T, int MODEL>
 static int launch_line_search(const pddp_problem& p, LineSearchArgs<T> a,
                               hipStream_t st) {
   const ProblemT<T> P = convert_problem<T>(p);
+  using D = ModelDims<MODEL>;
+  const size_t per = (size_t)(a.N + 1) * D::n + (size_t)a.N * D::m +
+                     (size_t)a.N * (D::m + D::m * D::n);
+  const size_t lds = 4 * per * sizeof(T);
+  if (a.A <= 16 && lds <= 64 * 1024) {  // nominal data staged in LDS
+    hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL>),
+                       dim3((a.B + 3) / 4), dim3(kWave), lds, st, P, a);
+    return launch_status();
+  }
   const int total = a.B * a.A;
   const int blocks = (total + kWave - 1) / kWave;
   hipLaunchKernelGGL((line_search_kernel<T, MODEL>), dim3(blocks), dim3(kWave),
