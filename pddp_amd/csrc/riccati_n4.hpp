@@ -27,10 +27,6 @@
 
 namespace pddp {
 
-#ifndef PDDP_N4_LS_MODE
-#define PDDP_N4_LS_MODE 0  // 0: 16 candidates per round; else sequential scan
-#endif
-
 namespace n4 {
 
 constexpr int kRec = 48;   // scalars per record (RecLayout(4,1).stride)
@@ -212,28 +208,25 @@ PDDP_DEV int group_min(int m) {
 // loop-invariant.
 // `lstep0` = T(0.6^l) for this lane (l = lane % 16); later rounds read LDS.
 template <typename T, bool FAST>
-PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, T lstep0, const T* ls_tail,
-                    int lane, T& x_out, T& U_out, bool& free_out) {
-  const T min_grad = T(1e-8), tol = T(1e-8), armijo = T(0.1);
-  const int l = lane & 15;
-  auto obj = [&](T v) { return T(0.5) * ((v * Q) * v) + v * c; };
+struct BoxQp1 {
+  static constexpr T kMinGrad = T(1e-8), kTol = T(1e-8), kArmijo = T(0.1);
+  T Q, c, lo, hi;           // the problem
+  T x, f, old_f, U, newton;  // iterate, objective, factor, Newton point
+  bool free_, not_pd;
+  int result;
+  // state handed from an iteration's head to its tail
+  bool live, found;
+  T search, sdotg, xc, fc;
 
-  T x = clamp1(x0, lo, hi);
-  x = ((x - x != T(0)) && (x == x)) ? T(0) : x;  // x[isinf(x)] = 0   (:179)
-  T f = obj(x);
-  T old_f = T(0);
-  bool free_ = true;
-  int result = 0;
-  const T U = sqrtx<FAST>(Q);
-  const T newton = -div_<FAST>(div_<FAST>(c, U), U);  // -potrs(g_clamped, U)
-  const bool not_pd = !(Q > T(0)) || !is_finite(Q);
+  PDDP_DEV T obj(T v) const { return T(0.5) * ((v * Q) * v) + v * c; }
 
-#if PDDP_N4_LS_MODE == 0
-  for (int it = 0; it < 100; ++it) {
-    bool live = (result == 0);
-    if (!__any(live)) break;
+  // Branch-free first half of iteration `it`: exit tests, Newton direction and
+  // the full-step candidate (the n = 0 the line search tests first, which
+  // passes whenever the Newton point lies inside the box).
+  PDDP_DEV void head(int it) {
+    live = (result == 0);
     if (it > 0) {  // convergence on the objective decrease       (:191-193)
-      const bool conv = (old_f - f) < tol * abs_(old_f);
+      const bool conv = (old_f - f) < kTol * abs_(old_f);
       result = (live && conv) ? 4 : result;
       live = live && !conv;
     }
@@ -247,28 +240,28 @@ PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, T lstep0, const T* ls_tail,
       result = (live && not_pd) ? -1 : result;
       live = live && !not_pd;
     }
-    const bool gsmall = abs_(g) < min_grad;           // (:231-234)
+    const bool gsmall = abs_(g) < kMinGrad;           // (:231-234)
     result = (live && gsmall) ? 5 : result;
     live = live && !gsmall;
+    search = newton - x;                              // (:237-239)
+    sdotg = search * g;
+    xc = clampq<FAST>(x + search, lo, hi);
+    fc = obj(xc);
+    found = !live || !(div_<FAST>(fc - old_f, sdotg) < kArmijo);
+  }
 
-    const T search = newton - x;                      // (:237-239)
-    const T sdotg = search * g;
-    // line search (:248-259).  The full step (n = 0) is what the scan tests
-    // first, and it passes whenever the Newton point is inside the box; every
-    // lane evaluates it (no cross-lane traffic).  Only trajectories that fail
-    // it enter the 16-candidates-per-round scan (candidate n = nb + l in
-    // lane l), which starts over from n = 0 so that the same n is found.
-    T xc = clampq<FAST>(x + search, lo, hi);
-    T fc = obj(xc);
+  // Second half: trajectories whose full step failed the Armijo test scan the
+  // step sizes 0.6^n, 16 candidates per round (candidate n = nb + l in lane
+  // l, restarting from n = 0 so that the reference's n is found); commit.
+  PDDP_DEV void tail(T lstep0, const T* ls_tail, int l) {
     int nsel = 0;
-    bool found = !live || !(div_<FAST>(fc - old_f, sdotg) < armijo);
     if (__any(!found)) {
       for (int nb = 0;; nb += 16) {
         const int n = nb + l;
         const T st = (nb == 0) ? lstep0 : ls_tail[n];
         const T xn = clampq<FAST>(x + st * search, lo, hi);
         const T fn = obj(xn);
-        const bool ok = !(div_<FAST>(fn - old_f, st * sdotg) < armijo) ||
+        const bool ok = !(div_<FAST>(fn - old_f, st * sdotg) < kArmijo) ||
                         (n >= kLs.n_fail);
         const int m = group_min(ok ? n : 0x7fffffff);
         const bool hit = (m != 0x7fffffff) && !found;
@@ -287,37 +280,45 @@ PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, T lstep0, const T* ls_tail,
     f = live ? fc : f;
     result = (live && nsel >= kLs.n_fail) ? 2 : result;  // step < min_step
   }
-#else
-  bool clamped = false;
-  for (int it = 0; it < 100; ++it) {
-    if (it > 0 && (old_f - f) < tol * abs_(old_f)) { result = 4; break; }
-    old_f = f;
-    const T g = Q * x + c;
-    clamped = ((x == lo) && (g > T(0))) || ((x == hi) && (g < T(0)));
-    free_ = !clamped;
-    if (clamped) { result = 6; break; }
-    if (it == 0 && not_pd) { result = -1; break; }
-    if (abs_(g) < min_grad) { result = 5; break; }
-    const T search = newton - x;
-    const T sdotg = search * g;
-    T xc = x, fc = f;
-    int nsel = 0;
-    for (;; ++nsel) {  // sequential reference scan
-      const T st = ls_tail[nsel];
-      xc = clampq<FAST>(x + st * search, lo, hi);
-      fc = obj(xc);
-      if (nsel >= kLs.n_fail) break;
-      if (!(div_<FAST>(fc - old_f, st * sdotg) < armijo)) break;
-    }
-    x = xc;
-    f = fc;
-    if (nsel >= kLs.n_fail) { result = 2; break; }
+
+  // Setup + head of iteration 0: straight-line code the scheduler can
+  // interleave with the independent 4x4 products of the same step.
+  PDDP_DEV void begin(T x0, T Q_, T c_, T lo_, T hi_) {
+    Q = Q_; c = c_; lo = lo_; hi = hi_;
+    x = clamp1(x0, lo, hi);
+    x = ((x - x != T(0)) && (x == x)) ? T(0) : x;  // x[isinf(x)] = 0 (:179)
+    f = obj(x);
+    old_f = T(0);
+    free_ = true;
+    result = 0;
+    U = sqrtx<FAST>(Q);
+    newton = -div_<FAST>(div_<FAST>(c, U), U);  // -potrs(g_clamped, U)
+    not_pd = !(Q > T(0)) || !is_finite(Q);
+    head(0);
   }
-#endif
-  x_out = x;
-  U_out = U;
-  free_out = free_;
-  return result;
+
+  PDDP_DEV int finish(T lstep0, const T* ls_tail, int lane) {
+    const int l = lane & 15;
+    tail(lstep0, ls_tail, l);
+    for (int it = 1; it < 100; ++it) {
+      if (!__any(result == 0)) break;
+      head(it);
+      tail(lstep0, ls_tail, l);
+    }
+    return result;
+  }
+};
+
+template <typename T, bool FAST>
+PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, T lstep0, const T* ls_tail,
+                    int lane, T& x_out, T& U_out, bool& free_out) {
+  BoxQp1<T, FAST> qp;
+  qp.begin(x0, Q, c, lo, hi);
+  const int res = qp.finish(lstep0, ls_tail, lane);
+  x_out = qp.x;
+  U_out = qp.U;
+  free_out = qp.free_;
+  return res;
 }
 
 template <typename T, bool CHOL, bool BOUNDED, bool FAST, int G>
@@ -444,46 +445,25 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
       const T Ft = w.Ft, Lzz = w.Lzz, fr = w.fr, fc = w.fc;
       const T Luzr = w.Luzr, Lzr = w.Lzr, Luu = w.Luu, Lu = w.Lu, Un = w.Un;
 
-      // A = F^T V : A[i][j] = sum_k F[k][i] V[k][j], k = (i + d) % 4
-      T A = Fs0 * V;
-      A += Fs1 * from_row_plus<1>(V);
-      A += Fs2 * from_row_plus<2>(V);
-      A += Fs3 * from_row_plus<3>(V);
-      // (f^T V)[j], column form
+      // ---- scalars that feed the gain computation first: (f^T V)[j]
+      // (column form), Q_uu, Q_u (and their V + reg I twins)
       const T bTc = dot_rows(fr, V);
-      // Q_zz (raw) = L_zz + A F : sum_k A[i][k] F[k][j], k = (j + d) % 4
-      T Qzz = Lzz + A * Fq0;
-      Qzz += from_col_plus<1>(A) * Fq1;
-      Qzz += from_col_plus<2>(A) * Fq2;
-      Qzz += from_col_plus<3>(A) * Fq3;
-      // Q_uz (row form) = L_uz + A f ; Q_uu ; Q_u ; Q_z (row form)
-      const T Quzr = Luzr + dot_cols(A, fc);
       const T Quu = Luu + dot_cols(bTc, fc);
       const T Qu = Lu + dot_cols(fc, Vzc);
-      const T Qzr = Lzr + dot_cols(Ft, Vzc);
-
-      T Quzgr = Quzr, Quug = Quu;  // operands of the gain solve
+      T Quug = Quu;
+      T Vr = V;
       if constexpr (CHOL) {
         // second Q() with V + reg I                           (ilqr.py:590-592)
-        const T Vr = (i == j) ? V + reg : V;
-        T Ar = Fs0 * Vr;
-        Ar += Fs1 * from_row_plus<1>(Vr);
-        Ar += Fs2 * from_row_plus<2>(Vr);
-        Ar += Fs3 * from_row_plus<3>(Vr);
+        Vr = (i == j) ? V + reg : V;
         const T bTrc = dot_rows(fr, Vr);
-        Quzgr = Luzr + dot_cols(Ar, fc);
         Quug = Luu + dot_cols(bTrc, fc);
       }
 
-      // transposes (lane (i,j) <- lane (j,i)); latency hidden by the gains
-      const T QzzT = bperm(tr_addr, Qzz);
-      const T Quzc = bperm(tr_addr, Quzr);
-      const T Qzc = bperm(tr_addr, Qzr);
-      T Quzgc = Quzc;
-      if constexpr (CHOL) Quzgc = bperm(tr_addr, Quzgr);
-
-      // ---- gains (every lane of the group computes the same scalars)
-      T kt;
+      // ---- gains, part 1 (every lane of the group computes the same
+      // scalars).  For the bounded branches this is the straight-line head of
+      // the BoxQP; it is independent of the 4x4 products below, so the
+      // scheduler interleaves the two dependency chains.
+      T kt = T(0);
       T Uch = T(1);
       bool Kzero = false, by_inv = false;
       T inv = T(0);
@@ -494,6 +474,7 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
       const T Qu_s = alive ? Qu : T(0);
       const T x0_s = alive ? kprev : T(0);
       const T Un_s = alive ? Un : T(0);
+      BoxQp1<T, FAST> qp;
       if constexpr (!CHOL) {
         if (!is_finite(Quu_s)) st = PDDP_BWD_NAN;  // eig raises (ilqr.py:631)
         T e = (Quu_s < T(0)) ? T(1e-12) : Quu_s;   // ilqr.py:633
@@ -505,12 +486,7 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
           if (kt != kt) st = PDDP_BWD_NAN;
         } else {
           const T Qg = (T(1) * e) * T(1);          // (E * e) E^T
-          bool fr_;
-          const int res = boxqp1<T, FAST>(x0_s, Qg, Qu_s, umin - Un_s,
-                                          umax - Un_s, lstep[0], ls_tail,
-                                          lane, kt, Uch, fr_);
-          if (res < 1) st = PDDP_BWD_BOXQP_FAILED;
-          Kzero = !fr_;
+          qp.begin(x0_s, Qg, Qu_s, umin - Un_s, umax - Un_s);
         }
       } else {
         if constexpr (!BOUNDED) {
@@ -518,13 +494,47 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
           Uch = sqrtx<FAST>(Quug_s);
           kt = -div_<FAST>(div_<FAST>(Qu_s, Uch), Uch);
         } else {
-          bool fr_;
-          const int res = boxqp1<T, FAST>(x0_s, Quug_s, Qu_s, umin - Un_s,
-                                          umax - Un_s, lstep[0], ls_tail,
-                                          lane, kt, Uch, fr_);
-          if (res < 1) st = PDDP_BWD_BOXQP_FAILED;
-          Kzero = !fr_;
+          qp.begin(x0_s, Quug_s, Qu_s, umin - Un_s, umax - Un_s);
         }
+      }
+
+      // ---- the 4x4 products
+      // A = F^T V : A[i][j] = sum_k F[k][i] V[k][j], k = (i + d) % 4
+      T A = Fs0 * V;
+      A += Fs1 * from_row_plus<1>(V);
+      A += Fs2 * from_row_plus<2>(V);
+      A += Fs3 * from_row_plus<3>(V);
+      // Q_zz (raw) = L_zz + A F : sum_k A[i][k] F[k][j], k = (j + d) % 4
+      T Qzz = Lzz + A * Fq0;
+      Qzz += from_col_plus<1>(A) * Fq1;
+      Qzz += from_col_plus<2>(A) * Fq2;
+      Qzz += from_col_plus<3>(A) * Fq3;
+      // Q_uz (row form) = L_uz + A f ; Q_z (row form)
+      const T Quzr = Luzr + dot_cols(A, fc);
+      const T Qzr = Lzr + dot_cols(Ft, Vzc);
+      T Quzgr = Quzr;  // operand of the K solve
+      if constexpr (CHOL) {
+        T Ar = Fs0 * Vr;
+        Ar += Fs1 * from_row_plus<1>(Vr);
+        Ar += Fs2 * from_row_plus<2>(Vr);
+        Ar += Fs3 * from_row_plus<3>(Vr);
+        Quzgr = Luzr + dot_cols(Ar, fc);
+      }
+
+      // transposes (lane (i,j) <- lane (j,i)); latency hidden by the BoxQP
+      const T QzzT = bperm(tr_addr, Qzz);
+      const T Quzc = bperm(tr_addr, Quzr);
+      const T Qzc = bperm(tr_addr, Qzr);
+      T Quzgc = Quzc;
+      if constexpr (CHOL) Quzgc = bperm(tr_addr, Quzgr);
+
+      // ---- gains, part 2: line-search scan and further BoxQP iterations
+      if constexpr (BOUNDED) {
+        const int res = qp.finish(lstep[0], ls_tail, lane);
+        kt = qp.x;
+        Uch = qp.U;
+        Kzero = !qp.free_;
+        if (res < 1) st = PDDP_BWD_BOXQP_FAILED;
       }
       // K in row and column form, same arithmetic on transposed copies
       T Kr, Kc;
