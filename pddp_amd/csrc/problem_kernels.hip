@@ -32,7 +32,12 @@ __global__ __launch_bounds__(kWave) void nominal_rollout_kernel(
   if (b >= a.B) return;
   if (a.mask != nullptr && a.mask[b] == 0) return;
   const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
-  T z[n], zn[n], u[m];
+  T z[n], zn[n], u[m], umin[m], umax[m];
+#pragma unroll
+  for (int r = 0; r < m; ++r) {
+    umin[r] = bounded ? a.u_min[r] : T(0);
+    umax[r] = bounded ? a.u_max[r] : T(0);
+  }
   T* Zb = a.Z + (size_t)b * (a.N + 1) * n;
   const T* Ub = a.U + (size_t)b * a.N * m;
 #pragma unroll
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(kWave) void nominal_rollout_kernel(
 #pragma unroll
     for (int j = 0; j < m; ++j) {
       u[j] = Ub[t * m + j];
-      if (bounded) u[j] = clamp1(u[j], a.u_min[j], a.u_max[j]);
+      if (bounded) u[j] = clamp1(u[j], umin[j], umax[j]);
     }
     const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
     dynamics<T, MODEL, false>(P, z, u, tr, zn, nullptr, nullptr);
@@ -196,6 +201,12 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
   if (a.active != nullptr && a.active[b] == 0) return;
   if (a.bwd_status != nullptr && a.bwd_status[b] != 0) return;
   const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
+  T umin[m], umax[m];
+#pragma unroll
+  for (int r = 0; r < m; ++r) {
+    umin[r] = bounded ? a.u_min[r] : T(0);
+    umax[r] = bounded ? a.u_max[r] : T(0);
+  }
   const int N = a.N;
   const T alpha = a.alphas[ai];
   const T* Zb = a.Z + (size_t)b * (N + 1) * n;
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
       for (int c = 0; c < n; ++c) s += (z[c] - zr[c]) * gr[m + r * n + c];
       du = du + s;  // + dz K^T                                   (ilqr.py:710)
       T v = ur[r] + du;
-      un[r] = bounded ? clamp1(v, a.u_min[r], a.u_max[r]) : v;
+      un[r] = bounded ? clamp1(v, umin[r], umax[r]) : v;
     }
 #pragma unroll
     for (int j = 0; j < n; ++j) Zci[(size_t)t * n + j] = z[j];
@@ -304,6 +315,12 @@ __global__ __launch_bounds__(kWave) void line_search_lds_kernel(
   if (a.active != nullptr && a.active[b] == 0) return;
   if (a.bwd_status != nullptr && a.bwd_status[b] != 0) return;
   const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
+  T umin[m], umax[m];  // hoisted: a load in the loop sits on the chain
+#pragma unroll
+  for (int r = 0; r < m; ++r) {
+    umin[r] = bounded ? a.u_min[r] : T(0);
+    umax[r] = bounded ? a.u_max[r] : T(0);
+  }
   const T alpha = a.alphas[ai];
   const T* Zs = smem + (size_t)grp * per;
   const T* Us = Zs + (N + 1) * n;
@@ -327,7 +344,7 @@ __global__ __launch_bounds__(kWave) void line_search_lds_kernel(
       for (int c = 0; c < n; ++c) s += (z[c] - zr[c]) * gr[m + r * n + c];
       du = du + s;  // + dz K^T                                   (ilqr.py:710)
       const T v = Us[t * m + r] + du;
-      un[r] = bounded ? clamp1(v, a.u_min[r], a.u_max[r]) : v;
+      un[r] = bounded ? clamp1(v, umin[r], umax[r]) : v;
     }
 #pragma unroll
     for (int j = 0; j < n; ++j) Zci[(size_t)t * n + j] = z[j];
