@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condenses gpurun_out/<tag>_* (tools/collect_profiles.sh) into profiles/."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = "profiles"
+os.makedirs(out, exist_ok=True)
+
+src = glob.glob("gpurun_out/%s_stats/*/*kernel_stats.csv" % tag)[0]
+with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w") as f:
+    w = csv.writer(f)
+    cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage",
+            "MinNs", "MaxNs", "StdDev"]
+    w.writerow(cols)
+    for r in csv.DictReader(open(src)):
+        w.writerow([r["Name"][:110]] + [r[c] for c in cols[1:]])
+
+traffic = {}
+for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    f = glob.glob("gpurun_out/%s_pmc_%s/*/*counter_collection.csv" % (tag, kind))[0]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "pddp" in r["Kernel_Name"]:
+            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(
+                float(r["Counter_Value"]))
+    for k, v in acc.items():
+        traffic.setdefault(k, {})[ctr + "_KB_avg"] = sum(v) / len(v)
+        traffic[k][ctr + "_launches"] = len(v)
+for k, v in traffic.items():
+    fe = v.get("FETCH_SIZE_KB_avg", 0.0) * 1024
+    wr = v.get("WRITE_SIZE_KB_avg", 0.0) * 1024
+    # gfx950: FETCH_SIZE counts 1/2 of a wide (16 B/lane) streaming read
+    v["hbm_bytes_per_launch"] = 2 * fe + wr
+json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE "
+                      "(separate passes) -- python3 bench.py --steps 10 "
+                      "--warmup 2 --no-cpu-baseline",
+           "formula": "2*FETCH_SIZE + WRITE_SIZE, KB = 1024 B "
+                      "(MI355X_MICROARCH.md, HBM section)",
+           "workload": "cartpole n=4 m=1 N=100 B=4096 fp32, bounds +-10",
+           "kernels": traffic},
+          open(os.path.join(out, "%s_pmc_traffic.json" % tag), "w"), indent=1)
+
+f = glob.glob("gpurun_out/%s_pmc_sq/*/*counter_collection.csv" % tag)[0]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for r in csv.DictReader(open(f)):
+    if "pddp" in r["Kernel_Name"]:
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][
+            r["Counter_Name"]].append(float(r["Counter_Value"]))
+sq = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+json.dump({"note": "averages per launch; SQ_WAVE_CYCLES / SQ_WAIT_* / "
+                   "SQ_ACTIVE_* count quad-cycles", "kernels": sq},
+          open(os.path.join(out, "%s_pmc_sq.json" % tag), "w"), indent=1)
+
+points = {}
+for p in sorted(glob.glob("gpurun_out/%s_bench*.json" % tag)):
+    try:
+        line = [l for l in open(p).read().splitlines() if l.startswith("{")][-1]
+        points[os.path.basename(p)[len(tag) + 1:-5]] = json.loads(line)
+    except (IndexError, ValueError):
+        pass
+json.dump(points, open(os.path.join(out, "%s_bench_points.json" % tag), "w"),
+          indent=1)
+for k, d in points.items():
+    print(k, round(d["ms_per_step"], 4), "ms/step; sweep",
+          round(d["roofline"]["avg_launch_us"], 1), "us, frac",
+          round(d["roofline"]["frac"], 4), "value", int(d["value"]))
