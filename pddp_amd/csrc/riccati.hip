@@ -17,7 +17,17 @@ static int dispatch_nmax(const RiccatiArgs<T>& a, hipStream_t st) {
   if (a.n <= 8) return launch_generic<T, 8, M>(a, st);
   if (a.n <= 16) return launch_generic<T, 16, M>(a, st);
   if (a.n <= 32) return launch_generic<T, 32, M>(a, st);
-  return PDDP_E_UNSUPPORTED;
+  // n > 32: four wavefronts per trajectory, LDS sized for this n.  The CU has
+  // 160 KB; f32 reaches n = 114, f64 n = 80.
+  const size_t bytes = riccati_lds_elems(a.n, M) * sizeof(T);
+  if (bytes > 160 * 1024) return PDDP_E_UNSUPPORTED;
+  auto kernel = riccati_large_kernel<T, M>;
+  const hipError_t e = hipFuncSetAttribute(
+      (const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(kernel, dim3(a.B), dim3(kLargeThreads), bytes, st, a);
+  return launch_status();
 }
 
 template <typename T>

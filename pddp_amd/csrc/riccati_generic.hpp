@@ -1,9 +1,15 @@
-// riccati_generic.hpp - backward Riccati sweep, any n <= NMAX, m == M <= 4.
+// riccati_generic.hpp - backward Riccati sweep, any n, m == M <= 4.
 //
-// One 64-lane wavefront (= one workgroup) owns one trajectory and walks its
-// records t = N-1 .. 0.  V_zz, V_z and the step's intermediates live in LDS;
-// the next record is prefetched into registers while the current step is
-// computed, so the HBM stream is always one step ahead of the dependent chain.
+// One workgroup owns one trajectory and walks its records t = N-1 .. 0.
+// V_zz, V_z and the step's intermediates live in LDS.  Two instantiations of
+// the same body:
+//   * n <= NMAX in {8, 16, 32}: one 64-lane wavefront, statically sized LDS,
+//     the next record prefetched into registers while the current step is
+//     computed, so the HBM stream is one step ahead of the dependent chain;
+//   * larger n (the FULL_COVARIANCE_MATRIX encoding of the 6- and 8-state
+//     problems has n = 42 and 72): four wavefronts, dynamically sized LDS
+//     (three n x n matrices, up to the CU's 160 KB), records read in place
+//     through L2 because a record no longer fits beside the matrices.
 // The action-space algebra (eig clamp / Cholesky / BoxQP) runs redundantly in
 // every lane's registers (gains.hpp).
 //
@@ -29,35 +35,70 @@ struct RiccatiArgs {
   int32_t* status;
 };
 
-template <typename T, int NMAX, int M>
-struct RiccatiSmem {
-  static constexpr int kRecMax =
-      ((2 * NMAX * NMAX + 2 * NMAX * M + NMAX + M * M + 2 * M) + 3) & ~3;
-  T rec[kRecMax];
-  T V[NMAX * NMAX];
-  T W[NMAX * NMAX];  // scratch: raw Q_zz, then raw V_zz
-  T A[NMAX * NMAX];  // F_z^T V
-  T Qzz[NMAX * NMAX];
-  T Vz[NMAX];
-  T Qz[NMAX];
-  T Bm[M * NMAX];   // F_u^T V
-  T Bmr[M * NMAX];  // F_u^T (V + reg I)
-  T Quz[M * NMAX];
-  T Quzr[M * NMAX];
-  T K[M * NMAX];
-  T Qu[M];
-  T Quu[M * M];   // raw until phase 4, then symmetrised
-  T Quur[M * M];  // regularised (Cholesky branch), raw
-  T kv[M];
+// LDS working set of one trajectory; Qzz may alias W (ALIAS: symmetrised in
+// place), rec is null when records are read from global memory.
+template <typename T>
+struct RiccatiLds {
+  T* rec;
+  T* V;
+  T* W;    // scratch: raw Q_zz, then raw V_zz
+  T* A;    // F_z^T V
+  T* Qzz;
+  T* Vz;
+  T* Qz;
+  T* Bm;   // F_u^T V
+  T* Bmr;  // F_u^T (V + reg I)
+  T* Quz;
+  T* Quzr;
+  T* K;
+  T* Qu;
+  T* Quu;   // raw until phase 4, then symmetrised
+  T* Quur;  // regularised (Cholesky branch), raw
 };
 
-template <typename T, int NMAX, int M>
-__global__ __launch_bounds__(kWave) void riccati_generic_kernel(
-    RiccatiArgs<T> a) {
-  using Smem = RiccatiSmem<T, NMAX, M>;
-  __shared__ Smem s;
-  constexpr int NREG = (Smem::kRecMax + kWave - 1) / kWave;
+template <int NMAX, int M>
+constexpr int rec_max() {
+  return ((2 * NMAX * NMAX + 2 * NMAX * M + NMAX + M * M + 2 * M) + 3) & ~3;
+}
 
+// Elements of LDS the body needs for state size n (ALIAS layout, no record).
+__host__ __device__ inline size_t riccati_lds_elems(int n, int M) {
+  return (size_t)3 * n * n + 2 * n + (size_t)5 * M * n + M + 2 * M * M;
+}
+
+template <typename T>
+__device__ inline RiccatiLds<T> carve_lds(T* p, int n, int M, int rec_elems,
+                                          bool alias) {
+  RiccatiLds<T> s;
+  s.rec = rec_elems ? p : nullptr;
+  p += rec_elems;
+  s.V = p; p += n * n;
+  s.W = p; p += n * n;
+  s.A = p; p += n * n;
+  if (alias) {
+    s.Qzz = s.W;
+  } else {
+    s.Qzz = p; p += n * n;
+  }
+  s.Vz = p; p += n;
+  s.Qz = p; p += n;
+  s.Bm = p; p += M * n;
+  s.Bmr = p; p += M * n;
+  s.Quz = p; p += M * n;
+  s.Quzr = p; p += M * n;
+  s.K = p; p += M * n;
+  s.Qu = p; p += M;
+  s.Quu = p; p += M * M;
+  s.Quur = p;
+  return s;
+}
+
+// NT threads; NREG > 0: records staged through registers into s.rec (needs
+// NT * NREG >= stride); NREG == 0: records read in place from global memory.
+template <typename T, int M, int NT, int NREG, bool ALIAS>
+__device__ __forceinline__ void riccati_body(const RiccatiArgs<T>& a,
+                                             const RiccatiLds<T>& s) {
+  constexpr int kWave = NT;  // loop stride of this body
   const int b = blockIdx.x;
   const int lane = threadIdx.x;
   if (a.active != nullptr && a.active[b] == 0) return;
@@ -85,7 +126,7 @@ __global__ __launch_bounds__(kWave) void riccati_generic_kernel(
     for (int i = lane; i < n; i += kWave) s.Vz[i] = term[lay.oLz + i];
   }
 
-  T pre[NREG];
+  T pre[NREG > 0 ? NREG : 1];
   auto prefetch = [&](int t) {
     const T* src = rec_b + (size_t)t * S;
 #pragma unroll
@@ -94,7 +135,7 @@ __global__ __launch_bounds__(kWave) void riccati_generic_kernel(
       pre[r] = (idx < S) ? src[idx] : T(0);
     }
   };
-  prefetch(N - 1);
+  if (NREG > 0) prefetch(N - 1);
 
   T kprev[M];  // warm start k[t+1]; zeros at t = N-1        (ilqr.py:604,649)
 #pragma unroll
@@ -102,22 +143,25 @@ __global__ __launch_bounds__(kWave) void riccati_generic_kernel(
   int status = PDDP_BWD_OK;
 
   for (int t = N - 1; t >= 0; --t) {
+    const T* R = rec_b + (size_t)t * S;
+    if (NREG > 0) {
 #pragma unroll
-    for (int r = 0; r < NREG; ++r) {
-      const int idx = lane + kWave * r;
-      if (idx < S) s.rec[idx] = pre[r];
+      for (int r = 0; r < NREG; ++r) {
+        const int idx = lane + kWave * r;
+        if (idx < S) s.rec[idx] = pre[r];
+      }
+      __syncthreads();
+      if (t > 0) prefetch(t - 1);
+      R = s.rec;
     }
-    __syncthreads();
-    if (t > 0) prefetch(t - 1);
-
-    const T* Fz = s.rec + lay.oFz;
-    const T* Fu = s.rec + lay.oFu;
-    const T* Lzz = s.rec + lay.oLzz;
-    const T* Luz = s.rec + lay.oLuz;
-    const T* Lz = s.rec + lay.oLz;
-    const T* Luu = s.rec + lay.oLuu;
-    const T* Lu = s.rec + lay.oLu;
-    const T* Un = s.rec + lay.oU;
+    const T* Fz = R + lay.oFz;
+    const T* Fu = R + lay.oFu;
+    const T* Lzz = R + lay.oLzz;
+    const T* Luz = R + lay.oLuz;
+    const T* Lz = R + lay.oLz;
+    const T* Luu = R + lay.oLuu;
+    const T* Lu = R + lay.oLu;
+    const T* Un = R + lay.oU;
 
     // ---- phase 1: F^T V products, Q_z, Q_u                    (ilqr.py:519-524)
     for (int w = lane; w < n * n; w += kWave) {
@@ -179,9 +223,22 @@ __global__ __launch_bounds__(kWave) void riccati_generic_kernel(
     __syncthreads();
 
     // ---- phase 3: symmetrise Q_zz                                (ilqr.py:522)
-    for (int w = lane; w < n * n; w += kWave) {
-      const int i = w / n, j = w - i * n;
-      s.Qzz[w] = (i == j) ? s.W[w] : T(0.5) * (s.W[i * n + j] + s.W[j * n + i]);
+    if (ALIAS) {  // Qzz is W: each pair (i < j) rewritten by one thread
+      for (int w = lane; w < n * n; w += kWave) {
+        const int i = w / n, j = w - i * n;
+        if (i < j) {
+          const T h = T(0.5) * (s.W[i * n + j] + s.W[j * n + i]);
+          s.W[i * n + j] = h;
+          s.W[j * n + i] = h;
+        }
+      }
+      __syncthreads();
+    } else {
+      for (int w = lane; w < n * n; w += kWave) {
+        const int i = w / n, j = w - i * n;
+        s.Qzz[w] =
+            (i == j) ? s.W[w] : T(0.5) * (s.W[i * n + j] + s.W[j * n + i]);
+      }
     }
 
     // ---- phase 4: gains (registers, every lane)             (ilqr.py:587-662)
@@ -318,7 +375,7 @@ __global__ __launch_bounds__(kWave) void riccati_generic_kernel(
         g_b[(size_t)t * lay.gstride + M + i * n + c] = col[i];
       }
     }
-    if (mode == 0 && __any(badK)) {  // ilqr.py:639-640
+    if (mode == 0 && __syncthreads_or(badK)) {  // ilqr.py:639-640
       status = PDDP_BWD_NAN;
       break;
     }
@@ -382,6 +439,27 @@ __global__ __launch_bounds__(kWave) void riccati_generic_kernel(
   }
 
   if (lane == 0) a.status[b] = status;
+}
+
+template <typename T, int NMAX, int M>
+__global__ __launch_bounds__(64) void riccati_generic_kernel(
+    RiccatiArgs<T> a) {
+  constexpr int kRec = rec_max<NMAX, M>();
+  constexpr int kElems = kRec + 4 * NMAX * NMAX + 2 * NMAX + 5 * M * NMAX + M +
+                         2 * M * M;
+  __shared__ T lds[kElems];
+  riccati_body<T, M, 64, (kRec + 63) / 64, false>(
+      a, carve_lds<T>(lds, a.n, M, kRec, false));
+}
+
+constexpr int kLargeThreads = 256;
+
+template <typename T, int M>
+__global__ __launch_bounds__(kLargeThreads) void riccati_large_kernel(
+    RiccatiArgs<T> a) {
+  extern __shared__ double lds_dyn[];
+  riccati_body<T, M, kLargeThreads, 0, true>(
+      a, carve_lds<T>(reinterpret_cast<T*>(lds_dyn), a.n, M, 0, true));
 }
 
 }  // namespace pddp

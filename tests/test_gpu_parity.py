@@ -653,3 +653,109 @@ def test_backward_ragged_shapes(B, N, dtype):
                 if sr == 0:
                     assert rel_err(k[b].cpu().numpy(), kr) < TOL[dtype]
                     assert rel_err(K[b].cpu().numpy(), Kr) < TOL[dtype]
+
+
+ALL_ENCODINGS = ["FULL_COVARIANCE_MATRIX", "UPPER_TRIANGULAR_CHOLESKY",
+                 "VARIANCE_ONLY", "STANDARD_DEVIATION_ONLY",
+                 "IGNORE_UNCERTAINTY"]
+
+
+@pytest.mark.parametrize("N", [1, 3])
+@pytest.mark.parametrize("enc_name", ALL_ENCODINGS)
+@pytest.mark.parametrize("problem", PROBLEMS)
+def test_reference_shape_contract(problem, enc_name, N):
+    """The reference's own iLQR tests (tests/controllers/test_ilqr.py:49-106),
+    run against pddp_amd on the GPU: shapes of forward / Q / backward for the
+    four problems x five encodings x N in {1, 3}, regularisation escalated x10
+    until backward stops raising, and fit() ends in a terminal state."""
+    import pddp_amd
+    from pddp_amd import GaussianVariable, StateEncoding
+    from pddp_amd.controllers.ilqr import Q, backward, forward
+    enc = getattr(StateEncoding, enc_name)
+    mod = getattr(pddp_amd.examples, problem)
+    model = [getattr(mod, n) for n in dir(mod) if n.endswith("DynamicsModel")
+             and n != "DynamicsModel"][0](0.1).cuda()
+    cost = [getattr(mod, n) for n in dir(mod) if n.endswith("Cost")
+            and n != "AugmentedQRCost"][0]().cuda()
+    env = [getattr(mod, n) for n in dir(mod) if n.endswith("Env")
+           and n != "ModelEnv"][0]()
+    torch.manual_seed(N)
+    z0 = GaussianVariable.random(model.state_size).encode(enc).cuda()
+    U = torch.randn(N, model.action_size, device="cuda")
+    n, m = z0.shape[-1], model.action_size
+
+    out = forward(z0, U, model, cost, enc)
+    Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu = out
+    assert Z.shape == (N + 1, n) and F_z.shape == (N, n, n)
+    assert F_u.shape == (N, n, m) and L.shape == (N + 1,)
+    assert L_z.shape == (N + 1, n) and L_u.shape == (N, m)
+    assert L_zz.shape == (N + 1, n, n) and L_uz.shape == (N, m, n)
+    assert L_uu.shape == (N, m, m)
+
+    Q_z, Q_u, Q_zz, Q_uz, Q_uu = Q(F_z[0], F_u[0], L_z[0], L_u[0], L_zz[0],
+                                   L_uz[0], L_uu[0], L_z[-1], L_zz[-1])
+    assert Q_z.shape == (n,) and Q_u.shape == (m,) and Q_zz.shape == (n, n)
+    assert Q_uz.shape == (m, n) and Q_uu.shape == (m, m)
+
+    reg = 1.0
+    while reg <= 1e10:
+        try:
+            k, K = backward(*out, reg=reg)
+            break
+        except RuntimeError:
+            reg *= 10
+    assert k.shape == (N, m) and K.shape == (N, m, n)
+    assert torch.isfinite(k).all() and torch.isfinite(K).all()
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ctrl = pddp_amd.controllers.iLQRController(env, model, cost)
+        Zf, Uf, state = ctrl.fit(U, encoding=enc)
+    assert state.is_terminal()
+    assert Zf.shape == (N + 1, n) and Uf.shape == (N, m)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("n,m", [(33, 1), (42, 1), (72, 4), (80, 2)])
+def test_backward_large_state_vs_oracle(n, m, dtype):
+    """n > 32 (FULL_COVARIANCE_MATRIX encodings: double cartpole 42, rendezvous
+    72): the four-wavefront kernel with dynamically sized LDS, all four gain
+    branches, against the oracle on random well-conditioned records."""
+    from pddp_amd.controllers.ilqr import backward
+    rng = np.random.default_rng(n * 7 + m)
+    B, N = 3, 6
+    npd = np_dtype(dtype)
+    F_z = (np.eye(n) + 0.05 * rng.standard_normal((B, N, n, n))).astype(npd)
+    F_u = (0.3 * rng.standard_normal((B, N, n, m))).astype(npd)
+    L = np.zeros((B, N + 1), npd)
+    L_z = rng.standard_normal((B, N + 1, n)).astype(npd)
+    L_u = rng.standard_normal((B, N, m)).astype(npd)
+    R = 0.2 * rng.standard_normal((B, N + 1, n, n))
+    L_zz = (np.eye(n) + R @ R.transpose(0, 1, 3, 2)).astype(npd)
+    L_uz = (0.05 * rng.standard_normal((B, N, m, n))).astype(npd)
+    Ru = 0.2 * rng.standard_normal((B, N, m, m))
+    L_uu = (np.eye(m) + Ru @ Ru.transpose(0, 1, 3, 2)).astype(npd)
+    U = (0.5 * rng.standard_normal((B, N, m))).astype(npd)
+    u_min, u_max = -np.ones(m, npd), np.ones(m, npd)
+    o = orc.load(npd)
+    g = lambda a: torch.as_tensor(a).cuda()
+    Z = torch.zeros(B, N + 1, n, dtype=g(F_z).dtype, device="cuda")
+    for V_zz_reg, bounded in ((False, False), (False, True), (True, False),
+                              (True, True)):
+        for reg in (0.0, 1.0):
+            kw = dict(reg=reg, V_zz_reg=V_zz_reg)
+            if bounded:
+                kw.update(u_min=g(u_min), u_max=g(u_max), U=g(U))
+            k, K, st = backward(Z, g(F_z), g(F_u), g(L), g(L_z), g(L_u),
+                                g(L_zz), g(L_uz), g(L_uu), return_status=True,
+                                **kw)
+            for b in range(B):
+                okw = dict(reg=reg, V_zz_reg=V_zz_reg)
+                if bounded:
+                    okw.update(u_min=u_min, u_max=u_max, U=U[b])
+                kr, Kr, sr = o.backward(F_z[b], F_u[b], L_z[b], L_u[b],
+                                        L_zz[b], L_uz[b], L_uu[b], **okw)
+                assert sr == 0 and int(st[b]) == 0, (V_zz_reg, bounded, reg, b)
+                assert rel_err(k[b].cpu().numpy(), kr) < TOL[dtype]
+                assert rel_err(K[b].cpu().numpy(), Kr) < TOL[dtype]
