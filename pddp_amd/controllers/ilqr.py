@@ -70,9 +70,12 @@ class iLQRController(Controller):
     `env.get_state()`)."""
 
     def __init__(self, env, model, cost, model_opts={}, cost_opts={},
-                 force_plugin=False, **kwargs):
+                 force_plugin=False, graph=False, **kwargs):
+        """`graph=True` replays each round as one captured hipGraph (native
+        sample problems only; see ILQRSolver.capture_round)."""
         super(iLQRController, self).__init__()
         self._force_plugin = force_plugin
+        self._graph = graph
         self.env = env
         self.cost = cost
         self.model = model
@@ -135,7 +138,8 @@ class iLQRController(Controller):
                     it -= 1  # the counter already points at the next step()
                 on_iteration(it, st, s.Z[0].detach(), s.U[0].detach(),
                              s.J_opt[0].detach())
-        s.fit(n_iterations, tol, max_reg, on_round)
+        s.fit(n_iterations, tol, max_reg, on_round,
+              graph=self._graph and s.plugin is None)
 
     # -- reference API ----------------------------------------------------------
     def fit(self, U, encoding=StateEncoding.DEFAULT, n_iterations=50, tol=5e-6,

@@ -88,6 +88,7 @@ class ILQRSolver(object):
         self.active = torch.zeros(B, **u8)
         self.fresh = torch.zeros(B, **u8)
         self.n_live = torch.zeros(256, **i32)  # PDDP_LIVE_SHARDS
+        self._graph = None  # (key, torch.cuda.CUDAGraph) of one round
         self._pp = None if problem is None else ctypes.addressof(problem)
 
     # -- views in the reference's tensor layout -----------------------------
@@ -189,18 +190,50 @@ class ILQRSolver(object):
         self.n_live.zero_()
         self.accept(tol, max_reg, n_iterations)
 
+    def capture_round(self, tol=5e-6, max_reg=1e10, n_iterations=50):
+        """Captures round() - five kernel launches and a memset, all on
+        device-resident state - into a hipGraph; `replay_round()` then issues
+        it with one launch.  For the launch-bound regime: small batches and
+        the receding-horizon loop (BASELINE.json configs[4])."""
+        if self.plugin is not None:
+            raise _native.NativeError(
+                "graph capture needs the native problem kernels; plugin "
+                "models run autograd inside a round")
+        key = (float(tol), float(max_reg), int(n_iterations))
+        if self._graph is not None and self._graph[0] == key:
+            return self._graph[1]
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self.round(tol, max_reg, n_iterations)
+        self._graph = (key, graph)
+        return graph
+
+    def replay_round(self):
+        self._graph[1].replay()
+
     def fit(self, n_iterations=50, tol=5e-6, max_reg=1e10, on_round=None,
-            max_rounds=None):
+            max_rounds=None, graph=False, rounds_per_sync=1):
         """Runs rounds until every trajectory left the fit loop
-        (ilqr.py:298-314). Returns the number of rounds."""
+        (ilqr.py:298-314). Returns the number of rounds.  With `graph=True`
+        rounds are hipGraph replays and the host looks at the live count only
+        every `rounds_per_sync` rounds (a round with nothing live is a no-op
+        on the device, so the result does not depend on it)."""
+        if graph:
+            self.capture_round(tol, max_reg, n_iterations)
         rounds = 0
         while True:
-            self.round(tol, max_reg, n_iterations)
+            if graph:
+                self.replay_round()
+            else:
+                self.round(tol, max_reg, n_iterations)
             rounds += 1
             if on_round is not None:
                 on_round(rounds, self)
-            if int(self.n_live.sum().item()) == 0:
-                break
             if max_rounds is not None and rounds >= max_rounds:
+                break
+            if rounds % rounds_per_sync:
+                continue
+            if int(self.n_live.sum().item()) == 0:
                 break
         return rounds

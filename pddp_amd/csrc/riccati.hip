@@ -45,14 +45,19 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   RiccatiArgs<T> a{B, N, n, rec, u_min, u_max, reg, branch, active, gains,
                    status};
   hipStream_t st = (hipStream_t)stream;
-  // variant: 0 auto, 1 generic, 2 specialised n=4 (IEEE div/sqrt),
-  //          3 specialised n=4 with rcp / sqrt approximations (f32 only),
-  //          4 / 5 = 2 / 3 with two trajectories per wavefront instead of four
+  // variant: 0 auto, 1 generic, 2 specialised n=4 (IEEE div/sqrt, BoxQP as
+  //          the reference's loop), 3 the same with rcp / sqrt approximations
+  //          (f32 only), 4 / 5 = 2 / 3 with two trajectories per wavefront,
+  //          6 / 7 = 2 / 3 with the BoxQP in closed form (loop as fall-back);
+  //          auto = 7 for f32, 6 for f64
   if (variant >= 2 && !(n == 4 && m == 1)) return PDDP_E_UNSUPPORTED;
+  if (variant < 0 || variant > 7) return PDDP_E_BADARG;
   if (variant != 1 && n == 4 && m == 1) {
-    const bool fast = (variant == 0 || variant == 3 || variant == 5) &&
-                      sizeof(T) == 4;
-    return launch_n4<T>(a, st, fast, (variant == 4 || variant == 5) ? 2 : 4);
+    const bool fast = (variant == 0 || variant == 3 || variant == 5 ||
+                       variant == 7) && sizeof(T) == 4;
+    const bool cf = (variant == 0 || variant == 6 || variant == 7);
+    return launch_n4<T>(a, st, fast, (variant == 4 || variant == 5) ? 2 : 4,
+                        cf);
   }
   switch (m) {
     case 1: return dispatch_nmax<T, 1>(a, st);

@@ -297,6 +297,41 @@ struct BoxQp1 {
     head(0);
   }
 
+  // Closed form of the loop for the paths a scalar QP almost always takes.
+  // Call after begin().  Iteration 0's head has run exactly as the reference
+  // runs it; what can follow for one action dimension is short:
+  //  * the full Newton step passes the Armijo test (always, when the Newton
+  //    point is inside the box: the ratio is 1/2), or it is cut short by a
+  //    bound and every back-tracked candidate down to the first passing step
+  //    size still clamps to that same bound (guard below), so whatever n the
+  //    scan stops at, the new iterate is the n = 0 candidate (xc, fc);
+  //  * iteration 1's exit tests run exactly (objective decrease -> 4 with the
+  //    stale `free`, clamped at the bound -> 6, small gradient -> 5);
+  //  * still live and strictly inside the box: the iterate is within rounding
+  //    of the Newton point; one more full step lands on it and later
+  //    iterations of the reference only move it by rounding errors before
+  //    they exit with a result >= 1 and `free` set.
+  // Returns true when none of this applies (cancellation in the Armijo
+  // ratio, non-finite data, an iterate on a bound with the gradient pointing
+  // inward); the caller then runs the loop itself: begin() + finish().
+  PDDP_DEV bool closed_form() {
+    const T ratio0 = div_<FAST>(fc - old_f, sdotg);
+    const bool on_bound = (xc == lo) || (xc == hi);
+    // all candidates x + 0.6^k search, k <= n, overshoot the bound by 2x:
+    // 0.6^n > 6 ratio0 for the first n with ratio0 / 0.6^n >= 0.1
+    const bool guard = on_bound && (ratio0 >= T(1e-18)) &&
+                       (abs_(xc - x) <= (T(3) * ratio0) * abs_(search));
+    bool slow = live && !(found || guard);
+    x = live ? xc : x;
+    f = live ? fc : f;
+    head(1);
+    const bool inside = (x > lo) && (x < hi) && (xc > lo) && (xc < hi);
+    slow = slow || (live && !inside);
+    x = live ? xc : x;
+    result = live ? 5 : result;
+    return slow;
+  }
+
   PDDP_DEV int finish(T lstep0, const T* ls_tail, int lane) {
     const int l = lane & 15;
     tail(lstep0, ls_tail, l);
@@ -321,8 +356,10 @@ PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, T lstep0, const T* ls_tail,
   return res;
 }
 
-template <typename T, bool CHOL, bool BOUNDED, bool FAST, int G>
+template <typename T, bool CHOL, bool BOUNDED, bool FAST, int G,
+          bool QPCF = false>
 __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
+  // QPCF: BoxQP through BoxQp1::closed_form(), the loop only as fall-back
   // G = trajectories per wavefront (4: all lanes busy; 2: half the lanes idle
   // but twice the wavefronts and less BoxQP divergence per wavefront)
   constexpr int CH = kRec * (int)sizeof(T) / 16;  // 16-B chunks per record
@@ -475,6 +512,8 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
       const T x0_s = alive ? kprev : T(0);
       const T Un_s = alive ? Un : T(0);
       BoxQp1<T, FAST> qp;
+      T qp_Q = T(1);
+      bool qp_slow = false;
       if constexpr (!CHOL) {
         if (!is_finite(Quu_s)) st = PDDP_BWD_NAN;  // eig raises (ilqr.py:631)
         T e = (Quu_s < T(0)) ? T(1e-12) : Quu_s;   // ilqr.py:633
@@ -486,7 +525,9 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
           if (kt != kt) st = PDDP_BWD_NAN;
         } else {
           const T Qg = (T(1) * e) * T(1);          // (E * e) E^T
+          qp_Q = Qg;
           qp.begin(x0_s, Qg, Qu_s, umin - Un_s, umax - Un_s);
+          if constexpr (QPCF) qp_slow = qp.closed_form();
         }
       } else {
         if constexpr (!BOUNDED) {
@@ -494,7 +535,9 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
           Uch = sqrtx<FAST>(Quug_s);
           kt = -div_<FAST>(div_<FAST>(Qu_s, Uch), Uch);
         } else {
+          qp_Q = Quug_s;
           qp.begin(x0_s, Quug_s, Qu_s, umin - Un_s, umax - Un_s);
+          if constexpr (QPCF) qp_slow = qp.closed_form();
         }
       }
 
@@ -530,7 +573,16 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
 
       // ---- gains, part 2: line-search scan and further BoxQP iterations
       if constexpr (BOUNDED) {
-        const int res = qp.finish(lstep[0], ls_tail, lane);
+        int res;
+        if constexpr (QPCF) {
+          if (__any(qp_slow)) {  // rare: run the reference's loop as written
+            qp.begin(x0_s, qp_Q, Qu_s, umin - Un_s, umax - Un_s);
+            qp.finish(lstep[0], ls_tail, lane);
+          }
+          res = qp.result;
+        } else {
+          res = qp.finish(lstep[0], ls_tail, lane);
+        }
         kt = qp.x;
         Uch = qp.U;
         Kzero = !qp.free_;
@@ -621,11 +673,20 @@ __global__ __launch_bounds__(kWave) void boxqp1_kernel(
 
 template <typename T>
 static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st, bool fast_math,
-                     int groups_per_wave) {
+                     int groups_per_wave, bool qp_closed_form) {
   const bool bounded = a.u_min != nullptr;
   const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
   const int G = (groups_per_wave == 2) ? 2 : 4;
   const dim3 grid((a.B + G - 1) / G), block(kWave);
+  if (bounded && qp_closed_form && G == 4) {
+#define PDDP_N4_CF(C, F)                                                     \
+  hipLaunchKernelGGL((n4::riccati_n4_kernel<T, C, true, F, 4, true>), grid,  \
+                     block, 0, st, a)
+    if (fast_math) { if (chol) PDDP_N4_CF(true, true); else PDDP_N4_CF(false, true); }
+    else { if (chol) PDDP_N4_CF(true, false); else PDDP_N4_CF(false, false); }
+#undef PDDP_N4_CF
+    return launch_status();
+  }
 #define PDDP_N4_LAUNCH(C, Bd, F)                                             \
   do {                                                                       \
     if (G == 2)                                                              \

@@ -98,13 +98,18 @@ def test_derivative_records_vs_oracle(problem, dtype):
         assert np.array_equal(got_U, U[b])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", PROBLEMS)
 def test_backward_vs_oracle(problem, dtype, variant):
-    """All four gain branches x regularisations, native record path."""
-    if variant == 3 and not (problem == "cartpole" and dtype == "f32"):
-        pytest.skip("variant 3 = n=4/m=1 f32 kernel with approximate division")
+    """All four gain branches x regularisations, native record path.
+    Variants (include/pddp_hip.h): 0 auto (closed-form BoxQP), 1 generic
+    kernel, 2 / 3 n=4 kernel with the BoxQP loop (IEEE / approximate division),
+    6 n=4 kernel, IEEE division, closed-form BoxQP."""
+    if variant >= 2 and problem != "cartpole":
+        pytest.skip("variants >= 2 are the n=4/m=1 kernel")
+    if variant == 3 and dtype != "f32":
+        pytest.skip("variant 3 = f32 kernel with approximate division")
     B, N = 5, 40
     s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N)
     s.nominal_rollout()
@@ -628,7 +633,7 @@ def test_backward_ragged_shapes(B, N, dtype):
     active = torch.ones(B, dtype=torch.uint8, device="cuda")
     if B > 2:
         active[1] = 0
-    for variant in (0, 1):
+    for variant in (0, 1, 2):
         for branch, bounded in ((0, True), (0, False), (1, True), (1, False)):
             regv = torch.full((B,), 1.0, dtype=torch.float64, device="cuda")
             s.gains.fill_(float("nan"))
@@ -759,3 +764,40 @@ def test_backward_large_state_vs_oracle(n, m, dtype):
                 assert sr == 0 and int(st[b]) == 0, (V_zz_reg, bounded, reg, b)
                 assert rel_err(k[b].cpu().numpy(), kr) < TOL[dtype]
                 assert rel_err(K[b].cpu().numpy(), Kr) < TOL[dtype]
+
+
+def test_graph_replay_equals_eager_rounds():
+    """ILQRSolver.capture_round(): a fit driven by hipGraph replays ends in
+    exactly the eager result (same kernels, same order, same buffers), also
+    when the host checks the live count only every 4th round."""
+    B, N = 64, 30
+    res = []
+    for graph, rps in ((False, 1), (True, 1), (True, 4)):
+        s, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=5)
+        s.reset_controller_state()
+        s.nominal_rollout()
+        rounds = s.fit(n_iterations=20, graph=graph, rounds_per_sync=rps)
+        res.append((rounds, s.Z.clone(), s.U.clone(), s.J_opt.clone(),
+                    s.state.clone(), s.iter.clone(), s.mu.clone()))
+    for r in res[1:]:
+        assert r[0] >= res[0][0] and r[0] - res[0][0] < 4
+        for a, b in zip(r[1:], res[0][1:]):
+            assert torch.equal(a, b)
+
+    import pddp_amd
+    from pddp_amd.examples import cartpole as cp
+    out = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        env = cp.CartpoleEnv()
+        ctrl = pddp_amd.controllers.iLQRController(
+            env, cp.CartpoleDynamicsModel(0.05).cuda(), cp.CartpoleCost().cuda(),
+            graph=graph)
+        U0 = torch.randn(8, 25, 1, device="cuda") * 0.1
+        Z, U, st = ctrl.fit(U0, encoding=pddp_amd.StateEncoding.IGNORE_UNCERTAINTY,
+                            n_iterations=10, u_min=torch.tensor([-10.0]),
+                            u_max=torch.tensor([10.0]),
+                            z0=torch.tensor([0.0, 0.0, 3.0, 0.0]))
+        out.append((Z.clone(), U.clone(), st.clone()))
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b)
