@@ -44,7 +44,7 @@ PDDP_DEV T clamp1(T v, T lo, T hi) {
 
 template <typename T>
 PDDP_DEV bool is_finite(T v) {
-  return (v == v) && ((v - v) == T(0));
+  return __builtin_isfinite(v);  // one v_cmp_class
 }
 
 PDDP_DEV float sqrt_(float x) { return __fsqrt_rn(x); }

@@ -72,6 +72,18 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
 
 extern "C" {
 
+#ifdef PDDP_QP_STATS
+int pddp_debug_qp_stats(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4::g_qp_stats), 32);
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4::g_qp_stats), z, 32);
+  }
+  return 0;
+}
+#endif
+
 int pddp_riccati_backward_f32(int B, int N, int n, int m, const float* rec,
                               const float* u_min, const float* u_max,
                               const double* reg, int branch,

@@ -77,11 +77,11 @@ PDDP_DEV T from_col_plus(T v) {
 // otherwise distributes the lane permutation over the multiply,
 // dpp(a * b) -> dpp(a) * dpp(b), and fuses THAT product into the add.)
 PDDP_DEV float opaque(float x) {
-  asm volatile("" : "+v"(x));
+  asm("" : "+v"(x));  // not volatile: free to move, never looked through
   return x;
 }
 PDDP_DEV double opaque(double x) {
-  asm volatile("" : "+v"(x));
+  asm("" : "+v"(x));
   return x;
 }
 template <typename T>
@@ -356,6 +356,94 @@ PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, T lstep0, const T* ls_tail,
   return res;
 }
 
+// The closed form of BoxQp1 (see BoxQp1::closed_form) as straight-line code
+// for the sweep kernel, which needs the minimiser, the `free` flag, failure
+// (result < 1: only "not positive definite" can occur for m = 1) and whether
+// the loop has to run instead - not the result code itself.
+// FAST: potrs through one reciprocal of Q instead of two divisions by
+// sqrt(Q), and the Armijo ratio tests cross-multiplied instead of divided.
+template <typename T, bool FAST>
+struct QpClosed {
+  T x, U, inv;  // minimiser; sqrt(Q) (IEEE) or 1 / Q (FAST)
+  bool free_, fail, slow;
+
+  // All flag logic below is written with the eager `&` / `|` on bools: with
+  // `&&` / `||` the compiler builds exec-mask branches around the compares.
+  // `slow` is conservative (it may ask for the loop where the closed form
+  // would have been right) and cheap: anything that is not a descent step
+  // with a comfortably passing Armijo test goes to the loop.
+  PDDP_DEV void solve(T x0, T Q, T c, T lo, T hi) {
+    constexpr T kMinGrad = T(1e-8), kTol = T(1e-8), kArmijo = T(0.1);
+    auto obj = [&](T v) { return T(0.5) * ((v * Q) * v) + v * c; };
+    T xs = clampq<FAST>(x0, lo, hi);
+    xs = __builtin_isinf(xs) ? T(0) : xs;                    // (:179)
+    const T f0 = obj(xs);
+    // ---- iteration 0                                        (:191-239)
+    const T g0 = Q * xs + c;
+    const bool ncl0 = ((xs == lo) & (g0 > T(0))) | ((xs == hi) & (g0 < T(0)));
+    const bool not_pd = !(Q > T(0)) | !is_finite(Q);
+    const bool done0 = ncl0 | not_pd | (abs_(g0) < kMinGrad);
+    fail = !ncl0 & not_pd;
+    T newton;
+    if constexpr (FAST) {
+      inv = div_<true>(T(1), Q);
+      U = T(0);
+      newton = -(c * inv);
+    } else {
+      U = sqrt_(Q);
+      inv = T(0);
+      newton = -((c / U) / U);
+    }
+    const T s0 = newton - xs;
+    const T sdotg = s0 * g0;
+    const T x1 = clampq<FAST>(xs + s0, lo, hi);
+    const T f1 = obj(x1);
+    const T num = f1 - f0;
+    // Armijo at the full step, (f1 - f0) / sdotg >= 0.1, cross-multiplied for
+    // the descent case sdotg < 0 (anything else, NaN included: the loop)
+    const bool pass0 = (sdotg < T(0)) & (num <= kArmijo * sdotg);
+    // cut short by a bound: every back-tracked candidate down to the first
+    // passing step size 0.6^n > 6 (num / sdotg) still overshoots the bound
+    const bool on_bound1 = (x1 == lo) | (x1 == hi);
+    const bool guard = on_bound1 & (sdotg < T(0)) & (num < T(0)) &
+                       (abs_(x1 - xs) * abs_(sdotg) <=
+                        (T(3) * abs_(num)) * abs_(s0));
+    // ---- iteration 1: exit tests, one more full step
+    const bool conv = (f0 - f1) < kTol * abs_(f0);
+    const T g1 = Q * x1 + c;
+    const bool ncl1 = ((x1 == lo) & (g1 > T(0))) | ((x1 == hi) & (g1 < T(0)));
+    const bool live1 = !(conv | ncl1 | (abs_(g1) < kMinGrad));
+    const T x2 = clampq<FAST>(x1 + (newton - x1), lo, hi);
+    slow = !done0 & (!(pass0 | guard) | (live1 & on_bound1));
+    x = done0 ? xs : (live1 ? x2 : x1);
+    free_ = done0 ? !ncl0 : (conv | !ncl1);
+  }
+};
+
+#ifdef PDDP_QP_STATS
+__device__ unsigned long long g_qp_stats[4];  // wave-steps: slow, total; traj-steps slow, total
+#endif
+// Out-of-line copy of the loop for the closed-form kernels: called on well
+// under 0.1 % of the steps, so it must not cost the hot path registers,
+// code size or scheduling freedom.
+template <typename T>
+struct SlowQpOut {
+  T x, U;
+  int result_free;  // result * 2 + free
+};
+template <typename T, bool FAST>
+__device__ __noinline__ SlowQpOut<T> boxqp1_outlined(T x0, T Q, T c, T lo,
+                                                     T hi, T lstep0,
+                                                     const T* ls_tail,
+                                                     int lane) {
+  SlowQpOut<T> o;
+  bool fr;
+  const int res =
+      boxqp1<T, FAST>(x0, Q, c, lo, hi, lstep0, ls_tail, lane, o.x, o.U, fr);
+  o.result_free = res * 2 + (fr ? 1 : 0);
+  return o;
+}
+
 template <typename T, bool CHOL, bool BOUNDED, bool FAST, int G,
           bool QPCF = false>
 __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
@@ -465,18 +553,10 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
     w.Un = BOUNDED ? rc[oU] : T(0);
     return w;
   };
-  Words nxt = gather(0);
-
   int t = N - 1;
-  while (t >= 0) {
-#pragma unroll
-    for (int s = 0; s < R; ++s) {
-      if (t < 0) break;
-      const Words w = nxt;
-      // DMA(t-1) has landed once at most (R-2) younger {store, DMA} pairs
-      // are outstanding; gather it now, use it in the next step
-      wait_vmcnt<(R - 2) * (1 + NI)>();
-      nxt = gather((s + 1) % R);  // (at t == 0 this reads a stale slot, unused)
+  // one step of the sweep on the words `w` of record t, ring slot s
+  auto step = [&](const Words& w, const int s) {
+    {
       const T Fs0 = w.Fs0, Fs1 = w.Fs1, Fs2 = w.Fs2, Fs3 = w.Fs3;
       const T Fq0 = w.Fq0, Fq1 = w.Fq1, Fq2 = w.Fq2, Fq3 = w.Fq3;
       const T Ft = w.Ft, Lzz = w.Lzz, fr = w.fr, fc = w.fc;
@@ -512,9 +592,19 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
       const T x0_s = alive ? kprev : T(0);
       const T Un_s = alive ? Un : T(0);
       BoxQp1<T, FAST> qp;
+      QpClosed<T, FAST> qc;
       T qp_Q = T(1);
-      bool qp_slow = false;
-      if constexpr (!CHOL) {
+      if constexpr (QPCF && BOUNDED) {
+        // closed form: straight-line, no sanitising needed (no loop to leave)
+        if constexpr (!CHOL) {
+          if (!is_finite(Quu)) st = PDDP_BWD_NAN;  // eig raises (ilqr.py:631)
+          const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
+          qp_Q = e + reg;                             // ilqr.py:634, (E e) E^T
+        } else {
+          qp_Q = Quug;
+        }
+        qc.solve(kprev, qp_Q, Qu, umin - Un, umax - Un);
+      } else if constexpr (!CHOL) {
         if (!is_finite(Quu_s)) st = PDDP_BWD_NAN;  // eig raises (ilqr.py:631)
         T e = (Quu_s < T(0)) ? T(1e-12) : Quu_s;   // ilqr.py:633
         e += reg;                                  // ilqr.py:634
@@ -525,9 +615,7 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
           if (kt != kt) st = PDDP_BWD_NAN;
         } else {
           const T Qg = (T(1) * e) * T(1);          // (E * e) E^T
-          qp_Q = Qg;
           qp.begin(x0_s, Qg, Qu_s, umin - Un_s, umax - Un_s);
-          if constexpr (QPCF) qp_slow = qp.closed_form();
         }
       } else {
         if constexpr (!BOUNDED) {
@@ -535,9 +623,7 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
           Uch = sqrtx<FAST>(Quug_s);
           kt = -div_<FAST>(div_<FAST>(Qu_s, Uch), Uch);
         } else {
-          qp_Q = Quug_s;
           qp.begin(x0_s, Quug_s, Qu_s, umin - Un_s, umax - Un_s);
-          if constexpr (QPCF) qp_slow = qp.closed_form();
         }
       }
 
@@ -571,28 +657,51 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
       T Quzgc = Quzc;
       if constexpr (CHOL) Quzgc = bperm(tr_addr, Quzgr);
 
-      // ---- gains, part 2: line-search scan and further BoxQP iterations
-      if constexpr (BOUNDED) {
-        int res;
-        if constexpr (QPCF) {
-          if (__any(qp_slow)) {  // rare: run the reference's loop as written
-            qp.begin(x0_s, qp_Q, Qu_s, umin - Un_s, umax - Un_s);
-            qp.finish(lstep[0], ls_tail, lane);
-          }
-          res = qp.result;
-        } else {
-          res = qp.finish(lstep[0], ls_tail, lane);
-        }
+      // ---- gains, part 2 (loop variants): line-search scan and further
+      // BoxQP iterations
+      bool fail = false;
+      if constexpr (BOUNDED && QPCF) {
+        kt = qc.x;
+        Uch = qc.U;
+        Kzero = !qc.free_;
+        fail = qc.fail;
+      } else if constexpr (BOUNDED) {
+        const int res = qp.finish(lstep[0], ls_tail, lane);
         kt = qp.x;
         Uch = qp.U;
         Kzero = !qp.free_;
-        if (res < 1) st = PDDP_BWD_BOXQP_FAILED;
+        fail = res < 1;
       }
+      if constexpr (BOUNDED && QPCF) {
+#ifdef PDDP_QP_STATS
+        if (lane == 0) {
+          atomicAdd(&g_qp_stats[1], 1ull);
+          if (__any(qc.slow && alive)) atomicAdd(&g_qp_stats[0], 1ull);
+        }
+#endif
+        if (__any(qc.slow && alive)) {  // rare: the reference's loop as written
+          // dead groups get a trivial QP so that their loop exits at once
+          const SlowQpOut<T> o = boxqp1_outlined<T, FAST>(
+              alive ? kprev : T(0), alive ? qp_Q : T(1), alive ? Qu : T(0),
+              umin - (alive ? Un : T(0)), umax - (alive ? Un : T(0)), lstep[0],
+              ls_tail, lane);
+          kt = o.x;
+          Uch = o.U;
+          Kzero = (o.result_free & 1) == 0;
+          fail = o.result_free < 2;
+        }
+      }
+      const T Qzzs = mul_nc(T(0.5), Qzz + QzzT);
+      const bool alive0 = alive;
+      int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
       // K in row and column form, same arithmetic on transposed copies
       T Kr, Kc;
       if (by_inv) {
         Kr = -(inv * Quzgr);
         Kc = -(inv * Quzgc);
+      } else if constexpr (BOUNDED && QPCF && FAST) {
+        Kr = Kzero ? T(0) : -(Quzgr * qc.inv);
+        Kc = Kzero ? T(0) : -(Quzgc * qc.inv);
       } else {
         Kr = Kzero ? T(0) : -div_<FAST>(div_<FAST>(Quzgr, Uch), Uch);
         Kc = Kzero ? T(0) : -div_<FAST>(div_<FAST>(Quzgc, Uch), Uch);
@@ -601,10 +710,10 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
         // NaN anywhere in K raises too (ilqr.py:639-640)
         const bool nanK = (Kc != Kc);
         const bool any4 = sum_cols(nanK ? T(1) : T(0)) != T(0);
-        if (any4 && st == PDDP_BWD_OK) st = PDDP_BWD_NAN;
+        if (any4 && stt == PDDP_BWD_OK) stt = PDDP_BWD_NAN;
       }
-      if (st != PDDP_BWD_OK && alive) {
-        status = st;
+      if (stt != PDDP_BWD_OK && alive0) {
+        status = stt;
         alive = false;
       }
 
@@ -616,9 +725,8 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
       }
       kprev = kt;
 
-      // ---- value update with the un-regularised Q_uu, Q_uz  (ilqr.py:664-672)
-      // on the diagonal QzzT == Qzz and 0.5 (q + q) == q exactly
-      const T Qzzs = mul_nc(T(0.5), Qzz + QzzT);
+      // ---- value update with the un-regularised Q_uu, Q_uz
+      // (ilqr.py:664-672); on the diagonal QzzT == Qzz, 0.5 (q + q) == q
       {
         T v = Qzc + Kc * Qu;
         v += (Kc * Quu) * kt;
@@ -626,9 +734,10 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
         Vzc = v;
       }
       {
-        // lane (i,j) forms V'[i][j] AND V'[j][i] from the row / column copies
-        // with mirrored operation trees, so that its partner lane (j,i)
-        // computes bit-identical values and 0.5 (a + b) is exactly symmetric
+        // lane (i,j) forms V'[i][j] AND V'[j][i] from the row / column
+        // copies with mirrored operation trees, so that its partner lane
+        // (j,i) computes bit-identical values and 0.5 (a + b) is exactly
+        // symmetric
         const T va = fma_(mul_nc(Kr, Quu), Kc, Qzzs) +
                      fma_(Kr, Quzc, mul_nc(Quzr, Kc));
         const T vb = fma_(mul_nc(Kc, Quu), Kr, Qzzs) +
@@ -638,6 +747,25 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
 
       // refill this slot with the record R steps further down the sweep
       dma(s, t - R);
+    }
+  };
+
+  // Two word sets alternate (one in use, one being gathered for the next
+  // step), so no register copies are needed between steps.  DMA(t-1) has
+  // landed once at most (R-2) younger {store, DMA} pairs are outstanding.
+  Words wa = gather(0), wb = wa;
+  while (t >= 0) {
+#pragma unroll
+    for (int s = 0; s < R; s += 2) {
+      if (t < 0) break;
+      wait_vmcnt<(R - 2) * (1 + NI)>();
+      wb = gather((s + 1) % R);  // (at t == 0 this reads a stale slot, unused)
+      step(wa, s);
+      --t;
+      if (t < 0) break;
+      wait_vmcnt<(R - 2) * (1 + NI)>();
+      wa = gather((s + 2) % R);
+      step(wb, s + 1);
       --t;
     }
   }
