@@ -416,7 +416,7 @@ struct QpClosed {
     const T x2 = clampq<FAST>(x1 + (newton - x1), lo, hi);
     slow = !done0 & (!(pass0 | guard) | (live1 & on_bound1));
     x = done0 ? xs : (live1 ? x2 : x1);
-    free_ = done0 ? !ncl0 : (conv | !ncl1);
+    free_ = (done0 & !ncl0) | (!done0 & (conv | !ncl1));
   }
 };
 
@@ -469,9 +469,11 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
   const int b = b0 + grp;
   const bool exists = (grp < G) && (b < a.B);
   const int bc = exists ? b : a.B - 1;
-  bool alive = exists && (a.active == nullptr || a.active[bc] != 0);
-  const bool counted = alive;  // writes its status at the end
-  if (!__any(alive)) return;
+  // `counted` trajectories write a status at the end; a trajectory is alive
+  // while it is counted and its status is still OK (one compare per step, no
+  // loop-carried flag)
+  const bool counted = exists && (a.active == nullptr || a.active[bc] != 0);
+  if (!__any(counted)) return;
 
   const T reg = (T)a.reg[bc];
   T umin = T(0), umax = T(0);
@@ -481,7 +483,11 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
   }
 
   // ---- DMA source addressing: chunk q of the wave's 4 records -> lane
-  const T* src[NI];
+  // (wave-uniform 64-bit base in SGPRs + a 32-bit lane offset: one VALU add
+  // per step instead of 64-bit address arithmetic)
+  const char* rec_w =
+      reinterpret_cast<const char*>(a.rec + (size_t)b0 * (size_t)(N + 1) * kRec);
+  uint32_t src_off[NI];
   bool dma_on[NI];
 #pragma unroll
   for (int r = 0; r < NI; ++r) {
@@ -490,16 +496,17 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
     dma_on[r] = q < G * CH;
     int tb = b0 + (dma_on[r] ? tg : 0);
     tb = tb < a.B ? tb : a.B - 1;
-    src[r] = a.rec + (size_t)tb * (size_t)(N + 1) * kRec + c * (16 / sizeof(T));
+    src_off[r] = (uint32_t)((tb - b0) * (N + 1) * kRec * (int)sizeof(T) + c * 16);
   }
   auto dma = [&](int slot, int t) {
     const int tt = t < 0 ? 0 : t;  // tail: harmless reload keeps vmcnt exact
+    const uint32_t toff = (uint32_t)tt * (uint32_t)(kRec * sizeof(T));
 #pragma unroll
     for (int r = 0; r < NI; ++r)
       if (dma_on[r])
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src[r] +
-                                                            (size_t)tt * kRec),
+            (const __attribute__((address_space(1))) void*)(rec_w +
+                                                            (src_off[r] + toff)),
             (__attribute__((address_space(3))) void*)((char*)&ring[slot][0] +
                                                       r * kWave * 16),
             16, 0, 0);
@@ -533,7 +540,12 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
 
   T kprev = T(0);
   int status = PDDP_BWD_OK;
-  T* gout = a.gains + (size_t)bc * (size_t)N * kGain;
+  char* gains_w = reinterpret_cast<char*>(a.gains + (size_t)b0 * (size_t)N * kGain);
+  // byte offset of this lane's k / K word of step t, walked down by one
+  // gain record per step
+  uint32_t gout_off = (uint32_t)(
+      ((bc - b0) * N * kGain + (N - 1) * kGain + ((l < 4) ? 1 + l : 0)) *
+      (int)sizeof(T));
 
   // The words a lane needs from one record, gathered from LDS one step ahead
   // of their use so that the ds_read latency overlaps the previous step.
@@ -562,6 +574,7 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
       const T Ft = w.Ft, Lzz = w.Lzz, fr = w.fr, fc = w.fc;
       const T Luzr = w.Luzr, Lzr = w.Lzr, Luu = w.Luu, Lu = w.Lu, Un = w.Un;
 
+      const bool alive = counted & (status == PDDP_BWD_OK);
       // ---- scalars that feed the gain computation first: (f^T V)[j]
       // (column form), Q_uu, Q_u (and their V + reg I twins)
       const T bTc = dot_rows(fr, V);
@@ -672,6 +685,62 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
         Kzero = !qp.free_;
         fail = res < 1;
       }
+      const T Qzzs = mul_nc(T(0.5), Qzz + QzzT);
+      // the rest of the step given the minimiser: K, status, stores, value
+      // update.  Instantiated twice in the closed-form kernels (after the
+      // closed form and after the rare loop call) so that the two paths only
+      // merge at the step boundary.
+      auto tail = [&]() {
+        int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
+        // K in row and column form, same arithmetic on transposed copies
+        T Kr, Kc;
+        if (by_inv) {
+          Kr = -(inv * Quzgr);
+          Kc = -(inv * Quzgc);
+        } else if constexpr (BOUNDED && QPCF && FAST) {
+          Kr = Kzero ? T(0) : -(Quzgr * qc.inv);
+          Kc = Kzero ? T(0) : -(Quzgc * qc.inv);
+        } else {
+          Kr = Kzero ? T(0) : -div_<FAST>(div_<FAST>(Quzgr, Uch), Uch);
+          Kc = Kzero ? T(0) : -div_<FAST>(div_<FAST>(Quzgc, Uch), Uch);
+        }
+        if constexpr (!CHOL && !BOUNDED) {
+          // NaN anywhere in K raises too (ilqr.py:639-640)
+          const bool nanK = (Kc != Kc);
+          const bool any4 = sum_cols(nanK ? T(1) : T(0)) != T(0);
+          if (any4 && stt == PDDP_BWD_OK) stt = PDDP_BWD_NAN;
+        }
+        status = (alive & (stt != PDDP_BWD_OK)) ? stt : status;
+
+        // ---- store k, K (lanes l < 5 of each group; dead groups write junk)
+        {
+          const T val = (l < 4) ? Kc : kt;
+          T* dst = reinterpret_cast<T*>(gains_w + gout_off);
+          if (exists && l < 5) *dst = val;
+        }
+        kprev = kt;
+
+        // ---- value update with the un-regularised Q_uu, Q_uz
+        // (ilqr.py:664-672); on the diagonal QzzT == Qzz, 0.5 (q + q) == q
+        {
+          T v = Qzc + Kc * Qu;
+          v += (Kc * Quu) * kt;
+          v += Quzc * kt;
+          Vzc = v;
+        }
+        {
+          // lane (i,j) forms V'[i][j] AND V'[j][i] from the row / column
+          // copies with mirrored operation trees, so that its partner lane
+          // (j,i) computes bit-identical values and 0.5 (a + b) is exactly
+          // symmetric
+          const T va = fma_(mul_nc(Kr, Quu), Kc, Qzzs) +
+                       fma_(Kr, Quzc, mul_nc(Quzr, Kc));
+          const T vb = fma_(mul_nc(Kc, Quu), Kr, Qzzs) +
+                       fma_(Kc, Quzr, mul_nc(Quzc, Kr));
+          V = T(0.5) * (va + vb);
+        }
+
+      };
       if constexpr (BOUNDED && QPCF) {
 #ifdef PDDP_QP_STATS
         if (lane == 0) {
@@ -689,63 +758,16 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
           Uch = o.U;
           Kzero = (o.result_free & 1) == 0;
           fail = o.result_free < 2;
+          tail();
+        } else {
+          tail();
         }
-      }
-      const T Qzzs = mul_nc(T(0.5), Qzz + QzzT);
-      const bool alive0 = alive;
-      int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
-      // K in row and column form, same arithmetic on transposed copies
-      T Kr, Kc;
-      if (by_inv) {
-        Kr = -(inv * Quzgr);
-        Kc = -(inv * Quzgc);
-      } else if constexpr (BOUNDED && QPCF && FAST) {
-        Kr = Kzero ? T(0) : -(Quzgr * qc.inv);
-        Kc = Kzero ? T(0) : -(Quzgc * qc.inv);
       } else {
-        Kr = Kzero ? T(0) : -div_<FAST>(div_<FAST>(Quzgr, Uch), Uch);
-        Kc = Kzero ? T(0) : -div_<FAST>(div_<FAST>(Quzgc, Uch), Uch);
-      }
-      if constexpr (!CHOL && !BOUNDED) {
-        // NaN anywhere in K raises too (ilqr.py:639-640)
-        const bool nanK = (Kc != Kc);
-        const bool any4 = sum_cols(nanK ? T(1) : T(0)) != T(0);
-        if (any4 && stt == PDDP_BWD_OK) stt = PDDP_BWD_NAN;
-      }
-      if (stt != PDDP_BWD_OK && alive0) {
-        status = stt;
-        alive = false;
-      }
-
-      // ---- store k, K (lanes l < 5 of each group; dead groups write junk)
-      {
-        const T val = (l < 4) ? Kc : kt;
-        T* dst = gout + (size_t)t * kGain + ((l < 4) ? 1 + l : 0);
-        if (exists && l < 5) *dst = val;
-      }
-      kprev = kt;
-
-      // ---- value update with the un-regularised Q_uu, Q_uz
-      // (ilqr.py:664-672); on the diagonal QzzT == Qzz, 0.5 (q + q) == q
-      {
-        T v = Qzc + Kc * Qu;
-        v += (Kc * Quu) * kt;
-        v += Quzc * kt;
-        Vzc = v;
-      }
-      {
-        // lane (i,j) forms V'[i][j] AND V'[j][i] from the row / column
-        // copies with mirrored operation trees, so that its partner lane
-        // (j,i) computes bit-identical values and 0.5 (a + b) is exactly
-        // symmetric
-        const T va = fma_(mul_nc(Kr, Quu), Kc, Qzzs) +
-                     fma_(Kr, Quzc, mul_nc(Quzr, Kc));
-        const T vb = fma_(mul_nc(Kc, Quu), Kr, Qzzs) +
-                     fma_(Kc, Quzr, mul_nc(Quzc, Kr));
-        V = T(0.5) * (va + vb);
+        tail();
       }
 
       // refill this slot with the record R steps further down the sweep
+      gout_off -= (uint32_t)(kGain * sizeof(T));
       dma(s, t - R);
     }
   };
