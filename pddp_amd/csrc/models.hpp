@@ -79,8 +79,50 @@ struct ModelDims<PDDP_MODEL_RENDEZVOUS> {
   static constexpr int kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
-PDDP_DEV void sincos_(float x, float& s, float& c) { sincosf(x, &s, &c); }
+// sin and cos of one float argument.  The rollouts sit on a chain of N
+// dependent steps with one wavefront per SIMD, where every instruction and
+// every branch of the step is paid in full; the library's sincosf carries a
+// per-lane branch to its huge-argument path.  Here: three-constant Cody-Waite
+// reduction by pi/2 (exact up to |x| < 2^16 with FMA) and the Cephes minimax
+// polynomials on [-pi/4, pi/4] (about 1 ulp), branch-free; larger arguments
+// (and NaN) take the library's result, computed under one wave-uniform test.
+PDDP_DEV void sincos_(float x, float& s, float& c) {
+  const float kf = __builtin_rintf(x * 0.636619772367581343f);  // 2 / pi
+  const int q = (int)kf;
+  float r = __builtin_fmaf(kf, -1.57079625129699707031e+00f, x);
+  r = __builtin_fmaf(kf, -7.54978941586159635335e-08f, r);
+  r = __builtin_fmaf(kf, -5.39030252995776476554e-15f, r);
+  const float z = r * r;
+  float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
+  ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
+  const float sr = __builtin_fmaf(r * z, ps, r);
+  float pc = __builtin_fmaf(z, 2.443315711809948e-5f, -1.388731625493765e-3f);
+  pc = __builtin_fmaf(z, pc, 4.166664568298827e-2f);
+  const float cr = __builtin_fmaf(z * z, pc, __builtin_fmaf(z, -0.5f, 1.0f));
+  const bool swap = (q & 1) != 0;
+  const unsigned ss = ((unsigned)q & 2u) << 30;
+  const unsigned cs = (((unsigned)q + 1u) & 2u) << 30;
+  s = __uint_as_float(__float_as_uint(swap ? cr : sr) ^ ss);
+  c = __uint_as_float(__float_as_uint(swap ? sr : cr) ^ cs);
+  // which path a lane takes depends on its own argument only (a trajectory's
+  // result must not depend on its neighbours in the wavefront)
+  const bool big = !(fabsf(x) < 65536.0f);
+  if (__builtin_expect(__any(big), 0)) {
+    float sl, cl;
+    sincosf(x, &sl, &cl);
+    s = big ? sl : s;
+    c = big ? cl : c;
+  }
+}
 PDDP_DEV void sincos_(double x, double& s, double& c) { sincos(x, &s, &c); }
+
+// 1 / a: float through v_rcp_f32 and one Newton step (<= 1 ulp, 3
+// instructions instead of the 11 of an IEEE division); double divides.
+PDDP_DEV float inv_(float a) {
+  const float r = __builtin_amdgcn_rcpf(a);
+  return __builtin_fmaf(__builtin_fmaf(-a, r, 1.0f), r, r);
+}
+PDDP_DEV double inv_(double a) { return 1.0 / a; }
 
 // sin / cos of a state's angles, evaluated once per state and shared by the
 // dynamics and the cost (both need them; each costs a range reduction).
@@ -173,9 +215,12 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
     const T a2 = F - mu * xd;
     const T a3 = T(4) * (mc + mp) - T(3) * mp * c * c;
     const T num_t = a0 * c + T(2) * ((mc + mp) * a1 + a2 * c);
-    const T thdd = T(-3) * num_t / (l * a3);
+    // one reciprocal of a3 serves both accelerations (and the Jacobians)
+    const T ia3 = inv_(a3);
+    const T il = T(1) / l;  // loop-invariant: hoisted out of the rollouts
+    const T thdd = (T(-3) * num_t) * (ia3 * il);
     const T num_x = T(2) * a0 + T(3) * mp * a1 * c + T(4) * a2;
-    const T xdd = num_x / a3;
+    const T xdd = num_x * ia3;
     const T nxd = xd + xdd * dt;
     const T nthd = thd + thdd * dt;
     zn[0] = x + nxd * dt;
@@ -195,8 +240,7 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
       const T dnx_thd = T(2) * da0_thd;
       const T dnx_xd = T(-4) * mu;
       const T dnx_F = T(4);
-      const T ia3 = T(1) / a3;
-      const T kt = T(-3) / l;
+      const T kt = T(-3) * il;
       const T dthdd_xd = kt * dnt_xd * ia3;
       const T dthdd_th = kt * (dnt_th * a3 - num_t * da3_th) * ia3 * ia3;
       const T dthdd_thd = kt * dnt_thd * ia3;

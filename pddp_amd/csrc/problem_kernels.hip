@@ -250,7 +250,7 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
       for (int c = 0; c < n; ++c) s += (z[c] - zr[c]) * gr[m + r * n + c];
       du = du + s;  // + dz K^T                                   (ilqr.py:710)
       T v = ur[r] + du;
-      un[r] = bounded ? clamp1(v, umin[r], umax[r]) : v;
+      un[r] = bounded ? clamp_nan(v, umin[r], umax[r]) : v;
     }
 #pragma unroll
     for (int j = 0; j < n; ++j) Zci[(size_t)t * n + j] = z[j];
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kWave) void line_search_lds_kernel(
       for (int c = 0; c < n; ++c) s += (z[c] - zr[c]) * gr[m + r * n + c];
       du = du + s;  // + dz K^T                                   (ilqr.py:710)
       const T v = Us[t * m + r] + du;
-      un[r] = bounded ? clamp1(v, umin[r], umax[r]) : v;
+      un[r] = bounded ? clamp_nan(v, umin[r], umax[r]) : v;
     }
 #pragma unroll
     for (int j = 0; j < n; ++j) Zci[(size_t)t * n + j] = z[j];
