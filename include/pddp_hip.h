@@ -169,9 +169,9 @@ int pddp_derivs_f64(const pddp_problem* problem, int B, int N, const double* Z,
 /* A candidate step sizes per trajectory.  Z [B][N+1][n], U [B][N][m] nominal;
  * gains [B][N][m+m*n]; alphas [A]; bwd_status [B] nullable (non-zero ->
  * skipped, the reference never reaches the line search then, ilqr.py:140-145);
- * Zc [B][A][N+1][n], Uc [B][A][N][m] candidates out (candidate-major: each
- * rollout is contiguous, so the accepted one is copied with full cache lines),
- * Jc [B][A] out. */
+ * Zc [B][N+1][A][n], Uc [B][N][A][m] candidates out (time-major, the
+ * reference's Z_new / U_new per trajectory: the A rollouts of a trajectory
+ * write one contiguous segment per step), Jc [B][A] out. */
 int pddp_line_search_f32(const pddp_problem* problem, int B, int N, int A,
                          const float* Z, const float* U, const float* gains,
                          const float* alphas, const float* u_min,

@@ -358,8 +358,8 @@ def _control_law(model, Z, U, k, K, alpha, encoding=StateEncoding.DEFAULT,
     s.gains[..., m:] = K.reshape(B, N, m * n)
     s.line_search(use_status=False)
     A = s.A
-    Zn = s.Zc.permute(2, 0, 1, 3)  # (N+1, B, A, n): the reference's time-major
-    Un = s.Uc.permute(2, 0, 1, 3)
+    Zn = s.Zc.permute(1, 0, 2, 3)  # (N+1, B, A, n): the reference's time-major
+    Un = s.Uc.permute(1, 0, 2, 3)
     J = s.Jc
     if not batched:
         Zn, Un, J = Zn[:, 0], Un[:, 0], J[0]

@@ -139,7 +139,7 @@ class TorchProblem(object):
         alpha = s.alphas.view(1, A, 1)
         z = s.Z[:, 0].unsqueeze(1).expand(B, A, n).contiguous()
         J = torch.zeros(B, A, dtype=s.dtype, device=s.device)
-        s.Zc[:, :, 0] = z
+        s.Zc[:, 0] = z
         for t in range(N):
             dz = z - s.Z[:, t].unsqueeze(1)
             du = alpha * k[:, t].unsqueeze(1) + dz @ K[:, t].transpose(-1, -2)
@@ -151,8 +151,8 @@ class TorchProblem(object):
                            **self.cost_opts).reshape(B, A)
             z = self.model(zf, uf, t, self.encoding,
                            **self.model_opts).reshape(B, A, n)
-            s.Uc[:, :, t] = u
-            s.Zc[:, :, t + 1] = z
+            s.Uc[:, t] = u
+            s.Zc[:, t + 1] = z
         J += self.cost(z.reshape(B * A, n), None, N, terminal=True,
                        encoding=self.encoding, **self.cost_opts).reshape(B, A)
         s.Jc.copy_(J)

@@ -74,8 +74,9 @@ class ILQRSolver(object):
         self.J_opt = torch.zeros(B, **opts)
         self.gains = torch.zeros(B, N, gs, **opts)
         self.gains_acc = torch.zeros(B, N, gs, **opts)
-        self.Zc = torch.zeros(B, A, N + 1, n, **opts)
-        self.Uc = torch.zeros(B, A, N, m, **opts)
+        # candidates, time-major like the reference's Z_new / U_new
+        self.Zc = torch.zeros(B, N + 1, A, n, **opts)
+        self.Uc = torch.zeros(B, N, A, m, **opts)
         self.Jc = torch.zeros(B, A, **opts)
         i32 = dict(dtype=torch.int32, device=self.device)
         u8 = dict(dtype=torch.uint8, device=self.device)

@@ -111,13 +111,20 @@ __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a)
   if (amin < 0) return;
   // nominal <- winning candidate; self._K <- K                (ilqr.py:167-169)
   const int n = a.n, m = a.m, N = a.N;
-  const size_t cidx = (size_t)b * a.A + amin;
+  // candidates are time-major: Zc [B][N+1][A][n], Uc [B][N][A][m]
   T* Zb = a.Z + (size_t)b * (N + 1) * n;
   T* Ub = a.U + (size_t)b * N * m;
-  const T* srcz = a.Zc + cidx * (size_t)(N + 1) * n;  // contiguous rollout
-  const T* srcu = a.Uc + cidx * (size_t)N * m;
-  for (int o = tid; o < (N + 1) * n; o += kAcceptThreads) Zb[o] = srcz[o];
-  for (int o = tid; o < N * m; o += kAcceptThreads) Ub[o] = srcu[o];
+  const T* srcz = a.Zc + ((size_t)b * (N + 1) * a.A + amin) * n;
+  const T* srcu = a.Uc + ((size_t)b * N * a.A + amin) * m;
+  const size_t zstep = (size_t)a.A * n, ustep = (size_t)a.A * m;
+  for (int o = tid; o < (N + 1) * n; o += kAcceptThreads) {
+    const int t = o / n, j = o - t * n;
+    Zb[o] = srcz[t * zstep + j];
+  }
+  for (int o = tid; o < N * m; o += kAcceptThreads) {
+    const int t = o / m, j = o - t * m;
+    Ub[o] = srcu[t * ustep + j];
+  }
   const int gs = m + m * n;
   const T* G = a.gains + (size_t)b * N * gs;
   T* Ga = a.gains_acc + (size_t)b * N * gs;

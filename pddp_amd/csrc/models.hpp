@@ -82,16 +82,21 @@ struct ModelDims<PDDP_MODEL_RENDEZVOUS> {
 // sin and cos of one float argument.  The rollouts sit on a chain of N
 // dependent steps with one wavefront per SIMD, where every instruction and
 // every branch of the step is paid in full; the library's sincosf carries a
-// per-lane branch to its huge-argument path.  Here: three-constant Cody-Waite
-// reduction by pi/2 (exact up to |x| < 2^16 with FMA) and the Cephes minimax
-// polynomials on [-pi/4, pi/4] (about 1 ulp), branch-free; larger arguments
-// (and NaN) take the library's result, computed under one wave-uniform test.
+// per-lane branch to its Payne-Hanek path, which diverging line-search
+// candidates (angles of 1e5 rad and beyond) keep taking.  Here: reduction by
+// pi/2 in double precision with a two-constant pi/2 (exact enough for
+// |x| < 2^30: the error is ~1e-23 rad), the Cephes minimax polynomials on
+// [-pi/4, pi/4] (about 1 ulp), branch-free.  Non-finite arguments give NaN
+// like the library; finite ones beyond 2^30 take the library's result,
+// computed under one wave-uniform test and selected per lane (a trajectory's
+// result must not depend on its neighbours in the wavefront).
 PDDP_DEV void sincos_(float x, float& s, float& c) {
-  const float kf = __builtin_rintf(x * 0.636619772367581343f);  // 2 / pi
-  const int q = (int)kf;
-  float r = __builtin_fmaf(kf, -1.57079625129699707031e+00f, x);
-  r = __builtin_fmaf(kf, -7.54978941586159635335e-08f, r);
-  r = __builtin_fmaf(kf, -5.39030252995776476554e-15f, r);
+  const double xd = (double)x;
+  const double kd = __builtin_rint(xd * 0.63661977236758138243);  // 2 / pi
+  double rd = __builtin_fma(kd, -1.57079632679489655800e+00, xd);
+  rd = __builtin_fma(kd, -6.12323399573676603587e-17, rd);
+  const float r = (float)rd;
+  const int q = (int)kd;
   const float z = r * r;
   float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
   ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
@@ -104,9 +109,11 @@ PDDP_DEV void sincos_(float x, float& s, float& c) {
   const unsigned cs = (((unsigned)q + 1u) & 2u) << 30;
   s = __uint_as_float(__float_as_uint(swap ? cr : sr) ^ ss);
   c = __uint_as_float(__float_as_uint(swap ? sr : cr) ^ cs);
-  // which path a lane takes depends on its own argument only (a trajectory's
-  // result must not depend on its neighbours in the wavefront)
-  const bool big = !(fabsf(x) < 65536.0f);
+  const float ax = fabsf(x);
+  const bool nonfinite = !(ax < __builtin_inff());
+  s = nonfinite ? __builtin_nanf("") : s;
+  c = nonfinite ? __builtin_nanf("") : c;
+  const bool big = (ax >= 1073741824.0f) & !nonfinite;
   if (__builtin_expect(__any(big), 0)) {
     float sl, cl;
     sincosf(x, &sl, &cl);

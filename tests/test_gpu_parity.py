@@ -203,8 +203,8 @@ def test_line_search_vs_oracle(problem, dtype):
     o = orc.load(np_dtype(dtype))
     k, K = s.gain_views()
     A = s.A
-    Zc = s.Zc.permute(2, 0, 1, 3).cpu().numpy()  # (N+1, B, A, n)
-    Uc = s.Uc.permute(2, 0, 1, 3).cpu().numpy()
+    Zc = s.Zc.permute(1, 0, 2, 3).cpu().numpy()  # (N+1, B, A, n)
+    Uc = s.Uc.permute(1, 0, 2, 3).cpu().numpy()
     Jc = s.Jc.cpu().numpy()
     tol = 1e-10 if dtype == "f64" else 2e-4
     for b in range(B):

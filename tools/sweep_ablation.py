@@ -46,6 +46,21 @@ def main():
             out["v%d_%s%s" % (variant, "chol" if branch else "eig",
                               "_box" if bounded else "")] = round(
                                   e0.elapsed_time(e1) / 20 * 1e3, 1)
+    # the other kernels of a round, timed alone on the same state
+    s.backward(reg=reg)
+    for name, fn in (("line_search", lambda: s.line_search()),
+                     ("derivs", lambda: s.derivs()),
+                     ("rollout", lambda: s.nominal_rollout())):
+        for _ in range(3):
+            fn()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = round(e0.elapsed_time(e1) / 20 * 1e3, 1)
     print(json.dumps({"B": a.batch, "N": a.horizon, "dtype": a.dtype, "us": out}))
 
 
