@@ -33,7 +33,8 @@ struct AcceptArgs {
 constexpr double kMuMin = 1e-6;   // ilqr.py:94
 constexpr double kDelta0 = 2.0;   // ilqr.py:95
 
-constexpr int kAcceptThreads = 256;
+constexpr int kAcceptThreads = 64;  // one wavefront: all 4096 blocks of the
+                                    // bench batch are resident at once
 constexpr int kMaxAlphas = 16;
 constexpr int kLiveShards = 256;  // PDDP_LIVE_SHARDS of include/pddp_hip.h
 
@@ -42,22 +43,30 @@ __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a)
   __shared__ int sh_amin;  // >= 0: accepted candidate, -1: nothing to copy
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
+  // every input of the state machine is loaded up front, side by side: the
+  // kernel is a chain of memory latencies otherwise
   const bool attempted = a.active[b] != 0;
+  const int bstat = a.bwd_status[b];
+  const double mu_in = a.mu[b], delta_in = a.delta[b];
+  const T J_opt_in = a.J_opt[b];
+  const int iter_in = a.iter[b];
+  T J[kMaxAlphas];
+  {
+    const T* Jg = a.Jc + (size_t)b * a.A;
+#pragma unroll
+    for (int i = 0; i < kMaxAlphas; ++i) J[i] = Jg[i < a.A ? i : 0];
+  }
   if (!attempted) return;  // masks of finished trajectories stay 0
 
   if (tid == 0) {
     int amin_out = -1;
-    double mu = a.mu[b], delta = a.delta[b];
+    double mu = mu_in, delta = delta_in;
     int st;
     bool increase = false;
-    if (a.bwd_status[b] != 0) {
+    if (bstat != 0) {
       increase = true;  // RuntimeError path                    (ilqr.py:140-145)
       st = PDDP_STATE_NOT_PD;
     } else {
-      const T* Jg = a.Jc + (size_t)b * a.A;
-      T J[kMaxAlphas];  // independent loads first, then the dependent scan
-#pragma unroll
-      for (int i = 0; i < kMaxAlphas; ++i) J[i] = Jg[i < a.A ? i : 0];
       int amin = 0;  // torch argmin: first minimum, a NaN wins     (ilqr.py:161)
       T Jm = J[0];
 #pragma unroll
@@ -67,7 +76,7 @@ __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a)
         Jm = take ? J[i] : Jm;
       }
       const T J_new = Jm;
-      const T J_opt = a.J_opt[b];
+      const T J_opt = J_opt_in;
       if (J_new < J_opt) {  // ilqr.py:166
         amin_out = amin;
         delta = (delta < 1.0 ? delta : 1.0) / kDelta0;  // _decrease_reg :369-374
@@ -94,8 +103,8 @@ __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a)
     if (st == PDDP_STATE_NOT_PD || st == PDDP_STATE_REJECTED) {
       act = 1;
     } else if (st == PDDP_STATE_ACCEPTED) {
-      if (a.iter[b] < a.n_iterations) {
-        a.iter[b] += 1;
+      if (iter_in < a.n_iterations) {
+        a.iter[b] = iter_in + 1;
         act = 1;
         fr = 1;
       }
@@ -117,14 +126,22 @@ __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a)
   const T* srcz = a.Zc + ((size_t)b * (N + 1) * a.A + amin) * n;
   const T* srcu = a.Uc + ((size_t)b * N * a.A + amin) * m;
   const size_t zstep = (size_t)a.A * n, ustep = (size_t)a.A * m;
-  for (int o = tid; o < (N + 1) * n; o += kAcceptThreads) {
-    const int t = o / n, j = o - t * n;
-    Zb[o] = srcz[t * zstep + j];
-  }
-  for (int o = tid; o < N * m; o += kAcceptThreads) {
-    const int t = o / m, j = o - t * m;
-    Ub[o] = srcu[t * ustep + j];
-  }
+  // lane -> (row t, word j) once; then whole rows per pass (no per-element
+  // division) whenever the row length divides the wavefront
+  auto gather = [&](T* dst, const T* src, int rows, int w, size_t step) {
+    if (kAcceptThreads % w == 0) {
+      const int per = kAcceptThreads / w;
+      const int j = tid % w;
+      for (int t = tid / w; t < rows; t += per) dst[t * w + j] = src[t * step + j];
+    } else {
+      for (int o = tid; o < rows * w; o += kAcceptThreads) {
+        const int t = o / w, j = o - t * w;
+        dst[o] = src[t * step + j];
+      }
+    }
+  };
+  gather(Zb, srcz, N + 1, n, zstep);
+  gather(Ub, srcu, N, m, ustep);
   const int gs = m + m * n;
   const T* G = a.gains + (size_t)b * N * gs;
   T* Ga = a.gains_acc + (size_t)b * N * gs;
