@@ -121,11 +121,8 @@ def main():
 
     def one_round(ev=None):
         s.derivs(mask=s.fresh)
-        if ev is not None:
-            lib.pddp_event_record(ev[0], s._s())
-        s.backward(active=s.active, variant=args.kernel_variant)
-        if ev is not None:
-            lib.pddp_event_record(ev[1], s._s())
+        # events attached to the sweep's own dispatch: the kernel's duration
+        s.backward(active=s.active, variant=args.kernel_variant, events=ev)
         s.line_search(active=s.active)
         s.accept(5e-6, 1e10, n_iter)
 

@@ -219,6 +219,24 @@ int pddp_accept_f64(int B, int N, int n, int m, int A, const double* Zc,
                     int32_t* iter, uint8_t* active, uint8_t* fresh,
                     int32_t* n_live, void* stream);
 
+/* The variant entry with two HIP events (pddp_event_create) attached to the
+ * sweep's own dispatch: elapsed(start, stop) is the kernel's duration as
+ * rocprofv3 --kernel-trace reports it (bench.py's roofline leg). */
+int pddp_riccati_backward_timed_f32(int B, int N, int n, int m,
+                                    const float* rec, const float* u_min,
+                                    const float* u_max, const double* reg,
+                                    int branch, const uint8_t* active,
+                                    float* gains, int32_t* status,
+                                    void* stream, int variant, void* start,
+                                    void* stop);
+int pddp_riccati_backward_timed_f64(int B, int N, int n, int m,
+                                    const double* rec, const double* u_min,
+                                    const double* u_max, const double* reg,
+                                    int branch, const uint8_t* active,
+                                    double* gains, int32_t* status,
+                                    void* stream, int variant, void* start,
+                                    void* stop);
+
 /* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only
  * sees torch's current stream). Host functions. */
 int pddp_event_create(void** ev);

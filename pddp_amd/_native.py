@@ -60,6 +60,8 @@ _SIGS = {
     "pddp_riccati_backward": [c_int] * 4 + [_P] * 4 + [c_int] + [_P] * 4,
     "pddp_riccati_backward_variant": [c_int] * 4 + [_P] * 4 + [c_int] +
                                      [_P] * 4 + [c_int],
+    "pddp_riccati_backward_timed": [c_int] * 4 + [_P] * 4 + [c_int] +
+                                   [_P] * 4 + [c_int, _P, _P],
     "pddp_boxqp_m1": [c_int] + [_P] * 9,
     "pddp_pack_records": [c_int] * 4 + [_P] * 10,
     "pddp_nominal_rollout": [_P, c_int, c_int] + [_P] * 7,
@@ -73,6 +75,7 @@ _SIGS = {
     "pddp_event_destroy": [_P],
 }
 _TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
+          "pddp_riccati_backward_timed",
           "pddp_boxqp_m1", "pddp_pack_records", "pddp_nominal_rollout",
           "pddp_derivs",
           "pddp_line_search", "pddp_accept")

@@ -150,18 +150,23 @@ class ILQRSolver(object):
                      p(self.state) if set_state else None, self._s())
 
     def backward(self, active=None, reg=None, branch=None, bounded=True,
-                 variant=0):
+                 variant=0, events=None):
         """variant: 0 auto, 1 generic kernel, 2 / 3 specialised n=4 kernel
-        (IEEE / approximate division), see include/pddp_hip.h."""
+        (IEEE / approximate division), see include/pddp_hip.h.  `events`: a
+        (start, stop) pair of pddp_event handles to attach to the dispatch."""
         p = _native.ptr
         reg = self.mu if reg is None else reg
         branch = self.branch if branch is None else branch
         umin = self.u_min if bounded else None
         umax = self.u_max if bounded else None
-        _native.call("pddp_riccati_backward_variant", self.dtype, self.B,
-                     self.N, self.n, self.m, p(self.rec), p(umin), p(umax),
-                     p(reg), int(branch), p(active), p(self.gains),
-                     p(self.bwd_status), self._s(), int(variant))
+        args = (self.B, self.N, self.n, self.m, p(self.rec), p(umin), p(umax),
+                p(reg), int(branch), p(active), p(self.gains),
+                p(self.bwd_status), self._s(), int(variant))
+        if events is None:
+            _native.call("pddp_riccati_backward_variant", self.dtype, *args)
+        else:
+            _native.call("pddp_riccati_backward_timed", self.dtype, *args,
+                         events[0], events[1])
 
     def line_search(self, active=None, use_status=True):
         if self.plugin is not None:

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/pddp_hip.h"
@@ -67,6 +68,29 @@ PDDP_DEV float cos_(float x) { return cosf(x); }
 PDDP_DEV double cos_(double x) { return cos(x); }
 PDDP_DEV float abs_(float x) { return fabsf(x); }
 PDDP_DEV double abs_(double x) { return fabs(x); }
+
+// Optional HIP events attached to the NEXT sweep dispatch itself
+// (hipExtLaunchKernelGGL): they time the kernel from its own start to its own
+// end - what rocprofv3 --kernel-trace reports - without the stream's dispatch
+// gaps that a pair of hipEventRecord calls around the launch includes.
+struct LaunchEvents {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+inline LaunchEvents& launch_events() {
+  static thread_local LaunchEvents ev;
+  return ev;
+}
+#define PDDP_LAUNCH(kernel, grid, block, shmem, st, ...)                      \
+  do {                                                                        \
+    ::pddp::LaunchEvents& ev_ = ::pddp::launch_events();                      \
+    if (ev_.start != nullptr) {                                               \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, ev_.start,        \
+                            ev_.stop, 0, __VA_ARGS__);                        \
+      ev_ = ::pddp::LaunchEvents();                                           \
+    } else {                                                                  \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);        \
+    }                                                                         \
+  } while (0)
 
 inline int launch_status() {
   hipError_t e = hipGetLastError();

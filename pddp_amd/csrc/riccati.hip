@@ -7,8 +7,8 @@ namespace pddp {
 
 template <typename T, int NMAX, int M>
 static int launch_generic(const RiccatiArgs<T>& a, hipStream_t st) {
-  hipLaunchKernelGGL((riccati_generic_kernel<T, NMAX, M>), dim3(a.B),
-                     dim3(kWave), 0, st, a);
+  PDDP_LAUNCH((riccati_generic_kernel<T, NMAX, M>), dim3(a.B), dim3(kWave), 0,
+              st, a);
   return launch_status();
 }
 
@@ -26,7 +26,7 @@ static int dispatch_nmax(const RiccatiArgs<T>& a, hipStream_t st) {
       (const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
       (int)bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(kernel, dim3(a.B), dim3(kLargeThreads), bytes, st, a);
+  PDDP_LAUNCH(kernel, dim3(a.B), dim3(kLargeThreads), bytes, st, a);
   return launch_status();
 }
 
@@ -124,6 +124,37 @@ int pddp_riccati_backward_variant_f64(int B, int N, int n, int m,
   return pddp::riccati_backward_impl<double>(B, N, n, m, rec, u_min, u_max,
                                              reg, branch, active, gains,
                                              status, stream, variant);
+}
+
+/* The sweep with two HIP events attached to its dispatch (bench.py's roofline
+ * leg): elapsed(start, stop) is the kernel's own duration. */
+int pddp_riccati_backward_timed_f32(int B, int N, int n, int m,
+                                    const float* rec, const float* u_min,
+                                    const float* u_max, const double* reg,
+                                    int branch, const uint8_t* active,
+                                    float* gains, int32_t* status,
+                                    void* stream, int variant, void* start,
+                                    void* stop) {
+  pddp::launch_events() = {(hipEvent_t)start, (hipEvent_t)stop};
+  const int rc = pddp::riccati_backward_impl<float>(
+      B, N, n, m, rec, u_min, u_max, reg, branch, active, gains, status,
+      stream, variant);
+  pddp::launch_events() = pddp::LaunchEvents();
+  return rc;
+}
+int pddp_riccati_backward_timed_f64(int B, int N, int n, int m,
+                                    const double* rec, const double* u_min,
+                                    const double* u_max, const double* reg,
+                                    int branch, const uint8_t* active,
+                                    double* gains, int32_t* status,
+                                    void* stream, int variant, void* start,
+                                    void* stop) {
+  pddp::launch_events() = {(hipEvent_t)start, (hipEvent_t)stop};
+  const int rc = pddp::riccati_backward_impl<double>(
+      B, N, n, m, rec, u_min, u_max, reg, branch, active, gains, status,
+      stream, variant);
+  pddp::launch_events() = pddp::LaunchEvents();
+  return rc;
 }
 
 int pddp_boxqp_m1_f32(int count, const float* x0, const float* Q,

@@ -830,8 +830,8 @@ static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st, bool fast_math,
   const dim3 grid((a.B + G - 1) / G), block(kWave);
   if (bounded && qp_closed_form && G == 4) {
 #define PDDP_N4_CF(C, F)                                                     \
-  hipLaunchKernelGGL((n4::riccati_n4_kernel<T, C, true, F, 4, true>), grid,  \
-                     block, 0, st, a)
+  PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, true, F, 4, true>), grid, block,  \
+              0, st, a)
     if (fast_math) { if (chol) PDDP_N4_CF(true, true); else PDDP_N4_CF(false, true); }
     else { if (chol) PDDP_N4_CF(true, false); else PDDP_N4_CF(false, false); }
 #undef PDDP_N4_CF
@@ -840,11 +840,11 @@ static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st, bool fast_math,
 #define PDDP_N4_LAUNCH(C, Bd, F)                                             \
   do {                                                                       \
     if (G == 2)                                                              \
-      hipLaunchKernelGGL((n4::riccati_n4_kernel<T, C, Bd, F, 2>), grid,      \
-                         block, 0, st, a);                                   \
+      PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, Bd, F, 2>), grid, block, 0,   \
+                  st, a);                                                    \
     else                                                                     \
-      hipLaunchKernelGGL((n4::riccati_n4_kernel<T, C, Bd, F, 4>), grid,      \
-                         block, 0, st, a);                                   \
+      PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, Bd, F, 4>), grid, block, 0,   \
+                  st, a);                                                    \
   } while (0)
   if (fast_math) {
     if (chol) { if (bounded) PDDP_N4_LAUNCH(true, true, true); else PDDP_N4_LAUNCH(true, false, true); }

@@ -7,11 +7,16 @@ import json
 import os
 import sys
 
+def newest(pattern):
+    """gpurun merges new output next to older runs' files: take the latest."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = "profiles"
 os.makedirs(out, exist_ok=True)
 
-src = glob.glob("gpurun_out/%s_stats/*/*kernel_stats.csv" % tag)[0]
+src = newest("gpurun_out/%s_stats/*/*kernel_stats.csv" % tag)
 with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w") as f:
     w = csv.writer(f)
     cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage",
@@ -22,7 +27,7 @@ with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w") as f:
 
 traffic = {}
 for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = glob.glob("gpurun_out/%s_pmc_%s/*/*counter_collection.csv" % (tag, kind))[0]
+    f = newest("gpurun_out/%s_pmc_%s/*/*counter_collection.csv" % (tag, kind))
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if "pddp" in r["Kernel_Name"]:
@@ -45,7 +50,7 @@ json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE "
            "kernels": traffic},
           open(os.path.join(out, "%s_pmc_traffic.json" % tag), "w"), indent=1)
 
-f = glob.glob("gpurun_out/%s_pmc_sq/*/*counter_collection.csv" % tag)[0]
+f = newest("gpurun_out/%s_pmc_sq/*/*counter_collection.csv" % tag)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     if "pddp" in r["Kernel_Name"]:
