@@ -355,16 +355,12 @@ __global__ __launch_bounds__(kWave) void line_search_lds_kernel(
       const T v = Us[t * m + r] + du;
       un[r] = bounded ? clamp_nan(v, umin[r], umax[r]) : v;
     }
-#ifndef LS_NO_STORE
 #pragma unroll
     for (int j = 0; j < n; ++j) Zci[(size_t)t * zstep + j] = z[j];
 #pragma unroll
     for (int j = 0; j < m; ++j) Uci[(size_t)t * ustep + j] = un[j];
-#endif
     const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
-#ifndef LS_NO_COST
     J += cost_value<T, MODEL>(P, z, un, tr, false);
-#endif
     dynamics<T, MODEL, false>(P, z, un, tr, zn, nullptr, nullptr);
 #pragma unroll
     for (int j = 0; j < n; ++j) z[j] = zn[j];
