@@ -120,11 +120,11 @@ def main():
     n_iter = 1 << 30  # the fit loop never runs out inside the benchmark
 
     def one_round(ev=None):
-        s.derivs(mask=s.fresh)
-        # events attached to the sweep's own dispatch: the kernel's duration
-        s.backward(active=s.active, variant=args.kernel_variant, events=ev)
-        s.line_search(active=s.active)
-        s.accept(5e-6, 1e10, n_iter)
+        # the product's round (ILQRSolver.round): records of fresh nominals,
+        # sweep (events attached to its own dispatch: the kernel's duration),
+        # fused line search + accept + records of the accepted nominals
+        s.round(5e-6, 1e10, n_iter, variant=args.kernel_variant,
+                backward_events=ev)
 
     for _ in range(W):
         one_round()

@@ -219,6 +219,33 @@ int pddp_accept_f64(int B, int N, int n, int m, int A, const double* Zc,
                     int32_t* iter, uint8_t* active, uint8_t* fresh,
                     int32_t* n_live, void* stream);
 
+/* ---- one launch for the rest of a round: pddp_line_search + pddp_accept +
+ * pddp_derivs (of the trajectories whose nominal changed and whose fit goes
+ * on).  Same arguments and semantics as the three calls; Z, U, active are
+ * in/out; `fresh` is cleared for the trajectories whose records were written
+ * here.  Sample problems with at most 16 step sizes; returns
+ * PDDP_E_UNSUPPORTED otherwise (make the three calls then). */
+int pddp_search_accept_f32(const pddp_problem* problem, int B, int N, int A,
+                           float* Z, float* U, const float* gains,
+                           const float* alphas, const float* u_min,
+                           const float* u_max, uint8_t* active,
+                           const int32_t* bwd_status, float* Zc, float* Uc,
+                           float* Jc, double tol, double max_reg,
+                           int n_iterations, float* gains_acc, float* J_opt,
+                           double* mu, double* delta, int32_t* state,
+                           int32_t* iter, uint8_t* fresh, int32_t* n_live,
+                           float* rec, float* L, void* stream);
+int pddp_search_accept_f64(const pddp_problem* problem, int B, int N, int A,
+                           double* Z, double* U, const double* gains,
+                           const double* alphas, const double* u_min,
+                           const double* u_max, uint8_t* active,
+                           const int32_t* bwd_status, double* Zc, double* Uc,
+                           double* Jc, double tol, double max_reg,
+                           int n_iterations, double* gains_acc, double* J_opt,
+                           double* mu, double* delta, int32_t* state,
+                           int32_t* iter, uint8_t* fresh, int32_t* n_live,
+                           double* rec, double* L, void* stream);
+
 /* The variant entry with two HIP events (pddp_event_create) attached to the
  * sweep's own dispatch: elapsed(start, stop) is the kernel's duration as
  * rocprofv3 --kernel-trace reports it (bench.py's roofline leg). */

@@ -67,6 +67,9 @@ _SIGS = {
     "pddp_nominal_rollout": [_P, c_int, c_int] + [_P] * 7,
     "pddp_derivs": [_P, c_int, c_int] + [_P] * 10,
     "pddp_line_search": [_P, c_int, c_int, c_int] + [_P] * 12,
+    "pddp_search_accept": [_P, c_int, c_int, c_int] + [_P] * 11 +
+                          [c_double, c_double, c_int] +
+                          [_P] * 11,
     "pddp_accept": [c_int] * 5 + [_P] * 5 + [c_double, c_double, c_int] +
                    [_P] * 12,
     "pddp_event_create": [_P],
@@ -78,7 +81,7 @@ _TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
           "pddp_riccati_backward_timed",
           "pddp_boxqp_m1", "pddp_pack_records", "pddp_nominal_rollout",
           "pddp_derivs",
-          "pddp_line_search", "pddp_accept")
+          "pddp_line_search", "pddp_search_accept", "pddp_accept")
 
 _lib = None
 
@@ -145,6 +148,19 @@ def check(rc, what):
 def call(name, dtype, *args):
     fn = getattr(lib(), "%s_%s" % (name, suffix(dtype)))
     check(fn(*args), name)
+
+
+E_UNSUPPORTED = -2  # PDDP_E_UNSUPPORTED of include/pddp_hip.h
+
+
+def call_rc(name, dtype, *args):
+    """Like call(), but hands PDDP_E_UNSUPPORTED back to the caller (entry
+    points that document it as 'make the separate calls instead')."""
+    fn = getattr(lib(), "%s_%s" % (name, suffix(dtype)))
+    rc = fn(*args)
+    if rc != E_UNSUPPORTED:
+        check(rc, name)
+    return rc
 
 
 def record_layout(n, m):

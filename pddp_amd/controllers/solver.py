@@ -88,8 +88,13 @@ class ILQRSolver(object):
         self.delta = torch.full((B,), 2.0, **f64)
         self.active = torch.zeros(B, **u8)
         self.fresh = torch.zeros(B, **u8)
-        self.n_live = torch.zeros(256, **i32)  # PDDP_LIVE_SHARDS
+        # PDDP_LIVE_SHARDS counters: running total of "still live after its
+        # attempt" since the last reset (bench.py's unit accounting; the fit
+        # loop itself looks at `active`)
+        self.n_live = torch.zeros(256, **i32)
         self._graph = None  # (key, torch.cuda.CUDAGraph) of one round
+        self._fused = None  # None: untried, True / False: fused kernel applies
+        self._derivs_due = True
         self._pp = None if problem is None else ctypes.addressof(problem)
 
     # -- views in the reference's tensor layout -----------------------------
@@ -125,6 +130,8 @@ class ILQRSolver(object):
         self.nominal_rollout()
 
     def reset_controller_state(self):
+        self._derivs_due = True  # every nominal is new: records at round start
+        self.n_live.zero_()
         self.mu.zero_()          # _reset_reg ilqr.py:364-367
         self.delta.fill_(2.0)
         self.state.zero_()       # UNDEFINED
@@ -188,13 +195,39 @@ class ILQRSolver(object):
                      p(self.delta), p(self.state), p(self.iter),
                      p(self.active), p(self.fresh), p(self.n_live), self._s())
 
-    def round(self, tol=5e-6, max_reg=1e10, n_iterations=50):
-        """One attempt of every live trajectory (no host sync)."""
-        self.derivs(mask=self.fresh)
-        self.backward(active=self.active)
-        self.line_search(active=self.active)
-        self.n_live.zero_()
-        self.accept(tol, max_reg, n_iterations)
+    def search_accept(self, tol, max_reg, n_iterations):
+        """Line search + accept + derivative records of the new nominals in
+        one launch (pddp_search_accept_*).  False when the fused kernel does
+        not apply; the caller then makes the separate calls."""
+        if self.plugin is not None or self._fused is False:
+            return False
+        p = _native.ptr
+        rc = _native.call_rc(
+            "pddp_search_accept", self.dtype, self._pp, self.B, self.N, self.A,
+            p(self.Z), p(self.U), p(self.gains), p(self.alphas), p(self.u_min),
+            p(self.u_max), p(self.active), p(self.bwd_status), p(self.Zc),
+            p(self.Uc), p(self.Jc), float(tol), float(max_reg),
+            int(n_iterations), p(self.gains_acc), p(self.J_opt), p(self.mu),
+            p(self.delta), p(self.state), p(self.iter), p(self.fresh),
+            p(self.n_live), p(self.rec), p(self.L), self._s())
+        self._fused = rc == 0
+        return self._fused
+
+    def round(self, tol=5e-6, max_reg=1e10, n_iterations=50, variant=0,
+              backward_events=None):
+        """One attempt of every live trajectory (no host sync): derivative
+        records of the trajectories whose nominal is new, backward sweep, and
+        - fused into one launch where the problem allows - line search,
+        accept / regularisation schedule and the records of the accepted
+        nominals (so the first call is a no-op from the second round on)."""
+        if self._derivs_due or not self._fused:
+            self.derivs(mask=self.fresh)
+            self._derivs_due = False
+        self.backward(active=self.active, variant=variant,
+                      events=backward_events)
+        if not self.search_accept(tol, max_reg, n_iterations):
+            self.line_search(active=self.active)
+            self.accept(tol, max_reg, n_iterations)
 
     def capture_round(self, tol=5e-6, max_reg=1e10, n_iterations=50):
         """Captures round() - five kernel launches and a memset, all on
@@ -240,6 +273,6 @@ class ILQRSolver(object):
                 break
             if rounds % rounds_per_sync:
                 continue
-            if int(self.n_live.sum().item()) == 0:
+            if int(self.active.sum().item()) == 0:  # the one host sync
                 break
         return rounds

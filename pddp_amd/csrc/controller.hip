@@ -3,53 +3,17 @@
 //
 //   accept / reject + mu schedule   pddp/controllers/ilqr.py:102-181,364-390
 //   fit() loop bookkeeping          pddp/controllers/ilqr.py:298-314
-#include "pddp_common.hpp"
+#include "accept.hpp"
 
 namespace pddp {
-
-template <typename T>
-struct AcceptArgs {
-  int B, N, n, m, A;
-  const T* Zc;
-  const T* Uc;
-  const T* Jc;
-  const T* gains;
-  const int32_t* bwd_status;
-  double tol, max_reg;
-  int n_iterations;
-  T* Z;
-  T* U;
-  T* gains_acc;
-  T* J_opt;
-  double* mu;
-  double* delta;
-  int32_t* state;
-  int32_t* iter;
-  uint8_t* active;
-  uint8_t* fresh;
-  int32_t* n_live;
-};
-
-constexpr double kMuMin = 1e-6;   // ilqr.py:94
-constexpr double kDelta0 = 2.0;   // ilqr.py:95
-
-constexpr int kAcceptThreads = 64;  // one wavefront: all 4096 blocks of the
-                                    // bench batch are resident at once
-constexpr int kMaxAlphas = 16;
-constexpr int kLiveShards = 256;  // PDDP_LIVE_SHARDS of include/pddp_hip.h
 
 template <typename T>
 __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a) {
   __shared__ int sh_amin;  // >= 0: accepted candidate, -1: nothing to copy
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
-  // every input of the state machine is loaded up front, side by side: the
-  // kernel is a chain of memory latencies otherwise
   const bool attempted = a.active[b] != 0;
-  const int bstat = a.bwd_status[b];
-  const double mu_in = a.mu[b], delta_in = a.delta[b];
-  const T J_opt_in = a.J_opt[b];
-  const int iter_in = a.iter[b];
+  const AcceptIn<T> in = accept_load(a, b);
   T J[kMaxAlphas];
   {
     const T* Jg = a.Jc + (size_t)b * a.A;
@@ -59,61 +23,10 @@ __global__ __launch_bounds__(kAcceptThreads) void accept_kernel(AcceptArgs<T> a)
   if (!attempted) return;  // masks of finished trajectories stay 0
 
   if (tid == 0) {
-    int amin_out = -1;
-    double mu = mu_in, delta = delta_in;
-    int st;
-    bool increase = false;
-    if (bstat != 0) {
-      increase = true;  // RuntimeError path                    (ilqr.py:140-145)
-      st = PDDP_STATE_NOT_PD;
-    } else {
-      int amin = 0;  // torch argmin: first minimum, a NaN wins     (ilqr.py:161)
-      T Jm = J[0];
-#pragma unroll
-      for (int i = 1; i < kMaxAlphas; ++i) {
-        const bool take = (i < a.A) && (Jm == Jm) && (J[i] < Jm || J[i] != J[i]);
-        amin = take ? i : amin;
-        Jm = take ? J[i] : Jm;
-      }
-      const T J_new = Jm;
-      const T J_opt = J_opt_in;
-      if (J_new < J_opt) {  // ilqr.py:166
-        amin_out = amin;
-        delta = (delta < 1.0 ? delta : 1.0) / kDelta0;  // _decrease_reg :369-374
-        mu *= delta;
-        if (mu <= kMuMin) mu = 0.0;
-        const T rel = abs_(J_opt - J_new) / J_opt;
-        st = (rel < (T)a.tol) ? PDDP_STATE_CONVERGED : PDDP_STATE_ACCEPTED;
-        a.J_opt[b] = J_new;
-      } else {
-        increase = true;
-        st = PDDP_STATE_REJECTED;
-      }
-    }
-    if (increase) {  // _increase_reg                            (ilqr.py:376-390)
-      delta = (delta > 1.0 ? delta : 1.0) * kDelta0;
-      mu = (kMuMin > mu * delta) ? kMuMin : mu * delta;
-      if (mu >= a.max_reg) st = PDDP_STATE_MAX_REG;
-    }
-    a.mu[b] = mu;
-    a.delta[b] = delta;
-    a.state[b] = st;
-    // masks of the next round (fit loop, ilqr.py:298-314)
-    uint8_t act = 0, fr = 0;
-    if (st == PDDP_STATE_NOT_PD || st == PDDP_STATE_REJECTED) {
-      act = 1;
-    } else if (st == PDDP_STATE_ACCEPTED) {
-      if (iter_in < a.n_iterations) {
-        a.iter[b] = iter_in + 1;
-        act = 1;
-        fr = 1;
-      }
-    }
-    a.active[b] = act;
-    a.fresh[b] = fr;
-    // sharded counter: 4096 adds on ONE word serialise at ~12 ns each (= 50 us)
-    if (act && a.n_live != nullptr) atomicAdd(a.n_live + (b & (kLiveShards - 1)), 1);
-    sh_amin = amin_out;
+    T J_new;
+    const int amin = argmin_first(J, a.A, J_new);
+    bool fresh;
+    sh_amin = accept_decide(a, b, in, amin, J_new, fresh);
   }
   __syncthreads();
   const int amin = sh_amin;

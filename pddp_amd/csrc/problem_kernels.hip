@@ -6,6 +6,8 @@
 //                      (parallel over trajectory AND time step)
 //   line search       ilqr.py:677-723 _control_law + :764-791 _trajectory_cost
 #include "models.hpp"
+#include "accept.hpp"
+#include "riccati_n4.hpp"  // DPP helpers of the 16-lane groups
 
 namespace pddp {
 
@@ -65,6 +67,88 @@ __global__ __launch_bounds__(kWave) void nominal_rollout_kernel(
 // derivative records: one workgroup per trajectory, one lane per time step;
 // records are staged through LDS so the HBM writes are fully coalesced.
 // --------------------------------------------------------------------------
+// dst[0..count) = src[0..count) by the 16 lanes of a trajectory group (lane
+// index l16).  Loads are issued eight at a time before the first store: a
+// plain load-store loop pays the full memory latency once per iteration.
+template <typename T>
+PDDP_DEV void group_copy(T* dst, const T* src, int count, int l16) {
+  constexpr int kDeep = 8;
+  for (int o0 = l16; o0 < count; o0 += 16 * kDeep) {
+    T tmp[kDeep];
+#pragma unroll
+    for (int r = 0; r < kDeep; ++r) {
+      const int o = o0 + 16 * r;
+      tmp[r] = src[o < count ? o : 0];
+    }
+#pragma unroll
+    for (int r = 0; r < kDeep; ++r) {
+      const int o = o0 + 16 * r;
+      if (o < count) dst[o] = tmp[r];
+    }
+  }
+}
+
+// 16-B aligned store of four consecutive words (two 16-B stores for double)
+PDDP_DEV void store4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+PDDP_DEV void store4(double* p, double a, double b, double c, double d) {
+  *reinterpret_cast<double2*>(p) = make_double2(a, b);
+  *reinterpret_cast<double2*>(p + 2) = make_double2(c, d);
+}
+
+// One derivative record (include/pddp_hip.h layout) of the nominal point
+// (z, u_nominal) in `w`; returns the cost l.  Derivatives are taken AT the
+// clamped action; the record keeps the un-clamped nominal u for the BoxQP
+// bounds (ilqr.py:457-473, 602-603).
+template <typename T, int MODEL>
+PDDP_DEV T record_of(const ProblemT<T>& P, const T* z, const T* un,
+                     bool terminal, bool bounded, const T* u_min,
+                     const T* u_max, T* w) {
+  using D = ModelDims<MODEL>;
+  constexpr int n = D::n, m = D::m;
+  constexpr RecLayout lay(n, m);
+  constexpr int S = lay.stride;
+  T u[m], zn[n];
+  T Fz[n * n], Fu[n * m], lz[n], lzz[n * n], lu[m], luu[m * m];
+#pragma unroll
+  for (int j = 0; j < m; ++j) {
+    u[j] = bounded ? clamp1(un[j], u_min[j], u_max[j]) : un[j];
+    lu[j] = T(0);
+  }
+#pragma unroll
+  for (int j = 0; j < m * m; ++j) luu[j] = T(0);
+  const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
+  const T l = cost_derivs<T, MODEL>(P, z, u, tr, terminal, lz, lzz, lu, luu);
+  if (!terminal) {
+    dynamics<T, MODEL, true>(P, z, u, tr, zn, Fz, Fu);
+  } else {
+#pragma unroll
+    for (int j = 0; j < n * n; ++j) Fz[j] = T(0);
+#pragma unroll
+    for (int j = 0; j < n * m; ++j) Fu[j] = T(0);
+  }
+#pragma unroll
+  for (int j = 0; j < n * n; ++j) w[lay.oFz + j] = Fz[j];
+#pragma unroll
+  for (int j = 0; j < n * n; ++j) w[lay.oLzz + j] = lzz[j];
+#pragma unroll
+  for (int j = 0; j < n * m; ++j) w[lay.oFu + j] = Fu[j];
+#pragma unroll
+  for (int j = 0; j < m * n; ++j) w[lay.oLuz + j] = T(0);
+#pragma unroll
+  for (int j = 0; j < n; ++j) w[lay.oLz + j] = lz[j];
+#pragma unroll
+  for (int j = 0; j < m * m; ++j) w[lay.oLuu + j] = luu[j];
+#pragma unroll
+  for (int j = 0; j < m; ++j) w[lay.oLu + j] = lu[j];
+#pragma unroll
+  for (int j = 0; j < m; ++j) w[lay.oU + j] = un[j];
+#pragma unroll
+  for (int j = lay.oU + m; j < S; ++j) w[j] = T(0);
+  return l;
+}
+
 template <typename T>
 struct DerivArgs {
   int B, N;
@@ -106,48 +190,16 @@ __global__ __launch_bounds__(kDerivThreads) void derivs_kernel(
     const int t = t0 + tid;
     T l = T(0);
     if (t <= N) {
-      T z[n], u[m], un[m], zn[n];
-      T Fz[n * n], Fu[n * m], lz[n], lzz[n * n], lu[m], luu[m * m];
+      T z[n], un[m], w[S];
 #pragma unroll
       for (int j = 0; j < n; ++j) z[j] = Zb[t * n + j];
       const bool terminal = (t == N);
 #pragma unroll
-      for (int j = 0; j < m; ++j) {
-        un[j] = terminal ? T(0) : Ub[t * m + j];
-        u[j] = bounded ? clamp1(un[j], a.u_min[j], a.u_max[j]) : un[j];
-        lu[j] = T(0);
-      }
-#pragma unroll
-      for (int j = 0; j < m * m; ++j) luu[j] = T(0);
-      const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
-      l = cost_derivs<T, MODEL>(P, z, u, tr, terminal, lz, lzz, lu, luu);
-      if (!terminal) {
-        dynamics<T, MODEL, true>(P, z, u, tr, zn, Fz, Fu);
-      } else {
-#pragma unroll
-        for (int j = 0; j < n * n; ++j) Fz[j] = T(0);
-#pragma unroll
-        for (int j = 0; j < n * m; ++j) Fu[j] = T(0);
-      }
+      for (int j = 0; j < m; ++j) un[j] = terminal ? T(0) : Ub[t * m + j];
+      l = record_of<T, MODEL>(P, z, un, terminal, bounded, a.u_min, a.u_max, w);
       T* col = stage + tid;
 #pragma unroll
-      for (int j = 0; j < n * n; ++j) col[(lay.oFz + j) * LD] = Fz[j];
-#pragma unroll
-      for (int j = 0; j < n * n; ++j) col[(lay.oLzz + j) * LD] = lzz[j];
-#pragma unroll
-      for (int j = 0; j < n * m; ++j) col[(lay.oFu + j) * LD] = Fu[j];
-#pragma unroll
-      for (int j = 0; j < m * n; ++j) col[(lay.oLuz + j) * LD] = T(0);
-#pragma unroll
-      for (int j = 0; j < n; ++j) col[(lay.oLz + j) * LD] = lz[j];
-#pragma unroll
-      for (int j = 0; j < m * m; ++j) col[(lay.oLuu + j) * LD] = luu[j];
-#pragma unroll
-      for (int j = 0; j < m; ++j) col[(lay.oLu + j) * LD] = lu[j];
-#pragma unroll
-      for (int j = 0; j < m; ++j) col[(lay.oU + j) * LD] = un[j];
-#pragma unroll
-      for (int j = lay.oU + m; j < S; ++j) col[j * LD] = T(0);
+      for (int j = 0; j < S; ++j) col[j * LD] = w[j];
       a.L[(size_t)b * (N + 1) + t] = l;
     }
     Lsum[tid] = l;
@@ -288,9 +340,17 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
 // Z, U and the gains of a trajectory (4 KB for cartpole at N = 100) are copied
 // into LDS once, coalesced, and every step then reads them as LDS broadcasts:
 // the dependent chain never waits on a global load.
-template <typename T, int MODEL>
+//
+// FUSED: the same wavefront goes on with what the round does next for its four
+// trajectories - argmin over the candidates (DPP butterflies), the accept /
+// regularisation state machine (accept.hpp), the copy of the winning
+// candidate into the nominal and, where the fit continues, the derivative
+// records of the new nominal - so that a round is three launches (records of
+// fresh nominals only at the start, sweep, this) instead of five, and the
+// winner's rows are read back while they are still in L2.
+template <typename T, int MODEL, bool FUSED>
 __global__ __launch_bounds__(kWave) void line_search_lds_kernel(
-    ProblemT<T> P, LineSearchArgs<T> a) {
+    ProblemT<T> P, LineSearchArgs<T> a, AcceptArgs<T> c, T* rec, T* Lout) {
   using D = ModelDims<MODEL>;
   constexpr int n = D::n, m = D::m;
   constexpr int GS = m + m * n;
@@ -319,9 +379,15 @@ __global__ __launch_bounds__(kWave) void line_search_lds_kernel(
   __syncthreads();
 
   const int b = b0 + grp;
-  if (b >= a.B || ai >= a.A) return;
-  if (a.active != nullptr && a.active[b] == 0) return;
-  if (a.bwd_status != nullptr && a.bwd_status[b] != 0) return;
+  const bool exists = b < a.B;
+  const int bc = exists ? b : a.B - 1;
+  const bool attempted =
+      exists && (a.active == nullptr || a.active[bc] != 0);
+  const bool run = attempted && ai < a.A &&
+                   (a.bwd_status == nullptr || a.bwd_status[bc] == 0);
+  if constexpr (!FUSED) {
+    if (!run) return;
+  }
   const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
   T umin[m], umax[m];  // hoisted: a load in the loop sits on the chain
 #pragma unroll
@@ -329,46 +395,165 @@ __global__ __launch_bounds__(kWave) void line_search_lds_kernel(
     umin[r] = bounded ? a.u_min[r] : T(0);
     umax[r] = bounded ? a.u_max[r] : T(0);
   }
-  const T alpha = a.alphas[ai];
   const T* Zs = smem + (size_t)grp * per;
   const T* Us = Zs + (N + 1) * n;
   const T* Gs = Us + N * m;
-  const int idx = b * a.A + ai;
-  T* Zci = a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
-  T* Uci = a.Uc + ((size_t)b * N * a.A + ai) * m;
   const size_t zstep = (size_t)a.A * n, ustep = (size_t)a.A * m;
+  // the state machine's inputs, requested now: their latency hides behind
+  // the rollout
+  AcceptIn<T> acc_in = {};
+  if constexpr (FUSED) {
+    if (attempted && ai == 0) acc_in = accept_load(c, b);
+  }
+  T Jmine = T(0);
+  if (run) {
+    const T alpha = a.alphas[ai];
+    const int idx = b * a.A + ai;
+    T* Zci = a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
+    T* Uci = a.Uc + ((size_t)b * N * a.A + ai) * m;
 
-  T z[n], zn[n], un[m];
+    T z[n], zn[n], un[m];
 #pragma unroll
-  for (int j = 0; j < n; ++j) z[j] = Zs[j];  // Z_new[0] = Z[0]    (ilqr.py:690)
-  T J = T(0);
-  for (int t = 0; t < N; ++t) {
-    const T* zr = Zs + t * n;
-    const T* gr = Gs + t * GS;
+    for (int j = 0; j < n; ++j) z[j] = Zs[j];  // Z_new[0] = Z[0]  (ilqr.py:690)
+    T J = T(0);
+    for (int t = 0; t < N; ++t) {
+      const T* zr = Zs + t * n;
+      const T* gr = Gs + t * GS;
 #pragma unroll
-    for (int r = 0; r < m; ++r) {
-      T du = alpha * gr[r];  // alpha * k[i]                      (ilqr.py:708)
-      T s = T(0);
+      for (int r = 0; r < m; ++r) {
+        T du = alpha * gr[r];  // alpha * k[i]                    (ilqr.py:708)
+        T s = T(0);
 #pragma unroll
-      for (int c = 0; c < n; ++c) s += (z[c] - zr[c]) * gr[m + r * n + c];
-      du = du + s;  // + dz K^T                                   (ilqr.py:710)
-      const T v = Us[t * m + r] + du;
-      un[r] = bounded ? clamp_nan(v, umin[r], umax[r]) : v;
+        for (int c = 0; c < n; ++c) s += (z[c] - zr[c]) * gr[m + r * n + c];
+        du = du + s;  // + dz K^T                                 (ilqr.py:710)
+        const T v = Us[t * m + r] + du;
+        un[r] = bounded ? clamp_nan(v, umin[r], umax[r]) : v;
+      }
+#pragma unroll
+      for (int j = 0; j < n; ++j) Zci[(size_t)t * zstep + j] = z[j];
+#pragma unroll
+      for (int j = 0; j < m; ++j) Uci[(size_t)t * ustep + j] = un[j];
+      const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
+      J += cost_value<T, MODEL>(P, z, un, tr, false);
+      dynamics<T, MODEL, false>(P, z, un, tr, zn, nullptr, nullptr);
+#pragma unroll
+      for (int j = 0; j < n; ++j) z[j] = zn[j];
     }
 #pragma unroll
-    for (int j = 0; j < n; ++j) Zci[(size_t)t * zstep + j] = z[j];
-#pragma unroll
-    for (int j = 0; j < m; ++j) Uci[(size_t)t * ustep + j] = un[j];
-    const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
-    J += cost_value<T, MODEL>(P, z, un, tr, false);
-    dynamics<T, MODEL, false>(P, z, un, tr, zn, nullptr, nullptr);
-#pragma unroll
-    for (int j = 0; j < n; ++j) z[j] = zn[j];
+    for (int j = 0; j < n; ++j) Zci[(size_t)N * zstep + j] = z[j];
+    const T lf =
+        cost_value<T, MODEL>(P, z, nullptr, trig_of<T, MODEL>(z), true);
+    Jmine = J + lf;  // L.sum(0) + l_f                             (ilqr.py:789)
+    a.Jc[idx] = Jmine;
   }
+
+  if constexpr (FUSED) {
+    // ---- argmin with torch's semantics: the first NaN wins, else the first
+    // minimum (ilqr.py:161); every lane of the group gets the same answer
+    constexpr int kNone = 99;
+    const T kInf = (T)__builtin_inff();
+    const int nan_first =
+        n4::group_min((run && Jmine != Jmine) ? ai : kNone);
+    T Jf = (run && Jmine == Jmine) ? Jmine : kInf;
+    {
+      T y = n4::dpp<0x128>(Jf); Jf = y < Jf ? y : Jf;
+      y = n4::dpp<0x12C>(Jf); Jf = y < Jf ? y : Jf;
+      y = n4::dpp<(2 | (3 << 2) | (0 << 4) | (1 << 6))>(Jf); Jf = y < Jf ? y : Jf;
+      y = n4::dpp<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(Jf); Jf = y < Jf ? y : Jf;
+    }
+    const int min_first = n4::group_min((run && Jmine == Jf) ? ai : kNone);
+    const int amin =
+        nan_first != kNone ? nan_first : (min_first != kNone ? min_first : 0);
+    const T J_new = nan_first != kNone ? (T)__builtin_nanf("") : Jf;
+
+    // ---- accept / reject, mu schedule, masks: lane 0 of the group
+    int amin_out = -1, fresh_i = 0;
+    if (attempted && ai == 0) {
+      bool fr;
+      amin_out = accept_decide(c, b, acc_in, amin, J_new, fr);
+      fresh_i = fr ? 1 : 0;
+    }
+    amin_out = __shfl(amin_out, lane & 48);
+    fresh_i = __shfl(fresh_i, lane & 48);
+    if (!__any(amin_out >= 0)) return;
+    // the candidate rows written above are read back below, by this same
+    // wavefront: workgroup scope (an agent-scope fence writes back the XCD's
+    // whole L2 on gfx950 - measured: +40 us per launch)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (amin_out >= 0) {
+      // nominal <- winning candidate; self._K <- K            (ilqr.py:167-169)
+      constexpr RecLayout lay(n, m);
+      constexpr int S = lay.stride;
+      const T* srcz = a.Zc + ((size_t)b * (N + 1) * a.A + amin_out) * n;
+      const T* srcu = a.Uc + ((size_t)b * N * a.A + amin_out) * m;
+      T* Zb = c.Z + (size_t)b * (N + 1) * n;
+      T* Ub = c.U + (size_t)b * N * m;
+      T* rec_b = rec + (size_t)b * (N + 1) * S;
+      T* Ls = smem + (size_t)grp * per;  // the staged nominal is dead: L[t]
+      // rows t = ai, ai + 16, ... of the winner; the next row is requested
+      // before this row's record is evaluated (a rolled loop: the record
+      // code is ~900 instructions, unrolled copies would not fit the I-cache)
+      const T* G = c.gains + (size_t)b * N * GS;
+      T* Ga = c.gains_acc + (size_t)b * N * GS;
+      T zc[n], uc[m];
+      {
+        const int tu = ai < N ? ai : 0;
 #pragma unroll
-  for (int j = 0; j < n; ++j) Zci[(size_t)N * zstep + j] = z[j];
-  const T lf = cost_value<T, MODEL>(P, z, nullptr, trig_of<T, MODEL>(z), true);
-  a.Jc[idx] = J + lf;  // L.sum(0) + l_f                           (ilqr.py:789)
+        for (int j = 0; j < n; ++j) zc[j] = srcz[(size_t)ai * zstep + j];
+#pragma unroll
+        for (int j = 0; j < m; ++j) uc[j] = srcu[(size_t)tu * ustep + j];
+      }
+#pragma unroll 1
+      for (int t = ai; t <= N; t += 16) {
+        T zn_[n], un_[m];
+        {
+          const int t2 = t + 16;
+          const int tz = t2 <= N ? t2 : N, tu = t2 < N ? t2 : 0;
+#pragma unroll
+          for (int j = 0; j < n; ++j) zn_[j] = srcz[(size_t)tz * zstep + j];
+#pragma unroll
+          for (int j = 0; j < m; ++j) un_[j] = srcu[(size_t)tu * ustep + j];
+        }
+        const bool terminal = (t == N);
+        T un[m];
+#pragma unroll
+        for (int j = 0; j < m; ++j) un[j] = terminal ? T(0) : uc[j];
+#pragma unroll
+        for (int j = 0; j < n; ++j) Zb[t * n + j] = zc[j];
+        if (!terminal) {
+#pragma unroll
+          for (int j = 0; j < m; ++j) Ub[t * m + j] = un[j];
+        }
+        if (fresh_i) {
+          // derivative record of the new nominal (the next round's sweep)
+          T w[S];
+          const T l = record_of<T, MODEL>(P, zc, un, terminal, bounded, a.u_min,
+                                         a.u_max, w);
+          T* dst = rec_b + (size_t)t * S;
+#pragma unroll
+          for (int j = 0; j < S; j += 4)
+            store4(dst + j, w[j], w[j + 1], w[j + 2], w[j + 3]);
+          Lout[(size_t)b * (N + 1) + t] = l;
+          Ls[t] = l;
+        }
+#pragma unroll
+        for (int j = 0; j < n; ++j) zc[j] = zn_[j];
+#pragma unroll
+        for (int j = 0; j < m; ++j) uc[j] = un_[j];
+      }
+      group_copy(Ga, G, N * GS, ai);
+      if (fresh_i) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (ai == 0) {
+          T Jacc = T(0);
+          for (int t = 0; t <= N; ++t) Jacc += Ls[t];  // L.sum(), in t order
+          c.J_opt[b] = Jacc;
+          c.fresh[b] = 0;  // its records are up to date
+        }
+      }
+    }
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -399,14 +584,41 @@ static int launch_line_search(const pddp_problem& p, LineSearchArgs<T> a,
                      (size_t)a.N * (D::m + D::m * D::n);
   const size_t lds = 4 * per * sizeof(T);
   if (a.A <= 16 && lds <= 64 * 1024) {  // nominal data staged in LDS
-    hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL>),
-                       dim3((a.B + 3) / 4), dim3(kWave), lds, st, P, a);
+    hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, false>),
+                       dim3((a.B + 3) / 4), dim3(kWave), lds, st, P, a,
+                       AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
     return launch_status();
   }
   const int total = a.B * a.A;
   const int blocks = (total + kWave - 1) / kWave;
   hipLaunchKernelGGL((line_search_kernel<T, MODEL>), dim3(blocks), dim3(kWave),
                      0, st, P, a);
+  return launch_status();
+}
+
+// fused line search + accept + derivative records; PDDP_E_UNSUPPORTED when the
+// LDS kernel does not apply (more than 16 step sizes, nominal data > 64 KB)
+template <typename T>
+struct SearchAcceptArgs {
+  LineSearchArgs<T> ls;
+  AcceptArgs<T> ac;
+  T* rec;
+  T* L;
+};
+template <typename T, int MODEL>
+static int launch_search_accept(const pddp_problem& p, SearchAcceptArgs<T> a,
+                                hipStream_t st) {
+  const ProblemT<T> P = convert_problem<T>(p);
+  using D = ModelDims<MODEL>;
+  const size_t per = (size_t)(a.ls.N + 1) * D::n + (size_t)a.ls.N * D::m +
+                     (size_t)a.ls.N * (D::m + D::m * D::n);
+  const size_t lds = 4 * per * sizeof(T);
+  if (a.ls.A > 16 || lds > 64 * 1024) return PDDP_E_UNSUPPORTED;
+  a.ac.n = D::n;
+  a.ac.m = D::m;
+  hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, true>),
+                     dim3((a.ls.B + 3) / 4), dim3(kWave), lds, st, P, a.ls,
+                     a.ac, a.rec, a.L);
   return launch_status();
 }
 
@@ -472,9 +684,66 @@ static int line_search_impl(const pddp_problem* p, int B, int N, int A,
   PDDP_DISPATCH_MODEL(launch_line_search, T, p, a, (hipStream_t)stream)
 }
 
+template <typename T>
+static int search_accept_impl(const pddp_problem* p, int B, int N, int A, T* Z,
+                              T* U, const T* gains, const T* alphas,
+                              const T* u_min, const T* u_max, uint8_t* active,
+                              const int32_t* bwd_status, T* Zc, T* Uc, T* Jc,
+                              double tol, double max_reg, int n_iterations,
+                              T* gains_acc, T* J_opt, double* mu,
+                              double* delta, int32_t* state, int32_t* iter,
+                              uint8_t* fresh, int32_t* n_live, T* rec, T* L,
+                              void* stream) {
+  if (int rc = check_problem(p)) return rc;
+  if (B <= 0 || N <= 0 || A <= 0 || !Z || !U || !gains || !alphas || !active ||
+      !bwd_status || !Zc || !Uc || !Jc || !gains_acc || !J_opt || !mu ||
+      !delta || !state || !iter || !fresh || !rec || !L)
+    return PDDP_E_BADARG;
+  SearchAcceptArgs<T> a;
+  a.ls = LineSearchArgs<T>{B, N, A, Z, U, gains, alphas, u_min, u_max, active,
+                           bwd_status, Zc, Uc, Jc};
+  a.ac = AcceptArgs<T>{B, N, 0, 0, A, Zc, Uc, Jc, gains, bwd_status, tol,
+                       max_reg, n_iterations, Z, U, gains_acc, J_opt, mu, delta,
+                       state, iter, active, fresh, n_live};
+  a.rec = rec;
+  a.L = L;
+  PDDP_DISPATCH_MODEL(launch_search_accept, T, p, a, (hipStream_t)stream)
+}
+
 }  // namespace pddp
 
 extern "C" {
+
+int pddp_search_accept_f32(const pddp_problem* p, int B, int N, int A, float* Z,
+                           float* U, const float* gains, const float* alphas,
+                           const float* u_min, const float* u_max,
+                           uint8_t* active, const int32_t* bwd_status,
+                           float* Zc, float* Uc, float* Jc, double tol,
+                           double max_reg, int n_iterations, float* gains_acc,
+                           float* J_opt, double* mu, double* delta,
+                           int32_t* state, int32_t* iter, uint8_t* fresh,
+                           int32_t* n_live, float* rec, float* L,
+                           void* stream) {
+  return pddp::search_accept_impl<float>(
+      p, B, N, A, Z, U, gains, alphas, u_min, u_max, active, bwd_status, Zc, Uc,
+      Jc, tol, max_reg, n_iterations, gains_acc, J_opt, mu, delta, state, iter,
+      fresh, n_live, rec, L, stream);
+}
+int pddp_search_accept_f64(const pddp_problem* p, int B, int N, int A,
+                           double* Z, double* U, const double* gains,
+                           const double* alphas, const double* u_min,
+                           const double* u_max, uint8_t* active,
+                           const int32_t* bwd_status, double* Zc, double* Uc,
+                           double* Jc, double tol, double max_reg,
+                           int n_iterations, double* gains_acc, double* J_opt,
+                           double* mu, double* delta, int32_t* state,
+                           int32_t* iter, uint8_t* fresh, int32_t* n_live,
+                           double* rec, double* L, void* stream) {
+  return pddp::search_accept_impl<double>(
+      p, B, N, A, Z, U, gains, alphas, u_min, u_max, active, bwd_status, Zc, Uc,
+      Jc, tol, max_reg, n_iterations, gains_acc, J_opt, mu, delta, state, iter,
+      fresh, n_live, rec, L, stream);
+}
 
 int pddp_nominal_rollout_f32(const pddp_problem* p, int B, int N,
                              const float* z0, const float* U,

@@ -801,3 +801,54 @@ def test_graph_replay_equals_eager_rounds():
         out.append((Z.clone(), U.clone(), st.clone()))
     for a, b in zip(out[0], out[1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("problem", ["cartpole", "pendulum", "double_cartpole"])
+def test_fused_round_equals_separate_kernels(problem, dtype):
+    """pddp_search_accept_* (line search + accept + derivative records of the
+    accepted nominals in one launch) against the three separate launches, round
+    by round from the same state: decisions, masks, nominals and gains are
+    bit-identical; the derivative records agree to rounding (the same code
+    inlined into two kernels is contracted into FMAs differently)."""
+    B, N = 37, 33
+    s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N, seed=3)
+    s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    names = ("Z", "U", "rec", "L", "J_opt", "mu", "delta", "state", "iter",
+             "active", "fresh", "gains", "gains_acc", "Jc", "Zc", "Uc",
+             "bwd_status", "n_live")
+    exact = ("Z", "U", "mu", "delta", "state", "iter", "active", "gains_acc",
+             "Jc", "bwd_status", "n_live")
+    tol = 1e-5 if dtype == "f32" else 1e-12
+    accepted = 0
+    for r in range(12):
+        pre = {k: getattr(s, k).clone() for k in names}
+        due = s._derivs_due
+        s._fused = None
+        s.round(n_iterations=8)
+        assert s._fused is True
+        fused = {k: getattr(s, k).clone() for k in names}
+        for k in names:  # rewind, run the separate launches
+            getattr(s, k).copy_(pre[k])
+        s._derivs_due = due
+        s._fused = False
+        s.round(n_iterations=8)
+        for k in exact:
+            x, y = fused[k], getattr(s, k)
+            assert torch.equal(torch.nan_to_num(x.double(), nan=1.5),
+                               torch.nan_to_num(y.double(), nan=1.5)), (r, k)
+        # records and J_opt = L.sum(): the fused launch wrote them for the
+        # accepted nominals, the separate path does at its next round start
+        s.derivs(mask=s.fresh)
+        live = s.active.bool()
+        accepted += int(s.fresh.sum())
+        for k in ("rec", "L", "J_opt"):
+            x, y = fused[k][live].double(), getattr(s, k)[live].double()
+            assert float((x - y).abs().max()) <= tol * float(
+                y.abs().max().clamp_min(1.0)), (r, k)
+        assert int(fused["fresh"].sum()) == 0  # nothing left for derivs
+        # go on from the fused state
+        for k in names:
+            getattr(s, k).copy_(fused[k])
+        s._derivs_due = False
+    assert accepted > 0
