@@ -219,9 +219,9 @@ int pddp_accept_f64(int B, int N, int n, int m, int A, const double* Zc,
                     int32_t* iter, uint8_t* active, uint8_t* fresh,
                     int32_t* n_live, void* stream);
 
-/* ---- one launch for the rest of a round: pddp_line_search + pddp_accept +
- * pddp_derivs (of the trajectories whose nominal changed and whose fit goes
- * on).  Same arguments and semantics as the three calls; Z, U, active are
+/* ---- one launch for the rest of a round: the line search, the accept step
+ * and the derivative records of the trajectories whose nominal changed and
+ * whose fit goes on.  Same arguments and semantics as the three calls; Z, U, active are
  * in/out; `fresh` is cleared for the trajectories whose records were written
  * here.  Sample problems with at most 16 step sizes; returns
  * PDDP_E_UNSUPPORTED otherwise (make the three calls then). */
