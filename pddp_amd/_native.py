@@ -72,6 +72,7 @@ _SIGS = {
                           [_P] * 11,
     "pddp_accept": [c_int] * 5 + [_P] * 5 + [c_double, c_double, c_int] +
                    [_P] * 12,
+    "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
     "pddp_event_create": [_P],
     "pddp_event_record": [_P, _P],
     "pddp_event_elapsed_ms": [_P, _P, _P],

@@ -138,7 +138,60 @@ class BayesianMLP(torch.nn.Module):
         return sum(d.regularization(l.weight, l.bias)
                    for d, l in zip(self.drops, nxt))
 
+    # -- fused inference kernel (csrc/bnn_mlp.hip) ------------------------------
+    _NATIVE_H = (64, 128, 200)
+
+    def _native_ok(self, x, resample):
+        if resample or not x.is_cuda or x.dtype != torch.float32:
+            return False
+        if x.dim() < 2 or len(self.hidden) != 2:
+            return False
+        if torch.is_grad_enabled() and (
+                x.requires_grad or self.out.weight.requires_grad):
+            return False  # the derivative rollout differentiates through us
+        h = self.hidden[0].out_features
+        return (h in self._NATIVE_H and self.hidden[1].out_features == h
+                and self.hidden[1].in_features == h
+                and self.hidden[0].in_features <= 15
+                and self.out.out_features <= 16
+                and getattr(self, "use_native", True))
+
+    def _mask_t(self, k, P, like):
+        """Layer k's mask [P, H] as the kernel wants it: transposed,
+        contiguous.  Same draw as ConcreteDropout.forward on first use;
+        cached until the noise or the dropout parameters change."""
+        drop = self.drops[k]
+        H = self.hidden[k].out_features
+        if drop.noise is None or drop.noise.shape != (P, H):
+            drop.noise = drop._draw(like.new_empty(P, H)).detach()
+        key = (id(drop.noise), drop.noise._version, drop.logit_p._version,
+               drop.temperature._version)
+        cache = self.__dict__.setdefault("_mask_cache", {})
+        if cache.get(k, (None, None))[0] != key:
+            cache[k] = (key, drop._mask(drop.noise).detach().t().contiguous())
+        return cache[k][1]
+
+    def _forward_native(self, x):
+        from .. import _native
+        P, in_dim = x.shape[-2], x.shape[-1]
+        H, out_dim = self.hidden[0].out_features, self.out.out_features
+        xc = x.detach().contiguous()
+        R = xc.numel() // in_dim
+        y = torch.empty(*x.shape[:-1], out_dim, dtype=x.dtype, device=x.device)
+        m1, m2 = self._mask_t(0, P, xc), self._mask_t(1, P, xc)
+        c = lambda t: t.detach().contiguous()
+        p = _native.ptr
+        rc = _native.lib().pddp_bnn_mlp_f32(
+            R, P, in_dim, H, out_dim, p(xc), p(c(self.hidden[0].weight)),
+            p(c(self.hidden[0].bias)), p(m1), p(c(self.hidden[1].weight)),
+            p(c(self.hidden[1].bias)), p(m2), p(c(self.out.weight)),
+            p(c(self.out.bias)), p(y), _native.stream_handle(x.device))
+        _native.check(rc, "pddp_bnn_mlp_f32")
+        return y
+
     def forward(self, x, resample=False):
+        if self._native_ok(x, resample):
+            return self._forward_native(x)
         for lin, drop in zip(self.hidden, self.drops):
             x = torch.relu(drop(lin(x), resample=resample))
         return self.out(x)

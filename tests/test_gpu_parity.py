@@ -852,3 +852,33 @@ def test_fused_round_equals_separate_kernels(problem, dtype):
             getattr(s, k).copy_(fused[k])
         s._derivs_due = False
     assert accepted > 0
+
+
+@pytest.mark.parametrize("H", [64, 128, 200])
+@pytest.mark.parametrize("rows,P,in_dim,out_dim", [(1, 100, 6, 8), (37, 100, 6, 8),
+                                                   (5, 7, 4, 4), (64, 33, 15, 16),
+                                                   (301, 100, 6, 8)])
+def test_bnn_mlp_kernel_vs_torch(rows, P, in_dim, out_dim, H):
+    """pddp_bnn_mlp_f32 (fused fc -> mask -> ReLU x2 -> fc on the f32 matrix
+    cores, csrc/bnn_mlp.hip) against the same network evaluated layer by layer
+    in float64 (modules.py:774-864): ragged row counts, particle counts that do
+    not divide the 32-row tile, the widest supported input / output."""
+    from pddp_amd.models.bnn import BayesianMLP
+    torch.manual_seed(H + rows)
+    net = BayesianMLP(in_dim, out_dim, [H, H]).cuda().eval()
+    x = torch.randn(rows, P, in_dim, device="cuda")
+    with torch.no_grad():
+        assert net._native_ok(x, False)
+        y = net(x)                       # native (draws the masks)
+        net.use_native = False
+        y32 = net(x)                     # library GEMMs, same masks
+        net64 = BayesianMLP(in_dim, out_dim, [H, H]).cuda().double().eval()
+        net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
+        for d64, d in zip(net64.drops, net.drops):
+            d64.noise = d.noise.double()
+        y64 = net64(x.double())
+    scale = float(y64.abs().max())
+    e_native = float((y.double() - y64).abs().max()) / scale
+    e_torch = float((y32.double() - y64).abs().max()) / scale
+    assert e_native < 2e-6, (e_native, e_torch)
+    assert e_native < 4 * e_torch + 1e-7, (e_native, e_torch)
