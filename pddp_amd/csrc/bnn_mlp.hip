@@ -40,10 +40,11 @@ struct BnnMlpArgs {
   const float* X;
   const float* W1;
   const float* b1;
-  const float* MT1;  // [H][P] mask of layer 1, transposed; nullable (= 1)
+  const float* MT1;  // layer-1 mask, parity-split [P][2][H/2]: M1[p][2 s + h]
+                     // at [p][h][s] - the order a producer lane consumes it
   const float* W2;
   const float* b2;
-  const float* MT2;
+  const float* MT2;  // layer-2 mask [P][H] (as the framework holds it)
   const float* W3;
   const float* b3;
   float* Y;
@@ -51,7 +52,7 @@ struct BnnMlpArgs {
 
 constexpr int kMlpThreads = 512;
 constexpr int kMlpTile = 32;     // rows per tile
-constexpr int kMlpW1Stride = 16; // W1 row (<= 15 inputs) | b1, in LDS
+constexpr int kMlpW1Max = 16;    // W1 row (<= 15 inputs) | b1, in LDS
 constexpr int kMlpMaxOut = 16;
 
 // unit index held by accumulator register r of lane-half h in block j
@@ -59,14 +60,25 @@ PDDP_DEV int unit_of(int j, int r, int h) {
   return 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
 
-template <int H>
+template <int H, int W1S>
+constexpr size_t bnn_mlp_lds_floats() {
+  return 2 * (H / 2) * 64 + H * W1S + 2 * ((H + 31) / 32) * kMlpMaxOut * 32;
+}
+
+// kMlpW1Stride: LDS stride of a W1 row | b1 (8: in_dim <= 7, 16: <= 15) - the
+// producer wavefront's work is proportional to it
+template <int H, int kMlpW1Stride>
 __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   static_assert(H % 8 == 0 && H <= 224, "H: multiple of 8, at most 224");
   constexpr int KS = H / 2;          // MFMA steps of layer 2
-  constexpr int NB = (H + 31) / 32;  // 32-unit blocks = working wavefronts
-  __shared__ __attribute__((aligned(16))) float h1t[KS * 64];
-  __shared__ __attribute__((aligned(16))) float w1b[H * kMlpW1Stride];
-  __shared__ float part[NB * kMlpMaxOut * 32];
+  constexpr int NB = (H + 31) / 32;  // 32-unit blocks = consumer wavefronts
+  static_assert(NB < kMlpThreads / 64, "one wavefront is the producer");
+  // LDS (dynamic): two h1^T buffers, W1 | b1, two buffers of partial outputs
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* h1t = lds;                       // [2][KS * 64]
+  float* w1b = h1t + 2 * KS * 64;         // [H][16]
+  float* part = w1b + H * kMlpW1Stride;   // [2][NB * 16 * 32]
+  constexpr int kH1 = KS * 64, kPart = NB * kMlpMaxOut * 32;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -78,35 +90,24 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     w1b[o] = c < IN ? a.W1[k * IN + c]
                     : (c == kMlpW1Stride - 1 ? a.b1[k] : 0.f);
   }
-
-  // ---- this wavefront's share of W2, W3, b2: registers for the whole kernel
-  const int j = wave;  // block of layer-2 units (wavefronts >= NB only help
-                       // with layers 1 and the output)
-  float a2[KS];
-  float a3[16], b2r[16];
-  {
-    const int u = 32 * j + li;  // A operand: row i = li is unit u
-#pragma unroll
-    for (int s = 0; s < KS; ++s)
-      a2[s] = (j < NB && u < H) ? a.W2[(size_t)u * H + 2 * s + lh] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = unit_of(j, r, lh);
-      const bool ok = j < NB && n < H;
-      // layer 3, step r: A[i = li = output][k-slot lh] = W3[li][n]
-      a3[r] = (ok && li < OUT) ? a.W3[(size_t)li * H + n] : 0.f;
-      b2r[r] = ok ? a.b2[n] : 0.f;
-    }
-  }
   __syncthreads();
 
   const int ntiles = (R + kMlpTile - 1) / kMlpTile;
-  const int row_a = tid & 31, grp_a = tid >> 5;  // phase A: row, unit group
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int row0 = tile * kMlpTile;
-    // ---- A: layer 1 for 32 rows x H units, transposed into LDS
-    {
-      const int row = row0 + row_a;
+  // tiles of this workgroup: blockIdx.x + i * gridDim.x, i < my
+  const int my = blockIdx.x < ntiles
+                     ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+
+  if (wave >= NB) {
+    // =====================================================================
+    // producer wavefront(s): layer 1 of tile i + 1 into h1t[(i + 1) & 1] and
+    // the output rows of tile i - 1 from part[(i - 1) & 1], while the
+    // consumers run tile i on the matrix cores.  Lane (row li, half lh)
+    // computes the units k = 2 s + lh, four s at a time (one ds_write_b128).
+    // =====================================================================
+    const bool first_prod = wave == NB;  // extra wavefronts just keep step
+    auto layer1 = [&](int i) {           // tile index in this workgroup's list
+      if (!first_prod || i >= my) return;
+      const int row = (blockIdx.x + i * gridDim.x) * kMlpTile + li;
       const bool live = row < R;
       const int p = live ? row % P : 0;
       float x[kMlpW1Stride];
@@ -114,77 +115,142 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       for (int c = 0; c < kMlpW1Stride; ++c)
         x[c] = (live && c < IN) ? a.X[(size_t)row * IN + c] : 0.f;
       x[kMlpW1Stride - 1] = 1.f;  // multiplies the bias slot
-      for (int k = grp_a; k < H; k += 16) {
-        const f32x4* wr = reinterpret_cast<const f32x4*>(w1b + k * kMlpW1Stride);
-        float acc = 0.f;
+      f32x4* dst = reinterpret_cast<f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
+      // this lane's KS mask values, contiguous in the parity-split layout:
+      // all requested up front (KS / 4 independent 16-B loads)
+      f32x4 mk[KS / 4];
+      {
+        const f32x4* msrc =
+            reinterpret_cast<const f32x4*>(a.MT1 + ((size_t)p * 2 + lh) * KS);
 #pragma unroll
-        for (int c4 = kMlpW1Stride / 4 - 1; c4 >= 0; --c4) {
-          const f32x4 w = wr[c4];
-          // bias first (slot 15), then inputs in ascending order within a
-          // quad: the accumulation order of a plain dot product is not
-          // reproduced bit for bit (torch's addmm order is unspecified too)
-          acc = __builtin_fmaf(x[4 * c4 + 3], w[3], acc);
-          acc = __builtin_fmaf(x[4 * c4 + 2], w[2], acc);
-          acc = __builtin_fmaf(x[4 * c4 + 1], w[1], acc);
-          acc = __builtin_fmaf(x[4 * c4 + 0], w[0], acc);
-        }
-        const float m = a.MT1 != nullptr ? a.MT1[(size_t)k * P + p] : 1.f;
-        const float v = fmaxf(acc * m, 0.f);
-        const int s = k >> 1, h = k & 1;
-        h1t[(((s >> 2) * 32 + row_a) * 2 + h) * 4 + (s & 3)] = v;
+        for (int q = 0; q < KS / 4; ++q) mk[q] = msrc[q];
       }
-    }
-    __syncthreads();
-
-    // ---- B: layer 2 on the matrix cores, layer 3 on its accumulators
-    if (j < NB) {
-      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      const f32x4* bsrc = reinterpret_cast<const f32x4*>(h1t) + (li * 2 + lh);
 #pragma unroll
       for (int q = 0; q < KS / 4; ++q) {
-        const f32x4 b4 = bsrc[q * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 0], b4[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 1], b4[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 2], b4[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 3], b4[3], acc, 0, 0, 0);
-      }
-      // accumulator register r of this lane: unit unit_of(j, r, lh), data
-      // row li - bias, mask, ReLU in place
-      const int row = row0 + li;
-      const int p = row < R ? row % P : 0;
-      f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = unit_of(j, r, lh);
-        const float m = (a.MT2 != nullptr && n < H) ? a.MT2[(size_t)n * P + p] : 1.f;
-        const float h2 = fmaxf((acc[r] + b2r[r]) * m, 0.f);
-        out = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[r], h2, out, 0, 0, 0);
-      }
-      // out: register r of lane-half lh = output unit (r & 3) + 8 (r >> 2)
-      // + 4 lh of data row li (partial sum over this block's units)
+        for (int e = 0; e < 4; ++e) {
+          const int k = 2 * (4 * q + e) + lh;
+          const f32x4* wr =
+              reinterpret_cast<const f32x4*>(w1b + k * kMlpW1Stride);
+          float acc = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int o = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (o < OUT) part[(j * kMlpMaxOut + o) * 32 + li] = out[r];
+          for (int c4 = kMlpW1Stride / 4 - 1; c4 >= 0; --c4) {
+            const f32x4 w = wr[c4];
+            // bias first (last slot), then the inputs: not the accumulation
+            // order of a library GEMM bit for bit (that order is unspecified)
+            acc = __builtin_fmaf(x[4 * c4 + 3], w[3], acc);
+            acc = __builtin_fmaf(x[4 * c4 + 2], w[2], acc);
+            acc = __builtin_fmaf(x[4 * c4 + 1], w[1], acc);
+            acc = __builtin_fmaf(x[4 * c4 + 0], w[0], acc);
+          }
+          v[e] = fmaxf(acc * mk[q][e], 0.f);
+        }
+        dst[q * 64] = v;
       }
+    };
+    auto store_out = [&](int i) {  // sum the blocks' partial outputs, + b3
+      if (!first_prod || i < 0) return;
+      const int row0 = (blockIdx.x + i * gridDim.x) * kMlpTile;
+      const float* pr = part + (i & 1) * kPart;
+      for (int t = lane; t < 32 * OUT; t += 64) {
+        const int rr = row0 + (t & 31), o = t >> 5;
+        float y = a.b3[o];
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj)
+          y += pr[(jj * kMlpMaxOut + o) * 32 + (t & 31)];
+        if (rr < R) a.Y[(size_t)rr * OUT + o] = y;
+      }
+    };
+    layer1(0);
+    __syncthreads();
+    for (int i = 0; i < my; ++i) {
+      store_out(i - 1);
+      layer1(i + 1);
+      __syncthreads();
+    }
+    store_out(my - 1);
+    return;
+  }
+
+  // =======================================================================
+  // consumer wavefront j: its 32 units of layer 2 - rows of W2 in registers
+  // for the whole kernel - and its share of layer 3
+  // =======================================================================
+  const int j = wave;
+  float a2[KS];
+  float a3[16], b2r[16];
+  {
+    const int u = 32 * j + li;  // A operand: row i = li is unit u
+    const bool uok = u < H;
+    const float* w2row = a.W2 + (size_t)(uok ? u : 0) * H + lh;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float v = w2row[2 * s];  // (clamped address + select: no branch
+      a2[s] = uok ? v : 0.f;         // per element)
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = unit_of(j, r, lh);
+      const int nc = n < H ? n : 0;
+      // layer 3, step r: A[i = li = output][k-slot lh] = W3[li][n]
+      const float w3 = a.W3[(size_t)(li < OUT ? li : 0) * H + nc];
+      const float bb = a.b2[nc];
+      a3[r] = (n < H && li < OUT) ? w3 : 0.f;
+      b2r[r] = n < H ? bb : 0.f;
+    }
+  }
+  __syncthreads();  // pairs with the producer's first barrier: h1t[0] ready
+
+  for (int i = 0; i < my; ++i) {
+    const int row0 = (blockIdx.x + i * gridDim.x) * kMlpTile;
+    // mask of layer 2, requested before the MFMAs so that its latency is
+    // theirs: registers 4 g .. 4 g + 3 are the units 32 j + 8 g + 4 lh +
+    // (0..3), one 16-B load of the mask row each (clamped inside the row for
+    // the padded units of the last block, whose weights are zero)
+    const int row = row0 + li;
+    const int p = row < R ? row % P : 0;
+    f32x4 m2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n0 = 32 * j + 8 * g + 4 * lh;
+      m2[g] = *reinterpret_cast<const f32x4*>(
+          a.MT2 + (size_t)p * H + (n0 + 4 <= H ? n0 : 0));
+    }
+    // ---- layer 2 on the matrix cores
+    f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const f32x4* bsrc =
+        reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
+#pragma unroll
+    for (int q = 0; q < KS / 4; ++q) {
+      const f32x4 b4 = bsrc[q * 64];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 0], b4[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 1], b4[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 2], b4[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 3], b4[3], acc, 0, 0, 0);
+    }
+    // accumulator register r of this lane: unit unit_of(j, r, lh), data row
+    // li - bias, mask, ReLU in place; layer 3 straight from the accumulators
+    f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float h2 = fmaxf((acc[r] + b2r[r]) * m2[r >> 2][r & 3], 0.f);
+      out = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[r], h2, out, 0, 0, 0);
+    }
+    // out: register r of lane-half lh = output unit (r & 3) + 8 (r >> 2)
+    // + 4 lh of data row li (partial sum over this block's units)
+    float* pw = part + (i & 1) * kPart;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (o < OUT) pw[(j * kMlpMaxOut + o) * 32 + li] = out[r];
     }
     __syncthreads();
-
-    // ---- C: sum the blocks' partial outputs, add b3, store
-    if (tid < 32 * OUT) {
-      const int row = row0 + (tid & 31), o = tid >> 5;
-      float y = a.b3[o];
-#pragma unroll
-      for (int jj = 0; jj < NB; ++jj) y += part[(jj * kMlpMaxOut + o) * 32 + (tid & 31)];
-      if (row < R) a.Y[(size_t)row * OUT + o] = y;
-    }
-    // (the next tile's phase A touches only h1t, its phase B waits at the
-    // barrier above before writing `part` again)
   }
 }
 
-template <int H>
-static int launch_bnn_mlp(const BnnMlpArgs& a, hipStream_t st) {
+template <int H, int W1S>
+static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   static int cus = 0;  // queried once: hipGetDeviceProperties costs ms
   if (cus == 0) {
     int dev = 0;
@@ -196,9 +262,24 @@ static int launch_bnn_mlp(const BnnMlpArgs& a, hipStream_t st) {
   }
   const int ntiles = (a.R + kMlpTile - 1) / kMlpTile;
   const int grid = ntiles < cus ? ntiles : cus;  // persistent: one per CU
-  hipLaunchKernelGGL((bnn_mlp_kernel<H>), dim3(grid), dim3(kMlpThreads), 0, st,
-                     a);
+  constexpr size_t lds = sizeof(float) * bnn_mlp_lds_floats<H, W1S>();
+  static bool attr_set = false;
+  if (!attr_set) {  // more than 64 KB of dynamic LDS needs the opt-in
+    const hipError_t e = hipFuncSetAttribute(
+        (const void*)bnn_mlp_kernel<H, W1S>,
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((bnn_mlp_kernel<H, W1S>), dim3(grid), dim3(kMlpThreads), lds,
+                     st, a);
   return launch_status();
+}
+
+template <int H>
+static int launch_bnn_mlp(const BnnMlpArgs& a, hipStream_t st) {
+  return a.in_dim < 8 ? launch_bnn_mlp_w<H, 8>(a, st)
+                      : launch_bnn_mlp_w<H, 16>(a, st);
 }
 
 }  // namespace pddp
@@ -211,9 +292,9 @@ int pddp_bnn_mlp_f32(int R, int P, int in_dim, int H, int out_dim,
                      const float* MT2, const float* W3, const float* b3,
                      float* Y, void* stream) {
   if (R <= 0 || P <= 0 || in_dim <= 0 || H <= 0 || out_dim <= 0 || !X || !W1 ||
-      !b1 || !W2 || !b2 || !W3 || !b3 || !Y)
+      !b1 || !MT1 || !W2 || !b2 || !MT2 || !W3 || !b3 || !Y)
     return PDDP_E_BADARG;
-  if (in_dim >= pddp::kMlpW1Stride || out_dim > pddp::kMlpMaxOut)
+  if (in_dim >= pddp::kMlpW1Max || out_dim > pddp::kMlpMaxOut)
     return PDDP_E_UNSUPPORTED;
   const pddp::BnnMlpArgs a{R, P, in_dim, H, out_dim, X, W1, b1, MT1, W2,
                            b2, MT2, W3, b3, Y};
