@@ -1,20 +1,40 @@
 """Angle -> (sin, cos) augmentation of state means (reference:
 pddp/utils/angular.py:251-354).  Output order
 [non_angular..., sin a1, cos a1, sin a2, cos a2, ...]."""
+import functools
+
 import torch
 
 from .encoding import (StateEncoding, decode_covar, decode_mean, decode_var,
                        encode)
 
 
+@functools.lru_cache(maxsize=None)
+def _index_tensor(indices, device):
+    return torch.tensor(indices, dtype=torch.long, device=device)
+
+
+def _idx(indices, like):
+    """The index list as a LongTensor on `like`'s device, built once: indexing
+    a CUDA tensor with a python list or a CPU tensor costs a host-to-device
+    copy per call, and these run once per rollout step."""
+    if torch.is_tensor(indices):
+        indices = indices.tolist()
+    return _index_tensor(tuple(int(i) for i in indices), like.device)
+
+
+def _take(x, indices, dim=-1):
+    return x.index_select(dim, _idx(indices, x))
+
+
 def augment_state(x, angular_indices, non_angular_indices):
     """angular.py:251-286"""
     if len(angular_indices) == 0:
         return x
-    ang = x[..., angular_indices]
+    ang = _take(x, angular_indices)
     sc = torch.stack([ang.sin(), ang.cos()], dim=-1).reshape(
         *x.shape[:-1], 2 * len(angular_indices))
-    return torch.cat([x[..., non_angular_indices], sc], dim=-1)
+    return torch.cat([_take(x, non_angular_indices), sc], dim=-1)
 
 
 def _angle_moments(mi, vi):
@@ -40,8 +60,8 @@ def augment_moments(mean, covar, angular_indices, non_angular_indices):
     na_, nn = len(ai), len(ni)
     if na_ == 0:
         return mean, covar
-    mi = mean[..., ai]
-    ci = covar[..., ai, :][..., :, ai]
+    mi = _take(mean, ai)
+    ci = _take(_take(covar, ai, -2), ai, -1)
     vi = torch.diagonal(ci, dim1=-2, dim2=-1)
     Ma = _angle_moments(mi, vi)
     lq = -0.5 * (vi.unsqueeze(-1) + vi.unsqueeze(-2))
@@ -58,12 +78,13 @@ def augment_moments(mean, covar, angular_indices, non_angular_indices):
     Va[..., 1::2, 1::2] = cc
     Va[..., 0::2, 1::2] = sc
     Va[..., 1::2, 0::2] = sc.transpose(-1, -2)
-    M = torch.cat([mean[..., ni], Ma], dim=-1)
+    M = torch.cat([_take(mean, ni), Ma], dim=-1)
     C = mean.new_zeros(*mean.shape[:-1], nn + 2 * na_, nn + 2 * na_)
     C[..., nn:, nn:] = Va
     if nn > 0:
-        C[..., :nn, :nn] = covar[..., ni, :][..., :, ni]
-        cols = covar[..., ni, :][..., :, ai]           # C[na, angle_i]
+        rows_ni = _take(covar, ni, -2)
+        C[..., :nn, :nn] = _take(rows_ni, ni, -1)
+        cols = _take(rows_ni, ai, -1)                  # C[na, angle_i]
         cross = mean.new_zeros(*mean.shape[:-1], nn, 2 * na_)
         cross[..., 0::2] = cols * Ma[..., 1::2].unsqueeze(-2)    # x, sin
         cross[..., 1::2] = -cols * Ma[..., 0::2].unsqueeze(-2)   # x, cos
@@ -77,15 +98,15 @@ def augment_moments_var(mean, var, angular_indices, non_angular_indices):
     ai, ni = list(angular_indices), list(non_angular_indices)
     if len(ai) == 0:
         return mean, var
-    mi, vi = mean[..., ai], var[..., ai]
+    mi, vi = _take(mean, ai), _take(var, ai)
     Ma = _angle_moments(mi, vi)
     q = (-vi).exp()
     u3 = (1.0 - q)                       # q (e^v - 1) cos(0)
     u4 = ((-2.0 * vi).exp() - q) * (2.0 * mi).cos()
     Va = torch.stack([0.5 * (u3 - u4), 0.5 * (u3 + u4)], dim=-1).reshape(
         *mi.shape[:-1], 2 * len(ai))
-    return (torch.cat([mean[..., ni], Ma], dim=-1),
-            torch.cat([var[..., ni], Va], dim=-1))
+    return (torch.cat([_take(mean, ni), Ma], dim=-1),
+            torch.cat([_take(var, ni), Va], dim=-1))
 
 
 def augment_encoded_state(z, angular_indices, non_angular_indices,
@@ -115,8 +136,8 @@ def reduce_state(x_, angular_indices, non_angular_indices):
     if n_non == 0:
         return angles
     x = x_.new_empty(*x_.shape[:-1], n_ang + n_non)
-    x[..., angular_indices] = angles
-    x[..., non_angular_indices] = x_[..., :n_non]
+    x.index_copy_(-1, _idx(angular_indices, x), angles)
+    x.index_copy_(-1, _idx(non_angular_indices, x), x_[..., :n_non])
     return x
 
 

@@ -8,6 +8,8 @@ encodings are host-side helpers here.
 """
 from enum import IntEnum
 
+import functools
+
 import torch
 
 
@@ -50,9 +52,21 @@ def infer_state_size(encoded_state_size, encoding=StateEncoding.DEFAULT):
     raise NotImplementedError("Unknown StateEncoding: {}".format(encoding))
 
 
+@functools.lru_cache(maxsize=None)
+def _triu(D, device):
+    """torch.triu_indices(D, D) on `device`, built once (these helpers run
+    once or twice per rollout step)."""
+    return torch.triu_indices(D, D, device=device)
+
+
+@functools.lru_cache(maxsize=None)
+def _eye(D, dtype, device):
+    return torch.eye(D, dtype=dtype, device=device)
+
+
 def _cholesky_upper(C, jitter=1e-12, max_jitter=10.0):
     """Jittered upper Cholesky, escalating x10 (encoding.py:536-564)."""
-    eye = torch.eye(C.shape[-1], dtype=C.dtype, device=C.device)
+    eye = _eye(C.shape[-1], C.dtype, C.device)
     while True:
         L, info = torch.linalg.cholesky_ex(C + jitter * eye, upper=True)
         if not bool((info != 0).any()):
@@ -91,7 +105,7 @@ def encode(M, C=None, V=None, S=None, encoding=StateEncoding.DEFAULT):
         other = _covar_from(C, V, S).reshape(*M.shape[:-1], D * D)
     elif encoding == StateEncoding.UPPER_TRIANGULAR_CHOLESKY:
         L = _cholesky_upper(_covar_from(C, V, S))
-        iu = torch.triu_indices(D, D, device=M.device)
+        iu = _triu(D, M.device)
         other = L[..., iu[0], iu[1]]
     elif encoding == StateEncoding.VARIANCE_ONLY:
         other = _var_from(C, V, S)
@@ -110,7 +124,7 @@ def _split(Z, encoding, state_size):
 
 def _upper_from_flat(X, D):
     L = X.new_zeros(*X.shape[:-1], D, D)
-    iu = torch.triu_indices(D, D, device=X.device)
+    iu = _triu(D, X.device)
     L[..., iu[0], iu[1]] = X
     return L
 
