@@ -6,11 +6,12 @@ library GEMMs: time per call and achieved TFLOP/s against the f32 matrix peak
 """
 import argparse
 import json
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pddp_amd.models.bnn import BayesianMLP  # noqa: E402
 
 

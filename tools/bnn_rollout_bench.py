@@ -8,12 +8,13 @@ the layer-by-layer library GEMMs.
 """
 import argparse
 import json
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pddp_amd  # noqa: E402
 from pddp_amd.controllers.ilqr import fit_alphas  # noqa: E402
 from pddp_amd.controllers.plugin import TorchProblem  # noqa: E402

@@ -8,7 +8,7 @@ Round 1, bench workload (B=4096, N=100, 40 iterations): 700 of 4 096 000
 wave-steps (0.017 %).  The counters cost ~1 ms per sweep: never ship this build.
 """
 import ctypes, json, subprocess, sys, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.argv = ["bench.py", "--steps", "40", "--warmup", "0", "--no-cpu-baseline"]
 from pddp_amd import _native
 lib = _native.lib()

@@ -3,11 +3,12 @@ derivative rollout - what the BoxQP / Cholesky twins cost on top of the bare
 Riccati recursion.  python tools/sweep_ablation.py [--batch 4096]"""
 import argparse
 import json
+import os
 import sys
 
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pddp_amd  # noqa: E402
 from pddp_amd.controllers.solver import ILQRSolver  # noqa: E402
 from pddp_amd.examples import cartpole as cp  # noqa: E402
