@@ -280,6 +280,53 @@ int pddp_bnn_mlp_f32(int R, int P, int in_dim, int H, int out_dim,
                      const float* M2, const float* W3, const float* b3,
                      float* Y, void* stream);
 
+/* ---- one time step of the moment-matched line-search rollout under a BNN
+ * dynamics model, everything but the network: ilqr.py:677-723 (_control_law),
+ * :764-791 (_trajectory_cost), modules.py:287-386 (BNNDynamicsModel.forward:
+ * particles in, particle moments out), encoding.py:99-141 (encode, DEFAULT) and
+ * angular.py:47-84,161-248 (angle augmentation of the moments for the cost).
+ * Called N + 1 times (t = 0 .. N) with the network (above) on F in between:
+ *   t > 0:  Xp += net_out[:, :D] * dX_std + dX_mean   (the particle cloud is
+ *           carried: `infer_noise_variables` re-whitens and re-colours with the
+ *           same factor), z_t = encode(mean, covariance of Xp); t = 0: z_0 =
+ *           Z[b][0], Xp as given (sampled by the caller, modules.py:312-330);
+ *   Zc[b][t][a] = z_t;  t < N: Uc[b][t][a] = u_t = clamp(U + alpha k + K (z_t -
+ *           Z)), J += l(z_t, u_t), F = network input rows of the particles;
+ *   t = N:  J += l_f(z_N), Jc = J.
+ * Candidate c = b * A + a; particle rows c * P + p.  DEFAULT encoding
+ * (n = D + D (D + 1) / 2), D <= 8, at most two angular states, m <= 2,
+ * P <= 128; the cost is a QR cost on the augmented moments. */
+typedef struct pddp_bnn_step {
+  int32_t B, A, P, D, m, N, t;
+  int32_t n_ang, ang[2], n_non, non[8]; /* angular / non-angular state indices */
+  int32_t in_dim, out_dim;              /* network: n_non + 2 n_ang + m, >= D */
+  const float* Z;        /* [B][N+1][n] nominal */
+  const float* U;        /* [B][N][m] */
+  const float* gains;    /* [B][N][m + m n] */
+  const float* alphas;   /* [A] */
+  const float* u_min;    /* [m], nullable with u_max */
+  const float* u_max;
+  const uint8_t* active;       /* [B] nullable */
+  const int32_t* bwd_status;   /* [B] nullable: non-zero -> skipped */
+  const float* Q;        /* [na][na], na = n_non + 2 n_ang */
+  const float* Q_term;
+  const float* R;        /* [m][m] */
+  const float* x_goal;   /* [na] */
+  const float* u_goal;   /* [m] */
+  const float* X_mean;   /* [in_dim] input normalisation (modules.py:181-186) */
+  const float* X_std_inv;
+  const float* dX_mean;  /* [D] output de-normalisation (modules.py:262) */
+  const float* dX_std;
+  const float* net_out;  /* [B A P][out_dim]: the network's output of step t-1 */
+  float* Xp;             /* [B A][P][D] particles, in / out */
+  float* F;              /* [B A P][in_dim] network input, out (t < N) */
+  float* Zc;             /* [B][N+1][A][n] out */
+  float* Uc;             /* [B][N][A][m] out */
+  float* J;              /* [B A] running cost, in / out */
+  float* Jc;             /* [B A] out at t = N */
+} pddp_bnn_step;
+int pddp_bnn_moment_step_f32(const pddp_bnn_step* step, void* stream);
+
 /* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only
  * sees torch's current stream). Host functions. */
 int pddp_event_create(void** ev);

@@ -73,6 +73,7 @@ _SIGS = {
     "pddp_accept": [c_int] * 5 + [_P] * 5 + [c_double, c_double, c_int] +
                    [_P] * 12,
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
+    "pddp_bnn_moment_step_f32": [_P, _P],
     "pddp_event_create": [_P],
     "pddp_event_record": [_P, _P],
     "pddp_event_elapsed_ms": [_P, _P, _P],
@@ -149,6 +150,21 @@ def check(rc, what):
 def call(name, dtype, *args):
     fn = getattr(lib(), "%s_%s" % (name, suffix(dtype)))
     check(fn(*args), name)
+
+
+class BnnStep(ctypes.Structure):
+    """pddp_bnn_step of include/pddp_hip.h."""
+    _fields_ = (
+        [(k, ctypes.c_int32) for k in ("B", "A", "P", "D", "m", "N", "t",
+                                       "n_ang")] +
+        [("ang", ctypes.c_int32 * 2), ("n_non", ctypes.c_int32),
+         ("non", ctypes.c_int32 * 8), ("in_dim", ctypes.c_int32),
+         ("out_dim", ctypes.c_int32)] +
+        [(k, ctypes.c_void_p) for k in (
+            "Z", "U", "gains", "alphas", "u_min", "u_max", "active",
+            "bwd_status", "Q", "Q_term", "R", "x_goal", "u_goal", "X_mean",
+            "X_std_inv", "dX_mean", "dX_std", "net_out", "Xp", "F", "Zc", "Uc",
+            "J", "Jc")])
 
 
 E_UNSUPPORTED = -2  # PDDP_E_UNSUPPORTED of include/pddp_hip.h

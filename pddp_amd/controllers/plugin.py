@@ -129,11 +129,115 @@ class TorchProblem(object):
             if set_state:
                 s.state[sel] = 0
 
+    # -- fused BNN rollout: csrc/bnn_rollout.hip + csrc/bnn_mlp.hip -------------
+    def _bnn_native_ok(self, s):
+        """True when the line search can run as N + 1 moment-step launches
+        with the fused network kernel in between (include/pddp_hip.h:
+        pddp_bnn_moment_step_f32, pddp_bnn_mlp_f32) instead of ~150 torch
+        launches per time step."""
+        from ..costs.quadratic import QRCost
+        from ..utils.encoding import StateEncoding
+        mo, co = self.model, self.cost
+        if not getattr(self, "use_native_bnn", True):
+            return False
+        if s.dtype != torch.float32 or self.cost_opts:
+            return False
+        if int(self.encoding) != int(StateEncoding.UPPER_TRIANGULAR_CHOLESKY):
+            return False
+        if not (hasattr(mo, "eps_in") and hasattr(mo, "n_particles")
+                and hasattr(mo, "angular_indices_")):
+            return False
+        opts = dict(use_predicted_std=False, infer_noise_variables=True,
+                    sample_input_distribution=True, resample=False,
+                    independent_noise=False)
+        for k, v in self.model_opts.items():
+            if k not in opts or bool(v) != opts[k]:
+                return False
+        mc = getattr(co, "model_class", None)
+        if not isinstance(co, QRCost) or mc is None:
+            return False
+        if tuple(int(i) for i in mc.angular_indices) != mo.angular_indices_ or \
+                tuple(int(i) for i in mc.non_angular_indices) != \
+                mo.non_angular_indices_:
+            return False
+        D, m, P = mo.state_size, mo.action_size, mo.n_particles
+        if D > 8 or m > 2 or P > 128 or P < 2 or len(mo.angular_indices_) > 2:
+            return False
+        probe = torch.empty(1, P, mo.model.hidden[0].in_features,
+                            dtype=s.dtype, device=s.device)
+        return mo.model._native_ok(probe, False)
+
+    @torch.no_grad()
+    def _line_search_bnn(self, s, active, use_status):
+        import ctypes
+        from ..utils.encoding import decode_covar_sqrt, decode_mean
+        mo, co = self.model, self.cost
+        B, N, n, m, A = s.B, s.N, s.n, s.m, s.A
+        D, P = mo.state_size, mo.n_particles
+        ang, non = mo.angular_indices_, mo.non_angular_indices_
+        na = len(non) + 2 * len(ang)
+        in_dim, out_dim = na + m, mo.model.out.out_features
+        opts = dict(dtype=s.dtype, device=s.device)
+        vec = lambda t, k: torch.as_tensor(t).detach().to(**opts).expand(
+            k).contiguous()
+        mat = lambda t: t.detach().to(**opts).contiguous()
+        # particles of step 0: mean + eps L, cached standardised normals
+        # (modules.py:312-330; the same draw the model itself would make)
+        z0 = s.Z[:, 0]
+        mean0 = decode_mean(z0, self.encoding)
+        if 0 not in mo.eps_in:
+            e = torch.randn(P, D, **opts)
+            mo.eps_in[0] = (e - e.mean(0)) / e.std(0)
+        X0 = mean0.unsqueeze(-2) + mo.eps_in[0] @ decode_covar_sqrt(
+            z0, self.encoding)
+        Xp = X0.unsqueeze(1).expand(B, A, P, D).contiguous()
+        F = torch.zeros(B * A, P, in_dim, **opts)
+        J = torch.zeros(B * A, **opts)
+        Jc = torch.zeros(B * A, **opts)
+        keep = [vec(mo.X_mean, in_dim), vec(mo.X_std_inv, in_dim),
+                vec(mo.dX_mean, D), vec(mo.dX_std, D), mat(co.Q),
+                mat(co.Q_term), mat(co.R), vec(co.x_goal, na),
+                vec(co.u_goal, m)]
+        st = _native.BnnStep()
+        st.B, st.A, st.P, st.D, st.m, st.N = B, A, P, D, m, N
+        st.n_ang, st.n_non = len(ang), len(non)
+        for i, v in enumerate(ang):
+            st.ang[i] = v
+        for i, v in enumerate(non):
+            st.non[i] = v
+        st.in_dim, st.out_dim = in_dim, out_dim
+        p = _native.ptr
+        for name, t in (("Z", s.Z), ("U", s.U), ("gains", s.gains),
+                        ("alphas", s.alphas), ("u_min", s.u_min),
+                        ("u_max", s.u_max), ("active", active),
+                        ("bwd_status", s.bwd_status if use_status else None),
+                        ("X_mean", keep[0]), ("X_std_inv", keep[1]),
+                        ("dX_mean", keep[2]), ("dX_std", keep[3]),
+                        ("Q", keep[4]), ("Q_term", keep[5]), ("R", keep[6]),
+                        ("x_goal", keep[7]), ("u_goal", keep[8]), ("Xp", Xp),
+                        ("F", F), ("Zc", s.Zc), ("Uc", s.Uc), ("J", J),
+                        ("Jc", Jc)):
+            setattr(st, name, p(t))
+        lib, stream = _native.lib(), _native.stream_handle(s.device)
+        out = None
+        for t in range(N + 1):
+            st.t = t
+            st.net_out = p(out)
+            _native.check(lib.pddp_bnn_moment_step_f32(ctypes.byref(st),
+                                                       stream),
+                          "pddp_bnn_moment_step_f32")
+            if t < N:
+                out = mo.model._forward_native(F)
+        s.Jc.copy_(Jc.view(B, A))
+        mo.output = {}  # the particle caches of a torch-path rollout: stale
+
     # -- ilqr.py:677-723, 764-791 ---------------------------------------------
     @torch.no_grad()
     def line_search(self, s, active=None, use_status=True):
         self.model.eval()
         self.cost.eval()
+        if self._bnn_native_ok(s):
+            return self._line_search_bnn(s, active, use_status)
         B, N, n, m, A = s.B, s.N, s.n, s.m, s.A
         k, K = s.gain_views()
         alpha = s.alphas.view(1, A, 1)

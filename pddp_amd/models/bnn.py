@@ -213,6 +213,12 @@ def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
 
     class ParticlesBNNDynamicsModel(DynamicsModel):
 
+        # state layout, for the fused rollout (controllers/plugin.py)
+        angular_indices_ = tuple(int(i) for i in angular_indices) \
+            if angular else ()
+        non_angular_indices_ = tuple(int(i) for i in non_angular_indices) \
+            if angular else tuple(range(state_size))
+
         def __init__(self):
             super(ParticlesBNNDynamicsModel, self).__init__()
             self.model = BayesianMLP(aug_size + action_size, 2 * state_size,

@@ -882,3 +882,63 @@ def test_bnn_mlp_kernel_vs_torch(rows, P, in_dim, out_dim, H):
     e_torch = float((y32.double() - y64).abs().max()) / scale
     assert e_native < 2e-6, (e_native, e_torch)
     assert e_native < 4 * e_torch + 1e-7, (e_native, e_torch)
+
+
+@pytest.mark.parametrize("problem,H,P", [("cartpole", 64, 30), ("cartpole", 200, 100),
+                                         ("pendulum", 64, 40),
+                                         ("double_cartpole", 128, 70)])
+def test_bnn_native_line_search_vs_torch_path(problem, H, P):
+    """The moment-matched line search under a BNN dynamics model as N + 1
+    pddp_bnn_moment_step_f32 launches with the fused network kernel in between
+    (csrc/bnn_rollout.hip, csrc/bnn_mlp.hip) against the same rollout made of
+    torch ops (controllers/plugin.py:line_search, itself pinned to the
+    reference by test_bnn_ilqr_fit_vs_reference_golden): candidates' encoded
+    states (mean | Cholesky of the particle covariance), controls and costs."""
+    import pddp_amd
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    torch.manual_seed(7)
+    mod = getattr(pddp_amd.examples, problem)
+    KM = [getattr(mod, k) for k in dir(mod) if k.endswith("DynamicsModel")
+          and k != "DynamicsModel"][0]
+    cost = [getattr(mod, k) for k in dir(mod) if k.endswith("Cost")
+            and k != "AugmentedQRCost"][0]().cuda()
+    D, m = KM.state_size, KM.action_size
+    cls = bnn_dynamics_model_factory(D, m, [H, H], KM.angular_indices,
+                                     KM.non_angular_indices)
+    model = cls(n_particles=P).cuda().eval()
+    with torch.no_grad():  # keep the learned dynamics gentle: dx ~ 1e-2
+        model.model.out.weight.mul_(0.05)
+        model.model.out.bias.mul_(0.05)
+    enc = pddp_amd.StateEncoding.DEFAULT
+    B, N, A = 5, 9, 10
+    n = D + D * (D + 1) // 2
+    bound = BOUND[problem]
+    res = []
+    for native in (True, False):
+        plugin = TorchProblem(model, cost, enc, {"use_predicted_std": False}, {})
+        plugin.use_native_bnn = native
+        s = ILQRSolver(None, B, N, torch.float32, "cuda",
+                       torch.full((m,), -bound), torch.full((m,), bound),
+                       fit_alphas(torch.float32, "cuda"), plugin=plugin, n=n,
+                       m=m)
+        g = torch.Generator().manual_seed(1)
+        mean = torch.tensor(MEAN0[problem], dtype=torch.float32)
+        z0 = torch.stack([pddp_amd.GaussianVariable(
+            mean + 1e-2 * torch.randn(D, generator=g),
+            var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).cuda()
+        U = (0.1 * torch.randn(B, N, m, generator=g)).cuda()
+        s.set_nominal(z0, U)
+        s.gains.copy_(1e-1 * torch.randn(s.gains.shape, generator=g).cuda())
+        with torch.no_grad():
+            assert plugin._bnn_native_ok(s) == native
+        s.line_search()
+        res.append((s.Zc.clone(), s.Uc.clone(), s.Jc.clone()))
+    (Za, Ua, Ja), (Zb, Ub, Jb) = res
+    assert torch.isfinite(Za).all() and torch.isfinite(Ja).all()
+    for x, y, name in ((Za, Zb, "Zc"), (Ua, Ub, "Uc"), (Ja, Jb, "Jc")):
+        err = float((x - y).abs().max()) / max(float(y.abs().max()), 1e-6)
+        assert err < 2e-3, (name, err)
+    assert float((Za[:, 1:] - Zb[:, :1]).abs().max()) > 1e-4  # it did move

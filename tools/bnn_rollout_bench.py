@@ -1,8 +1,9 @@
 """BASELINE.json configs[2] in the small: cartpole with a BNN dynamics model
 ([200, 200] hidden, P particles), DEFAULT encoding (n = 14), moment-matched
 line-search rollouts of B trajectories x A = 10 step sizes over N steps through
-the plugin path - with the fused network kernel (pddp_bnn_mlp_f32) and with
-the layer-by-layer library GEMMs.
+the plugin path - as N + 1 moment-step launches with the fused network kernel
+in between (pddp_bnn_moment_step_f32 + pddp_bnn_mlp_f32), as torch ops around
+the fused network kernel, and as torch ops on library GEMMs.
 
     python tools/bnn_rollout_bench.py [--batch 256] [--horizon 100]
 """
@@ -28,6 +29,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--particles", type=int, default=100)
+    ap.add_argument("--native-only", action="store_true")
     a = ap.parse_args()
     torch.manual_seed(0)
     dev = "cuda"
@@ -55,15 +57,19 @@ def main():
                        "N=%d A=%d fp32" % (a.particles, B, N, A),
            "rows_per_step": B * A * a.particles}
     flop = 2.0 * B * A * a.particles * (6 * 200 + 200 * 200 + 200 * 8) * N
-    for native in (True, False):
-        model.model.use_native = native
+    modes = [("native_rollout", True, True)]
+    if not a.native_only:
+        modes += [("torch_ops_fused_network", False, True),
+                  ("torch_ops_library_gemms", False, False)]
+    for key, rollout_native, net_native in modes:
+        plugin.use_native_bnn = rollout_native
+        model.model.use_native = net_native
         s.line_search()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         s.line_search()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        key = "fused_kernel" if native else "library_gemms"
         out[key] = {"line_search_s": dt,
                     "candidate_steps_per_s": B * A * N / dt,
                     "network_TFLOPs": flop / dt * 1e-12}
