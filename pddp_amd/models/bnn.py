@@ -211,13 +211,15 @@ def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
                                            non_angular_indices)
                 if angular else state_size)
 
+    _ang = tuple(int(i) for i in angular_indices) if angular else ()
+    _non = (tuple(int(i) for i in non_angular_indices) if angular
+            else tuple(range(state_size)))
+
     class ParticlesBNNDynamicsModel(DynamicsModel):
 
         # state layout, for the fused rollout (controllers/plugin.py)
-        angular_indices_ = tuple(int(i) for i in angular_indices) \
-            if angular else ()
-        non_angular_indices_ = tuple(int(i) for i in non_angular_indices) \
-            if angular else tuple(range(state_size))
+        angular_indices_ = _ang
+        non_angular_indices_ = _non
 
         def __init__(self):
             super(ParticlesBNNDynamicsModel, self).__init__()
