@@ -92,7 +92,11 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  * 0 auto (what the entry points above use), 1 generic kernel (one wavefront
  * per trajectory, any n <= 32, m <= 4), 2 specialised n=4/m=1 kernel
  * (16 lanes per trajectory), 3 variant 2 with v_rcp/v_sqrt approximations
- * instead of IEEE division / square root (f32 only). */
+ * instead of IEEE division / square root (f32 only), 6 / 7 = 2 / 3 with the
+ * scalar BoxQP in closed form (the reference's loop as fall-back), 8 / 9 =
+ * 6 / 7 with every step split over two wavefronts (bounded problems only),
+ * 10 / 11 = 6 / 7 in workgroups of four wavefronts.  Auto: n=4/m=1 bounded
+ * f32 -> 9 up to 8192 trajectories, 7 beyond; f64 -> 6. */
 int pddp_riccati_backward_variant_f32(int B, int N, int n, int m,
                                       const float* rec, const float* u_min,
                                       const float* u_max, const double* reg,

@@ -159,7 +159,8 @@ class ILQRSolver(object):
     def backward(self, active=None, reg=None, branch=None, bounded=True,
                  variant=0, events=None):
         """variant: 0 auto, 1 generic kernel, 2 / 3 specialised n=4 kernel
-        (IEEE / approximate division), see include/pddp_hip.h.  `events`: a
+        (IEEE / approximate division), 6 / 7 closed-form BoxQP, 8 / 9 split
+        over two wavefronts, see include/pddp_hip.h.  `events`: a
         (start, stop) pair of pddp_event handles to attach to the dispatch."""
         p = _native.ptr
         reg = self.mu if reg is None else reg

@@ -348,19 +348,25 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
 // records of the new nominal - so that a round is three launches (records of
 // fresh nominals only at the start, sweep, this) instead of five, and the
 // winner's rows are read back while they are still in L2.
-template <typename T, int MODEL, bool FUSED>
-__global__ __launch_bounds__(kWave) void line_search_lds_kernel(
+// WPB wavefronts per workgroup, each with its own four trajectories and LDS
+// slice (no interaction after the staging barrier).  WPB = 4 makes a workgroup
+// one wave per SIMD of a CU whatever the dispatcher did before - with
+// one-wave workgroups the placement of 1024 of them on 1024 SIMDs depended on
+// the previous kernel's shape (measured: +13 us after a 128-thread kernel).
+template <typename T, int MODEL, bool FUSED, int WPB>
+__global__ __launch_bounds__(kWave * WPB) void line_search_lds_kernel(
     ProblemT<T> P, LineSearchArgs<T> a, AcceptArgs<T> c, T* rec, T* Lout) {
   using D = ModelDims<MODEL>;
   constexpr int n = D::n, m = D::m;
   constexpr int GS = m + m * n;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x >> 6;
   const int grp = lane >> 4, ai = lane & 15;
   const int N = a.N;
   const int per = (N + 1) * n + N * m + N * GS;  // scalars per trajectory
-  const int b0 = blockIdx.x * 4;
+  T* smem = reinterpret_cast<T*>(smem_raw) + (size_t)wave * 4 * per;
+  const int b0 = (blockIdx.x * WPB + wave) * 4;
 
   // cooperative, coalesced staging of up to four trajectories
   for (int g = 0; g < 4; ++g) {
@@ -584,9 +590,14 @@ static int launch_line_search(const pddp_problem& p, LineSearchArgs<T> a,
                      (size_t)a.N * (D::m + D::m * D::n);
   const size_t lds = 4 * per * sizeof(T);
   if (a.A <= 16 && lds <= 64 * 1024) {  // nominal data staged in LDS
-    hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, false>),
-                       dim3((a.B + 3) / 4), dim3(kWave), lds, st, P, a,
-                       AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
+    if (4 * lds <= 64 * 1024)
+      hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, false, 4>),
+                         dim3((a.B + 15) / 16), dim3(kWave * 4), 4 * lds, st, P,
+                         a, AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
+    else
+      hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, false, 1>),
+                         dim3((a.B + 3) / 4), dim3(kWave), lds, st, P, a,
+                         AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
     return launch_status();
   }
   const int total = a.B * a.A;
@@ -616,9 +627,14 @@ static int launch_search_accept(const pddp_problem& p, SearchAcceptArgs<T> a,
   if (a.ls.A > 16 || lds > 64 * 1024) return PDDP_E_UNSUPPORTED;
   a.ac.n = D::n;
   a.ac.m = D::m;
-  hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, true>),
-                     dim3((a.ls.B + 3) / 4), dim3(kWave), lds, st, P, a.ls,
-                     a.ac, a.rec, a.L);
+  if (4 * lds <= 64 * 1024)
+    hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, true, 4>),
+                       dim3((a.ls.B + 15) / 16), dim3(kWave * 4), 4 * lds, st, P,
+                       a.ls, a.ac, a.rec, a.L);
+  else
+    hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, true, 1>),
+                       dim3((a.ls.B + 3) / 4), dim3(kWave), lds, st, P, a.ls,
+                       a.ac, a.rec, a.L);
   return launch_status();
 }
 

@@ -2,6 +2,7 @@
 // (pddp/controllers/ilqr.py:529-674) and their dispatch.
 #include "riccati_generic.hpp"
 #include "riccati_n4.hpp"
+#include "riccati_n4_split.hpp"
 
 namespace pddp {
 
@@ -47,17 +48,27 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   hipStream_t st = (hipStream_t)stream;
   // variant: 0 auto, 1 generic, 2 specialised n=4 (IEEE div/sqrt, BoxQP as
   //          the reference's loop), 3 the same with rcp / sqrt approximations
-  //          (f32 only), 4 / 5 = 2 / 3 with two trajectories per wavefront,
-  //          6 / 7 = 2 / 3 with the BoxQP in closed form (loop as fall-back);
-  //          auto = 7 for f32, 6 for f64
+  //          (f32 only), 6 / 7 = 2 / 3 with the BoxQP in closed form (loop as
+  //          fall-back), 8 / 9 = 6 / 7 with the step split over two
+  //          wavefronts (riccati_n4_split.hpp; bounded problems only),
+  //          10 / 11 = 6 / 7 in workgroups of four wavefronts;
+  //          auto: bounded f32 -> 9 up to 8192 trajectories, else 7; f64 -> 6
   if (variant >= 2 && !(n == 4 && m == 1)) return PDDP_E_UNSUPPORTED;
-  if (variant < 0 || variant > 7) return PDDP_E_BADARG;
+  if (variant < 0 || variant > 11 || variant == 4 || variant == 5)
+    return PDDP_E_BADARG;
+  if (variant == 0 && n == 4 && m == 1 && sizeof(T) == 4 && u_min != nullptr &&
+      B <= 8192)
+    variant = 9;
+  if (variant == 8 || variant == 9) {
+    if (u_min == nullptr) return PDDP_E_UNSUPPORTED;
+    return launch_n4_split<T>(a, st, variant == 9 && sizeof(T) == 4);
+  }
   if (variant != 1 && n == 4 && m == 1) {
-    const bool fast = (variant == 0 || variant == 3 || variant == 5 ||
-                       variant == 7) && sizeof(T) == 4;
-    const bool cf = (variant == 0 || variant == 6 || variant == 7);
-    return launch_n4<T>(a, st, fast, (variant == 4 || variant == 5) ? 2 : 4,
-                        cf);
+    const bool fast = (variant == 0 || variant == 3 || variant == 7 ||
+                       variant == 11) && sizeof(T) == 4;
+    const bool cf = (variant == 0 || variant == 6 || variant == 7 ||
+                     variant >= 10);
+    return launch_n4<T>(a, st, fast, variant >= 10 ? 4 : 1, cf);
   }
   switch (m) {
     case 1: return dispatch_nmax<T, 1>(a, st);

@@ -154,6 +154,23 @@ PDDP_DEV void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// One full-wave 16-byte LDS DMA: lane l's 16 bytes at sbase + voff land at LDS
+// byte `lds` + 16 l.  Hand-issued: with __builtin_amdgcn_global_load_lds the
+// compiler's waitcnt pass drains vmcnt(0) before any LDS read it cannot prove
+// disjoint from the DMA target (seen: once per ring revolution, +4 us per
+// sweep); the record ring is ordered by the hand-counted wait_vmcnt<> below.
+// m0 is written behind the compiler's back - nothing else in these kernels
+// uses it.
+PDDP_DEV void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+               ::"v"(voff), "s"(sbase), "s"(lds)
+               : "memory");
+}
+template <typename P>
+PDDP_DEV uint32_t lds_addr(P* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+}
+
 // Step sizes of the reference's backtracking line search: python
 // `step *= step_dec` in double, rounded to T when it multiplies a tensor
 // (utils/constraint.py:248-259).  kLsFail = first n with step < min_step.
@@ -444,28 +461,49 @@ __device__ __noinline__ SlowQpOut<T> boxqp1_outlined(T x0, T Q, T c, T lo,
   return o;
 }
 
+// WPB wavefronts per workgroup, independent of each other after the one
+// barrier that publishes the step-size table: WPB = 4 puts one wave on every
+// SIMD of a CU by construction (one-wave workgroups left that to the
+// dispatcher, whose placement depends on the previous kernel's shape).
 template <typename T, bool CHOL, bool BOUNDED, bool FAST, int G,
-          bool QPCF = false>
-__global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
+          bool QPCF = false, int WPB = 1>
+__global__ __launch_bounds__(kWave * WPB) void riccati_n4_kernel(
+    RiccatiArgs<T> a) {
   // QPCF: BoxQP through BoxQp1::closed_form(), the loop only as fall-back
   // G = trajectories per wavefront (4: all lanes busy; 2: half the lanes idle
   // but twice the wavefronts and less BoxQP divergence per wavefront)
-  constexpr int CH = kRec * (int)sizeof(T) / 16;  // 16-B chunks per record
+  // Record DMAs are FULL-wave 16-byte instructions: the four records of a
+  // wave are 48 (f32) / 96 (f64) chunks; the lanes past them re-load an earlier
+  // chunk into the slot's padding (a slot is NI KiB).  No lane-dependent
+  // branch around a DMA: the compiler merges such divergent calls into one
+  // whose LDS base is a per-lane value, i.e. wrong data (seen with f64).
+  // (global_load_lds_dwordx3 is no way out: its 12 bytes land at lane * 16.)
+  static_assert(G == 4, "four trajectories per wavefront");
+  constexpr int CB = 16;                            // bytes per chunk
+  constexpr int CH = kRec * (int)sizeof(T) / CB;    // chunks per record
   constexpr int NI = (4 * CH + kWave - 1) / kWave;  // DMA instructions / step
-  constexpr int R = kRing;
-  __shared__ __attribute__((aligned(16))) T ring[R][4 * kRec];
+  constexpr int kSlot = NI * kWave * CB / (int)sizeof(T);  // scalars per slot
+  // ring depth: 8 slots; 6 where four waves' rings of 2 KiB slots (f64) would
+  // not fit the 64 KiB of static LDS
+  constexpr int R = (WPB * kRing * kSlot * (int)sizeof(T) > 60 * 1024) ? 6 : kRing;
+  __shared__ __attribute__((aligned(16))) T ring_all[WPB][R][kSlot];
   __shared__ T ls_tail[kLsSteps];  // T(0.6^n), read only past n = 31
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave =
+      WPB == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  T (*ring)[kSlot] = ring_all[wave];
   T lstep[1] = {T(0)};
   if constexpr (BOUNDED) {
-    for (int q = lane; q < kLsSteps; q += kWave) ls_tail[q] = (T)kLs.v[q];
+    for (int q = threadIdx.x; q < kLsSteps; q += kWave * WPB)
+      ls_tail[q] = (T)kLs.v[q];
     lstep[0] = (T)kLs.v[lane & 15];
     __syncthreads();
   }
   const int grp = lane >> 4, l = lane & 15, i = l >> 2, j = l & 3;
   const int N = a.N;
-  const int b0 = blockIdx.x * G;
+  const int b0 = (blockIdx.x * WPB + wave) * G;
+  if (b0 >= a.B) return;  // a whole wave past the batch (WPB > 1)
   const int b = b0 + grp;
   const bool exists = (grp < G) && (b < a.B);
   const int bc = exists ? b : a.B - 1;
@@ -488,28 +526,23 @@ __global__ __launch_bounds__(kWave) void riccati_n4_kernel(RiccatiArgs<T> a) {
   const char* rec_w =
       reinterpret_cast<const char*>(a.rec + (size_t)b0 * (size_t)(N + 1) * kRec);
   uint32_t src_off[NI];
-  bool dma_on[NI];
 #pragma unroll
   for (int r = 0; r < NI; ++r) {
-    const int q = lane + kWave * r;
+    int q = lane + kWave * r;
+    q = q < 4 * CH ? q : q - 4 * CH;  // padding lanes: any valid chunk
     const int tg = q / CH, c = q - tg * CH;
-    dma_on[r] = q < G * CH;
-    int tb = b0 + (dma_on[r] ? tg : 0);
+    int tb = b0 + tg;
     tb = tb < a.B ? tb : a.B - 1;
-    src_off[r] = (uint32_t)((tb - b0) * (N + 1) * kRec * (int)sizeof(T) + c * 16);
+    src_off[r] = (uint32_t)((tb - b0) * (N + 1) * kRec * (int)sizeof(T) + c * CB);
   }
   auto dma = [&](int slot, int t) {
     const int tt = t < 0 ? 0 : t;  // tail: harmless reload keeps vmcnt exact
     const uint32_t toff = (uint32_t)tt * (uint32_t)(kRec * sizeof(T));
 #pragma unroll
     for (int r = 0; r < NI; ++r)
-      if (dma_on[r])
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(rec_w +
-                                                            (src_off[r] + toff)),
-            (__attribute__((address_space(3))) void*)((char*)&ring[slot][0] +
-                                                      r * kWave * 16),
-            16, 0, 0);
+      lds_dma16(rec_w, src_off[r] + toff,
+                __builtin_amdgcn_readfirstlane(lds_addr(&ring[slot][0])) +
+                    r * kWave * CB);
   };
 
   // ---- LDS gather offsets (words inside this group's record)
@@ -823,29 +856,29 @@ __global__ __launch_bounds__(kWave) void boxqp1_kernel(
 
 template <typename T>
 static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st, bool fast_math,
-                     int groups_per_wave, bool qp_closed_form) {
+                     int waves_per_group, bool qp_closed_form) {
   const bool bounded = a.u_min != nullptr;
   const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
-  const int G = (groups_per_wave == 2) ? 2 : 4;
+  constexpr int G = 4;
   const dim3 grid((a.B + G - 1) / G), block(kWave);
-  if (bounded && qp_closed_form && G == 4) {
+  if (bounded && qp_closed_form) {
+    const dim3 grid4((a.B + 15) / 16), block4(kWave * 4);
 #define PDDP_N4_CF(C, F)                                                     \
-  PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, true, F, 4, true>), grid, block,  \
-              0, st, a)
+  do {                                                                       \
+    if (waves_per_group == 4)                                                \
+      PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, true, F, 4, true, 4>), grid4, \
+                  block4, 0, st, a);                                         \
+    else                                                                     \
+      PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, true, F, 4, true, 1>), grid,  \
+                  block, 0, st, a);                                          \
+  } while (0)
     if (fast_math) { if (chol) PDDP_N4_CF(true, true); else PDDP_N4_CF(false, true); }
     else { if (chol) PDDP_N4_CF(true, false); else PDDP_N4_CF(false, false); }
 #undef PDDP_N4_CF
     return launch_status();
   }
 #define PDDP_N4_LAUNCH(C, Bd, F)                                             \
-  do {                                                                       \
-    if (G == 2)                                                              \
-      PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, Bd, F, 2>), grid, block, 0,   \
-                  st, a);                                                    \
-    else                                                                     \
-      PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, Bd, F, 4>), grid, block, 0,   \
-                  st, a);                                                    \
-  } while (0)
+  PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, Bd, F, 4>), grid, block, 0, st, a)
   if (fast_math) {
     if (chol) { if (bounded) PDDP_N4_LAUNCH(true, true, true); else PDDP_N4_LAUNCH(true, false, true); }
     else { if (bounded) PDDP_N4_LAUNCH(false, true, true); else PDDP_N4_LAUNCH(false, false, true); }

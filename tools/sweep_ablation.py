@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--variants", default="",
+                    help="comma-separated kernel variants (default: all)")
+    ap.add_argument("--sweep-only", action="store_true")
     a = ap.parse_args()
     td = torch.float32 if a.dtype == "f32" else torch.float64
     model, cost = cp.CartpoleDynamicsModel(0.05), cp.CartpoleCost()
@@ -33,8 +36,13 @@ def main():
     s.derivs()
     reg = torch.full((a.batch,), 1.0, dtype=torch.float64, device="cuda")
     out = {}
-    for variant in (2, 3, 6, 7) if a.dtype == "f32" else (2, 6):
+    variants = (2, 3, 6, 7, 8, 9) if a.dtype == "f32" else (2, 6, 8)
+    if a.variants:
+        variants = tuple(int(v) for v in a.variants.split(","))
+    for variant in variants:
         for branch, bounded in ((0, False), (0, True), (1, False), (1, True)):
+            if variant >= 8 and not bounded:
+                continue
             for _ in range(3):
                 s.backward(reg=reg, branch=branch, bounded=bounded, variant=variant)
             e0 = torch.cuda.Event(enable_timing=True)
@@ -49,9 +57,10 @@ def main():
                                   e0.elapsed_time(e1) / 20 * 1e3, 1)
     # the other kernels of a round, timed alone on the same state
     s.backward(reg=reg)
-    for name, fn in (("line_search", lambda: s.line_search()),
-                     ("derivs", lambda: s.derivs()),
-                     ("rollout", lambda: s.nominal_rollout())):
+    for name, fn in (() if a.sweep_only else
+                     (("line_search", lambda: s.line_search()),
+                      ("derivs", lambda: s.derivs()),
+                      ("rollout", lambda: s.nominal_rollout()))):
         for _ in range(3):
             fn()
         e0 = torch.cuda.Event(enable_timing=True)
