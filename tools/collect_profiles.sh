@@ -27,7 +27,7 @@ for B in 1024 8192 16384; do
   python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --batch $B 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_B$B.json
 done
 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --dtype f64 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_f64.json
-for v in 1 2 3 6; do
+for v in 1 2 3 6 7 9; do
   python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --kernel-variant $v 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_variant$v.json
 done
 tail -c 600 gpurun_out/${TAG}_bench.json
