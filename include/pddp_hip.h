@@ -331,6 +331,85 @@ typedef struct pddp_bnn_step {
 } pddp_bnn_step;
 int pddp_bnn_moment_step_f32(const pddp_bnn_step* step, void* stream);
 
+/* ---- the same network in forward mode (JVP), for the derivative rollout
+ * (ilqr.py:457-468 -> utils/evaluation.py:203-235 batch_eval_dynamics, which
+ * replicates the input n times and back-propagates an identity): rows come in
+ * groups of 16 = one (state, particle) input row followed by 15 tangent rows
+ * d X / d direction; a tangent row passes through the weights without biases
+ * and through the ReLUs linearised at its group's first row.  p = (r / 16) % P,
+ * R a multiple of 16; everything else as pddp_bnn_mlp_f32. */
+int pddp_bnn_mlp_jvp_f32(int R, int P, int in_dim, int H, int out_dim,
+                         const float* X, const float* W1, const float* b1,
+                         const float* M1S, const float* W2, const float* b2,
+                         const float* M2, const float* W3, const float* b3,
+                         float* Y, void* stream);
+
+/* ---- Jacobians F_z, F_u of one moment-matched BNN step (modules.py:287-386
+ * under DEFAULT encoding) in forward mode, around pddp_bnn_mlp_jvp_f32:
+ *   features(t): eps = (Xp - mean_t) U_t^-1 (the detached re-whitening of
+ *                modules.py:333-348), F = [B P][16][in_dim] primal + tangent
+ *                input rows for the directions (mean_d | U_ab row-major upper
+ *                triangle | u), derivatives at the clamped action;
+ *   moments(t):  net_out [B P][16][out_dim] -> Xp_next (output particles =
+ *                the cloud of step t + 1), Z_next = encode(mean, covariance),
+ *                F_z[b][t], F_u[b][t] through the differential of the Cholesky
+ *                factor.
+ * D <= 4 and D + D (D + 1) / 2 + m <= 15 (cartpole, pendulum); otherwise
+ * PDDP_E_UNSUPPORTED (the autograd path then). */
+typedef struct pddp_bnn_jvp {
+  int32_t B, P, D, m, N, t;
+  int32_t n_ang, ang[2], n_non, non[8];
+  int32_t in_dim, out_dim;
+  const float* Z;        /* [B][N+1][n] nominal */
+  const float* U;        /* [B][N][m] */
+  const float* u_min;    /* [m], nullable with u_max */
+  const float* u_max;
+  const float* X_mean;   /* [in_dim] */
+  const float* X_std_inv;
+  const float* dX_mean;  /* [D] */
+  const float* dX_std;
+  const float* net_out;  /* [B P][16][out_dim] (moments) */
+  const float* Xp;       /* [B][P][D] particles of step t */
+  float* Xp_next;        /* [B][P][D] out (moments), nullable */
+  float* eps;            /* [B][P][D] out (features), in (moments) */
+  float* F;              /* [B P][16][in_dim] out (features) */
+  float* Z_next;         /* [B][n] out (moments), nullable */
+  float* F_z;            /* [B][N][n][n] out (moments) */
+  float* F_u;            /* [B][N][n][m] out (moments) */
+} pddp_bnn_jvp;
+int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* step, void* stream);
+int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* step, void* stream);
+
+/* ---- value, gradient and Hessian of the QR cost on the angle-augmented
+ * Gaussian state under DEFAULT encoding, every (trajectory, time step) in one
+ * launch: costs/quadratic.py:60-99 on examples/cartpole/cost.py:60-87's
+ * augmented state (utils/angular.py:161-248), differentiated as
+ * utils/evaluation.py:238-288 batch_eval_cost does (L_z, L_u, L_zz, L_uz, L_uu
+ * at the clamped action), by hyper-dual evaluation instead of autograd's double
+ * backward.  Step N is the terminal state (Q_term, no action; its L_u / L_uz /
+ * L_uu rows do not exist).  D in {2, 4, 6}, m <= 2, at most two angular
+ * states; PDDP_E_UNSUPPORTED otherwise. */
+typedef struct pddp_qr_cost {
+  int32_t B, N, D, m;
+  int32_t n_ang, ang[2], n_non, non[8];
+  const float* Z;       /* [B][N+1][n], n = D + D (D + 1) / 2 */
+  const float* U;       /* [B][N][m] */
+  const float* u_min;   /* [m], nullable with u_max */
+  const float* u_max;
+  const float* Q;       /* [na][na], na = n_non + 2 n_ang */
+  const float* Q_term;
+  const float* R;       /* [m][m] */
+  const float* x_goal;  /* [na] */
+  const float* u_goal;  /* [m] */
+  float* L;             /* [B][N+1] */
+  float* L_z;           /* [B][N+1][n] */
+  float* L_u;           /* [B][N][m] */
+  float* L_zz;          /* [B][N+1][n][n] */
+  float* L_uz;          /* [B][N][m][n] */
+  float* L_uu;          /* [B][N][m][m] */
+} pddp_qr_cost;
+int pddp_qr_cost_derivs_f32(const pddp_qr_cost* cost, void* stream);
+
 /* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only
  * sees torch's current stream). Host functions. */
 int pddp_event_create(void** ev);

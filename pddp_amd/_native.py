@@ -74,6 +74,10 @@ _SIGS = {
                    [_P] * 12,
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
     "pddp_bnn_moment_step_f32": [_P, _P],
+    "pddp_bnn_mlp_jvp_f32": [c_int] * 5 + [_P] * 11,
+    "pddp_bnn_jvp_features_f32": [_P, _P],
+    "pddp_bnn_jvp_moments_f32": [_P, _P],
+    "pddp_qr_cost_derivs_f32": [_P, _P],
     "pddp_event_create": [_P],
     "pddp_event_record": [_P, _P],
     "pddp_event_elapsed_ms": [_P, _P, _P],
@@ -165,6 +169,30 @@ class BnnStep(ctypes.Structure):
             "bwd_status", "Q", "Q_term", "R", "x_goal", "u_goal", "X_mean",
             "X_std_inv", "dX_mean", "dX_std", "net_out", "Xp", "F", "Zc", "Uc",
             "J", "Jc")])
+
+
+class BnnJvp(ctypes.Structure):
+    """pddp_bnn_jvp of include/pddp_hip.h."""
+    _fields_ = (
+        [(k, ctypes.c_int32) for k in ("B", "P", "D", "m", "N", "t", "n_ang")] +
+        [("ang", ctypes.c_int32 * 2), ("n_non", ctypes.c_int32),
+         ("non", ctypes.c_int32 * 8), ("in_dim", ctypes.c_int32),
+         ("out_dim", ctypes.c_int32)] +
+        [(k, ctypes.c_void_p) for k in (
+            "Z", "U", "u_min", "u_max", "X_mean", "X_std_inv", "dX_mean",
+            "dX_std", "net_out", "Xp", "Xp_next", "eps", "F", "Z_next", "F_z",
+            "F_u")])
+
+
+class QrCost(ctypes.Structure):
+    """pddp_qr_cost of include/pddp_hip.h."""
+    _fields_ = (
+        [(k, ctypes.c_int32) for k in ("B", "N", "D", "m", "n_ang")] +
+        [("ang", ctypes.c_int32 * 2), ("n_non", ctypes.c_int32),
+         ("non", ctypes.c_int32 * 8)] +
+        [(k, ctypes.c_void_p) for k in (
+            "Z", "U", "u_min", "u_max", "Q", "Q_term", "R", "x_goal", "u_goal",
+            "L", "L_z", "L_u", "L_zz", "L_uz", "L_uu")])
 
 
 E_UNSUPPORTED = -2  # PDDP_E_UNSUPPORTED of include/pddp_hip.h

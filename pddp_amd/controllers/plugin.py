@@ -22,6 +22,11 @@ from .. import _native
 from ..utils.constraint import clamp
 
 
+def _augmented_forward():
+    from ..examples._common import AugmentedQRCost
+    return AugmentedQRCost.forward
+
+
 class TorchProblem(object):
     """Adapter with the three problem-dependent operations of ILQRSolver."""
 
@@ -76,8 +81,11 @@ class TorchProblem(object):
         zu = torch.cat([z, u], -1)
         rep = zu.unsqueeze(1).expand(B, n, n + m).reshape(B * n, n + m)
         rep = rep.detach().clone().requires_grad_()
+        # `identical_inputs` tells a stateful model (the BNN's re-whitening,
+        # modules.py:333-348) that all rows are ONE input; with B trajectories
+        # in the batch that only holds for B = 1
         zn = self.model(rep[:, :n], rep[:, n:], t, self.encoding,
-                        identical_inputs=True, **self.model_opts)
+                        identical_inputs=(B == 1), **self.model_opts)
         eye = torch.eye(n, dtype=z.dtype, device=z.device).repeat(B, 1)
         J, = torch.autograd.grad(zn, rep, eye)
         J = J.reshape(B, n, n + m)
@@ -97,18 +105,35 @@ class TorchProblem(object):
         L_zz = torch.zeros(B, N + 1, n, n, **opts)
         L_uz = torch.zeros(B, N, m, n, **opts)
         L_uu = torch.zeros(B, N, m, m, **opts)
+        with torch.no_grad():  # (the network's kernel refuses when autograd
+            # could be asked to differentiate through it)
+            native_dyn = self._bnn_native_ok(s, need_cost=False) and \
+                self._bnn_jvp_ok(s)
+        native_cost = self._qr_cost_native_ok(s)
+        # which code produced the records (tests assert on it)
+        self.last_derivs_path = {"dynamics": "hip" if native_dyn else "autograd",
+                                 "cost": "hip" if native_cost else "autograd"}
+        if native_dyn:
+            self._dyn_derivs_bnn(s, F_z, F_u)
+        if native_cost:
+            self._cost_derivs_qr(s, L, L_z, L_u, L_zz, L_uz, L_uu)
         with torch.enable_grad():
             for t in range(N):
+                if native_dyn and native_cost:
+                    break
                 z = s.Z[:, t].detach()
                 u = s.U[:, t].detach()
                 if s.u_min is not None:  # derivatives AT the clamped action
                     u = clamp(u, s.u_min, s.u_max)
-                (L[:, t], L_z[:, t], L_u[:, t], L_zz[:, t], L_uz[:, t],
-                 L_uu[:, t]) = self._cost_derivs(z, u, t, False)
-                F_z[:, t], F_u[:, t] = self._dyn_derivs(z, u, t)
+                if not native_cost:
+                    (L[:, t], L_z[:, t], L_u[:, t], L_zz[:, t], L_uz[:, t],
+                     L_uu[:, t]) = self._cost_derivs(z, u, t, False)
+                if not native_dyn:
+                    F_z[:, t], F_u[:, t] = self._dyn_derivs(z, u, t)
             # terminal cost, evaluated with the stale index N-1 (ilqr.py:471-473)
-            L[:, N], L_z[:, N], _, L_zz[:, N], _, _ = self._cost_derivs(
-                s.Z[:, N].detach(), None, N - 1, True)
+            if not native_cost:
+                L[:, N], L_z[:, N], _, L_zz[:, N], _, _ = self._cost_derivs(
+                    s.Z[:, N].detach(), None, N - 1, True)
         rec = torch.empty_like(s.rec)
         p = _native.ptr
         _native.call("pddp_pack_records", s.dtype, B, N, n, m, p(F_z), p(F_u),
@@ -130,7 +155,124 @@ class TorchProblem(object):
                 s.state[sel] = 0
 
     # -- fused BNN rollout: csrc/bnn_rollout.hip + csrc/bnn_mlp.hip -------------
-    def _bnn_native_ok(self, s):
+    def _qr_cost_native_ok(self, s):
+        """QR cost on the angle-augmented state, DEFAULT encoding, f32: value,
+        gradient and Hessian of every (trajectory, step) in one launch
+        (include/pddp_hip.h pddp_qr_cost_derivs_f32)."""
+        from ..costs.quadratic import QRCost
+        from ..utils.encoding import StateEncoding
+        co = self.cost
+        mc = getattr(co, "model_class", None)
+        if not getattr(self, "use_native_cost", True) or self.cost_opts:
+            return False
+        if s.dtype != torch.float32 or type(co).forward is not \
+                _augmented_forward() or mc is None:
+            return False
+        if int(self.encoding) != int(StateEncoding.UPPER_TRIANGULAR_CHOLESKY):
+            return False
+        D = mc.state_size
+        return (D in (2, 4, 6) and s.m <= 2 and len(mc.angular_indices) <= 2
+                and s.n == D + D * (D + 1) // 2
+                and isinstance(co, QRCost))
+
+    @torch.no_grad()
+    def _cost_derivs_qr(self, s, L, L_z, L_u, L_zz, L_uz, L_uu):
+        import ctypes
+        co, mc = self.cost, self.cost.model_class
+        ang = [int(i) for i in mc.angular_indices]
+        non = [int(i) for i in mc.non_angular_indices]
+        na, m = len(non) + 2 * len(ang), s.m
+        opts = dict(dtype=s.dtype, device=s.device)
+        vec = lambda t, k: torch.as_tensor(t).detach().to(**opts).expand(
+            k).contiguous()
+        mat = lambda t: t.detach().to(**opts).contiguous()
+        keep = [mat(co.Q), mat(co.Q_term), mat(co.R), vec(co.x_goal, na),
+                vec(co.u_goal, m), s.Z.contiguous(), s.U.contiguous()]
+        st = _native.QrCost()
+        st.B, st.N, st.D, st.m = s.B, s.N, mc.state_size, m
+        st.n_ang, st.n_non = len(ang), len(non)
+        for i, v in enumerate(ang):
+            st.ang[i] = v
+        for i, v in enumerate(non):
+            st.non[i] = v
+        p = _native.ptr
+        for name, t in (("Q", keep[0]), ("Q_term", keep[1]), ("R", keep[2]),
+                        ("x_goal", keep[3]), ("u_goal", keep[4]),
+                        ("Z", keep[5]), ("U", keep[6]), ("u_min", s.u_min),
+                        ("u_max", s.u_max), ("L", L), ("L_z", L_z),
+                        ("L_u", L_u), ("L_zz", L_zz), ("L_uz", L_uz),
+                        ("L_uu", L_uu)):
+            setattr(st, name, p(t))
+        _native.check(_native.lib().pddp_qr_cost_derivs_f32(
+            ctypes.byref(st), _native.stream_handle(s.device)),
+            "pddp_qr_cost_derivs_f32")
+
+    def _bnn_jvp_ok(self, s):
+        """The forward-mode kernels cover D <= 4 with n + m <= 15 tangent
+        directions (include/pddp_hip.h pddp_bnn_jvp)."""
+        mo = self.model
+        return (getattr(self, "use_native_bnn_jvp", True)
+                and mo.state_size <= 4 and s.n + s.m <= 15)
+
+    @torch.no_grad()
+    def _dyn_derivs_bnn(self, s, F_z, F_u):
+        """F_z, F_u of the whole nominal in forward mode: per time step one
+        feature launch, the fused network in JVP mode on B P 16 rows, one
+        moment launch (csrc/bnn_jvp.hip, csrc/bnn_mlp.hip) - instead of
+        autograd over n replicated inputs (utils/evaluation.py:203-235)."""
+        import ctypes
+        from ..utils.encoding import decode_covar_sqrt, decode_mean
+        mo = self.model
+        B, N, n, m = s.B, s.N, s.n, s.m
+        D, P = mo.state_size, mo.n_particles
+        ang, non = mo.angular_indices_, mo.non_angular_indices_
+        in_dim = len(non) + 2 * len(ang) + m
+        opts = dict(dtype=s.dtype, device=s.device)
+        vec = lambda t, k: torch.as_tensor(t).detach().to(**opts).expand(
+            k).contiguous()
+        z0 = s.Z[:, 0]
+        if 0 not in mo.eps_in:
+            e = torch.randn(P, D, **opts)
+            mo.eps_in[0] = (e - e.mean(0)) / e.std(0)
+        Xp = (decode_mean(z0, self.encoding).unsqueeze(-2) +
+              mo.eps_in[0] @ decode_covar_sqrt(z0, self.encoding)).contiguous()
+        Xn = torch.empty_like(Xp)
+        eps = torch.empty_like(Xp)
+        F = torch.empty(B * P * 16, in_dim, **opts)
+        keep = [vec(mo.X_mean, in_dim), vec(mo.X_std_inv, in_dim),
+                vec(mo.dX_mean, D), vec(mo.dX_std, D), s.Z.contiguous(),
+                s.U.contiguous()]
+        st = _native.BnnJvp()
+        st.B, st.P, st.D, st.m, st.N = B, P, D, m, N
+        st.n_ang, st.n_non = len(ang), len(non)
+        for i, v in enumerate(ang):
+            st.ang[i] = v
+        for i, v in enumerate(non):
+            st.non[i] = v
+        st.in_dim, st.out_dim = in_dim, D
+        p = _native.ptr
+        for name, t in (("X_mean", keep[0]), ("X_std_inv", keep[1]),
+                        ("dX_mean", keep[2]), ("dX_std", keep[3]),
+                        ("Z", keep[4]), ("U", keep[5]), ("u_min", s.u_min),
+                        ("u_max", s.u_max), ("eps", eps), ("F", F),
+                        ("F_z", F_z), ("F_u", F_u)):
+            setattr(st, name, p(t))
+        lib, stream = _native.lib(), _native.stream_handle(s.device)
+        for t in range(N):
+            st.t = t
+            st.Xp, st.Xp_next = p(Xp), p(Xn)
+            _native.check(lib.pddp_bnn_jvp_features_f32(ctypes.byref(st),
+                                                        stream),
+                          "pddp_bnn_jvp_features_f32")
+            Y = mo.model._jvp_native(F, P, D)
+            st.net_out = p(Y)
+            _native.check(lib.pddp_bnn_jvp_moments_f32(ctypes.byref(st),
+                                                       stream),
+                          "pddp_bnn_jvp_moments_f32")
+            Xp, Xn = Xn, Xp
+        mo.output = {}  # the particle caches of a torch-path rollout: stale
+
+    def _bnn_native_ok(self, s, need_cost=True):
         """True when the line search can run as N + 1 moment-step launches
         with the fused network kernel in between (include/pddp_hip.h:
         pddp_bnn_moment_step_f32, pddp_bnn_mlp_f32) instead of ~150 torch
@@ -154,12 +296,14 @@ class TorchProblem(object):
             if k not in opts or bool(v) != opts[k]:
                 return False
         mc = getattr(co, "model_class", None)
-        if not isinstance(co, QRCost) or mc is None:
-            return False
-        if tuple(int(i) for i in mc.angular_indices) != mo.angular_indices_ or \
-                tuple(int(i) for i in mc.non_angular_indices) != \
-                mo.non_angular_indices_:
-            return False
+        if need_cost:
+            if not isinstance(co, QRCost) or mc is None:
+                return False
+            if tuple(int(i) for i in mc.angular_indices) != \
+                    mo.angular_indices_ or \
+                    tuple(int(i) for i in mc.non_angular_indices) != \
+                    mo.non_angular_indices_:
+                return False
         D, m, P = mo.state_size, mo.action_size, mo.n_particles
         if D > 8 or m > 2 or P > 128 or P < 2 or len(mo.angular_indices_) > 2:
             return False

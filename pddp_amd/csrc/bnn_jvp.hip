@@ -1,0 +1,277 @@
+// bnn_jvp.hip - Jacobians of one moment-matched BNN dynamics step in forward
+// mode, everything except the network itself (csrc/bnn_mlp.hip, JVP mode).
+//
+// What the reference obtains per time step from autograd on n replicated
+// inputs (pddp/controllers/ilqr.py:457-468 -> pddp/utils/evaluation.py:203-235
+// batch_eval_dynamics through pddp/models/bnn/modules.py:287-386):
+//   F_z = d z' / d z,  F_u = d z' / d u,   z = (mean | triu(upper Cholesky))
+// of   z' = encode(mean_p(out), cov_p(out)),   out_p = X_p + dX_std * net(
+//          ((augment(X_p) | u) - X_mean) * X_std_inv)[:D] + dX_mean,
+//      X_p = mean + eps_p U      with eps DETACHED: `infer_noise_variables`
+//          re-whitens the previous call's output particles,
+//          eps = (out_prev - mean) U^-1 (modules.py:333-348), a constant of the
+//          differentiation.
+// Forward mode: one tangent direction per input coordinate, 15 for cartpole
+// (D = 4: 4 means, 10 Cholesky entries, 1 action), pushed through the network
+// together with the primal row as a group of 16 rows (bnn_mlp.hip JVP mode):
+//   jvp_features:  (X_p, z_t, u_t) -> eps_p, the primal input row and the 15
+//                  tangent rows  d feat / d (mean_d | U_ab | u);
+//   jvp_moments :  network output rows -> out_p (the particle cloud carried to
+//                  step t + 1), M, C, U' = chol(C), and per direction k
+//                  dM_k = mean_p dout_pk,
+//                  dC_k = (S_k + S_k^T) / (P - 1),  S_k = sum_p dout_pk (out_p - M)^T,
+//                  dU'_k = Phi(U'^-T dC_k U'^-1) U'   (Phi: upper triangle, half
+//                  the diagonal - the differential of the Cholesky factor),
+//                  column k of (F_z | F_u) = (dM_k | triu(dU'_k)).
+// 16 lanes per (trajectory, particle) in jvp_features, 16 lanes per trajectory
+// in jvp_moments: lane k owns direction k.
+#include "pddp_common.hpp"
+
+namespace pddp {
+
+constexpr int kJvpMaxD = 4;   // D (D + 1) / 2 + D + m <= 15 tangent rows
+constexpr int kJvpRows = 16;  // rows per (state, particle): primal + tangents
+
+// tangent of X_p (D values) for direction d (0-based): mean_d, then the upper
+// triangle of U row-major (np.triu_indices, encoding.py:126-130), then u
+PDDP_DEV void x_tangent(int d, int D, const float* eps, float* dX) {
+  for (int i = 0; i < D; ++i) dX[i] = 0.f;
+  if (d < 0) return;
+  if (d < D) { dX[d] = 1.f; return; }
+  int o = D;
+  for (int a = 0; a < D; ++a)
+    for (int b = a; b < D; ++b, ++o)
+      if (o == d) dX[b] = eps[a];  // X = mean + eps U:  dX[b] / dU[a][b] = eps[a]
+}
+
+__global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
+  const int lane = threadIdx.x;
+  const int k = lane & 15;                      // row of the group
+  const int bp = blockIdx.x * 4 + (lane >> 4);  // (trajectory, particle)
+  if (bp >= s.B * s.P) return;
+  const int b = bp / s.P;
+  const int D = s.D, m = s.m, n = D + D * (D + 1) / 2;
+  const float* z = s.Z + ((size_t)b * (s.N + 1) + s.t) * n;
+  const float* xp = s.Xp + (size_t)bp * D;
+  // eps = (X - mean) U^-1: forward substitution against the upper factor
+  float U[kJvpMaxD][kJvpMaxD], eps[kJvpMaxD], x[kJvpMaxD];
+  {
+    int o = D;
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) U[i][j] = j >= i ? z[o++] : 0.f;
+  }
+  for (int j = 0; j < D; ++j) {
+    x[j] = xp[j];
+    float v = x[j] - z[j];
+    for (int i = 0; i < j; ++i) v -= eps[i] * U[i][j];
+    eps[j] = v / U[j][j];
+  }
+  if (k == 0)
+    for (int j = 0; j < D; ++j) s.eps[(size_t)bp * D + j] = eps[j];
+  float dX[kJvpMaxD];
+  x_tangent(k - 1, D, eps, dX);
+  float* f = s.F + ((size_t)bp * kJvpRows + k) * s.in_dim;
+  int o = 0;
+  for (int i = 0; i < s.n_non; ++i, ++o) {
+    const int c = s.non[i];
+    f[o] = k == 0 ? (x[c] - s.X_mean[o]) * s.X_std_inv[o]
+                  : dX[c] * s.X_std_inv[o];
+  }
+  for (int a = 0; a < s.n_ang; ++a) {
+    const int c = s.ang[a];
+    float sn, cs;
+    sincosf(x[c], &sn, &cs);
+    f[o] = k == 0 ? (sn - s.X_mean[o]) * s.X_std_inv[o]
+                  : (cs * dX[c]) * s.X_std_inv[o];
+    ++o;
+    f[o] = k == 0 ? (cs - s.X_mean[o]) * s.X_std_inv[o]
+                  : (-sn * dX[c]) * s.X_std_inv[o];
+    ++o;
+  }
+  for (int r = 0; r < m; ++r, ++o) {
+    // derivatives AT the clamped action (ilqr.py:461-462: the clamp is not
+    // differentiated through)
+    float u = s.U[((size_t)b * s.N + s.t) * m + r];
+    if (s.u_min != nullptr && s.u_max != nullptr)
+      u = clamp1(u, s.u_min[r], s.u_max[r]);
+    f[o] = k == 0 ? (u - s.X_mean[o]) * s.X_std_inv[o]
+                  : ((k - 1 == n + r) ? s.X_std_inv[o] : 0.f);
+  }
+}
+
+__global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
+  const int lane = threadIdx.x;
+  const int k = lane & 15;
+  const int b = blockIdx.x * 4 + (lane >> 4);
+  if (b >= s.B) return;
+  const int D = s.D, P = s.P, m = s.m, n = D + D * (D + 1) / 2;
+  const int OUT = s.out_dim;
+  const float* Y = s.net_out + (size_t)b * P * kJvpRows * OUT;
+  const float* Xin = s.Xp + (size_t)b * P * D;
+  float sd[kJvpMaxD], mu[kJvpMaxD];
+  for (int d = 0; d < D; ++d) { sd[d] = s.dX_std[d]; mu[d] = s.dX_mean[d]; }
+
+  // ---- primal moments (every lane of the group, same arithmetic)
+  float M[kJvpMaxD];
+  for (int d = 0; d < D; ++d) M[d] = 0.f;
+  for (int p = 0; p < P; ++p)
+    for (int d = 0; d < D; ++d)
+      M[d] += Xin[p * D + d] + (Y[(size_t)p * kJvpRows * OUT + d] * sd[d] + mu[d]);
+  for (int d = 0; d < D; ++d) M[d] /= (float)P;
+
+  // ---- covariance, and this lane's tangent sums
+  float C[kJvpMaxD][kJvpMaxD], S[kJvpMaxD][kJvpMaxD], dM[kJvpMaxD];
+  for (int i = 0; i < D; ++i) {
+    dM[i] = 0.f;
+    for (int j = 0; j < D; ++j) { C[i][j] = 0.f; S[i][j] = 0.f; }
+  }
+  for (int p = 0; p < P; ++p) {
+    float dev[kJvpMaxD], dout[kJvpMaxD], dX[kJvpMaxD];
+    x_tangent(k - 1, D, s.eps + ((size_t)b * P + p) * D, dX);
+    for (int d = 0; d < D; ++d) {
+      const float out =
+          Xin[p * D + d] + (Y[(size_t)p * kJvpRows * OUT + d] * sd[d] + mu[d]);
+      dev[d] = out - M[d];
+      dout[d] = dX[d] + Y[((size_t)p * kJvpRows + k) * OUT + d] * sd[d];
+      if (k == 0 && s.Xp_next != nullptr)
+        s.Xp_next[((size_t)b * P + p) * D + d] = out;
+    }
+    for (int i = 0; i < D; ++i) {
+      dM[i] += dout[i];
+      for (int j = 0; j < D; ++j) {
+        C[i][j] += dev[i] * dev[j];
+        S[i][j] += dout[i] * dev[j];
+      }
+    }
+  }
+  for (int i = 0; i < D; ++i) {
+    dM[i] /= (float)P;
+    for (int j = 0; j < D; ++j) C[i][j] /= (float)(P - 1);
+  }
+
+  // ---- U' = chol(C + jitter I), upper (encoding.py:536-564)
+  float Uc[kJvpMaxD][kJvpMaxD];
+  bool ok = false;
+  {
+    double jit = 1e-12;
+    while (!ok && jit <= 10.0) {
+      ok = true;
+      for (int i = 0; i < D && ok; ++i)
+        for (int j = i; j < D; ++j) {
+          float v = C[i][j] + (i == j ? (float)jit : 0.f);
+          for (int q = 0; q < i; ++q) v -= Uc[q][i] * Uc[q][j];
+          if (i == j) {
+            if (!(v > 0.f)) { ok = false; break; }
+            Uc[i][i] = sqrtf(v);
+          } else {
+            Uc[i][j] = v / Uc[i][i];
+          }
+        }
+      jit *= 10.0;
+    }
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < i; ++j) Uc[i][j] = 0.f;
+  }
+
+  float dU[kJvpMaxD][kJvpMaxD];
+  for (int i = 0; i < D; ++i)
+    for (int j = 0; j < D; ++j) dU[i][j] = 0.f;
+  if (ok) {
+    // dC = (S + S^T) / (P - 1);  W = U'^-T dC U'^-1;  dU' = Phi(W) U'
+    float dC[kJvpMaxD][kJvpMaxD], T1[kJvpMaxD][kJvpMaxD], W[kJvpMaxD][kJvpMaxD];
+    for (int i = 0; i < D; ++i)
+      for (int j = 0; j < D; ++j) dC[i][j] = (S[i][j] + S[j][i]) / (float)(P - 1);
+    // T1 = U'^-T dC: solve U'^T T1 = dC (U'^T lower): forward substitution
+    for (int c = 0; c < D; ++c)
+      for (int i = 0; i < D; ++i) {
+        float v = dC[i][c];
+        for (int q = 0; q < i; ++q) v -= Uc[q][i] * T1[q][c];
+        T1[i][c] = v / Uc[i][i];
+      }
+    // W = T1 U'^-1: solve W U' = T1 row by row, forward in the column index
+    for (int r = 0; r < D; ++r)
+      for (int j = 0; j < D; ++j) {
+        float v = T1[r][j];
+        for (int q = 0; q < j; ++q) v -= W[r][q] * Uc[q][j];
+        W[r][j] = v / Uc[j][j];
+      }
+    for (int i = 0; i < D; ++i)
+      for (int j = i; j < D; ++j) {
+        float v = 0.f;
+        for (int q = i; q <= j; ++q)
+          v += (q == i ? 0.5f * W[i][i] : W[i][q]) * Uc[q][j];
+        dU[i][j] = v;
+      }
+  } else {
+    // encode()'s fall-back: the diagonal of standard deviations
+    // (modules.py:380-386 -> encoding.py:99-141)
+    for (int i = 0; i < D; ++i) {
+      const float sdev = sqrtf(C[i][i]);
+      Uc[i][i] = sdev;
+      dU[i][i] = (S[i][i] + S[i][i]) / (float)(P - 1) / (2.f * sdev);
+    }
+  }
+
+  // ---- outputs: the next encoded state (lane 0) and column k - 1 of (F_z|F_u)
+  if (k == 0) {
+    if (s.Z_next != nullptr) {
+      float* zn = s.Z_next + (size_t)b * n;
+      for (int d = 0; d < D; ++d) zn[d] = M[d];
+      int o = D;
+      for (int i = 0; i < D; ++i)
+        for (int j = i; j < D; ++j) zn[o++] = Uc[i][j];
+    }
+    return;
+  }
+  const int col = k - 1;
+  if (col >= n + m) return;
+  float* dst;
+  int ld;
+  if (col < n) {
+    dst = s.F_z + ((size_t)b * s.N + s.t) * n * n + col;
+    ld = n;
+  } else {
+    dst = s.F_u + ((size_t)b * s.N + s.t) * n * m + (col - n);
+    ld = m;
+  }
+  for (int d = 0; d < D; ++d) dst[(size_t)d * ld] = dM[d];
+  int o = D;
+  for (int i = 0; i < D; ++i)
+    for (int j = i; j < D; ++j, ++o) dst[(size_t)o * ld] = dU[i][j];
+}
+
+}  // namespace pddp
+
+extern "C" {
+
+static int bnn_jvp_check(const pddp_bnn_jvp* s) {
+  if (s == nullptr) return PDDP_E_BADARG;
+  if (s->B <= 0 || s->P <= 1 || s->N <= 0 || s->t < 0 || s->t >= s->N ||
+      !s->Z || !s->U || !s->X_mean || !s->X_std_inv || !s->dX_mean ||
+      !s->dX_std || !s->Xp || !s->eps || !s->F)
+    return PDDP_E_BADARG;
+  const int n = s->D + s->D * (s->D + 1) / 2;
+  if (s->D < 1 || s->D > pddp::kJvpMaxD || s->m < 1 ||
+      n + s->m > pddp::kJvpRows - 1 || s->n_ang < 0 || s->n_ang > 2 ||
+      s->n_non < 0 || s->n_non + s->n_ang != s->D ||
+      s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D)
+    return PDDP_E_UNSUPPORTED;
+  return 0;
+}
+
+int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* s, void* stream) {
+  if (int rc = bnn_jvp_check(s)) return rc;
+  hipLaunchKernelGGL(pddp::bnn_jvp_features_kernel, dim3((s->B * s->P + 3) / 4),
+                     dim3(64), 0, (hipStream_t)stream, *s);
+  return pddp::launch_status();
+}
+
+int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* s, void* stream) {
+  if (int rc = bnn_jvp_check(s)) return rc;
+  if (!s->net_out || !s->F_z || !s->F_u) return PDDP_E_BADARG;
+  hipLaunchKernelGGL(pddp::bnn_jvp_moments_kernel, dim3((s->B + 3) / 4),
+                     dim3(64), 0, (hipStream_t)stream, *s);
+  return pddp::launch_status();
+}
+
+}  // extern "C"

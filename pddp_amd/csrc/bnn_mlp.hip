@@ -28,6 +28,17 @@
 //      32 j + (i & 3) + 8 (i >> 2) + 4 h), so layer 3 takes it with W3
 //      permuted to match: 16 more MFMAs, no LDS, no shuffles;
 //   C  the NB partial outputs are summed from LDS, b3 added, rows stored.
+//
+// JVP mode (the derivative rollout, ilqr.py:457-468 through
+// utils/evaluation.py:203-235): rows come in groups of 16 = one (state,
+// particle) input and 15 tangent directions of it.  A tangent row goes through
+// the same weights without biases, and through the ReLUs linearised at its
+// group's primal row: d relu(m h) = m dh [m h > 0].  Groups are aligned to the
+// 16-lane DPP rows of both the producer and the accumulator layout (data row =
+// lane & 31), so the primal's pre-activation of the same unit arrives by one
+// `row_newbcast:0` move.  Forward-mode replaces autograd's replicate-the-input
+// pass: (1 + 15) network evaluations per state instead of 14 forward + 14
+// backward ones, and nothing is stored.
 #include "pddp_common.hpp"
 
 namespace pddp {
@@ -67,7 +78,14 @@ constexpr size_t bnn_mlp_lds_floats() {
 
 // kMlpW1Stride: LDS stride of a W1 row | b1 (8: in_dim <= 7, 16: <= 15) - the
 // producer wavefront's work is proportional to it
-template <int H, int kMlpW1Stride>
+// value of lane 0 of this lane's 16-lane row (gfx90a+ DPP row_newbcast)
+PDDP_DEV float row_first(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150,
+                                                    0xf, 0xf, true));
+}
+constexpr int kJvpGroup = 16;  // rows per (state, particle) in JVP mode
+
+template <int H, int kMlpW1Stride, bool JVP = false>
 __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   static_assert(H % 8 == 0 && H <= 224, "H: multiple of 8, at most 224");
   constexpr int KS = H / 2;          // MFMA steps of layer 2
@@ -109,12 +127,13 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       if (!first_prod || i >= my) return;
       const int row = (blockIdx.x + i * gridDim.x) * kMlpTile + li;
       const bool live = row < R;
-      const int p = live ? row % P : 0;
+      const int p = live ? (JVP ? (row / kJvpGroup) % P : row % P) : 0;
       float x[kMlpW1Stride];
 #pragma unroll
       for (int c = 0; c < kMlpW1Stride; ++c)
         x[c] = (live && c < IN) ? a.X[(size_t)row * IN + c] : 0.f;
-      x[kMlpW1Stride - 1] = 1.f;  // multiplies the bias slot
+      // multiplies the bias slot (tangent rows carry no bias)
+      x[kMlpW1Stride - 1] = (JVP && (li & (kJvpGroup - 1)) != 0) ? 0.f : 1.f;
       f32x4* dst = reinterpret_cast<f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
       // this lane's KS mask values, contiguous in the parity-split layout:
       // all requested up front (KS / 4 independent 16-B loads)
@@ -144,7 +163,12 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
             acc = __builtin_fmaf(x[4 * c4 + 1], w[1], acc);
             acc = __builtin_fmaf(x[4 * c4 + 0], w[0], acc);
           }
-          v[e] = fmaxf(acc * mk[q][e], 0.f);
+          if constexpr (JVP) {
+            // linearised at the group's primal row (for which this IS relu)
+            v[e] = (row_first(acc) * mk[q][e] > 0.f) ? acc * mk[q][e] : 0.f;
+          } else {
+            v[e] = fmaxf(acc * mk[q][e], 0.f);
+          }
         }
         dst[q * 64] = v;
       }
@@ -155,7 +179,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       const float* pr = part + (i & 1) * kPart;
       for (int t = lane; t < 32 * OUT; t += 64) {
         const int rr = row0 + (t & 31), o = t >> 5;
-        float y = a.b3[o];
+        float y = (JVP && ((t & 31) & (kJvpGroup - 1)) != 0) ? 0.f : a.b3[o];
 #pragma unroll
         for (int jj = 0; jj < NB; ++jj)
           y += pr[(jj * kMlpMaxOut + o) * 32 + (t & 31)];
@@ -209,7 +233,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     // (0..3), one 16-B load of the mask row each (clamped inside the row for
     // the padded units of the last block, whose weights are zero)
     const int row = row0 + li;
-    const int p = row < R ? row % P : 0;
+    const int p = row < R ? (JVP ? (row / kJvpGroup) % P : row % P) : 0;
     f32x4 m2[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -234,7 +258,15 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float h2 = fmaxf((acc[r] + b2r[r]) * m2[r >> 2][r & 3], 0.f);
+      float h2;
+      if constexpr (JVP) {
+        const float pre =
+            acc[r] + ((li & (kJvpGroup - 1)) != 0 ? 0.f : b2r[r]);
+        const float mm = m2[r >> 2][r & 3];
+        h2 = (row_first(pre) * mm > 0.f) ? pre * mm : 0.f;
+      } else {
+        h2 = fmaxf((acc[r] + b2r[r]) * m2[r >> 2][r & 3], 0.f);
+      }
       out = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[r], h2, out, 0, 0, 0);
     }
     // out: register r of lane-half lh = output unit (r & 3) + 8 (r >> 2)
@@ -249,7 +281,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   }
 }
 
-template <int H, int W1S>
+template <int H, int W1S, bool JVP = false>
 static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   static int cus = 0;  // queried once: hipGetDeviceProperties costs ms
   if (cus == 0) {
@@ -266,20 +298,20 @@ static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {  // more than 64 KB of dynamic LDS needs the opt-in
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)bnn_mlp_kernel<H, W1S>,
+        (const void*)bnn_mlp_kernel<H, W1S, JVP>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((bnn_mlp_kernel<H, W1S>), dim3(grid), dim3(kMlpThreads), lds,
-                     st, a);
+  hipLaunchKernelGGL((bnn_mlp_kernel<H, W1S, JVP>), dim3(grid),
+                     dim3(kMlpThreads), lds, st, a);
   return launch_status();
 }
 
-template <int H>
+template <int H, bool JVP = false>
 static int launch_bnn_mlp(const BnnMlpArgs& a, hipStream_t st) {
-  return a.in_dim < 8 ? launch_bnn_mlp_w<H, 8>(a, st)
-                      : launch_bnn_mlp_w<H, 16>(a, st);
+  return a.in_dim < 8 ? launch_bnn_mlp_w<H, 8, JVP>(a, st)
+                      : launch_bnn_mlp_w<H, 16, JVP>(a, st);
 }
 
 }  // namespace pddp
@@ -303,6 +335,28 @@ int pddp_bnn_mlp_f32(int R, int P, int in_dim, int H, int out_dim,
     case 64: return pddp::launch_bnn_mlp<64>(a, st);
     case 128: return pddp::launch_bnn_mlp<128>(a, st);
     case 200: return pddp::launch_bnn_mlp<200>(a, st);
+  }
+  return PDDP_E_UNSUPPORTED;
+}
+
+int pddp_bnn_mlp_jvp_f32(int R, int P, int in_dim, int H, int out_dim,
+                         const float* X, const float* W1, const float* b1,
+                         const float* MT1, const float* W2, const float* b2,
+                         const float* MT2, const float* W3, const float* b3,
+                         float* Y, void* stream) {
+  if (R <= 0 || P <= 0 || in_dim <= 0 || H <= 0 || out_dim <= 0 || !X || !W1 ||
+      !b1 || !MT1 || !W2 || !b2 || !MT2 || !W3 || !b3 || !Y)
+    return PDDP_E_BADARG;
+  if (R % pddp::kJvpGroup != 0) return PDDP_E_BADARG;
+  if (in_dim >= pddp::kMlpW1Max || out_dim > pddp::kMlpMaxOut)
+    return PDDP_E_UNSUPPORTED;
+  const pddp::BnnMlpArgs a{R, P, in_dim, H, out_dim, X, W1, b1, MT1, W2,
+                           b2, MT2, W3, b3, Y};
+  hipStream_t st = (hipStream_t)stream;
+  switch (H) {
+    case 64: return pddp::launch_bnn_mlp<64, true>(a, st);
+    case 128: return pddp::launch_bnn_mlp<128, true>(a, st);
+    case 200: return pddp::launch_bnn_mlp<200, true>(a, st);
   }
   return PDDP_E_UNSUPPORTED;
 }
