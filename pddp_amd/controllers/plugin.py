@@ -40,6 +40,17 @@ class TorchProblem(object):
     def rollout(self, s):
         self.model.eval()
         Z, U = s.Z, s.U
+        if self._bnn_native_ok(s):
+            # the nominal is the alpha = 0 "candidate" of zero gains
+            opts = dict(dtype=s.dtype, device=s.device)
+            Z.zero_()
+            Z[:, 0] = s.z0
+            Zc = torch.empty(s.B, s.N + 1, 1, s.n, **opts)
+            Uc = torch.empty(s.B, s.N, 1, s.m, **opts)
+            self._bnn_rollouts(s, 1, torch.zeros(1, **opts),
+                               torch.zeros_like(s.gains), Zc, Uc, None, None)
+            Z.copy_(Zc[:, :, 0])
+            return
         Z[:, 0] = s.z0
         for t in range(s.N):
             u = U[:, t]
@@ -313,10 +324,19 @@ class TorchProblem(object):
 
     @torch.no_grad()
     def _line_search_bnn(self, s, active, use_status):
+        Jc = self._bnn_rollouts(s, s.A, s.alphas, s.gains, s.Zc, s.Uc, active,
+                                s.bwd_status if use_status else None)
+        s.Jc.copy_(Jc.view(s.B, s.A))
+
+    @torch.no_grad()
+    def _bnn_rollouts(self, s, A, alphas, gains, Zc, Uc, active, status):
+        """A moment-matched rollouts per trajectory under the control law
+        u = clamp(U + alpha k + K (z - Z)): N + 1 moment-step launches with the
+        fused network kernel in between.  Returns the costs [B A]."""
         import ctypes
         from ..utils.encoding import decode_covar_sqrt, decode_mean
         mo, co = self.model, self.cost
-        B, N, n, m, A = s.B, s.N, s.n, s.m, s.A
+        B, N, n, m = s.B, s.N, s.n, s.m
         D, P = mo.state_size, mo.n_particles
         ang, non = mo.angular_indices_, mo.non_angular_indices_
         na = len(non) + 2 * len(ang)
@@ -351,15 +371,15 @@ class TorchProblem(object):
             st.non[i] = v
         st.in_dim, st.out_dim = in_dim, out_dim
         p = _native.ptr
-        for name, t in (("Z", s.Z), ("U", s.U), ("gains", s.gains),
-                        ("alphas", s.alphas), ("u_min", s.u_min),
+        for name, t in (("Z", s.Z), ("U", s.U), ("gains", gains),
+                        ("alphas", alphas), ("u_min", s.u_min),
                         ("u_max", s.u_max), ("active", active),
-                        ("bwd_status", s.bwd_status if use_status else None),
+                        ("bwd_status", status),
                         ("X_mean", keep[0]), ("X_std_inv", keep[1]),
                         ("dX_mean", keep[2]), ("dX_std", keep[3]),
                         ("Q", keep[4]), ("Q_term", keep[5]), ("R", keep[6]),
                         ("x_goal", keep[7]), ("u_goal", keep[8]), ("Xp", Xp),
-                        ("F", F), ("Zc", s.Zc), ("Uc", s.Uc), ("J", J),
+                        ("F", F), ("Zc", Zc), ("Uc", Uc), ("J", J),
                         ("Jc", Jc)):
             setattr(st, name, p(t))
         lib, stream = _native.lib(), _native.stream_handle(s.device)
@@ -372,8 +392,8 @@ class TorchProblem(object):
                           "pddp_bnn_moment_step_f32")
             if t < N:
                 out = mo.model._forward_native(F)
-        s.Jc.copy_(Jc.view(B, A))
         mo.output = {}  # the particle caches of a torch-path rollout: stale
+        return Jc
 
     # -- ilqr.py:677-723, 764-791 ---------------------------------------------
     @torch.no_grad()

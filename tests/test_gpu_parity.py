@@ -940,8 +940,11 @@ def test_bnn_native_line_search_vs_torch_path(problem, H, P):
         with torch.no_grad():
             assert plugin._bnn_native_ok(s) == native
         s.line_search()
-        res.append((s.Zc.clone(), s.Uc.clone(), s.Jc.clone()))
-    (Za, Ua, Ja), (Zb, Ub, Jb) = res
+        res.append((s.Zc.clone(), s.Uc.clone(), s.Jc.clone(), s.Z.clone()))
+    (Za, Ua, Ja, Zna), (Zb, Ub, Jb, Znb) = res
+    # the nominal rollout of set_nominal: moment-step kernels vs torch ops
+    assert float((Zna - Znb).abs().max()) / float(Znb.abs().max()) < 2e-3
+    assert float((Znb[:, 1:] - Znb[:, :1]).abs().max()) > 1e-4
     assert torch.isfinite(Za).all() and torch.isfinite(Ja).all()
     for x, y, name in ((Za, Zb, "Zc"), (Ua, Ub, "Uc"), (Ja, Jb, "Jc")):
         err = float((x - y).abs().max()) / max(float(y.abs().max()), 1e-6)
