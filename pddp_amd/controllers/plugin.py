@@ -104,6 +104,11 @@ class TorchProblem(object):
 
     def derivs(self, s, mask=None, set_state=True):
         """Fills s.rec, s.L, s.J_opt (and resets s.state) for masked rows."""
+        if mask is not None and not bool(mask.any()):
+            # a round of retries only (ilqr.py:125-139 with a larger mu): every
+            # nominal is unchanged, so are its records.  One host sync, against
+            # a derivative rollout of the whole batch.
+            return
         self.model.eval()
         self.cost.eval()
         B, N, n, m = s.B, s.N, s.n, s.m

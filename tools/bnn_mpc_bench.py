@@ -51,10 +51,16 @@ def main():
          1e-2 * torch.randn(B, 4)).to(dev)
     ienc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
 
+    rounds = [0]
+
+    def on_iteration(*args):
+        rounds[0] += 1
+
     def control_step():
         nonlocal x
         z = _encode(x)
-        u = ctrl(z, 0, enc, mpc=True, u_min=u_min, u_max=u_max)
+        u = ctrl(z, 0, enc, mpc=True, u_min=u_min, u_max=u_max,
+                 on_iteration=on_iteration)
         with torch.no_grad():
             x = plant(x, u.clamp(-10.0, 10.0), 0, ienc)
 
@@ -72,6 +78,7 @@ def main():
     for _ in range(3):
         control_step()
     torch.cuda.synchronize()
+    rounds[0] = 0
     t0 = time.perf_counter()
     for _ in range(a.steps):
         control_step()
@@ -84,6 +91,7 @@ def main():
                     "control steps, fp32" % (a.particles, N, B, a.steps),
         "s_total": dt, "ms_per_control_step": dt / a.steps * 1e3,
         "restart_control_steps_per_s": B * a.steps / dt,
+        "rounds_per_control_step": rounds[0] / a.steps,
         "derivative_path": path}))
 
 
