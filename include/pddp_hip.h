@@ -95,8 +95,10 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  * instead of IEEE division / square root (f32 only), 6 / 7 = 2 / 3 with the
  * scalar BoxQP in closed form (the reference's loop as fall-back), 8 / 9 =
  * 6 / 7 with every step split over two wavefronts (bounded problems only),
- * 10 / 11 = 6 / 7 in workgroups of four wavefronts.  Auto: n=4/m=1 bounded
- * f32 -> 9 up to 8192 trajectories, 7 beyond; f64 -> 6. */
+ * 10 / 11 = 6 / 7 in workgroups of four wavefronts, 12 / 13 = 8 / 9 with the
+ * BoxQP chain decoupled from the value update (bounded eig-clamp branch only).
+ * Auto: n=4/m=1 bounded f32, up to 16384 trajectories -> 13 (eig-clamp branch)
+ * or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64). */
 int pddp_riccati_backward_variant_f32(int B, int N, int n, int m,
                                       const float* rec, const float* u_min,
                                       const float* u_max, const double* reg,

@@ -3,6 +3,7 @@
 #include "riccati_generic.hpp"
 #include "riccati_n4.hpp"
 #include "riccati_n4_split.hpp"
+#include "riccati_n4_pipe.hpp"
 
 namespace pddp {
 
@@ -51,14 +52,29 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          (f32 only), 6 / 7 = 2 / 3 with the BoxQP in closed form (loop as
   //          fall-back), 8 / 9 = 6 / 7 with the step split over two
   //          wavefronts (riccati_n4_split.hpp; bounded problems only),
-  //          10 / 11 = 6 / 7 in workgroups of four wavefronts;
-  //          auto: bounded f32 -> 9 up to 8192 trajectories, else 7; f64 -> 6
+  //          10 / 11 = 6 / 7 in workgroups of four wavefronts,
+  //          12 / 13 = 8 / 9 with the BoxQP chain decoupled from the value
+  //          update (riccati_n4_pipe.hpp; bounded eig-clamp branch only);
+  //          auto: bounded f32, up to 16384 trajectories -> 13 (eig-clamp
+  //          branch) or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64)
   if (variant >= 2 && !(n == 4 && m == 1)) return PDDP_E_UNSUPPORTED;
-  if (variant < 0 || variant > 11 || variant == 4 || variant == 5)
+  if (variant < 0 || variant > 13 || variant == 4 || variant == 5)
     return PDDP_E_BADARG;
-  if (variant == 0 && n == 4 && m == 1 && sizeof(T) == 4 && u_min != nullptr &&
-      B <= 8192)
-    variant = 9;
+
+  if (variant == 0 && n == 4 && m == 1 && u_min != nullptr && B <= 16384) {
+    // latency-bound batches: the two-wavefront kernels
+    // (f32 only: with f64 the one-wave line search that follows is placed
+    // badly after a kernel of two-wave workgroups - DESIGN.md 3.1b - and its
+    // LDS slice does not leave room for four-wave workgroups)
+    if (sizeof(T) == 4) variant = branch == PDDP_BRANCH_EIG ? 13 : 9;
+  }
+  if (variant == 12 || variant == 13) {
+    // BoxQP chain decoupled from the value update (riccati_n4_pipe.hpp):
+    // bounded eig-clamp branch only
+    if (u_min == nullptr || branch != PDDP_BRANCH_EIG)
+      return PDDP_E_UNSUPPORTED;
+    return launch_n4_pipe<T>(a, st, variant == 13 && sizeof(T) == 4);
+  }
   if (variant == 8 || variant == 9) {
     if (u_min == nullptr) return PDDP_E_UNSUPPORTED;
     return launch_n4_split<T>(a, st, variant == 9 && sizeof(T) == 4);
@@ -67,7 +83,7 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
     const bool fast = (variant == 0 || variant == 3 || variant == 7 ||
                        variant == 11) && sizeof(T) == 4;
     const bool cf = (variant == 0 || variant == 6 || variant == 7 ||
-                     variant >= 10);
+                     variant == 10 || variant == 11);
     return launch_n4<T>(a, st, fast, variant >= 10 ? 4 : 1, cf);
   }
   switch (m) {
@@ -82,6 +98,18 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
 }  // namespace pddp
 
 extern "C" {
+
+#ifdef PDDP_PIPE_TIMING
+int pddp_debug_pipe_wait(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4::g_pipe_wait), 32);
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4::g_pipe_wait), z, 32);
+  }
+  return 0;
+}
+#endif
 
 #ifdef PDDP_QP_STATS
 int pddp_debug_qp_stats(unsigned long long* out, int reset) {

@@ -98,7 +98,7 @@ def test_derivative_records_vs_oracle(problem, dtype):
         assert np.array_equal(got_U, U[b])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 12, 13])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", PROBLEMS)
 def test_backward_vs_oracle(problem, dtype, variant):
@@ -109,8 +109,9 @@ def test_backward_vs_oracle(problem, dtype, variant):
     split over two wavefronts (bounded branches only)."""
     if variant >= 2 and problem != "cartpole":
         pytest.skip("variants >= 2 are the n=4/m=1 kernel")
-    if variant in (3, 7, 9) and dtype != "f32":
-        pytest.skip("variants 3 / 7 / 9 = f32 kernels with approximate division")
+    if variant in (3, 7, 9, 13) and dtype != "f32":
+        pytest.skip("variants 3 / 7 / 9 / 13 = f32 kernels with approximate "
+                    "division")
     B, N = 5, 40
     s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N)
     s.nominal_rollout()
@@ -121,6 +122,8 @@ def test_backward_vs_oracle(problem, dtype, variant):
     for branch, bounded in ((0, False), (0, True), (1, False), (1, True)):
         if variant >= 8 and not bounded:
             continue
+        if variant >= 12 and branch != 0:
+            continue  # the decoupled kernel is the eig-clamp + BoxQP branch
         for reg in (0.0, 1e-6, 1.0, 100.0):
             regv = torch.full((B,), reg, dtype=torch.float64, device="cuda")
             s.gains.zero_()
@@ -636,9 +639,11 @@ def test_backward_ragged_shapes(B, N, dtype):
     active = torch.ones(B, dtype=torch.uint8, device="cuda")
     if B > 2:
         active[1] = 0
-    for variant in (0, 1, 2, 8):
+    for variant in (0, 1, 2, 8, 12):
         for branch, bounded in ((0, True), (0, False), (1, True), (1, False)):
             if variant >= 8 and not bounded:
+                continue
+            if variant >= 12 and branch != 0:
                 continue
             regv = torch.full((B,), 1.0, dtype=torch.float64, device="cuda")
             s.gains.fill_(float("nan"))
