@@ -336,12 +336,14 @@ int pddp_bnn_moment_step_f32(const pddp_bnn_step* step, void* stream);
 /* ---- the same network in forward mode (JVP), for the derivative rollout
  * (ilqr.py:457-468 -> utils/evaluation.py:203-235 batch_eval_dynamics, which
  * replicates the input n times and back-propagates an identity): rows come in
- * groups of 16 = one (state, particle) input row followed by 15 tangent rows
- * d X / d direction; a tangent row passes through the weights without biases
- * and through the ReLUs linearised at its group's first row.  p = (r / 16) % P,
- * R a multiple of 16; everything else as pddp_bnn_mlp_f32. */
-int pddp_bnn_mlp_jvp_f32(int R, int P, int in_dim, int H, int out_dim,
-                         const float* X, const float* W1, const float* b1,
+ * groups of `group` = 16 or 32 = one (state, particle) input row followed by
+ * group - 1 tangent rows d X / d direction; a tangent row passes through the
+ * weights without biases and through the ReLUs linearised at its group's first
+ * row.  p = (r / group) % P, R a multiple of group; everything else as
+ * pddp_bnn_mlp_f32. */
+int pddp_bnn_mlp_jvp_f32(int R, int P, int group, int in_dim, int H,
+                         int out_dim, const float* X, const float* W1,
+                         const float* b1,
                          const float* M1S, const float* W2, const float* b2,
                          const float* M2, const float* W3, const float* b3,
                          float* Y, void* stream);
@@ -356,8 +358,11 @@ int pddp_bnn_mlp_jvp_f32(int R, int P, int in_dim, int H, int out_dim,
  *                the cloud of step t + 1), Z_next = encode(mean, covariance),
  *                F_z[b][t], F_u[b][t] through the differential of the Cholesky
  *                factor.
- * D <= 4 and D + D (D + 1) / 2 + m <= 15 (cartpole, pendulum); otherwise
- * PDDP_E_UNSUPPORTED (the autograd path then). */
+ * Rows per group G = pddp_bnn_jvp_group(D, m): 16 for D <= 4 with at most 15
+ * directions (cartpole, pendulum), 32 for D <= 6 with at most 31 (double
+ * cartpole), 0 = PDDP_E_UNSUPPORTED (the autograd path then); F and net_out
+ * are [B P][G][.]. */
+int pddp_bnn_jvp_group(int D, int m);
 typedef struct pddp_bnn_jvp {
   int32_t B, P, D, m, N, t;
   int32_t n_ang, ang[2], n_non, non[8];
@@ -370,11 +375,11 @@ typedef struct pddp_bnn_jvp {
   const float* X_std_inv;
   const float* dX_mean;  /* [D] */
   const float* dX_std;
-  const float* net_out;  /* [B P][16][out_dim] (moments) */
+  const float* net_out;  /* [B P][G][out_dim] (moments) */
   const float* Xp;       /* [B][P][D] particles of step t */
   float* Xp_next;        /* [B][P][D] out (moments), nullable */
   float* eps;            /* [B][P][D] out (features), in (moments) */
-  float* F;              /* [B P][16][in_dim] out (features) */
+  float* F;              /* [B P][G][in_dim] out (features) */
   float* Z_next;         /* [B][n] out (moments), nullable */
   float* F_z;            /* [B][N][n][n] out (moments) */
   float* F_u;            /* [B][N][n][m] out (moments) */

@@ -224,11 +224,12 @@ class TorchProblem(object):
             "pddp_qr_cost_derivs_f32")
 
     def _bnn_jvp_ok(self, s):
-        """The forward-mode kernels cover D <= 4 with n + m <= 15 tangent
-        directions (include/pddp_hip.h pddp_bnn_jvp)."""
+        """The forward-mode kernels cover D <= 4 with up to 15 tangent
+        directions (groups of 16 rows) and D <= 6 with up to 31 (groups of 32;
+        include/pddp_hip.h pddp_bnn_jvp_group)."""
         mo = self.model
-        return (getattr(self, "use_native_bnn_jvp", True)
-                and mo.state_size <= 4 and s.n + s.m <= 15)
+        return (getattr(self, "use_native_bnn_jvp", True) and
+                _native.lib().pddp_bnn_jvp_group(mo.state_size, s.m) != 0)
 
     @torch.no_grad()
     def _dyn_derivs_bnn(self, s, F_z, F_u):
@@ -254,7 +255,8 @@ class TorchProblem(object):
               mo.eps_in[0] @ decode_covar_sqrt(z0, self.encoding)).contiguous()
         Xn = torch.empty_like(Xp)
         eps = torch.empty_like(Xp)
-        F = torch.empty(B * P * 16, in_dim, **opts)
+        G = _native.lib().pddp_bnn_jvp_group(D, m)
+        F = torch.empty(B * P * G, in_dim, **opts)
         keep = [vec(mo.X_mean, in_dim), vec(mo.X_std_inv, in_dim),
                 vec(mo.dX_mean, D), vec(mo.dX_std, D), s.Z.contiguous(),
                 s.U.contiguous()]
@@ -280,7 +282,7 @@ class TorchProblem(object):
             _native.check(lib.pddp_bnn_jvp_features_f32(ctypes.byref(st),
                                                         stream),
                           "pddp_bnn_jvp_features_f32")
-            Y = mo.model._jvp_native(F, P, D)
+            Y = mo.model._jvp_native(F, P, D, G)
             st.net_out = p(Y)
             _native.check(lib.pddp_bnn_jvp_moments_f32(ctypes.byref(st),
                                                        stream),

@@ -23,14 +23,15 @@
 //                  dU'_k = Phi(U'^-T dC_k U'^-1) U'   (Phi: upper triangle, half
 //                  the diagonal - the differential of the Cholesky factor),
 //                  column k of (F_z | F_u) = (dM_k | triu(dU'_k)).
-// 16 lanes per (trajectory, particle) in jvp_features, 16 lanes per trajectory
-// in jvp_moments: lane k owns direction k.
+// G lanes per (trajectory, particle) in jvp_features, G lanes per trajectory
+// in jvp_moments (G = 16 or 32 rows per group): lane k owns direction k.
 #include "pddp_common.hpp"
 
 namespace pddp {
 
-constexpr int kJvpMaxD = 4;   // D (D + 1) / 2 + D + m <= 15 tangent rows
-constexpr int kJvpRows = 16;  // rows per (state, particle): primal + tangents
+// G = rows per (state, particle): the input row + up to G - 1 tangent rows.
+// G = 16: D <= 4 (cartpole: 4 + 10 + 1 directions); G = 32: D <= 6 (double
+// cartpole: 6 + 21 + 1).
 
 // tangent of X_p (D values) for direction d (0-based): mean_d, then the upper
 // triangle of U row-major (np.triu_indices, encoding.py:126-130), then u
@@ -44,10 +45,11 @@ PDDP_DEV void x_tangent(int d, int D, const float* eps, float* dX) {
       if (o == d) dX[b] = eps[a];  // X = mean + eps U:  dX[b] / dU[a][b] = eps[a]
 }
 
+template <int kJvpRows, int kJvpMaxD>
 __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   const int lane = threadIdx.x;
-  const int k = lane & 15;                      // row of the group
-  const int bp = blockIdx.x * 4 + (lane >> 4);  // (trajectory, particle)
+  const int k = lane & (kJvpRows - 1);  // row of the group
+  const int bp = blockIdx.x * (64 / kJvpRows) + lane / kJvpRows;  // (b, p)
   if (bp >= s.B * s.P) return;
   const int b = bp / s.P;
   const int D = s.D, m = s.m, n = D + D * (D + 1) / 2;
@@ -99,10 +101,11 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   }
 }
 
+template <int kJvpRows, int kJvpMaxD>
 __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   const int lane = threadIdx.x;
-  const int k = lane & 15;
-  const int b = blockIdx.x * 4 + (lane >> 4);
+  const int k = lane & (kJvpRows - 1);
+  const int b = blockIdx.x * (64 / kJvpRows) + lane / kJvpRows;
   if (b >= s.B) return;
   const int D = s.D, P = s.P, m = s.m, n = D + D * (D + 1) / 2;
   const int OUT = s.out_dim;
@@ -244,6 +247,14 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
 
 extern "C" {
 
+/* rows per (state, particle) group for a problem: 16 or 32 (0: unsupported) */
+int pddp_bnn_jvp_group(int D, int m) {
+  const int dirs = D + D * (D + 1) / 2 + m;
+  if (D <= 4 && dirs <= 15) return 16;
+  if (D <= 6 && dirs <= 31) return 32;
+  return 0;
+}
+
 static int bnn_jvp_check(const pddp_bnn_jvp* s) {
   if (s == nullptr) return PDDP_E_BADARG;
   if (s->B <= 0 || s->P <= 1 || s->N <= 0 || s->t < 0 || s->t >= s->N ||
@@ -251,8 +262,8 @@ static int bnn_jvp_check(const pddp_bnn_jvp* s) {
       !s->dX_std || !s->Xp || !s->eps || !s->F)
     return PDDP_E_BADARG;
   const int n = s->D + s->D * (s->D + 1) / 2;
-  if (s->D < 1 || s->D > pddp::kJvpMaxD || s->m < 1 ||
-      n + s->m > pddp::kJvpRows - 1 || s->n_ang < 0 || s->n_ang > 2 ||
+  if (s->D < 1 || s->D > 6 || s->m < 1 || n + s->m > 31 || s->n_ang < 0 ||
+      s->n_ang > 2 ||
       s->n_non < 0 || s->n_non + s->n_ang != s->D ||
       s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D)
     return PDDP_E_UNSUPPORTED;
@@ -261,16 +272,28 @@ static int bnn_jvp_check(const pddp_bnn_jvp* s) {
 
 int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
-  hipLaunchKernelGGL(pddp::bnn_jvp_features_kernel, dim3((s->B * s->P + 3) / 4),
-                     dim3(64), 0, (hipStream_t)stream, *s);
+  if (pddp_bnn_jvp_group(s->D, s->m) == 16)
+    hipLaunchKernelGGL((pddp::bnn_jvp_features_kernel<16, 4>),
+                       dim3((s->B * s->P + 3) / 4), dim3(64), 0,
+                       (hipStream_t)stream, *s);
+  else
+    hipLaunchKernelGGL((pddp::bnn_jvp_features_kernel<32, 6>),
+                       dim3((s->B * s->P + 1) / 2), dim3(64), 0,
+                       (hipStream_t)stream, *s);
   return pddp::launch_status();
 }
 
 int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
   if (!s->net_out || !s->F_z || !s->F_u) return PDDP_E_BADARG;
-  hipLaunchKernelGGL(pddp::bnn_jvp_moments_kernel, dim3((s->B + 3) / 4),
-                     dim3(64), 0, (hipStream_t)stream, *s);
+  if (pddp_bnn_jvp_group(s->D, s->m) == 16)
+    hipLaunchKernelGGL((pddp::bnn_jvp_moments_kernel<16, 4>),
+                       dim3((s->B + 3) / 4), dim3(64), 0, (hipStream_t)stream,
+                       *s);
+  else
+    hipLaunchKernelGGL((pddp::bnn_jvp_moments_kernel<32, 6>),
+                       dim3((s->B + 1) / 2), dim3(64), 0, (hipStream_t)stream,
+                       *s);
   return pddp::launch_status();
 }
 

@@ -30,8 +30,8 @@
 //   C  the NB partial outputs are summed from LDS, b3 added, rows stored.
 //
 // JVP mode (the derivative rollout, ilqr.py:457-468 through
-// utils/evaluation.py:203-235): rows come in groups of 16 = one (state,
-// particle) input and 15 tangent directions of it.  A tangent row goes through
+// utils/evaluation.py:203-235): rows come in groups of 16 (or 32) = one (state,
+// particle) input and 15 (31) tangent directions of it.  A tangent row goes through
 // the same weights without biases, and through the ReLUs linearised at its
 // group's primal row: d relu(m h) = m dh [m h > 0].  Groups are aligned to the
 // 16-lane DPP rows of both the producer and the accumulator layout (data row =
@@ -78,15 +78,26 @@ constexpr size_t bnn_mlp_lds_floats() {
 
 // kMlpW1Stride: LDS stride of a W1 row | b1 (8: in_dim <= 7, 16: <= 15) - the
 // producer wavefront's work is proportional to it
-// value of lane 0 of this lane's 16-lane row (gfx90a+ DPP row_newbcast)
+// value of the group's first row for this lane's unit set.  G = 16: lane 0 of
+// this lane's 16-lane row (gfx90a+ DPP row_newbcast).  G = 32 (a whole tile is
+// one group): lane 0 for the lanes of half 0, lane 32 for half 1.
+template <int G>
 PDDP_DEV float row_first(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150,
-                                                    0xf, 0xf, true));
+  if constexpr (G == 16) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(
+        0, __float_as_int(v), 0x150, 0xf, 0xf, true));
+  } else {
+    const int lo = __builtin_amdgcn_readlane(__float_as_int(v), 0);
+    const int hi = __builtin_amdgcn_readlane(__float_as_int(v), 32);
+    return __int_as_float((threadIdx.x & 32) ? hi : lo);
+  }
 }
-constexpr int kJvpGroup = 16;  // rows per (state, particle) in JVP mode
 
-template <int H, int kMlpW1Stride, bool JVP = false>
+// kJvpGroup = rows per (state, particle) in JVP mode (0: plain inference)
+template <int H, int kMlpW1Stride, int kJvpGroup = 0>
 __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
+  constexpr bool JVP = kJvpGroup != 0;
+  static_assert(kJvpGroup == 0 || kJvpGroup == 16 || kJvpGroup == 32, "");
   static_assert(H % 8 == 0 && H <= 224, "H: multiple of 8, at most 224");
   constexpr int KS = H / 2;          // MFMA steps of layer 2
   constexpr int NB = (H + 31) / 32;  // 32-unit blocks = consumer wavefronts
@@ -127,13 +138,14 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       if (!first_prod || i >= my) return;
       const int row = (blockIdx.x + i * gridDim.x) * kMlpTile + li;
       const bool live = row < R;
-      const int p = live ? (JVP ? (row / kJvpGroup) % P : row % P) : 0;
+      const int p = live ? (JVP ? (row / (JVP ? kJvpGroup : 1)) % P : row % P) : 0;
       float x[kMlpW1Stride];
 #pragma unroll
       for (int c = 0; c < kMlpW1Stride; ++c)
         x[c] = (live && c < IN) ? a.X[(size_t)row * IN + c] : 0.f;
       // multiplies the bias slot (tangent rows carry no bias)
-      x[kMlpW1Stride - 1] = (JVP && (li & (kJvpGroup - 1)) != 0) ? 0.f : 1.f;
+      x[kMlpW1Stride - 1] =
+          (JVP && (li & ((JVP ? kJvpGroup : 1) - 1)) != 0) ? 0.f : 1.f;
       f32x4* dst = reinterpret_cast<f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
       // this lane's KS mask values, contiguous in the parity-split layout:
       // all requested up front (KS / 4 independent 16-B loads)
@@ -165,7 +177,8 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
           }
           if constexpr (JVP) {
             // linearised at the group's primal row (for which this IS relu)
-            v[e] = (row_first(acc) * mk[q][e] > 0.f) ? acc * mk[q][e] : 0.f;
+            v[e] = (row_first<JVP ? kJvpGroup : 16>(acc) * mk[q][e] > 0.f)
+                       ? acc * mk[q][e] : 0.f;
           } else {
             v[e] = fmaxf(acc * mk[q][e], 0.f);
           }
@@ -179,7 +192,8 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       const float* pr = part + (i & 1) * kPart;
       for (int t = lane; t < 32 * OUT; t += 64) {
         const int rr = row0 + (t & 31), o = t >> 5;
-        float y = (JVP && ((t & 31) & (kJvpGroup - 1)) != 0) ? 0.f : a.b3[o];
+        float y = (JVP && ((t & 31) & ((JVP ? kJvpGroup : 1) - 1)) != 0)
+                      ? 0.f : a.b3[o];
 #pragma unroll
         for (int jj = 0; jj < NB; ++jj)
           y += pr[(jj * kMlpMaxOut + o) * 32 + (t & 31)];
@@ -233,7 +247,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     // (0..3), one 16-B load of the mask row each (clamped inside the row for
     // the padded units of the last block, whose weights are zero)
     const int row = row0 + li;
-    const int p = row < R ? (JVP ? (row / kJvpGroup) % P : row % P) : 0;
+    const int p = row < R ? (JVP ? (row / (JVP ? kJvpGroup : 1)) % P : row % P) : 0;
     f32x4 m2[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -261,9 +275,9 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       float h2;
       if constexpr (JVP) {
         const float pre =
-            acc[r] + ((li & (kJvpGroup - 1)) != 0 ? 0.f : b2r[r]);
+            acc[r] + ((li & ((JVP ? kJvpGroup : 1) - 1)) != 0 ? 0.f : b2r[r]);
         const float mm = m2[r >> 2][r & 3];
-        h2 = (row_first(pre) * mm > 0.f) ? pre * mm : 0.f;
+        h2 = (row_first<JVP ? kJvpGroup : 16>(pre) * mm > 0.f) ? pre * mm : 0.f;
       } else {
         h2 = fmaxf((acc[r] + b2r[r]) * m2[r >> 2][r & 3], 0.f);
       }
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   }
 }
 
-template <int H, int W1S, bool JVP = false>
+template <int H, int W1S, int JVP = 0>
 static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   static int cus = 0;  // queried once: hipGetDeviceProperties costs ms
   if (cus == 0) {
@@ -308,7 +322,7 @@ static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   return launch_status();
 }
 
-template <int H, bool JVP = false>
+template <int H, int JVP = 0>
 static int launch_bnn_mlp(const BnnMlpArgs& a, hipStream_t st) {
   return a.in_dim < 8 ? launch_bnn_mlp_w<H, 8, JVP>(a, st)
                       : launch_bnn_mlp_w<H, 16, JVP>(a, st);
@@ -339,24 +353,32 @@ int pddp_bnn_mlp_f32(int R, int P, int in_dim, int H, int out_dim,
   return PDDP_E_UNSUPPORTED;
 }
 
-int pddp_bnn_mlp_jvp_f32(int R, int P, int in_dim, int H, int out_dim,
-                         const float* X, const float* W1, const float* b1,
+int pddp_bnn_mlp_jvp_f32(int R, int P, int group, int in_dim, int H,
+                         int out_dim, const float* X, const float* W1, const float* b1,
                          const float* MT1, const float* W2, const float* b2,
                          const float* MT2, const float* W3, const float* b3,
                          float* Y, void* stream) {
   if (R <= 0 || P <= 0 || in_dim <= 0 || H <= 0 || out_dim <= 0 || !X || !W1 ||
       !b1 || !MT1 || !W2 || !b2 || !MT2 || !W3 || !b3 || !Y)
     return PDDP_E_BADARG;
-  if (R % pddp::kJvpGroup != 0) return PDDP_E_BADARG;
+  if ((group != 16 && group != 32) || R % group != 0) return PDDP_E_BADARG;
   if (in_dim >= pddp::kMlpW1Max || out_dim > pddp::kMlpMaxOut)
     return PDDP_E_UNSUPPORTED;
   const pddp::BnnMlpArgs a{R, P, in_dim, H, out_dim, X, W1, b1, MT1, W2,
                            b2, MT2, W3, b3, Y};
   hipStream_t st = (hipStream_t)stream;
-  switch (H) {
-    case 64: return pddp::launch_bnn_mlp<64, true>(a, st);
-    case 128: return pddp::launch_bnn_mlp<128, true>(a, st);
-    case 200: return pddp::launch_bnn_mlp<200, true>(a, st);
+  if (group == 16) {
+    switch (H) {
+      case 64: return pddp::launch_bnn_mlp<64, 16>(a, st);
+      case 128: return pddp::launch_bnn_mlp<128, 16>(a, st);
+      case 200: return pddp::launch_bnn_mlp<200, 16>(a, st);
+    }
+  } else {
+    switch (H) {
+      case 64: return pddp::launch_bnn_mlp<64, 32>(a, st);
+      case 128: return pddp::launch_bnn_mlp<128, 32>(a, st);
+      case 200: return pddp::launch_bnn_mlp<200, 32>(a, st);
+    }
   }
   return PDDP_E_UNSUPPORTED;
 }

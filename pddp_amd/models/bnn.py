@@ -193,9 +193,9 @@ class BayesianMLP(torch.nn.Module):
         _native.check(rc, "pddp_bnn_mlp_f32")
         return y
 
-    def _jvp_native(self, F, P, out_rows):
-        """Forward-mode pass of csrc/bnn_mlp.hip: F [(states P) 16, in_dim],
-        groups of 16 rows = primal input + 15 tangent rows; returns the first
+    def _jvp_native(self, F, P, out_rows, group=16):
+        """Forward-mode pass of csrc/bnn_mlp.hip: F [(states P) group, in_dim],
+        groups of 16 / 32 rows = primal input + tangent rows; returns the first
         `out_rows` outputs per row (include/pddp_hip.h pddp_bnn_mlp_jvp_f32)."""
         from .. import _native
         in_dim = F.shape[-1]
@@ -206,7 +206,8 @@ class BayesianMLP(torch.nn.Module):
         c = lambda t: t.detach().contiguous()
         p = _native.ptr
         rc = _native.lib().pddp_bnn_mlp_jvp_f32(
-            R, P, in_dim, H, out_rows, p(F), p(c(self.hidden[0].weight)),
+            R, P, int(group), in_dim, H, out_rows, p(F),
+            p(c(self.hidden[0].weight)),
             p(c(self.hidden[0].bias)), p(m1), p(c(self.hidden[1].weight)),
             p(c(self.hidden[1].bias)), p(m2), p(c(self.out.weight[:out_rows])),
             p(c(self.out.bias[:out_rows])), p(Y),

@@ -957,10 +957,11 @@ def test_bnn_native_line_search_vs_torch_path(problem, H, P):
     assert float((Za[:, 1:] - Zb[:, :1]).abs().max()) > 1e-4  # it did move
 
 
+@pytest.mark.parametrize("G", [16, 32])
 @pytest.mark.parametrize("H", [64, 200])
 @pytest.mark.parametrize("groups,P,in_dim,out_dim", [(1, 100, 6, 4), (37, 100, 6, 4),
                                                      (203, 7, 4, 2), (64, 33, 15, 16)])
-def test_bnn_mlp_jvp_kernel_vs_float64(groups, P, in_dim, out_dim, H):
+def test_bnn_mlp_jvp_kernel_vs_float64(groups, P, in_dim, out_dim, H, G):
     """pddp_bnn_mlp_jvp_f32 (csrc/bnn_mlp.hip in JVP mode: groups of 16 rows =
     one input and 15 tangent directions, biases only on the input row, ReLUs
     linearised at it) against the same forward-mode pass written out layer by
@@ -969,10 +970,10 @@ def test_bnn_mlp_jvp_kernel_vs_float64(groups, P, in_dim, out_dim, H):
     from pddp_amd.models.bnn import BayesianMLP
     torch.manual_seed(H + groups)
     net = BayesianMLP(in_dim, out_dim, [H, H]).cuda().eval()
-    F = torch.randn(groups, 16, in_dim, device="cuda")
+    F = torch.randn(groups, G, in_dim, device="cuda")
     with torch.no_grad():
-        Y = net._jvp_native(F.reshape(groups * 16, in_dim).contiguous(), P,
-                            out_dim).reshape(groups, 16, out_dim)
+        Y = net._jvp_native(F.reshape(groups * G, in_dim).contiguous(), P,
+                            out_dim, G).reshape(groups, G, out_dim)
         d = lambda t: t.detach().double()
         W1, b1 = d(net.hidden[0].weight), d(net.hidden[0].bias)
         W2, b2 = d(net.hidden[1].weight), d(net.hidden[1].bias)
@@ -1009,7 +1010,8 @@ def test_bnn_mlp_jvp_kernel_vs_float64(groups, P, in_dim, out_dim, H):
 @pytest.mark.parametrize("problem,H,P,B", [("cartpole", 64, 30, 3),
                                            ("cartpole", 200, 100, 2),
                                            ("pendulum", 64, 40, 5),
-                                           ("cartpole", 64, 50, 1)])
+                                           ("cartpole", 64, 50, 1),
+                                           ("double_cartpole", 128, 60, 3)])
 def test_bnn_native_jacobians_vs_autograd_path(problem, H, P, B):
     """F_z, F_u of the moment-matched BNN step in forward mode
     (csrc/bnn_jvp.hip + the network's JVP mode) against autograd over the

@@ -42,37 +42,52 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--particles", type=int, default=100)
+    ap.add_argument("--problem", default="cartpole",
+                    choices=["cartpole", "double_cartpole"],
+                    help="double_cartpole: BASELINE.json configs[3]'s problem "
+                         "with the reference's own BNN model "
+                         "(examples/double_cartpole.py:133-139; no GP exists "
+                         "in the reference), e.g. --batch 1024 --horizon 150 "
+                         "= one GPU's shard of 8192")
     ap.add_argument("--autograd-too", action="store_true",
                     help="also time the autograd Jacobians (small batches)")
     a = ap.parse_args()
     torch.manual_seed(0)
     dev = "cuda"
-    CM = cartpole.CartpoleDynamicsModel
-    cls = bnn_dynamics_model_factory(4, 1, [200, 200], CM.angular_indices,
+    if a.problem == "cartpole":
+        CM, cost_cls = cartpole.CartpoleDynamicsModel, cartpole.CartpoleCost
+        mean0, bound = [0.0, 0.0, 3.14159, 0.0], 10.0
+    else:
+        from pddp_amd.examples import double_cartpole as dc
+        CM, cost_cls = dc.DoubleCartpoleDynamicsModel, dc.DoubleCartpoleCost
+        mean0, bound = [0.0, 0.0, 3.14159, 0.0, 3.14159, 0.0], 20.0
+    D = CM.state_size
+    cls = bnn_dynamics_model_factory(D, 1, [200, 200], CM.angular_indices,
                                      CM.non_angular_indices)
     model = cls(n_particles=a.particles).to(dev).eval()
     with torch.no_grad():  # an untrained network: keep its dynamics gentle
         model.model.out.weight.mul_(0.05)
         model.model.out.bias.mul_(0.05)
-    cost = cartpole.CartpoleCost().to(dev)
+    cost = cost_cls().to(dev)
     enc = pddp_amd.StateEncoding.DEFAULT
     B, N, A, P = a.batch, a.horizon, 10, a.particles
-    n, m = 14, 1
+    n, m = D + D * (D + 1) // 2, 1
+    in_dim = len(CM.non_angular_indices) + 2 * len(CM.angular_indices) + m
+    G = 16 if D <= 4 else 32
     plugin = TorchProblem(model, cost, enc,
                           {"use_predicted_std": False,
                            "infer_noise_variables": True}, {})
-    s = ILQRSolver(None, B, N, torch.float32, dev, torch.tensor([-10.0]),
-                   torch.tensor([10.0]), fit_alphas(torch.float32, dev),
+    s = ILQRSolver(None, B, N, torch.float32, dev, torch.tensor([-bound]),
+                   torch.tensor([bound]), fit_alphas(torch.float32, dev),
                    plugin=plugin, n=n, m=m)
     g = torch.Generator().manual_seed(0)
     z0 = torch.stack([pddp_amd.GaussianVariable(
-        torch.tensor([0.0, 0.0, 3.14159, 0.0]) + 1e-2 * torch.randn(4, generator=g),
-        var=1e-2 * torch.ones(4)).encode(enc) for _ in range(B)]).to(dev)
+        torch.tensor(mean0) + 1e-2 * torch.randn(D, generator=g),
+        var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).to(dev)
     t_roll = timed(lambda: s.set_nominal(
         z0, (0.1 * torch.randn(B, N, m, generator=g)).to(dev)))
-    out = {"workload": "BASELINE.json configs[2]: cartpole BNN [200,200] P=%d, "
-                       "DEFAULT encoding n=14 m=1, B=%d N=%d A=%d fp32"
-                       % (P, B, N, A)}
+    out = {"workload": "%s BNN [200,200] P=%d, DEFAULT encoding n=%d m=1, "
+                       "B=%d N=%d A=%d fp32" % (a.problem, P, n, B, N, A)}
     # --- derivative rollout
     opts = dict(dtype=torch.float32, device=dev)
     Fz = torch.zeros(B, N, n, n, **opts)
@@ -81,7 +96,7 @@ def main():
     t_jvp = timed(lambda: plugin._dyn_derivs_bnn(s, Fz, Fu))
     s.derivs()
     t_derivs = timed(lambda: s.derivs())
-    net_flop = 2.0 * B * P * 16 * (6 * 200 + 200 * 200 + 200 * 4) * N
+    net_flop = 2.0 * B * P * G * (in_dim * 200 + 200 * 200 + 200 * D) * N
     out["derivative_rollout"] = {
         "total_s": t_derivs, "dynamics_jacobians_s": t_jvp,
         "cost_derivatives_and_packing_s": t_derivs - t_jvp,
@@ -105,7 +120,7 @@ def main():
     # --- line search + accept
     s.line_search()
     t_ls = timed(lambda: s.line_search())
-    ls_flop = 2.0 * B * A * P * (6 * 200 + 200 * 200 + 200 * 8) * N
+    ls_flop = 2.0 * B * A * P * (in_dim * 200 + 200 * 200 + 200 * 2 * D) * N
     out["line_search"] = {"s": t_ls, "network_TFLOPs": ls_flop / t_ls * 1e-12}
     t_acc = timed(lambda: s.accept(5e-6, 1e10, 1 << 30))
     out["accept_s"] = t_acc
