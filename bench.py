@@ -70,11 +70,115 @@ def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
                                              os.cpu_count())}
 
 
+MFMA_F32_PEAK_TFLOPS = 157.0  # MI355X_MICROARCH.md: dense f32 matrix peak
+
+
+def bench_bnn(args):
+    """Secondary workload (--workload cartpole_bnn) = BASELINE.json configs[2]:
+    cartpole with the BNN dynamics model ([200, 200] hidden, 100 particles,
+    moment-matched rollouts, DEFAULT encoding n = 14), horizon 100, B
+    trajectories on one GPU.  A step is one round of the fit loop: forward-mode
+    derivative rollout of the trajectories whose nominal changed, backward
+    sweep, 10-candidate line search, accept.  The dominant kernel is the fused
+    network (f32 matrix cores): roofline bound "mfma"."""
+    import pddp_amd
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.examples import cartpole
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    B, N, P, A, H = args.batch, args.horizon, 100, 10, 200
+    K = args.steps if args.steps != 30 else 3
+    W = args.warmup if args.warmup != 5 else 1
+    CM = cartpole.CartpoleDynamicsModel
+    model = bnn_dynamics_model_factory(4, 1, [H, H], CM.angular_indices,
+                                       CM.non_angular_indices)(
+        n_particles=P).to(dev).eval()
+    with torch.no_grad():  # untrained weights: keep the dynamics gentle
+        model.model.out.weight.mul_(0.05)
+        model.model.out.bias.mul_(0.05)
+    cost = cartpole.CartpoleCost().to(dev)
+    enc = pddp_amd.StateEncoding.DEFAULT
+    plugin = TorchProblem(model, cost, enc, {"use_predicted_std": False,
+                                             "infer_noise_variables": True}, {})
+    s = ILQRSolver(None, B, N, torch.float32, dev, torch.tensor([-10.0]),
+                   torch.tensor([10.0]), fit_alphas(torch.float32, dev),
+                   plugin=plugin, n=14, m=1)
+    g = torch.Generator().manual_seed(0)
+    mean = torch.tensor([0.0, 0.0, 3.14159, 0.0])
+    z0 = torch.stack([pddp_amd.GaussianVariable(
+        mean + 1e-2 * torch.randn(4, generator=g),
+        var=1e-2 * torch.ones(4)).encode(enc) for _ in range(B)]).to(dev)
+    s.set_nominal(z0, (0.1 * torch.randn(B, N, 1, generator=g)).to(dev))
+    n_iter = 1 << 30
+    for _ in range(W):
+        s.round(5e-6, 1e10, n_iter)
+    s.n_live.zero_()
+    live0 = int(s.active.sum().item())
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        s.round(5e-6, 1e10, n_iter)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    liveK = int(s.active.sum().item())
+    attempted = live0 + int(s.n_live.sum().item()) - liveK
+    # the dominant kernel, timed alone on torch's current stream (the stream it
+    # is launched on): one forward-mode network pass of a time step
+    F = torch.randn(B * P * 16, 6, device=dev)
+    model.model._jvp_native(F, P, 4, 16)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        model.model._jvp_native(F, P, 4, 16)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    dur = e0.elapsed_time(e1) * 1e-3 / reps
+    flop = 2.0 * B * P * 16 * (6 * H + H * H + H * 4)
+    out = {
+        "metric": "pddp_iterations_per_sec", "value": attempted / elapsed,
+        "unit": "trajectory-iterations/s", "n_gpus": 1, "steps": K,
+        "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[2]: cartpole with BNN dynamics "
+                        "([200,200] hidden, %d particles, moment-matched "
+                        "rollouts, DEFAULT encoding n=14 m=1), horizon=%d, "
+                        "batch=%d trajectories, bounds +-10, 10 line-search "
+                        "alphas, random-init network weights" % (P, N, B),
+            "batch_per_gpu": B, "horizon": N, "alphas": A,
+            "unit_definition": "one iLQR attempt of one trajectory (derivative "
+                               "rollout when its nominal changed + backward "
+                               "sweep + line search + accept)",
+            "live_trajectories_start_end": [live0, liveK],
+            "derivative_path": getattr(plugin, "last_derivs_path", None),
+        },
+        "roofline": {
+            "bound": "mfma",
+            "kernel": "fused BNN network, forward-mode (bnn_mlp_kernel<200, 8, 16>)",
+            "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
+            "avg_launch_us": dur * 1e6,
+            "algorithmic_flop_per_launch": flop, "traffic": None,
+        },
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cartpole",
+                    choices=["cartpole", "cartpole_bnn"],
+                    help="cartpole = BASELINE configs[1] (the headline line); "
+                         "cartpole_bnn = configs[2], one GPU")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -82,6 +186,8 @@ def main():
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="backward kernel: 0 auto, 1 generic, 2 n4, 3 n4 fast")
     args = ap.parse_args()
+    if args.workload == "cartpole_bnn":
+        return bench_bnn(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
