@@ -4,6 +4,7 @@
 #include "riccati_n4.hpp"
 #include "riccati_n4_split.hpp"
 #include "riccati_n4_pipe.hpp"
+#include "riccati_mfma16.hpp"
 
 namespace pddp {
 
@@ -57,6 +58,19 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          update (riccati_n4_pipe.hpp; bounded eig-clamp branch only);
   //          auto: bounded f32, up to 16384 trajectories -> 13 (eig-clamp
   //          branch) or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64)
+  //          14 / 15: the matrix-core kernel for n <= 14, m = 1, fp32,
+  //          eig-clamp branch (riccati_mfma16.hpp; IEEE / approximate
+  //          division) - auto for those shapes other than n = 4
+  if (variant == 14 || variant == 15 ||
+      (variant == 0 && sizeof(T) == 4 && m == 1 && n != 4 && n <= 14 &&
+       branch == PDDP_BRANCH_EIG)) {
+    if constexpr (sizeof(T) == 4) {
+      if (m != 1) return PDDP_E_UNSUPPORTED;
+      return launch_mfma16(a, st, variant != 14);
+    } else {
+      return PDDP_E_UNSUPPORTED;
+    }
+  }
   if (variant >= 2 && !(n == 4 && m == 1)) return PDDP_E_UNSUPPORTED;
   if (variant < 0 || variant > 13 || variant == 4 || variant == 5)
     return PDDP_E_BADARG;

@@ -1,0 +1,254 @@
+// riccati_mfma16.hpp - backward Riccati sweep for n + 1 <= 15, m = 1 in fp32 on
+// the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32, bitwise an fmaf
+// chain), eig-clamp branch (ilqr.py:629-672), bounded or not.  The DEFAULT
+// (Cholesky) encoding of cartpole is n = 14: BASELINE.json configs[2]'s sweep,
+// 744 MB per launch at B = 4096, N = 100.
+//
+// One wavefront per trajectory; the whole step is TWO 16x16x16 products on
+// augmented matrices and stays in registers:
+//   F~ = [F_z | F_u | 0]            (rows k < n, column n = F_u)
+//   X  = V F~                       A operand = V, B operand = F~
+//   X[:, 15] := V_z                 (column 15 is free: n + 1 <= 15)
+//   Q~ = L~ + F~^T X                A operand = F~^T, B operand = X
+// with L~ = [[L_zz, L_uz^T, L_z], [L_uz, L_uu, L_u]]:  Q~ holds Q_zz (raw), Q_uz
+// (row n), Q_uu ([n][n]) and in column 15 Q_z, Q_u (ilqr.py:489-526) - every
+// second- AND first-order term of the step from eight MFMA instructions.
+// Why nothing moves between lanes:
+//   * the C/D layout (column on the lane, rows 4g + r in register r of lane
+//     group g) of V' is, V' being symmetric, exactly the A operand of the next
+//     X = V F~ when k-slab r of lane group g is taken to be k = 4g + r;
+//   * with the same k assignment the D registers of X are the B operand of
+//     the second product, and the four F~ words a lane reads from the record
+//     (F~[4g + r][j], j = lane & 15) serve as B operand of the first product
+//     AND as A operand (F~^T[i][k], i = lane & 15) of the second.
+// One LDS round trip per step remains: the transpose for 0.5 (Q + Q^T) and the
+// broadcast of Q_uz for the rank-one value update
+//   V' = sym(Q_zz) + c Q_uz^T Q_uz,  V_z' = Q_z + Q_uz^T w
+// (c, w from the scalar BoxQP; riccati_n4_pipe.hpp).  Records stream HBM -> LDS
+// by full-wave LDS-DMA, R slots ahead.
+#pragma once
+
+#include "riccati_n4_split.hpp"
+
+namespace pddp {
+namespace m16 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kWaves = 4;  // independent trajectories (wavefronts) per workgroup
+constexpr int kRing = 4;   // record slots in flight per wavefront
+
+template <bool BOUNDED, bool FAST>
+__global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
+    RiccatiArgs<float> a, int slot_words, int ndma) {
+  using T = float;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  // per wave: kRing record slots, the 16x16 transpose tile; shared: step sizes
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int per_wave = kRing * slot_words + 256;
+  float* ring = smem + wave * per_wave;
+  float* tile = ring + kRing * slot_words;
+  float* ls_tail = smem + kWaves * per_wave;
+  if constexpr (BOUNDED) {
+    for (int q = threadIdx.x; q < n4::kLsSteps; q += kWave * kWaves)
+      ls_tail[q] = (T)n4::kLs.v[q];
+  }
+  const T lstep0 = (T)n4::kLs.v[lane & 15];
+  __syncthreads();
+
+  const int b = blockIdx.x * kWaves + wave;
+  if (b >= a.B) return;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  const int n = a.n, N = a.N;
+  const RecLayout lay(n, 1);
+  const int S = lay.stride;
+  const int g = lane >> 4, j = lane & 15;
+  const T reg = (T)a.reg[b];
+  T umin = T(0), umax = T(0);
+  if constexpr (BOUNDED) { umin = a.u_min[0]; umax = a.u_max[0]; }
+
+  // ---- word offsets of this lane's operands inside a record (-1: zero)
+  int oF[4], oL[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k = 4 * g + r;  // F~ row / L~ row
+    oF[r] = (k < n) ? (j < n ? lay.oFz + k * n + j
+                             : (j == n ? lay.oFu + k : -1))
+                    : -1;
+    int o = -1;
+    if (k < n) {
+      if (j < n) o = lay.oLzz + k * n + j;
+      else if (j == n) o = lay.oLuz + k;  // L_uz^T
+      else if (j == 15) o = lay.oLz + k;
+    } else if (k == n) {
+      if (j < n) o = lay.oLuz + j;
+      else if (j == n) o = lay.oLuu;
+      else if (j == 15) o = lay.oLu;
+    }
+    oL[r] = o;
+  }
+
+  // ---- record DMA: chunk q of 16 bytes -> lane q % 64 of instruction q / 64
+  const char* rec_b = reinterpret_cast<const char*>(
+      a.rec + (size_t)b * (size_t)(N + 1) * S);
+  const int chunks = S / 4;  // S is a multiple of 4 words
+  // (padding lanes past the record re-load an early chunk into the slot's pad)
+  const uint32_t qoff0 = (uint32_t)(lane % chunks) * 16u;
+  const uint32_t qoff1 = (uint32_t)((lane + kWave) % chunks) * 16u;
+  auto dma = [&](int slot, int t) {
+    const int tt = t < 0 ? 0 : t;
+    const uint32_t base = (uint32_t)tt * (uint32_t)(S * sizeof(T));
+    const uint32_t lbase =
+        __builtin_amdgcn_readfirstlane(n4::lds_addr(ring + slot * slot_words));
+    n4::lds_dma16(rec_b, base + qoff0, lbase);
+    if (ndma == 2) n4::lds_dma16(rec_b, base + qoff1, lbase + kWave * 16);
+  };
+
+  // ---- terminal value function in the accumulator layout (ilqr.py:581-583)
+  T V[4], Vz[4];
+  {
+    const T* term = a.rec + ((size_t)b * (size_t)(N + 1) + N) * S;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * g + r;
+      V[r] = (k < n && j < n) ? term[lay.oLzz + k * n + j] : T(0);
+      Vz[r] = (k < n) ? term[lay.oLz + k] : T(0);
+    }
+  }
+  for (int s = 0; s < kRing; ++s) dma(s, N - 1 - s);
+  n4::wait_vmcnt<0>();  // (also the terminal loads above)
+
+  T* gains_b = a.gains + (size_t)b * (size_t)N * lay.gstride;
+  T kprev = T(0);
+  int status = PDDP_BWD_OK;
+  int slot = 0;
+  for (int t = N - 1; t >= 0; --t) {
+    // record t has landed once at most (kRing - 1) younger {DMA x ndma, store}
+    // groups are outstanding; counted waits need immediates: ndma is 1 or 2
+    if (ndma == 1) n4::wait_vmcnt<(kRing - 1) * 2>();
+    else n4::wait_vmcnt<(kRing - 1) * 3>();
+    const T* R = ring + slot * slot_words;
+    T Fa[4], La[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const T f = R[oF[r] < 0 ? 0 : oF[r]];
+      const T l = R[oL[r] < 0 ? 0 : oL[r]];
+      Fa[r] = oF[r] < 0 ? T(0) : f;
+      La[r] = oL[r] < 0 ? T(0) : l;
+    }
+    const T Un = BOUNDED ? R[lay.oU] : T(0);
+
+    // ---- X = V F~ ; X[:, 15] = V_z
+    f32x4 X = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      X = __builtin_amdgcn_mfma_f32_16x16x4f32(V[r], Fa[r], X, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X[r] = (j == 15) ? Vz[r] : X[r];
+    // ---- Q~ = L~ + F~^T X
+    f32x4 Q = {La[0], La[1], La[2], La[3]};
+    Q = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[0], X[0], Q, 0, 0, 0);
+    Q = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[1], X[1], Q, 0, 0, 0);
+    Q = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[2], X[2], Q, 0, 0, 0);
+    Q = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[3], X[3], Q, 0, 0, 0);
+
+    // row n = 4 gn + rn of Q~ is (Q_uz | Q_uu | Q_u at column 15)
+    const int gn = n >> 2, rn = n & 3;
+    const T rowv = rn == 0 ? Q[0] : (rn == 1 ? Q[1] : (rn == 2 ? Q[2] : Q[3]));
+    const T Quu = __int_as_float(
+        __builtin_amdgcn_readlane(__float_as_int(rowv), gn * 16 + n));
+    const T Qu = __int_as_float(
+        __builtin_amdgcn_readlane(__float_as_int(rowv), gn * 16 + 15));
+    // transpose tile: T[col][row] = Q~[row][col]
+    *reinterpret_cast<f32x4*>(tile + j * 16 + 4 * g) = Q;
+
+    // ---- gains (every lane the same scalars)                 (ilqr.py:629-657)
+    int st = PDDP_BWD_OK;
+    if (!is_finite(Quu)) st = PDDP_BWD_NAN;     // eig raises (ilqr.py:631)
+    const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
+    const T qp_Q = e + reg;                     // ilqr.py:634
+    T kt, sE;
+    bool Kz = false;
+    int stt = st;
+    if constexpr (BOUNDED) {
+      n4::QpClosed<T, FAST> qc;
+      qc.solve(kprev, qp_Q, Qu, umin - Un, umax - Un);
+      kt = qc.x;
+      Kz = !qc.free_;
+      bool fail = qc.fail;
+      if (__builtin_amdgcn_ballot_w64(qc.slow) != 0) {
+        const n4::SlowQpOut<T> o = n4::boxqp1_outlined<T, FAST>(
+            kprev, qp_Q, Qu, umin - Un, umax - Un, lstep0, ls_tail, lane);
+        kt = o.x;
+        Kz = (o.result_free & 1) == 0;
+        fail = o.result_free < 2;
+      }
+      if (fail) stt = PDDP_BWD_BOXQP_FAILED;
+      if constexpr (FAST) sE = Kz ? T(0) : qc.inv;
+      else sE = Kz ? T(0) : n4::div_<false>(n4::div_<false>(T(1), qc.U), qc.U);
+    } else {
+      sE = n4::div_<FAST>(T(1), qp_Q);  // (E / e) E^T             (ilqr.py:636)
+      kt = -(sE * Qu);
+      // NaN in k or K raises (ilqr.py:639-640)
+      const bool nanK = (g == (n >> 2)) && (j < n) && (sE * rowv != sE * rowv);
+      if (kt != kt || __builtin_amdgcn_ballot_w64(nanK) != 0)
+        stt = PDDP_BWD_NAN;
+    }
+    if (status == PDDP_BWD_OK && stt != PDDP_BWD_OK) status = stt;
+    kprev = kt;
+    const T c = sE * (sE * Quu - T(2));
+    const T w = kt - sE * (Qu + Quu * kt);
+
+    // ---- k, K of step t: lanes of row n hold Q_uz[j] (j < n), lane j = n: k
+    {
+      const T val = (j < n) ? -(sE * rowv) : kt;
+      T* dst = gains_b + (size_t)t * lay.gstride + (j < n ? 1 + j : 0);
+      if (g == gn && j <= n) *dst = val;
+    }
+    // this slot is consumed: refill it, kRing steps further down the sweep
+    dma(slot, t - kRing);
+
+    // ---- V' = sym(Q_zz) + c Q_uz^T Q_uz,  V_z' = Q_z + Q_uz^T w
+    const T Quz_j = tile[j * 16 + n];  // Q~[n][j]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 4 * g + r;
+      const T QT = tile[k * 16 + j];      // Q~[j][k]
+      const T Quz_k = tile[k * 16 + n];   // Q~[n][k]
+      const T sym = T(0.5) * (Q[r] + QT);
+      V[r] = (k < n && j < n) ? __builtin_fmaf(c * Quz_k, Quz_j, sym) : T(0);
+      Vz[r] = (k < n) ? __builtin_fmaf(Quz_k, w, Q[r]) : T(0);  // (lanes j = 15)
+    }
+    slot = slot + 1 == kRing ? 0 : slot + 1;
+  }
+  n4::wait_vmcnt<0>();
+  if (j == 0 && g == 0) a.status[b] = status;
+}
+
+}  // namespace m16
+
+// n + 1 <= 15, m = 1, fp32, eig-clamp branch; PDDP_E_UNSUPPORTED otherwise
+static int launch_mfma16(const RiccatiArgs<float>& a, hipStream_t st,
+                         bool fast_math) {
+  if (a.n + 1 > 15 || a.branch != PDDP_BRANCH_EIG) return PDDP_E_UNSUPPORTED;
+  const RecLayout lay(a.n, 1);
+  const int chunks = lay.stride / 4;
+  const int ndma = (chunks + kWave - 1) / kWave;
+  if (ndma > 2) return PDDP_E_UNSUPPORTED;
+  const int slot_words = ndma * kWave * 4;
+  const size_t lds = sizeof(float) * ((size_t)m16::kWaves *
+                                          (m16::kRing * slot_words + 256) +
+                                      n4::kLsSteps);
+  const dim3 grid((a.B + m16::kWaves - 1) / m16::kWaves),
+      block(kWave * m16::kWaves);
+  const bool bounded = a.u_min != nullptr;
+#define PDDP_M16(Bd, F)                                                        \
+  PDDP_LAUNCH((m16::riccati_mfma16_kernel<Bd, F>), grid, block, lds, st, a,    \
+              slot_words, ndma)
+  if (bounded) { if (fast_math) PDDP_M16(true, true); else PDDP_M16(true, false); }
+  else { if (fast_math) PDDP_M16(false, true); else PDDP_M16(false, false); }
+#undef PDDP_M16
+  return launch_status();
+}
+
+}  // namespace pddp

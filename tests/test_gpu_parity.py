@@ -98,7 +98,7 @@ def test_derivative_records_vs_oracle(problem, dtype):
         assert np.array_equal(got_U, U[b])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 12, 13])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 12, 13, 14, 15])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", PROBLEMS)
 def test_backward_vs_oracle(problem, dtype, variant):
@@ -107,7 +107,10 @@ def test_backward_vs_oracle(problem, dtype, variant):
     kernel, 2 / 3 n=4 kernel with the BoxQP loop (IEEE / approximate division),
     6 / 7 n=4 kernel with the closed-form BoxQP, 8 / 9 the same with the step
     split over two wavefronts (bounded branches only)."""
-    if variant >= 2 and problem != "cartpole":
+    if variant in (14, 15):
+        if dtype != "f32" or problem == "rendezvous":
+            pytest.skip("variants 14 / 15 = fp32 matrix-core kernel, m = 1")
+    elif variant >= 2 and problem != "cartpole":
         pytest.skip("variants >= 2 are the n=4/m=1 kernel")
     if variant in (3, 7, 9, 13) and dtype != "f32":
         pytest.skip("variants 3 / 7 / 9 / 13 = f32 kernels with approximate "
@@ -120,9 +123,12 @@ def test_backward_vs_oracle(problem, dtype, variant):
     fwd = [o.forward(op, z0[b], U[b], u_min, u_max) for b in range(B)]
     checked = 0
     for branch, bounded in ((0, False), (0, True), (1, False), (1, True)):
-        if variant >= 8 and not bounded:
+        if variant in (14, 15):
+            if branch != 0:
+                continue  # eig-clamp branch, bounded or not
+        elif variant >= 8 and not bounded:
             continue
-        if variant >= 12 and branch != 0:
+        if variant in (12, 13) and branch != 0:
             continue  # the decoupled kernel is the eig-clamp + BoxQP branch
         for reg in (0.0, 1e-6, 1.0, 100.0):
             regv = torch.full((B,), reg, dtype=torch.float64, device="cuda")

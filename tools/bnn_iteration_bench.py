@@ -5,7 +5,8 @@ phase by phase:
 
   derivative rollout  F_z, F_u in forward mode (csrc/bnn_jvp.hip + the fused
                       network in JVP mode), cost derivatives (autograd, torch);
-  backward sweep      generic HIP kernel, n = 14 (eig-clamp + BoxQP branch);
+  backward sweep      matrix-core HIP kernel for n <= 14 (riccati_mfma16.hpp),
+                      generic kernel beside it (eig-clamp + BoxQP branch);
   line search         A = 10 candidates, native moment-step + network kernels;
   accept              HIP state machine.
 
@@ -107,16 +108,31 @@ def main():
         out["derivative_rollout"]["autograd_total_s"] = timed(lambda: s.derivs())
         plugin.use_native_bnn_jvp = True
         s.derivs()
-    # --- backward sweep (generic kernel, n = 14)
+    # --- backward sweep: matrix-core kernel (n <= 14) vs the generic one
     reg = torch.full((B,), 1.0, dtype=torch.float64, device=dev)
-    s.backward(reg=reg)
-    t_bwd = timed(lambda: s.backward(reg=reg), reps=5)
     words = N * (2 * n * n + 3 * n * m + n + 2 * m + m * m + m) + n + n * n
+
+    def sweep_us(variant, reps=20):
+        s.backward(reg=reg, variant=variant)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            s.backward(reg=reg, variant=variant)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    t_bwd = sweep_us(0) * 1e-6
     out["backward_sweep"] = {
         "s": t_bwd, "algorithmic_MB": B * 4 * words / 1e6,
         "GBps": B * 4 * words / t_bwd / 1e9,
         "frac_of_8TBps": B * 4 * words / t_bwd / 8e12,
-        "failed": int((s.bwd_status != 0).sum())}
+        "failed": int((s.bwd_status != 0).sum()),
+        "kernel": "riccati_mfma16 (auto)" if n <= 14 else "riccati_generic",
+        "generic_kernel_us": sweep_us(1, 3)}
+    if n <= 14:
+        out["backward_sweep"]["mfma16_ieee_division_us"] = sweep_us(14)
     # --- line search + accept
     s.line_search()
     t_ls = timed(lambda: s.line_search())
