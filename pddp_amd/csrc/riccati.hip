@@ -5,6 +5,7 @@
 #include "riccati_n4_split.hpp"
 #include "riccati_n4_pipe.hpp"
 #include "riccati_mfma16.hpp"
+#include "riccati_mfma32.hpp"
 
 namespace pddp {
 
@@ -61,12 +62,14 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          14 / 15: the matrix-core kernel for n <= 14, m = 1, fp32,
   //          eig-clamp branch (riccati_mfma16.hpp; IEEE / approximate
   //          division) - auto for those shapes other than n = 4
+  //          (n = 15 .. 30: the 32x32-tile form, riccati_mfma32.hpp)
   if (variant == 14 || variant == 15 ||
-      (variant == 0 && sizeof(T) == 4 && m == 1 && n != 4 && n <= 14 &&
+      (variant == 0 && sizeof(T) == 4 && m == 1 && n != 4 && n <= 30 &&
        branch == PDDP_BRANCH_EIG)) {
     if constexpr (sizeof(T) == 4) {
       if (m != 1) return PDDP_E_UNSUPPORTED;
-      return launch_mfma16(a, st, variant != 14);
+      return n <= 14 ? launch_mfma16(a, st, variant != 14)
+                     : launch_mfma32(a, st, variant != 14);
     } else {
       return PDDP_E_UNSUPPORTED;
     }

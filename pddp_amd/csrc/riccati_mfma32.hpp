@@ -1,0 +1,268 @@
+// riccati_mfma32.hpp - riccati_mfma16.hpp's scheme on 32x32 tiles
+// (v_mfma_f32_32x32x2_f32) for 15 <= n <= 30, m = 1, fp32, eig-clamp branch:
+// the DEFAULT (Cholesky) encoding of the double cartpole is n = 27
+// (BASELINE.json configs[3]: 0.96 GB of records per GPU and sweep).
+//
+// One wavefront per trajectory, two 32x32x32 products per step (16 MFMA
+// instructions each) on the augmented F~ = [F_z | F_u | 0], L~ = [[L_zz, L_uz^T,
+// L_z], [L_uz, L_uu, L_u]] with V_z riding in column 31 of X = V F~.  The
+// accumulator layout (column on the lane, row (r & 3) + 8 (r >> 2) + 4 h in
+// register r of lane half h) of the symmetric V' is the A operand of the next
+// product when the k-slot h of instruction r is taken to be that row; X's
+// registers are then the B operand of Q~ = L~ + F~^T X, and the sixteen F~
+// words a lane gathers serve both products (see riccati_mfma16.hpp).
+#pragma once
+
+#include "riccati_mfma16.hpp"
+
+namespace pddp {
+namespace m32 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kWaves = 2;  // wavefronts (trajectories) per workgroup
+constexpr int kRing = 3;   // record slots in flight per wavefront
+constexpr int kTileLd = 36;  // row stride of the transpose tile (16-B aligned,
+                             // spreads the b128 writes over the banks)
+constexpr int kTile = 32 * kTileLd;
+
+PDDP_DEV int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <bool BOUNDED, bool FAST, int NDMA>
+__global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
+    RiccatiArgs<float> a) {
+  using T = float;
+  constexpr int kSlotWords = NDMA * kWave * 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  constexpr int per_wave = kRing * kSlotWords + kTile;
+  float* ring = smem + wave * per_wave;
+  float* tile = ring + kRing * kSlotWords;
+  float* ls_tail = smem + kWaves * per_wave;
+  if constexpr (BOUNDED) {
+    for (int q = threadIdx.x; q < n4::kLsSteps; q += kWave * kWaves)
+      ls_tail[q] = (T)n4::kLs.v[q];
+  }
+  const T lstep0 = (T)n4::kLs.v[lane & 15];
+  __syncthreads();
+
+  const int b = blockIdx.x * kWaves + wave;
+  if (b >= a.B) return;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  const int n = a.n, N = a.N;
+  const RecLayout lay(n, 1);
+  const int S = lay.stride;
+  const int h = lane >> 5, j = lane & 31;
+  const T reg = (T)a.reg[b];
+  T umin = T(0), umax = T(0);
+  if constexpr (BOUNDED) { umin = a.u_min[0]; umax = a.u_max[0]; }
+
+  // ---- word offsets of this lane's operands inside a record.  Entries
+  // outside the matrices read word 0 and are multiplied by a 0 / 1 mask held
+  // in a VGPR: 64 boolean lane masks would not fit the SGPR file (the first
+  // version spilled them: 117 v_readlane + their hazard nops per step).
+  int oF[16], oL[16];
+  T mF[16], mL[16], mK[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int k = row_of(r, h);
+    int f = (k < n) ? (j < n ? lay.oFz + k * n + j
+                             : (j == n ? lay.oFu + k : -1))
+                    : -1;
+    int o = -1;
+    if (k < n) {
+      if (j < n) o = lay.oLzz + k * n + j;
+      else if (j == n) o = lay.oLuz + k;  // L_uz^T
+      else if (j == 31) o = lay.oLz + k;
+    } else if (k == n) {
+      if (j < n) o = lay.oLuz + j;
+      else if (j == n) o = lay.oLuu;
+      else if (j == 31) o = lay.oLu;
+    }
+    mF[r] = f < 0 ? T(0) : T(1);
+    mL[r] = o < 0 ? T(0) : T(1);
+    mK[r] = k < n ? T(1) : T(0);
+    oF[r] = f < 0 ? 0 : f;
+    oL[r] = o < 0 ? 0 : o;
+  }
+  const T mJ = j < n ? T(1) : T(0);
+
+  // ---- record DMA: NDMA full-wave 16-byte instructions per record; lanes
+  // past the record re-load an early chunk into the slot's padding
+  const char* rec_b = reinterpret_cast<const char*>(
+      a.rec + (size_t)b * (size_t)(N + 1) * S);
+  const int chunks = S / 4;
+  uint32_t qoff[NDMA];
+#pragma unroll
+  for (int r = 0; r < NDMA; ++r)
+    qoff[r] = (uint32_t)((lane + kWave * r) % chunks) * 16u;
+  auto dma = [&](int slot, int t) {
+    const int tt = t < 0 ? 0 : t;
+    const uint32_t base = (uint32_t)tt * (uint32_t)(S * sizeof(T));
+    const uint32_t lbase =
+        __builtin_amdgcn_readfirstlane(n4::lds_addr(ring + slot * kSlotWords));
+#pragma unroll
+    for (int r = 0; r < NDMA; ++r)
+      n4::lds_dma16(rec_b, base + qoff[r], lbase + r * kWave * 16);
+  };
+
+  // ---- terminal value function in the accumulator layout (ilqr.py:581-583)
+  T V[16], Vz[16];
+  {
+    const T* term = a.rec + ((size_t)b * (size_t)(N + 1) + N) * S;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = row_of(r, h);
+      V[r] = (k < n && j < n) ? term[lay.oLzz + k * n + j] : T(0);
+      Vz[r] = (k < n) ? term[lay.oLz + k] : T(0);
+    }
+  }
+  for (int s = 0; s < kRing; ++s) dma(s, N - 1 - s);
+  n4::wait_vmcnt<0>();
+
+  // row n of Q~ = (Q_uz | Q_uu | .. | Q_u at column 31): register rn of the
+  // lanes of half hn
+  const int hn = (n >> 2) & 1, rn = (n & 3) + 4 * (n >> 3);
+  T* gains_b = a.gains + (size_t)b * (size_t)N * lay.gstride;
+  T kprev = T(0);
+  int status = PDDP_BWD_OK;
+  int slot = 0;
+  for (int t = N - 1; t >= 0; --t) {
+    // record t has landed once at most (kRing - 1) younger {DMA x NDMA, store}
+    // groups are outstanding
+    n4::wait_vmcnt<(kRing - 1) * (NDMA + 1)>();
+    const T* R = ring + slot * kSlotWords;
+    T Fa[16];
+    f32x16 Q;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      Fa[r] = R[oF[r]] * mF[r];
+      Q[r] = R[oL[r]] * mL[r];
+    }
+    const T Un = BOUNDED ? R[lay.oU] : T(0);
+
+    // ---- X = V F~ ; X[:, 31] = V_z
+    f32x16 X = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      X = __builtin_amdgcn_mfma_f32_32x32x2f32(V[r], Fa[r], X, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) X[r] = (j == 31) ? Vz[r] : X[r];
+    // ---- Q~ = L~ + F~^T X
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      Q = __builtin_amdgcn_mfma_f32_32x32x2f32(Fa[r], X[r], Q, 0, 0, 0);
+
+    T rowv = Q[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) rowv = (r == rn) ? Q[r] : rowv;
+    const T Quu = __int_as_float(
+        __builtin_amdgcn_readlane(__float_as_int(rowv), hn * 32 + n));
+    const T Qu = __int_as_float(
+        __builtin_amdgcn_readlane(__float_as_int(rowv), hn * 32 + 31));
+    // transpose tile: T[col][row] = Q~[row][col]; registers 4q .. 4q + 3 are
+    // the consecutive rows 8q + 4h + (0..3)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      m16::f32x4 v = {Q[4 * q], Q[4 * q + 1], Q[4 * q + 2], Q[4 * q + 3]};
+      *reinterpret_cast<m16::f32x4*>(tile + j * kTileLd + 8 * q + 4 * h) = v;
+    }
+
+    // ---- gains (every lane the same scalars)                 (ilqr.py:629-657)
+    int st = PDDP_BWD_OK;
+    if (!is_finite(Quu)) st = PDDP_BWD_NAN;     // eig raises (ilqr.py:631)
+    const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
+    const T qp_Q = e + reg;                     // ilqr.py:634
+    T kt, sE;
+    int stt = st;
+    if constexpr (BOUNDED) {
+      n4::QpClosed<T, FAST> qc;
+      qc.solve(kprev, qp_Q, Qu, umin - Un, umax - Un);
+      kt = qc.x;
+      bool Kz = !qc.free_, fail = qc.fail;
+      if (__builtin_amdgcn_ballot_w64(qc.slow) != 0) {
+        const n4::SlowQpOut<T> o = n4::boxqp1_outlined<T, FAST>(
+            kprev, qp_Q, Qu, umin - Un, umax - Un, lstep0, ls_tail, lane);
+        kt = o.x;
+        Kz = (o.result_free & 1) == 0;
+        fail = o.result_free < 2;
+      }
+      if (fail) stt = PDDP_BWD_BOXQP_FAILED;
+      if constexpr (FAST) sE = Kz ? T(0) : qc.inv;
+      else sE = Kz ? T(0) : n4::div_<false>(n4::div_<false>(T(1), qc.U), qc.U);
+    } else {
+      sE = n4::div_<FAST>(T(1), qp_Q);  // (E / e) E^T             (ilqr.py:636)
+      kt = -(sE * Qu);
+      // NaN in k or K raises (ilqr.py:639-640)
+      const bool nanK = (h == hn) && (j < n) && (sE * rowv != sE * rowv);
+      if (kt != kt || __builtin_amdgcn_ballot_w64(nanK) != 0)
+        stt = PDDP_BWD_NAN;
+    }
+    if (status == PDDP_BWD_OK && stt != PDDP_BWD_OK) status = stt;
+    kprev = kt;
+    const T c = sE * (sE * Quu - T(2));
+    const T w = kt - sE * (Qu + Quu * kt);
+
+    // ---- k, K of step t: lanes of row n hold Q_uz[j] (j < n), lane j = n: k
+    {
+      const T val = (j < n) ? -(sE * rowv) : kt;
+      T* dst = gains_b + (size_t)t * lay.gstride + (j < n ? 1 + j : 0);
+      if (h == hn && j <= n) *dst = val;
+    }
+    dma(slot, t - kRing);  // this slot is consumed: refill it
+
+    // ---- V' = sym(Q_zz) + c Q_uz^T Q_uz,  V_z' = Q_z + Q_uz^T w
+    const T Quz_j = tile[j * kTileLd + n];  // Q~[n][j]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = row_of(r, h);
+      const T QT = tile[k * kTileLd + j];     // Q~[j][k]
+      const T Quz_k = tile[k * kTileLd + n];  // Q~[n][k]
+      const T sym = T(0.5) * (Q[r] + QT);
+      V[r] = __builtin_fmaf(c * Quz_k, Quz_j, sym) * (mK[r] * mJ);
+      Vz[r] = __builtin_fmaf(Quz_k, w, Q[r]) * mK[r];  // (lanes j = 31)
+    }
+    slot = slot + 1 == kRing ? 0 : slot + 1;
+  }
+  n4::wait_vmcnt<0>();
+  if (lane == 0) a.status[b] = status;
+}
+
+}  // namespace m32
+
+// 15 <= n <= 30, m = 1, fp32, eig-clamp branch; PDDP_E_UNSUPPORTED otherwise
+static int launch_mfma32(const RiccatiArgs<float>& a, hipStream_t st,
+                         bool fast_math) {
+  if (a.n < 15 || a.n > 30 || a.branch != PDDP_BRANCH_EIG)
+    return PDDP_E_UNSUPPORTED;
+  const RecLayout lay(a.n, 1);
+  const int chunks = lay.stride / 4;
+  const int ndma = (chunks + kWave - 1) / kWave <= 4 ? 4 : 8;
+  const size_t lds = sizeof(float) * ((size_t)m32::kWaves *
+                                          (m32::kRing * ndma * kWave * 4 +
+                                           m32::kTile) +
+                                      n4::kLsSteps);
+  const dim3 grid((a.B + m32::kWaves - 1) / m32::kWaves),
+      block(kWave * m32::kWaves);
+  const bool bounded = a.u_min != nullptr;
+#define PDDP_M32(Bd, F, ND)                                                    \
+  do {                                                                         \
+    auto kern = m32::riccati_mfma32_kernel<Bd, F, ND>;                         \
+    const hipError_t e_ = hipFuncSetAttribute(                                 \
+        (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+        (int)lds);                                                             \
+    if (e_ != hipSuccess) return (int)e_;                                      \
+    PDDP_LAUNCH(kern, grid, block, lds, st, a);                                \
+  } while (0)
+#define PDDP_M32_ND(Bd, F)                                                     \
+  do {                                                                         \
+    if (ndma == 4) PDDP_M32(Bd, F, 4); else PDDP_M32(Bd, F, 8);                \
+  } while (0)
+  if (bounded) { if (fast_math) PDDP_M32_ND(true, true); else PDDP_M32_ND(true, false); }
+  else { if (fast_math) PDDP_M32_ND(false, true); else PDDP_M32_ND(false, false); }
+#undef PDDP_M32_ND
+#undef PDDP_M32
+  return launch_status();
+}
+
+}  // namespace pddp

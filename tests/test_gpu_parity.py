@@ -738,11 +738,16 @@ def test_reference_shape_contract(problem, enc_name, N):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-@pytest.mark.parametrize("n,m", [(33, 1), (42, 1), (72, 4), (80, 2)])
+@pytest.mark.parametrize("n,m", [(9, 1), (14, 1), (15, 1), (21, 1), (27, 1),
+                                 (30, 1), (33, 1), (42, 1), (72, 4), (80, 2)])
 def test_backward_large_state_vs_oracle(n, m, dtype):
     """n > 32 (FULL_COVARIANCE_MATRIX encodings: double cartpole 42, rendezvous
-    72): the four-wavefront kernel with dynamically sized LDS, all four gain
-    branches, against the oracle on random well-conditioned records."""
+    72): the four-wavefront kernel with dynamically sized LDS; n <= 30 with
+    m = 1 in fp32: the matrix-core kernels (riccati_mfma16.hpp for n <= 14,
+    riccati_mfma32.hpp for 15 .. 30; n = 14 / 27 are the DEFAULT encodings of
+    cartpole / double cartpole) on the eig-clamp branches, the generic kernel
+    on the Cholesky ones - all four gain branches, against the oracle on random
+    well-conditioned records."""
     from pddp_amd.controllers.ilqr import backward
     rng = np.random.default_rng(n * 7 + m)
     B, N = 3, 6

@@ -129,7 +129,7 @@ def main():
         "GBps": B * 4 * words / t_bwd / 1e9,
         "frac_of_8TBps": B * 4 * words / t_bwd / 8e12,
         "failed": int((s.bwd_status != 0).sum()),
-        "kernel": "riccati_mfma16 (auto)" if n <= 14 else "riccati_generic",
+        "kernel": "riccati_mfma16 (auto)" if n <= 14 else "riccati_mfma32 (auto)",
         "generic_kernel_us": sweep_us(1, 3)}
     if n <= 14:
         out["backward_sweep"]["mfma16_ieee_division_us"] = sweep_us(14)
