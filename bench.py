@@ -127,17 +127,17 @@ def bench_bnn(args):
     attempted = live0 + int(s.n_live.sum().item()) - liveK
     # the dominant kernel, timed alone on torch's current stream (the stream it
     # is launched on): one forward-mode network pass of a time step
-    F = torch.randn(B * P * 16, 6, device=dev)
-    model.model._jvp_native(F, P, 4, 16)
+    F = torch.randn(B * P * 8, 6, device=dev)
+    model.model._jvp_native(F, P, 4, 8)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 5
     e0.record()
     for _ in range(reps):
-        model.model._jvp_native(F, P, 4, 16)
+        model.model._jvp_native(F, P, 4, 8)
     e1.record()
     torch.cuda.synchronize(dev)
     dur = e0.elapsed_time(e1) * 1e-3 / reps
-    flop = 2.0 * B * P * 16 * (6 * H + H * H + H * 4)
+    flop = 2.0 * B * P * 8 * (6 * H + H * H + H * 4)
     out = {
         "metric": "pddp_iterations_per_sec", "value": attempted / elapsed,
         "unit": "trajectory-iterations/s", "n_gpus": 1, "steps": K,
@@ -159,7 +159,7 @@ def bench_bnn(args):
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "fused BNN network, forward-mode (bnn_mlp_kernel<200, 8, 16>)",
+            "kernel": "fused BNN network, forward-mode (bnn_mlp_kernel<200, 8, 8>)",
             "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
             "avg_launch_us": dur * 1e6,

@@ -336,8 +336,8 @@ int pddp_bnn_moment_step_f32(const pddp_bnn_step* step, void* stream);
 /* ---- the same network in forward mode (JVP), for the derivative rollout
  * (ilqr.py:457-468 -> utils/evaluation.py:203-235 batch_eval_dynamics, which
  * replicates the input n times and back-propagates an identity): rows come in
- * groups of `group` = 16 or 32 = one (state, particle) input row followed by
- * group - 1 tangent rows d X / d direction; a tangent row passes through the
+ * groups of `group` = 8, 16 or 32 = one (state, particle) input row followed
+ * by group - 1 tangent rows d X / d direction; a tangent row passes through the
  * weights without biases and through the ReLUs linearised at its group's first
  * row.  p = (r / group) % P, R a multiple of group; everything else as
  * pddp_bnn_mlp_f32. */
@@ -351,17 +351,20 @@ int pddp_bnn_mlp_jvp_f32(int R, int P, int group, int in_dim, int H,
 /* ---- Jacobians F_z, F_u of one moment-matched BNN step (modules.py:287-386
  * under DEFAULT encoding) in forward mode, around pddp_bnn_mlp_jvp_f32:
  *   features(t): eps = (Xp - mean_t) U_t^-1 (the detached re-whitening of
- *                modules.py:333-348), F = [B P][16][in_dim] primal + tangent
- *                input rows for the directions (mean_d | U_ab row-major upper
- *                triangle | u), derivatives at the clamped action;
- *   moments(t):  net_out [B P][16][out_dim] -> Xp_next (output particles =
+ *                modules.py:333-348), F = [B P][8][in_dim]: the input row, the
+ *                D + m tangent rows for the directions (mean_d | u) at the
+ *                clamped action, zero rows.  The Cholesky directions U_ab need
+ *                no rows of their own: d X / d U_ab = eps[a] d X / d mean_b per
+ *                particle, and the network pass is linear in the tangent;
+ *   moments(t):  net_out [B P][8][out_dim] -> Xp_next (output particles =
  *                the cloud of step t + 1), Z_next = encode(mean, covariance),
  *                F_z[b][t], F_u[b][t] through the differential of the Cholesky
  *                factor.
- * Rows per group G = pddp_bnn_jvp_group(D, m): 16 for D <= 4 with at most 15
- * directions (cartpole, pendulum), 32 for D <= 6 with at most 31 (double
- * cartpole), 0 = PDDP_E_UNSUPPORTED (the autograd path then); F and net_out
- * are [B P][G][.]. */
+ * pddp_bnn_jvp_group(D, m) = lanes per trajectory of the moments launch: 16
+ * for D <= 4 with at most 15 directions of (z | u) (cartpole, pendulum), 32
+ * for D <= 6 with at most 31 (double cartpole), 0 = PDDP_E_UNSUPPORTED (D + m >
+ * 7 or more directions: the autograd path then).  The network launch in
+ * between is pddp_bnn_mlp_jvp_f32 with group = 8. */
 int pddp_bnn_jvp_group(int D, int m);
 typedef struct pddp_bnn_jvp {
   int32_t B, P, D, m, N, t;
@@ -375,11 +378,11 @@ typedef struct pddp_bnn_jvp {
   const float* X_std_inv;
   const float* dX_mean;  /* [D] */
   const float* dX_std;
-  const float* net_out;  /* [B P][G][out_dim] (moments) */
+  const float* net_out;  /* [B P][8][out_dim] (moments) */
   const float* Xp;       /* [B][P][D] particles of step t */
   float* Xp_next;        /* [B][P][D] out (moments), nullable */
   float* eps;            /* [B][P][D] out (features), in (moments) */
-  float* F;              /* [B P][G][in_dim] out (features) */
+  float* F;              /* [B P][8][in_dim] out (features) */
   float* Z_next;         /* [B][n] out (moments), nullable */
   float* F_z;            /* [B][N][n][n] out (moments) */
   float* F_u;            /* [B][N][n][m] out (moments) */

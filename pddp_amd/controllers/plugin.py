@@ -234,7 +234,7 @@ class TorchProblem(object):
     @torch.no_grad()
     def _dyn_derivs_bnn(self, s, F_z, F_u):
         """F_z, F_u of the whole nominal in forward mode: per time step one
-        feature launch, the fused network in JVP mode on B P 16 rows, one
+        feature launch, the fused network in JVP mode on B P 8 rows, one
         moment launch (csrc/bnn_jvp.hip, csrc/bnn_mlp.hip) - instead of
         autograd over n replicated inputs (utils/evaluation.py:203-235)."""
         import ctypes
@@ -255,7 +255,7 @@ class TorchProblem(object):
               mo.eps_in[0] @ decode_covar_sqrt(z0, self.encoding)).contiguous()
         Xn = torch.empty_like(Xp)
         eps = torch.empty_like(Xp)
-        G = _native.lib().pddp_bnn_jvp_group(D, m)
+        G = 8  # network rows per (state, particle): input + D + m tangents
         F = torch.empty(B * P * G, in_dim, **opts)
         keep = [vec(mo.X_mean, in_dim), vec(mo.X_std_inv, in_dim),
                 vec(mo.dX_mean, D), vec(mo.dX_std, D), s.Z.contiguous(),

@@ -23,8 +23,15 @@
 //                  dU'_k = Phi(U'^-T dC_k U'^-1) U'   (Phi: upper triangle, half
 //                  the diagonal - the differential of the Cholesky factor),
 //                  column k of (F_z | F_u) = (dM_k | triu(dU'_k)).
-// G lanes per (trajectory, particle) in jvp_features, G lanes per trajectory
-// in jvp_moments (G = 16 or 32 rows per group): lane k owns direction k.
+// Only the D + m directions (mean_d | u) go through the network: X = mean +
+// eps U makes the tangent of X for a Cholesky direction U_ab the PARTICLE'S
+// scalar eps[a] times its tangent for mean_b, and everything downstream of X is
+// linear in the tangent, so d out / d U_ab = eps[a] d out / d mean_b per
+// particle.  Network rows per (state, particle): 8 = input + D + m <= 7
+// tangents (instead of 16 / 32: the Cholesky directions were 10 of cartpole's
+// 15, 21 of the double cartpole's 28).  jvp_moments still has one lane per
+// direction of z (G = 16 or 32 lanes per trajectory), each reading its base
+// direction's row and scaling.
 #include "pddp_common.hpp"
 
 namespace pddp {
@@ -33,20 +40,11 @@ namespace pddp {
 // G = 16: D <= 4 (cartpole: 4 + 10 + 1 directions); G = 32: D <= 6 (double
 // cartpole: 6 + 21 + 1).
 
-// tangent of X_p (D values) for direction d (0-based): mean_d, then the upper
-// triangle of U row-major (np.triu_indices, encoding.py:126-130), then u
-PDDP_DEV void x_tangent(int d, int D, const float* eps, float* dX) {
-  for (int i = 0; i < D; ++i) dX[i] = 0.f;
-  if (d < 0) return;
-  if (d < D) { dX[d] = 1.f; return; }
-  int o = D;
-  for (int a = 0; a < D; ++a)
-    for (int b = a; b < D; ++b, ++o)
-      if (o == d) dX[b] = eps[a];  // X = mean + eps U:  dX[b] / dU[a][b] = eps[a]
-}
+constexpr int kNetRows = 8;  // network rows per (state, particle)
 
-template <int kJvpRows, int kJvpMaxD>
+template <int kJvpMaxD>
 __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
+  constexpr int kJvpRows = kNetRows;
   const int lane = threadIdx.x;
   const int k = lane & (kJvpRows - 1);  // row of the group
   const int bp = blockIdx.x * (64 / kJvpRows) + lane / kJvpRows;  // (b, p)
@@ -70,8 +68,9 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   }
   if (k == 0)
     for (int j = 0; j < D; ++j) s.eps[(size_t)bp * D + j] = eps[j];
+  // row k >= 1: direction mean_{k-1} (k - 1 < D) or u_{k-1-D}
   float dX[kJvpMaxD];
-  x_tangent(k - 1, D, eps, dX);
+  for (int q = 0; q < D; ++q) dX[q] = (k - 1 == q) ? 1.f : 0.f;
   float* f = s.F + ((size_t)bp * kJvpRows + k) * s.in_dim;
   int o = 0;
   for (int i = 0; i < s.n_non; ++i, ++o) {
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
     if (s.u_min != nullptr && s.u_max != nullptr)
       u = clamp1(u, s.u_min[r], s.u_max[r]);
     f[o] = k == 0 ? (u - s.X_mean[o]) * s.X_std_inv[o]
-                  : ((k - 1 == n + r) ? s.X_std_inv[o] : 0.f);
+                  : ((k - 1 == D + r) ? s.X_std_inv[o] : 0.f);
   }
 }
 
@@ -109,7 +108,21 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   if (b >= s.B) return;
   const int D = s.D, P = s.P, m = s.m, n = D + D * (D + 1) / 2;
   const int OUT = s.out_dim;
-  const float* Y = s.net_out + (size_t)b * P * kJvpRows * OUT;
+  const float* Y = s.net_out + (size_t)b * P * kNetRows * OUT;
+  // direction k - 1 of (z | u) -> network row (1 + base direction) and, for a
+  // Cholesky direction U_ab, the index a of the particle's eps that scales it
+  int yrow = 0, ea = -1;
+  {
+    const int d = k - 1;
+    if (d >= 0 && d < D) yrow = 1 + d;
+    else if (d >= n && d < n + m) yrow = 1 + D + (d - n);
+    else if (d >= D && d < n) {
+      int o = D;
+      for (int aa = 0; aa < D; ++aa)
+        for (int bb = aa; bb < D; ++bb, ++o)
+          if (o == d) { yrow = 1 + bb; ea = aa; }
+    }
+  }
   const float* Xin = s.Xp + (size_t)b * P * D;
   float sd[kJvpMaxD], mu[kJvpMaxD];
   for (int d = 0; d < D; ++d) { sd[d] = s.dX_std[d]; mu[d] = s.dX_mean[d]; }
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   for (int d = 0; d < D; ++d) M[d] = 0.f;
   for (int p = 0; p < P; ++p)
     for (int d = 0; d < D; ++d)
-      M[d] += Xin[p * D + d] + (Y[(size_t)p * kJvpRows * OUT + d] * sd[d] + mu[d]);
+      M[d] += Xin[p * D + d] + (Y[(size_t)p * kNetRows * OUT + d] * sd[d] + mu[d]);
   for (int d = 0; d < D; ++d) M[d] /= (float)P;
 
   // ---- covariance, and this lane's tangent sums
@@ -129,13 +142,15 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
     for (int j = 0; j < D; ++j) { C[i][j] = 0.f; S[i][j] = 0.f; }
   }
   for (int p = 0; p < P; ++p) {
-    float dev[kJvpMaxD], dout[kJvpMaxD], dX[kJvpMaxD];
-    x_tangent(k - 1, D, s.eps + ((size_t)b * P + p) * D, dX);
+    float dev[kJvpMaxD], dout[kJvpMaxD];
+    // tangent of X for the base direction: e_b (mean_b / U_ab), 0 (u); scale
+    const float sc = ea < 0 ? 1.f : s.eps[((size_t)b * P + p) * D + ea];
     for (int d = 0; d < D; ++d) {
       const float out =
-          Xin[p * D + d] + (Y[(size_t)p * kJvpRows * OUT + d] * sd[d] + mu[d]);
+          Xin[p * D + d] + (Y[(size_t)p * kNetRows * OUT + d] * sd[d] + mu[d]);
       dev[d] = out - M[d];
-      dout[d] = dX[d] + Y[((size_t)p * kJvpRows + k) * OUT + d] * sd[d];
+      const float dXd = (yrow >= 1 && yrow <= D && yrow - 1 == d) ? 1.f : 0.f;
+      dout[d] = sc * (dXd + Y[((size_t)p * kNetRows + yrow) * OUT + d] * sd[d]);
       if (k == 0 && s.Xp_next != nullptr)
         s.Xp_next[((size_t)b * P + p) * D + d] = out;
     }
@@ -250,6 +265,7 @@ extern "C" {
 /* rows per (state, particle) group for a problem: 16 or 32 (0: unsupported) */
 int pddp_bnn_jvp_group(int D, int m) {
   const int dirs = D + D * (D + 1) / 2 + m;
+  if (D + m > 7) return 0;  // network rows per particle: input + D + m <= 8
   if (D <= 4 && dirs <= 15) return 16;
   if (D <= 6 && dirs <= 31) return 32;
   return 0;
@@ -262,8 +278,8 @@ static int bnn_jvp_check(const pddp_bnn_jvp* s) {
       !s->dX_std || !s->Xp || !s->eps || !s->F)
     return PDDP_E_BADARG;
   const int n = s->D + s->D * (s->D + 1) / 2;
-  if (s->D < 1 || s->D > 6 || s->m < 1 || n + s->m > 31 || s->n_ang < 0 ||
-      s->n_ang > 2 ||
+  if (s->D < 1 || s->D > 6 || s->m < 1 || n + s->m > 31 ||
+      s->D + s->m > pddp::kNetRows - 1 || s->n_ang < 0 || s->n_ang > 2 ||
       s->n_non < 0 || s->n_non + s->n_ang != s->D ||
       s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D)
     return PDDP_E_UNSUPPORTED;
@@ -272,13 +288,13 @@ static int bnn_jvp_check(const pddp_bnn_jvp* s) {
 
 int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
-  if (pddp_bnn_jvp_group(s->D, s->m) == 16)
-    hipLaunchKernelGGL((pddp::bnn_jvp_features_kernel<16, 4>),
-                       dim3((s->B * s->P + 3) / 4), dim3(64), 0,
+  if (s->D <= 4)
+    hipLaunchKernelGGL((pddp::bnn_jvp_features_kernel<4>),
+                       dim3((s->B * s->P + 7) / 8), dim3(64), 0,
                        (hipStream_t)stream, *s);
   else
-    hipLaunchKernelGGL((pddp::bnn_jvp_features_kernel<32, 6>),
-                       dim3((s->B * s->P + 1) / 2), dim3(64), 0,
+    hipLaunchKernelGGL((pddp::bnn_jvp_features_kernel<6>),
+                       dim3((s->B * s->P + 7) / 8), dim3(64), 0,
                        (hipStream_t)stream, *s);
   return pddp::launch_status();
 }

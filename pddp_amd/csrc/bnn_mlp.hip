@@ -30,8 +30,8 @@
 //   C  the NB partial outputs are summed from LDS, b3 added, rows stored.
 //
 // JVP mode (the derivative rollout, ilqr.py:457-468 through
-// utils/evaluation.py:203-235): rows come in groups of 16 (or 32) = one (state,
-// particle) input and 15 (31) tangent directions of it.  A tangent row goes through
+// utils/evaluation.py:203-235): rows come in groups of 8, 16 or 32 = one (state,
+// particle) input and 7 / 15 / 31 tangent directions of it.  A tangent row goes through
 // the same weights without biases, and through the ReLUs linearised at its
 // group's primal row: d relu(m h) = m dh [m h > 0].  Groups are aligned to the
 // 16-lane DPP rows of both the producer and the accumulator layout (data row =
@@ -83,7 +83,14 @@ constexpr size_t bnn_mlp_lds_floats() {
 // one group): lane 0 for the lanes of half 0, lane 32 for half 1.
 template <int G>
 PDDP_DEV float row_first(float v) {
-  if constexpr (G == 16) {
+  if constexpr (G == 8) {
+    // two groups per 16-lane DPP row: lanes 0-7 take lane 0, lanes 8-15 lane 8
+    const float lo = __int_as_float(__builtin_amdgcn_update_dpp(
+        0, __float_as_int(v), 0x150, 0xf, 0xf, true));
+    const float hi = __int_as_float(__builtin_amdgcn_update_dpp(
+        0, __float_as_int(v), 0x158, 0xf, 0xf, true));
+    return (threadIdx.x & 8) ? hi : lo;
+  } else if constexpr (G == 16) {
     return __int_as_float(__builtin_amdgcn_update_dpp(
         0, __float_as_int(v), 0x150, 0xf, 0xf, true));
   } else {
@@ -97,7 +104,8 @@ PDDP_DEV float row_first(float v) {
 template <int H, int kMlpW1Stride, int kJvpGroup = 0>
 __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   constexpr bool JVP = kJvpGroup != 0;
-  static_assert(kJvpGroup == 0 || kJvpGroup == 16 || kJvpGroup == 32, "");
+  static_assert(kJvpGroup == 0 || kJvpGroup == 8 || kJvpGroup == 16 ||
+                    kJvpGroup == 32, "");
   static_assert(H % 8 == 0 && H <= 224, "H: multiple of 8, at most 224");
   constexpr int KS = H / 2;          // MFMA steps of layer 2
   constexpr int NB = (H + 31) / 32;  // 32-unit blocks = consumer wavefronts
@@ -361,13 +369,20 @@ int pddp_bnn_mlp_jvp_f32(int R, int P, int group, int in_dim, int H,
   if (R <= 0 || P <= 0 || in_dim <= 0 || H <= 0 || out_dim <= 0 || !X || !W1 ||
       !b1 || !MT1 || !W2 || !b2 || !MT2 || !W3 || !b3 || !Y)
     return PDDP_E_BADARG;
-  if ((group != 16 && group != 32) || R % group != 0) return PDDP_E_BADARG;
+  if ((group != 8 && group != 16 && group != 32) || R % group != 0)
+    return PDDP_E_BADARG;
   if (in_dim >= pddp::kMlpW1Max || out_dim > pddp::kMlpMaxOut)
     return PDDP_E_UNSUPPORTED;
   const pddp::BnnMlpArgs a{R, P, in_dim, H, out_dim, X, W1, b1, MT1, W2,
                            b2, MT2, W3, b3, Y};
   hipStream_t st = (hipStream_t)stream;
-  if (group == 16) {
+  if (group == 8) {
+    switch (H) {
+      case 64: return pddp::launch_bnn_mlp<64, 8>(a, st);
+      case 128: return pddp::launch_bnn_mlp<128, 8>(a, st);
+      case 200: return pddp::launch_bnn_mlp<200, 8>(a, st);
+    }
+  } else if (group == 16) {
     switch (H) {
       case 64: return pddp::launch_bnn_mlp<64, 16>(a, st);
       case 128: return pddp::launch_bnn_mlp<128, 16>(a, st);

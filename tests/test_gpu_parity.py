@@ -971,7 +971,7 @@ def test_bnn_native_line_search_vs_torch_path(problem, H, P):
     assert float((Za[:, 1:] - Zb[:, :1]).abs().max()) > 1e-4  # it did move
 
 
-@pytest.mark.parametrize("G", [16, 32])
+@pytest.mark.parametrize("G", [8, 16, 32])
 @pytest.mark.parametrize("H", [64, 200])
 @pytest.mark.parametrize("groups,P,in_dim,out_dim", [(1, 100, 6, 4), (37, 100, 6, 4),
                                                      (203, 7, 4, 2), (64, 33, 15, 16)])

@@ -74,7 +74,7 @@ def main():
     B, N, A, P = a.batch, a.horizon, 10, a.particles
     n, m = D + D * (D + 1) // 2, 1
     in_dim = len(CM.non_angular_indices) + 2 * len(CM.angular_indices) + m
-    G = 16 if D <= 4 else 32
+    G = 8  # network rows per (state, particle) in forward mode
     plugin = TorchProblem(model, cost, enc,
                           {"use_predicted_std": False,
                            "infer_noise_variables": True}, {})
