@@ -102,13 +102,22 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
 
 template <int kJvpRows, int kJvpMaxD>
 __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
+  // one wavefront per trajectory: lane = (particle slice, direction k); the
+  // NS = 64 / G slices split the particle loop and meet in xor butterflies
+  constexpr int NS = 64 / kJvpRows;
   const int lane = threadIdx.x;
   const int k = lane & (kJvpRows - 1);
-  const int b = blockIdx.x * (64 / kJvpRows) + lane / kJvpRows;
+  const int slice = lane / kJvpRows;
+  const int b = blockIdx.x;
   if (b >= s.B) return;
   const int D = s.D, P = s.P, m = s.m, n = D + D * (D + 1) / 2;
   const int OUT = s.out_dim;
   const float* Y = s.net_out + (size_t)b * P * kNetRows * OUT;
+  auto across_slices = [&](float v) {
+#pragma unroll
+    for (int o = kJvpRows; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+  };
   // direction k - 1 of (z | u) -> network row (1 + base direction) and, for a
   // Cholesky direction U_ab, the index a of the particle's eps that scales it
   int yrow = 0, ea = -1;
@@ -130,10 +139,10 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   // ---- primal moments (every lane of the group, same arithmetic)
   float M[kJvpMaxD];
   for (int d = 0; d < D; ++d) M[d] = 0.f;
-  for (int p = 0; p < P; ++p)
+  for (int p = slice; p < P; p += NS)
     for (int d = 0; d < D; ++d)
       M[d] += Xin[p * D + d] + (Y[(size_t)p * kNetRows * OUT + d] * sd[d] + mu[d]);
-  for (int d = 0; d < D; ++d) M[d] /= (float)P;
+  for (int d = 0; d < D; ++d) M[d] = across_slices(M[d]) / (float)P;
 
   // ---- covariance, and this lane's tangent sums
   float C[kJvpMaxD][kJvpMaxD], S[kJvpMaxD][kJvpMaxD], dM[kJvpMaxD];
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
     dM[i] = 0.f;
     for (int j = 0; j < D; ++j) { C[i][j] = 0.f; S[i][j] = 0.f; }
   }
-  for (int p = 0; p < P; ++p) {
+  for (int p = slice; p < P; p += NS) {
     float dev[kJvpMaxD], dout[kJvpMaxD];
     // tangent of X for the base direction: e_b (mean_b / U_ab), 0 (u); scale
     const float sc = ea < 0 ? 1.f : s.eps[((size_t)b * P + p) * D + ea];
@@ -163,9 +172,13 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
     }
   }
   for (int i = 0; i < D; ++i) {
-    dM[i] /= (float)P;
-    for (int j = 0; j < D; ++j) C[i][j] /= (float)(P - 1);
+    dM[i] = across_slices(dM[i]) / (float)P;
+    for (int j = 0; j < D; ++j) {
+      C[i][j] = across_slices(C[i][j]) / (float)(P - 1);
+      S[i][j] = across_slices(S[i][j]);
+    }
   }
+  if (slice != 0) return;  // (every slice holds the totals; one writes)
 
   // ---- U' = chol(C + jitter I), upper (encoding.py:536-564)
   float Uc[kJvpMaxD][kJvpMaxD];
@@ -303,13 +316,11 @@ int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
   if (!s->net_out || !s->F_z || !s->F_u) return PDDP_E_BADARG;
   if (pddp_bnn_jvp_group(s->D, s->m) == 16)
-    hipLaunchKernelGGL((pddp::bnn_jvp_moments_kernel<16, 4>),
-                       dim3((s->B + 3) / 4), dim3(64), 0, (hipStream_t)stream,
-                       *s);
+    hipLaunchKernelGGL((pddp::bnn_jvp_moments_kernel<16, 4>), dim3(s->B),
+                       dim3(64), 0, (hipStream_t)stream, *s);
   else
-    hipLaunchKernelGGL((pddp::bnn_jvp_moments_kernel<32, 6>),
-                       dim3((s->B + 1) / 2), dim3(64), 0, (hipStream_t)stream,
-                       *s);
+    hipLaunchKernelGGL((pddp::bnn_jvp_moments_kernel<32, 6>), dim3(s->B),
+                       dim3(64), 0, (hipStream_t)stream, *s);
   return pddp::launch_status();
 }
 
