@@ -11,7 +11,7 @@ The iLQR inside every trial runs on the HIP path: forward-mode derivative
 rollout and line search through the fused network kernel, matrix-core backward
 sweep (n = 14), device-resident accept / regularisation state machine.
 
-    python examples/cartpole.py [--trials 3] [--iterations 10] [--train-iters 300]
+    python tools/run_cartpole_pddp.py [--trials 3] [--iterations 10] [--train-iters 300]
 """
 import argparse
 import os
