@@ -26,29 +26,19 @@ import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
-
-def algorithmic_bytes_per_trajectory(N, n, m, itemsize, bounded):
-    """BASELINE.md 3 / SURVEY.md 8(d): bytes the backward sweep must move."""
-    per_step = 2 * n * n + 3 * n * m + n + 2 * m + m * m + (m if bounded else 0)
-    return itemsize * (N * per_step + n + n * n)
-
-
-def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
-    """Times the oracle (plain C port of the reference's algorithm, one core)
-    on a bounded sample of the same workload; unit = the same
-    trajectory-iterations/s."""
+def _cpu_baseline_worker(problem_name, dt, N, bound, seconds, seed):
+    """One core's share of the CPU baseline: oracle fits until the time is up.
+    Returns (attempts, trajectories, elapsed)."""
     import oracle as orc
     o = orc.load(np.float32)
     op = orc.make_problem(problem_name, dt)
-    rng = np.random.RandomState(12345)
+    rng = np.random.RandomState(seed)
     alphas = (1.025 ** (-np.arange(10.0) ** 2)).astype(np.float32)
     u_min = np.full(op.action_size, -bound, np.float32)
     u_max = np.full(op.action_size, bound, np.float32)
@@ -61,13 +51,53 @@ def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
                                   u_min=u_min, u_max=u_max)
         attempts += trace.shape[0]
         trajs += 1
-    el = time.perf_counter() - t0
+    return attempts, trajs, time.perf_counter() - t0
+
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
+    # a CPU-baseline worker: no torch, no GPU (see cpu_baseline below)
+    _name, _dt, _N, _bound, _seconds, _seed = sys.argv[2:8]
+    print("%d %d %.6f" % _cpu_baseline_worker(
+        _name, float(_dt), int(_N), float(_bound), float(_seconds), int(_seed)))
+    sys.exit(0)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_trajectory(N, n, m, itemsize, bounded):
+    """BASELINE.md 3 / SURVEY.md 8(d): bytes the backward sweep must move."""
+    per_step = 2 * n * n + 3 * n * m + n + 2 * m + m * m + (m if bounded else 0)
+    return itemsize * (N * per_step + n + n * n)
+
+
+def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
+    """Times the oracle (plain C port of the reference's algorithm) on the
+    host's cores on a bounded sample of the same workload; unit = the same
+    trajectory-iterations/s.  One worker process per core (trajectories are
+    independent, as on the GPU), at most 16 - a GPU box's CPU share; the
+    workers are fresh interpreters that never touch the GPU."""
+    import subprocess
+    workers = max(1, min(16, os.cpu_count() or 1))
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
+           problem_name, repr(dt), str(N), repr(bound), repr(seconds)]
+    procs = [subprocess.Popen(cmd + [str(12345 + w)], stdout=subprocess.PIPE,
+                              text=True) for w in range(workers)]
+    attempts, trajs, el = 0, 0, 0.0
+    for p in procs:
+        out = p.communicate()[0].strip().splitlines()[-1].split()
+        attempts += int(out[0])
+        trajs += int(out[1])
+        el = max(el, float(out[2]))
     return {"value": attempts / el, "unit": "trajectory-iterations/s",
-            "cores": 1, "kind": "port",
+            "cores": workers, "kind": "port",
+            "per_core_value": attempts / el / workers,
             "sample": "%d cartpole trajectories x up to 8 iLQR iterations "
-                      "(%d attempts) in %.1f s, oracle C port, fp32, "
-                      "host has %d cores" % (trajs, attempts, el,
-                                             os.cpu_count())}
+                      "(%d attempts) in %.1f s on %d worker processes, oracle "
+                      "C port, fp32, host has %d cores"
+                      % (trajs, attempts, el, workers, os.cpu_count())}
 
 
 MFMA_F32_PEAK_TFLOPS = 157.0  # MI355X_MICROARCH.md: dense f32 matrix peak
