@@ -59,13 +59,12 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          update (riccati_n4_pipe.hpp; bounded eig-clamp branch only);
   //          auto: bounded f32, up to 16384 trajectories -> 13 (eig-clamp
   //          branch) or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64)
-  //          14 / 15: the matrix-core kernel for n <= 14, m = 1, fp32,
-  //          eig-clamp branch (riccati_mfma16.hpp; IEEE / approximate
+  //          14 / 15: the matrix-core kernels for n <= 30, m = 1, fp32
+  //          (riccati_mfma16.hpp / riccati_mfma32.hpp; IEEE / approximate
   //          division) - auto for those shapes other than n = 4
   //          (n = 15 .. 30: the 32x32-tile form, riccati_mfma32.hpp)
   if (variant == 14 || variant == 15 ||
-      (variant == 0 && sizeof(T) == 4 && m == 1 && n != 4 && n <= 30 &&
-       branch == PDDP_BRANCH_EIG)) {
+      (variant == 0 && sizeof(T) == 4 && m == 1 && n != 4 && n <= 30)) {
     if constexpr (sizeof(T) == 4) {
       if (m != 1) return PDDP_E_UNSUPPORTED;
       return n <= 14 ? launch_mfma16(a, st, variant != 14)

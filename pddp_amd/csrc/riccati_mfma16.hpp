@@ -1,6 +1,7 @@
 // riccati_mfma16.hpp - backward Riccati sweep for n + 1 <= 15, m = 1 in fp32 on
 // the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32, bitwise an fmaf
-// chain), eig-clamp branch (ilqr.py:629-672), bounded or not.  The DEFAULT
+// chain), both gain branches (eig clamp ilqr.py:629-672, V_zz-regularised
+// Cholesky :587-625), bounded or not.  The DEFAULT
 // (Cholesky) encoding of cartpole is n = 14: BASELINE.json configs[2]'s sweep,
 // 744 MB per launch at B = 4096, N = 100.
 //
@@ -37,7 +38,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kWaves = 4;  // independent trajectories (wavefronts) per workgroup
 constexpr int kRing = 4;   // record slots in flight per wavefront
 
-template <bool BOUNDED, bool FAST>
+template <bool BOUNDED, bool FAST, bool CHOL>
 __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
     RiccatiArgs<float> a, int slot_words, int ndma) {
   using T = float;
@@ -87,6 +88,11 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
     }
     oL[r] = o;
   }
+  // Cholesky branch (ilqr.py:587-625): Q_uu, Q_uz once more with V + reg I,
+  // i.e. + reg f^T F~ (row n of F~^T F~): this lane's share needs f[4g + r]
+  int oFf[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) oFf[r] = (4 * g + r < n) ? lay.oFu + 4 * g + r : -1;
 
   // ---- record DMA: chunk q of 16 bytes -> lane q % 64 of instruction q / 64
   const char* rec_b = reinterpret_cast<const char*>(
@@ -137,6 +143,16 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
       La[r] = oL[r] < 0 ? T(0) : l;
     }
     const T Un = BOUNDED ? R[lay.oU] : T(0);
+    T ffrow = T(0);  // (f^T F~)[j]: f^T F_z for j < n, f.f at j = n
+    if constexpr (CHOL) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const T fk = R[oFf[r] < 0 ? 0 : oFf[r]];
+        ffrow += (oFf[r] < 0 ? T(0) : fk) * Fa[r];
+      }
+      ffrow += __shfl_xor(ffrow, 16);
+      ffrow += __shfl_xor(ffrow, 32);
+    }
 
     // ---- X = V F~ ; X[:, 15] = V_z
     f32x4 X = {0.f, 0.f, 0.f, 0.f};
@@ -159,14 +175,29 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
         __builtin_amdgcn_readlane(__float_as_int(rowv), gn * 16 + n));
     const T Qu = __int_as_float(
         __builtin_amdgcn_readlane(__float_as_int(rowv), gn * 16 + 15));
-    // transpose tile: T[col][row] = Q~[row][col]
+    // the regularised row (Q_uz_reg | Q_uu_reg) of the Cholesky branch
+    const T rowg = CHOL ? rowv + reg * ffrow : rowv;
+    const T Quug = CHOL ? __int_as_float(__builtin_amdgcn_readlane(
+                              __float_as_int(rowg), gn * 16 + n))
+                        : Quu;
+    // transpose tile: T[col][row] = Q~[row][col]; row 15 (free: n + 1 <= 15)
+    // carries Q_uz_reg
     *reinterpret_cast<f32x4*>(tile + j * 16 + 4 * g) = Q;
+    if constexpr (CHOL) {
+      if (g == gn) tile[j * 16 + 15] = rowg;
+    }
 
     // ---- gains (every lane the same scalars)                 (ilqr.py:629-657)
     int st = PDDP_BWD_OK;
-    if (!is_finite(Quu)) st = PDDP_BWD_NAN;     // eig raises (ilqr.py:631)
-    const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
-    const T qp_Q = e + reg;                     // ilqr.py:634
+    T qp_Q;
+    if constexpr (CHOL) {
+      qp_Q = Quug;  // Cholesky of Q_uu_reg                        (ilqr.py:595)
+      if (!BOUNDED && (!(Quug > T(0)) || !is_finite(Quug))) st = PDDP_BWD_NOT_PD;
+    } else {
+      if (!is_finite(Quu)) st = PDDP_BWD_NAN;     // eig raises (ilqr.py:631)
+      const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
+      qp_Q = e + reg;                             // ilqr.py:634
+    }
     T kt, sE;
     bool Kz = false;
     int stt = st;
@@ -190,18 +221,20 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
       sE = n4::div_<FAST>(T(1), qp_Q);  // (E / e) E^T             (ilqr.py:636)
       kt = -(sE * Qu);
       // NaN in k or K raises (ilqr.py:639-640)
-      const bool nanK = (g == (n >> 2)) && (j < n) && (sE * rowv != sE * rowv);
-      if (kt != kt || __builtin_amdgcn_ballot_w64(nanK) != 0)
+      const bool nanK = (g == (n >> 2)) && (j < n) && (sE * rowg != sE * rowg);
+      if (!CHOL && (kt != kt || __builtin_amdgcn_ballot_w64(nanK) != 0))
         stt = PDDP_BWD_NAN;
     }
     if (status == PDDP_BWD_OK && stt != PDDP_BWD_OK) status = stt;
     kprev = kt;
     const T c = sE * (sE * Quu - T(2));
     const T w = kt - sE * (Qu + Quu * kt);
+    const T c2 = sE * sE * Quu;        // Cholesky branch: K = -sE Q_uz_reg
+    const T wz = sE * (Qu + Quu * kt);
 
     // ---- k, K of step t: lanes of row n hold Q_uz[j] (j < n), lane j = n: k
     {
-      const T val = (j < n) ? -(sE * rowv) : kt;
+      const T val = (j < n) ? -(sE * rowg) : kt;
       T* dst = gains_b + (size_t)t * lay.gstride + (j < n ? 1 + j : 0);
       if (g == gn && j <= n) *dst = val;
     }
@@ -210,14 +243,23 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
 
     // ---- V' = sym(Q_zz) + c Q_uz^T Q_uz,  V_z' = Q_z + Q_uz^T w
     const T Quz_j = tile[j * 16 + n];  // Q~[n][j]
+    const T Qg_j = CHOL ? tile[j * 16 + 15] : T(0);  // Q_uz_reg[j]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = 4 * g + r;
       const T QT = tile[k * 16 + j];      // Q~[j][k]
       const T Quz_k = tile[k * 16 + n];   // Q~[n][k]
       const T sym = T(0.5) * (Q[r] + QT);
-      V[r] = (k < n && j < n) ? __builtin_fmaf(c * Quz_k, Quz_j, sym) : T(0);
-      Vz[r] = (k < n) ? __builtin_fmaf(Quz_k, w, Q[r]) : T(0);  // (lanes j = 15)
+      if constexpr (CHOL) {
+        // V' = sym + K^T Quu K + K^T Quz + Quz^T K,  K = -sE Q_uz_reg
+        const T Qg_k = tile[k * 16 + 15];
+        const T v = sym + c2 * (Qg_k * Qg_j) - sE * (Qg_k * Quz_j + Quz_k * Qg_j);
+        V[r] = (k < n && j < n) ? v : T(0);
+        Vz[r] = (k < n) ? Q[r] + Quz_k * kt - Qg_k * wz : T(0);
+      } else {
+        V[r] = (k < n && j < n) ? __builtin_fmaf(c * Quz_k, Quz_j, sym) : T(0);
+        Vz[r] = (k < n) ? __builtin_fmaf(Quz_k, w, Q[r]) : T(0);  // (lanes j = 15)
+      }
     }
     slot = slot + 1 == kRing ? 0 : slot + 1;
   }
@@ -227,10 +269,11 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
 
 }  // namespace m16
 
-// n + 1 <= 15, m = 1, fp32, eig-clamp branch; PDDP_E_UNSUPPORTED otherwise
+// n + 1 <= 15, m = 1, fp32; PDDP_E_UNSUPPORTED otherwise
 static int launch_mfma16(const RiccatiArgs<float>& a, hipStream_t st,
                          bool fast_math) {
-  if (a.n + 1 > 15 || a.branch != PDDP_BRANCH_EIG) return PDDP_E_UNSUPPORTED;
+  if (a.n + 1 > 15) return PDDP_E_UNSUPPORTED;
+  const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
   const RecLayout lay(a.n, 1);
   const int chunks = lay.stride / 4;
   const int ndma = (chunks + kWave - 1) / kWave;
@@ -243,8 +286,14 @@ static int launch_mfma16(const RiccatiArgs<float>& a, hipStream_t st,
       block(kWave * m16::kWaves);
   const bool bounded = a.u_min != nullptr;
 #define PDDP_M16(Bd, F)                                                        \
-  PDDP_LAUNCH((m16::riccati_mfma16_kernel<Bd, F>), grid, block, lds, st, a,    \
-              slot_words, ndma)
+  do {                                                                         \
+    if (chol)                                                                  \
+      PDDP_LAUNCH((m16::riccati_mfma16_kernel<Bd, F, true>), grid, block, lds, \
+                  st, a, slot_words, ndma);                                    \
+    else                                                                       \
+      PDDP_LAUNCH((m16::riccati_mfma16_kernel<Bd, F, false>), grid, block,     \
+                  lds, st, a, slot_words, ndma);                               \
+  } while (0)
   if (bounded) { if (fast_math) PDDP_M16(true, true); else PDDP_M16(true, false); }
   else { if (fast_math) PDDP_M16(false, true); else PDDP_M16(false, false); }
 #undef PDDP_M16

@@ -1,5 +1,5 @@
 // riccati_mfma32.hpp - riccati_mfma16.hpp's scheme on 32x32 tiles
-// (v_mfma_f32_32x32x2_f32) for 15 <= n <= 30, m = 1, fp32, eig-clamp branch:
+// (v_mfma_f32_32x32x2_f32) for 15 <= n <= 30, m = 1, fp32, both gain branches:
 // the DEFAULT (Cholesky) encoding of the double cartpole is n = 27
 // (BASELINE.json configs[3]: 0.96 GB of records per GPU and sweep).
 //
@@ -27,7 +27,7 @@ constexpr int kTile = 32 * kTileLd;
 
 PDDP_DEV int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-template <bool BOUNDED, bool FAST, int NDMA>
+template <bool BOUNDED, bool FAST, int NDMA, bool CHOL>
 __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
     RiccatiArgs<float> a) {
   using T = float;
@@ -86,6 +86,11 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
     oL[r] = o < 0 ? 0 : o;
   }
   const T mJ = j < n ? T(1) : T(0);
+  // Cholesky branch (ilqr.py:587-625): + reg f^T F~ on row n (mfma16.hpp)
+  int oFf[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+    oFf[r] = lay.oFu + (row_of(r, h) < n ? row_of(r, h) : 0);
 
   // ---- record DMA: NDMA full-wave 16-byte instructions per record; lanes
   // past the record re-load an early chunk into the slot's padding
@@ -140,6 +145,12 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
       Q[r] = R[oL[r]] * mL[r];
     }
     const T Un = BOUNDED ? R[lay.oU] : T(0);
+    T ffrow = T(0);  // (f^T F~)[j]: f^T F_z for j < n, f.f at j = n
+    if constexpr (CHOL) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ffrow += (R[oFf[r]] * mK[r]) * Fa[r];
+      ffrow += __shfl_xor(ffrow, 32);
+    }
 
     // ---- X = V F~ ; X[:, 31] = V_z
     f32x16 X = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -160,6 +171,10 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
         __builtin_amdgcn_readlane(__float_as_int(rowv), hn * 32 + n));
     const T Qu = __int_as_float(
         __builtin_amdgcn_readlane(__float_as_int(rowv), hn * 32 + 31));
+    const T rowg = CHOL ? rowv + reg * ffrow : rowv;  // (Q_uz_reg | Q_uu_reg)
+    const T Quug = CHOL ? __int_as_float(__builtin_amdgcn_readlane(
+                              __float_as_int(rowg), hn * 32 + n))
+                        : Quu;
     // transpose tile: T[col][row] = Q~[row][col]; registers 4q .. 4q + 3 are
     // the consecutive rows 8q + 4h + (0..3)
 #pragma unroll
@@ -167,12 +182,21 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
       m16::f32x4 v = {Q[4 * q], Q[4 * q + 1], Q[4 * q + 2], Q[4 * q + 3]};
       *reinterpret_cast<m16::f32x4*>(tile + j * kTileLd + 8 * q + 4 * h) = v;
     }
+    if constexpr (CHOL) {  // row 31 (free: n + 1 <= 31) carries Q_uz_reg
+      if (h == hn) tile[j * kTileLd + 31] = rowg;
+    }
 
     // ---- gains (every lane the same scalars)                 (ilqr.py:629-657)
     int st = PDDP_BWD_OK;
-    if (!is_finite(Quu)) st = PDDP_BWD_NAN;     // eig raises (ilqr.py:631)
-    const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
-    const T qp_Q = e + reg;                     // ilqr.py:634
+    T qp_Q;
+    if constexpr (CHOL) {
+      qp_Q = Quug;  // Cholesky of Q_uu_reg                        (ilqr.py:595)
+      if (!BOUNDED && (!(Quug > T(0)) || !is_finite(Quug))) st = PDDP_BWD_NOT_PD;
+    } else {
+      if (!is_finite(Quu)) st = PDDP_BWD_NAN;     // eig raises (ilqr.py:631)
+      const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
+      qp_Q = e + reg;                             // ilqr.py:634
+    }
     T kt, sE;
     int stt = st;
     if constexpr (BOUNDED) {
@@ -194,18 +218,20 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
       sE = n4::div_<FAST>(T(1), qp_Q);  // (E / e) E^T             (ilqr.py:636)
       kt = -(sE * Qu);
       // NaN in k or K raises (ilqr.py:639-640)
-      const bool nanK = (h == hn) && (j < n) && (sE * rowv != sE * rowv);
-      if (kt != kt || __builtin_amdgcn_ballot_w64(nanK) != 0)
+      const bool nanK = (h == hn) && (j < n) && (sE * rowg != sE * rowg);
+      if (!CHOL && (kt != kt || __builtin_amdgcn_ballot_w64(nanK) != 0))
         stt = PDDP_BWD_NAN;
     }
     if (status == PDDP_BWD_OK && stt != PDDP_BWD_OK) status = stt;
     kprev = kt;
     const T c = sE * (sE * Quu - T(2));
     const T w = kt - sE * (Qu + Quu * kt);
+    const T c2 = sE * sE * Quu;        // Cholesky branch: K = -sE Q_uz_reg
+    const T wz = sE * (Qu + Quu * kt);
 
     // ---- k, K of step t: lanes of row n hold Q_uz[j] (j < n), lane j = n: k
     {
-      const T val = (j < n) ? -(sE * rowv) : kt;
+      const T val = (j < n) ? -(sE * rowg) : kt;
       T* dst = gains_b + (size_t)t * lay.gstride + (j < n ? 1 + j : 0);
       if (h == hn && j <= n) *dst = val;
     }
@@ -213,14 +239,23 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
 
     // ---- V' = sym(Q_zz) + c Q_uz^T Q_uz,  V_z' = Q_z + Q_uz^T w
     const T Quz_j = tile[j * kTileLd + n];  // Q~[n][j]
+    const T Qg_j = CHOL ? tile[j * kTileLd + 31] : T(0);  // Q_uz_reg[j]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = row_of(r, h);
       const T QT = tile[k * kTileLd + j];     // Q~[j][k]
       const T Quz_k = tile[k * kTileLd + n];  // Q~[n][k]
       const T sym = T(0.5) * (Q[r] + QT);
-      V[r] = __builtin_fmaf(c * Quz_k, Quz_j, sym) * (mK[r] * mJ);
-      Vz[r] = __builtin_fmaf(Quz_k, w, Q[r]) * mK[r];  // (lanes j = 31)
+      if constexpr (CHOL) {
+        // V' = sym + K^T Quu K + K^T Quz + Quz^T K,  K = -sE Q_uz_reg
+        const T Qg_k = tile[k * kTileLd + 31];
+        const T v = sym + c2 * (Qg_k * Qg_j) - sE * (Qg_k * Quz_j + Quz_k * Qg_j);
+        V[r] = v * (mK[r] * mJ);
+        Vz[r] = (Q[r] + Quz_k * kt - Qg_k * wz) * mK[r];
+      } else {
+        V[r] = __builtin_fmaf(c * Quz_k, Quz_j, sym) * (mK[r] * mJ);
+        Vz[r] = __builtin_fmaf(Quz_k, w, Q[r]) * mK[r];  // (lanes j = 31)
+      }
     }
     slot = slot + 1 == kRing ? 0 : slot + 1;
   }
@@ -230,11 +265,11 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
 
 }  // namespace m32
 
-// 15 <= n <= 30, m = 1, fp32, eig-clamp branch; PDDP_E_UNSUPPORTED otherwise
+// 15 <= n <= 30, m = 1, fp32; PDDP_E_UNSUPPORTED otherwise
 static int launch_mfma32(const RiccatiArgs<float>& a, hipStream_t st,
                          bool fast_math) {
-  if (a.n < 15 || a.n > 30 || a.branch != PDDP_BRANCH_EIG)
-    return PDDP_E_UNSUPPORTED;
+  if (a.n < 15 || a.n > 30) return PDDP_E_UNSUPPORTED;
+  const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
   const RecLayout lay(a.n, 1);
   const int chunks = lay.stride / 4;
   const int ndma = (chunks + kWave - 1) / kWave <= 4 ? 4 : 8;
@@ -247,7 +282,8 @@ static int launch_mfma32(const RiccatiArgs<float>& a, hipStream_t st,
   const bool bounded = a.u_min != nullptr;
 #define PDDP_M32(Bd, F, ND)                                                    \
   do {                                                                         \
-    auto kern = m32::riccati_mfma32_kernel<Bd, F, ND>;                         \
+    auto kern = chol ? m32::riccati_mfma32_kernel<Bd, F, ND, true>             \
+                     : m32::riccati_mfma32_kernel<Bd, F, ND, false>;           \
     const hipError_t e_ = hipFuncSetAttribute(                                 \
         (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,         \
         (int)lds);                                                             \

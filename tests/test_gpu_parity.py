@@ -124,8 +124,7 @@ def test_backward_vs_oracle(problem, dtype, variant):
     checked = 0
     for branch, bounded in ((0, False), (0, True), (1, False), (1, True)):
         if variant in (14, 15):
-            if branch != 0:
-                continue  # eig-clamp branch, bounded or not
+            pass  # all four branches
         elif variant >= 8 and not bounded:
             continue
         if variant in (12, 13) and branch != 0:
