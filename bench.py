@@ -104,82 +104,122 @@ MFMA_F32_PEAK_TFLOPS = 157.0  # MI355X_MICROARCH.md: dense f32 matrix peak
 
 
 def bench_bnn(args):
-    """Secondary workload (--workload cartpole_bnn) = BASELINE.json configs[2]:
+    """Secondary workloads.  --workload cartpole_bnn = BASELINE.json configs[2]:
     cartpole with the BNN dynamics model ([200, 200] hidden, 100 particles,
-    moment-matched rollouts, DEFAULT encoding n = 14), horizon 100, B
-    trajectories on one GPU.  A step is one round of the fit loop: forward-mode
-    derivative rollout of the trajectories whose nominal changed, backward
-    sweep, 10-candidate line search, accept.  The dominant kernel is the fused
-    network (f32 matrix cores): roofline bound "mfma"."""
+    moment-matched rollouts, DEFAULT encoding n = 14), horizon 100, B = 4096
+    trajectories per GPU.  --workload double_cartpole_bnn = configs[3]'s problem
+    with the reference's own double-cartpole model (a BNN,
+    examples/double_cartpole.py:133-139; the reference has no GP): n = 27,
+    horizon 150, B = 1024 per GPU (8192 over 8), ranks own disjoint shards and
+    exchange their best rollout once through RCCL.  A step is one round of the
+    fit loop: forward-mode derivative rollout of the trajectories whose nominal
+    changed, backward sweep, 10-candidate line search, accept.  The dominant
+    kernel is the fused network (f32 matrix cores): roofline bound "mfma"."""
     import pddp_amd
+    import torch.distributed as dist
     from pddp_amd.controllers.ilqr import fit_alphas
     from pddp_amd.controllers.plugin import TorchProblem
     from pddp_amd.controllers.solver import ILQRSolver
-    from pddp_amd.examples import cartpole
     from pddp_amd.models.bnn import bnn_dynamics_model_factory
-    dev = torch.device("cuda", 0)
-    torch.manual_seed(0)
-    B, N, P, A, H = args.batch, args.horizon, 100, 10, 200
+    from pddp_amd.parallel import gather_best_rollout
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(
+            "cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.manual_seed(0)  # the same network on every rank
+    if args.workload == "cartpole_bnn":
+        from pddp_amd.examples import cartpole as ex
+        CM, cost_cls = ex.CartpoleDynamicsModel, ex.CartpoleCost
+        mean0, bound, tag = [0.0, 0.0, 3.14159, 0.0], 10.0, "configs[2]: cartpole"
+        B = args.batch
+        N = args.horizon
+    else:
+        from pddp_amd.examples import double_cartpole as ex
+        CM, cost_cls = ex.DoubleCartpoleDynamicsModel, ex.DoubleCartpoleCost
+        mean0, bound = [0.0, 0.0, 3.14159, 0.0, 3.14159, 0.0], 20.0
+        tag = "configs[3]'s problem: double cartpole"
+        B = args.batch if args.batch != 4096 else 1024
+        N = args.horizon if args.horizon != 100 else 150
+    D, m, P, A, H = CM.state_size, 1, 100, 10, 200
+    n = D + D * (D + 1) // 2
+    in_dim = len(CM.non_angular_indices) + 2 * len(CM.angular_indices) + m
     K = args.steps if args.steps != 30 else 3
     W = args.warmup if args.warmup != 5 else 1
-    CM = cartpole.CartpoleDynamicsModel
-    model = bnn_dynamics_model_factory(4, 1, [H, H], CM.angular_indices,
+    model = bnn_dynamics_model_factory(D, m, [H, H], CM.angular_indices,
                                        CM.non_angular_indices)(
         n_particles=P).to(dev).eval()
     with torch.no_grad():  # untrained weights: keep the dynamics gentle
         model.model.out.weight.mul_(0.05)
         model.model.out.bias.mul_(0.05)
-    cost = cartpole.CartpoleCost().to(dev)
+    cost = cost_cls().to(dev)
     enc = pddp_amd.StateEncoding.DEFAULT
     plugin = TorchProblem(model, cost, enc, {"use_predicted_std": False,
                                              "infer_noise_variables": True}, {})
-    s = ILQRSolver(None, B, N, torch.float32, dev, torch.tensor([-10.0]),
-                   torch.tensor([10.0]), fit_alphas(torch.float32, dev),
-                   plugin=plugin, n=14, m=1)
-    g = torch.Generator().manual_seed(0)
-    mean = torch.tensor([0.0, 0.0, 3.14159, 0.0])
+    s = ILQRSolver(None, B, N, torch.float32, dev, torch.tensor([-bound]),
+                   torch.tensor([bound]), fit_alphas(torch.float32, dev),
+                   plugin=plugin, n=n, m=m)
+    g = torch.Generator().manual_seed(rank)
+    mean = torch.tensor(mean0)
     z0 = torch.stack([pddp_amd.GaussianVariable(
-        mean + 1e-2 * torch.randn(4, generator=g),
-        var=1e-2 * torch.ones(4)).encode(enc) for _ in range(B)]).to(dev)
-    s.set_nominal(z0, (0.1 * torch.randn(B, N, 1, generator=g)).to(dev))
+        mean + 1e-2 * torch.randn(D, generator=g),
+        var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).to(dev)
+    s.set_nominal(z0, (0.1 * torch.randn(B, N, m, generator=g)).to(dev))
     n_iter = 1 << 30
     for _ in range(W):
         s.round(5e-6, 1e10, n_iter)
     s.n_live.zero_()
     live0 = int(s.active.sum().item())
     torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(K):
         s.round(5e-6, 1e10, n_iter)
+    if world > 1:  # the one exchange of the path: best rollout over RCCL
+        gather_best_rollout(s.J_opt, s.Z, s.U, offset=rank * B)
     torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
     liveK = int(s.active.sum().item())
     attempted = live0 + int(s.n_live.sum().item()) - liveK
+    total_attempted = attempted
+    if world > 1:
+        t = torch.tensor([elapsed, attempted], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, total_attempted = float(tmax[0].item()), int(t[1].item())
     # the dominant kernel, timed alone on torch's current stream (the stream it
     # is launched on): one forward-mode network pass of a time step
-    F = torch.randn(B * P * 8, 6, device=dev)
-    model.model._jvp_native(F, P, 4, 8)
+    F = torch.randn(B * P * 8, in_dim, device=dev)
+    model.model._jvp_native(F, P, D, 8)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 5
     e0.record()
     for _ in range(reps):
-        model.model._jvp_native(F, P, 4, 8)
+        model.model._jvp_native(F, P, D, 8)
     e1.record()
     torch.cuda.synchronize(dev)
     dur = e0.elapsed_time(e1) * 1e-3 / reps
-    flop = 2.0 * B * P * 8 * (6 * H + H * H + H * 4)
+    flop = 2.0 * B * P * 8 * (in_dim * H + H * H + H * D)
     out = {
-        "metric": "pddp_iterations_per_sec", "value": attempted / elapsed,
-        "unit": "trajectory-iterations/s", "n_gpus": 1, "steps": K,
+        "metric": "pddp_iterations_per_sec", "value": total_attempted / elapsed,
+        "unit": "trajectory-iterations/s", "n_gpus": world, "steps": K,
         "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
-            "workload": "BASELINE.json configs[2]: cartpole with BNN dynamics "
-                        "([200,200] hidden, %d particles, moment-matched "
-                        "rollouts, DEFAULT encoding n=14 m=1), horizon=%d, "
-                        "batch=%d trajectories, bounds +-10, 10 line-search "
-                        "alphas, random-init network weights" % (P, N, B),
+            "workload": "BASELINE.json %s with BNN dynamics ([200,200] hidden, "
+                        "%d particles, moment-matched rollouts, DEFAULT "
+                        "encoding n=%d m=1), horizon=%d, batch=%d trajectories "
+                        "per GPU, bounds +-%g, 10 line-search alphas, "
+                        "random-init network weights" % (tag, P, n, N, B, bound),
             "batch_per_gpu": B, "horizon": N, "alphas": A,
             "unit_definition": "one iLQR attempt of one trajectory (derivative "
                                "rollout when its nominal changed + backward "
@@ -197,7 +237,11 @@ def bench_bnn(args):
         },
         "cpu_baseline": None,
     }
-    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
 
 
 def main():
@@ -206,9 +250,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cartpole",
-                    choices=["cartpole", "cartpole_bnn"],
+                    choices=["cartpole", "cartpole_bnn", "double_cartpole_bnn"],
                     help="cartpole = BASELINE configs[1] (the headline line); "
-                         "cartpole_bnn = configs[2], one GPU")
+                         "cartpole_bnn = configs[2]; double_cartpole_bnn = "
+                         "configs[3]'s problem with the reference's BNN model")
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
@@ -216,7 +261,7 @@ def main():
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="backward kernel: 0 auto, 1 generic, 2 n4, 3 n4 fast")
     args = ap.parse_args()
-    if args.workload == "cartpole_bnn":
+    if args.workload != "cartpole":
         return bench_bnn(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
