@@ -224,9 +224,9 @@ class TorchProblem(object):
             "pddp_qr_cost_derivs_f32")
 
     def _bnn_jvp_ok(self, s):
-        """The forward-mode kernels cover D <= 4 with up to 15 tangent
-        directions (groups of 16 rows) and D <= 6 with up to 31 (groups of 32;
-        include/pddp_hip.h pddp_bnn_jvp_group)."""
+        """The forward-mode kernels cover D <= 6 with D + m <= 7 network
+        tangent rows and up to 31 directions of (z | u) (include/pddp_hip.h
+        pddp_bnn_jvp_group)."""
         mo = self.model
         return (getattr(self, "use_native_bnn_jvp", True) and
                 _native.lib().pddp_bnn_jvp_group(mo.state_size, s.m) != 0)

@@ -35,10 +35,11 @@
 // the same weights without biases, and through the ReLUs linearised at its
 // group's primal row: d relu(m h) = m dh [m h > 0].  Groups are aligned to the
 // 16-lane DPP rows of both the producer and the accumulator layout (data row =
-// lane & 31), so the primal's pre-activation of the same unit arrives by one
-// `row_newbcast:0` move.  Forward-mode replaces autograd's replicate-the-input
-// pass: (1 + 15) network evaluations per state instead of 14 forward + 14
-// backward ones, and nothing is stored.
+// lane & 31), so the primal's pre-activation of the same unit arrives by
+// `row_newbcast` moves (two lane reads for 32-row groups).  Forward mode
+// replaces autograd's replicate-the-input pass; the caller (bnn_jvp.hip) sends
+// 8-row groups: the input and the D + m mean / action directions - the
+// Cholesky directions are per-particle multiples of the mean ones.
 #include "pddp_common.hpp"
 
 namespace pddp {
