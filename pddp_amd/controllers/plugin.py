@@ -347,7 +347,7 @@ class TorchProblem(object):
         D, P = mo.state_size, mo.n_particles
         ang, non = mo.angular_indices_, mo.non_angular_indices_
         na = len(non) + 2 * len(ang)
-        in_dim, out_dim = na + m, mo.model.out.out_features
+        in_dim, out_dim = na + m, D  # (the log-std rows of fc_out are unused)
         opts = dict(dtype=s.dtype, device=s.device)
         vec = lambda t, k: torch.as_tensor(t).detach().to(**opts).expand(
             k).contiguous()
@@ -398,7 +398,7 @@ class TorchProblem(object):
                                                        stream),
                           "pddp_bnn_moment_step_f32")
             if t < N:
-                out = mo.model._forward_native(F)
+                out = mo.model._forward_native(F, out_dim)
         mo.output = {}  # the particle caches of a torch-path rollout: stale
         return Jc
 

@@ -175,10 +175,13 @@ class BayesianMLP(torch.nn.Module):
             cache[k] = (key, m.contiguous())
         return cache[k][1]
 
-    def _forward_native(self, x):
+    def _forward_native(self, x, out_rows=None):
+        """`out_rows`: only the first rows of fc_out (the mean increments when
+        the predicted std is not used, modules.py:262)."""
         from .. import _native
         P, in_dim = x.shape[-2], x.shape[-1]
-        H, out_dim = self.hidden[0].out_features, self.out.out_features
+        H = self.hidden[0].out_features
+        out_dim = self.out.out_features if out_rows is None else int(out_rows)
         xc = x.detach().contiguous()
         R = xc.numel() // in_dim
         y = torch.empty(*x.shape[:-1], out_dim, dtype=x.dtype, device=x.device)
@@ -188,8 +191,8 @@ class BayesianMLP(torch.nn.Module):
         rc = _native.lib().pddp_bnn_mlp_f32(
             R, P, in_dim, H, out_dim, p(xc), p(c(self.hidden[0].weight)),
             p(c(self.hidden[0].bias)), p(m1), p(c(self.hidden[1].weight)),
-            p(c(self.hidden[1].bias)), p(m2), p(c(self.out.weight)),
-            p(c(self.out.bias)), p(y), _native.stream_handle(x.device))
+            p(c(self.hidden[1].bias)), p(m2), p(c(self.out.weight[:out_dim])),
+            p(c(self.out.bias[:out_dim])), p(y), _native.stream_handle(x.device))
         _native.check(rc, "pddp_bnn_mlp_f32")
         return y
 

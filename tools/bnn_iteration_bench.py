@@ -136,7 +136,7 @@ def main():
     # --- line search + accept
     s.line_search()
     t_ls = timed(lambda: s.line_search())
-    ls_flop = 2.0 * B * A * P * (in_dim * 200 + 200 * 200 + 200 * 2 * D) * N
+    ls_flop = 2.0 * B * A * P * (in_dim * 200 + 200 * 200 + 200 * D) * N
     out["line_search"] = {"s": t_ls, "network_TFLOPs": ls_flop / t_ls * 1e-12}
     t_acc = timed(lambda: s.accept(5e-6, 1e10, 1 << 30))
     out["accept_s"] = t_acc
