@@ -416,6 +416,14 @@ def main():
                 "min_launch_us": float(np.min(durs)) * 1e6,
                 "algorithmic_bytes_per_launch": (attempted / K) * per_traj,
                 "traffic": traffic,
+                # what the memory system allows for this transfer with no
+                # arithmetic at all (tools/probe/record_stream_probe.hip on a
+                # cold cache, B = 4096, N = 100, fp32): informational
+                "transfer_only_us": ({"plain_coalesced_read": 27.9,
+                                      "this_kernels_streaming_pattern": 33.0,
+                                      "source": "profiles/r01_record_stream_probe.txt"}
+                                     if (B == 4096 and N == 100 and
+                                         args.dtype == "f32") else None),
             },
         }
         if not args.no_cpu_baseline and world == 1:
