@@ -14,9 +14,17 @@ Inputs are resident in HBM before the timed region.
 
     python bench.py --gpus N --steps K --warmup W
 
-prints ONE JSON line (rank 0).  For N > 1 launch through torch.distributed.run;
-ranks own disjoint shards (weak scaling, no data-path collective) and exchange
-their best rollout once through RCCL.
+prints ONE JSON line (rank 0).  With --gpus N > 1 and no torchrun environment
+the script starts N ranks itself (a fresh `python -m torch.distributed.run`
+child, before this process has touched the GPU) and relays its line; under the
+driver's own torchrun launch it simply is one of the ranks.  Ranks own disjoint
+shards (--scaling weak: --batch trajectories per GPU; strong: --batch in total;
+no data-path collective) and exchange their best rollout once per timed region
+through RCCL.
+
+The timed region (W warm-up rounds, then exactly K rounds between barrier +
+synchronize pairs) is repeated --repeats times from the same nominal; the line
+reports the MEDIAN repetition (and the minimum and every repetition beside it).
 """
 import argparse
 import ctypes
@@ -73,14 +81,93 @@ def algorithmic_bytes_per_trajectory(N, n, m, itemsize, bounded):
     return itemsize * (N * per_step + n + n * n)
 
 
+def available_cores():
+    """Cores this process may actually use: the scheduler affinity capped by
+    the cgroup CPU quota (a 1-GPU box shows 256 cores but is granted 16:
+    cpu.max = 1600000 100000).  More worker processes than that only
+    time-slice."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+            cores = max(1, min(cores, int(quota + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return cores, quota
+
+
+def launch_ranks_if_asked(args):
+    """`--gpus N` without a torchrun environment: start the N ranks as a child
+    `python -m torch.distributed.run` (this process has not touched the GPU
+    and never will), relay the child's output and exit with its code."""
+    import socket
+    import subprocess
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s\n"
+                             % (args.gpus, env_world))
+            sys.exit(2)
+        return
+    if args.gpus <= 1:
+        return
+    have = torch.cuda.device_count()  # (does not initialise the GPU)
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n"
+                         % (args.gpus, have))
+        sys.exit(2)
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def init_ranks():
+    """(world, rank, device) from the torchrun environment; RCCL process group
+    when world > 1."""
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device(
+            "cuda", local_rank))
+    return world, rank, torch.device("cuda", local_rank)
+
+
+def ranks_seen(world, device):
+    """World size as the collective library reports it after a real exchange
+    (an all_gather of every rank's id over RCCL)."""
+    import torch.distributed as dist
+    if world == 1:
+        return 1
+    mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=device)
+    out = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine)
+    return int(out.unique().numel())
+
+
 def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
     """Times the oracle (plain C port of the reference's algorithm) on the
     host's cores on a bounded sample of the same workload; unit = the same
     trajectory-iterations/s.  One worker process per core (trajectories are
-    independent, as on the GPU), at most 16 - a GPU box's CPU share; the
-    workers are fresh interpreters that never touch the GPU."""
+    independent, as on the GPU) this process is granted (available_cores();
+    the workers are fresh interpreters that never touch the GPU."""
     import subprocess
-    workers = max(1, min(16, os.cpu_count() or 1))
+    workers, quota = available_cores()
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker",
            problem_name, repr(dt), str(N), repr(bound), repr(seconds)]
     procs = [subprocess.Popen(cmd + [str(12345 + w)], stdout=subprocess.PIPE,
@@ -93,10 +180,12 @@ def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
         el = max(el, float(out[2]))
     return {"value": attempts / el, "unit": "trajectory-iterations/s",
             "cores": workers, "kind": "port",
+            "host_cores": os.cpu_count(), "cgroup_cpu_quota": quota,
             "per_core_value": attempts / el / workers,
             "sample": "%d cartpole trajectories x up to 8 iLQR iterations "
-                      "(%d attempts) in %.1f s on %d worker processes, oracle "
-                      "C port, fp32, host has %d cores"
+                      "(%d attempts) in %.1f s on %d worker processes (= the "
+                      "cores granted: affinity capped by the cgroup quota), "
+                      "oracle C port, fp32, host has %d cores"
                       % (trajs, attempts, el, workers, os.cpu_count())}
 
 
@@ -121,30 +210,27 @@ def bench_bnn(args):
     from pddp_amd.controllers.plugin import TorchProblem
     from pddp_amd.controllers.solver import ILQRSolver
     from pddp_amd.models.bnn import bnn_dynamics_model_factory
-    from pddp_amd.parallel import gather_best_rollout
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(
-            "cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+    from pddp_amd.parallel import gather_best_rollout, shard_bounds
+    world, rank, dev = init_ranks()
+    seen = ranks_seen(world, dev)
     torch.manual_seed(0)  # the same network on every rank
     if args.workload == "cartpole_bnn":
         from pddp_amd.examples import cartpole as ex
         CM, cost_cls = ex.CartpoleDynamicsModel, ex.CartpoleCost
         mean0, bound, tag = [0.0, 0.0, 3.14159, 0.0], 10.0, "configs[2]: cartpole"
-        B = args.batch
-        N = args.horizon
+        B = args.batch or 4096
+        N = args.horizon or 100
     else:
         from pddp_amd.examples import double_cartpole as ex
         CM, cost_cls = ex.DoubleCartpoleDynamicsModel, ex.DoubleCartpoleCost
         mean0, bound = [0.0, 0.0, 3.14159, 0.0, 3.14159, 0.0], 20.0
         tag = "configs[3]'s problem: double cartpole"
-        B = args.batch if args.batch != 4096 else 1024
-        N = args.horizon if args.horizon != 100 else 150
+        B = args.batch or 1024
+        N = args.horizon or 150
+    lo = rank * B
+    if args.scaling == "strong":  # --batch in total, sharded
+        lo, hi = shard_bounds(B, rank, world)
+        B = hi - lo
     D, m, P, A, H = CM.state_size, 1, 100, 10, 200
     n = D + D * (D + 1) // 2
     in_dim = len(CM.non_angular_indices) + 2 * len(CM.angular_indices) + m
@@ -181,7 +267,7 @@ def bench_bnn(args):
     for _ in range(K):
         s.round(5e-6, 1e10, n_iter)
     if world > 1:  # the one exchange of the path: best rollout over RCCL
-        gather_best_rollout(s.J_opt, s.Z, s.U, offset=rank * B)
+        gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -212,8 +298,8 @@ def bench_bnn(args):
         "metric": "pddp_iterations_per_sec", "value": total_attempted / elapsed,
         "unit": "trajectory-iterations/s", "n_gpus": world, "steps": K,
         "warmup": W, "ms_per_step": elapsed / K * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic", "rccl_ranks_seen": seen,
         "config": {
             "workload": "BASELINE.json %s with BNN dynamics ([200,200] hidden, "
                         "%d particles, moment-matched rollouts, DEFAULT "
@@ -244,45 +330,138 @@ def bench_bnn(args):
         print(json.dumps(out))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cartpole",
-                    choices=["cartpole", "cartpole_bnn", "double_cartpole_bnn"],
-                    help="cartpole = BASELINE configs[1] (the headline line); "
-                         "cartpole_bnn = configs[2]; double_cartpole_bnn = "
-                         "configs[3]'s problem with the reference's BNN model")
-    ap.add_argument("--batch", type=int, default=4096)
-    ap.add_argument("--horizon", type=int, default=100)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kernel-variant", type=int, default=0,
-                    help="backward kernel: 0 auto, 1 generic, 2 n4, 3 n4 fast")
-    args = ap.parse_args()
-    if args.workload != "cartpole":
-        return bench_bnn(args)
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(
-            "cuda", local_rank))
-    device = torch.device("cuda", local_rank)
-
+def bench_mpc_bnn(args):
+    """--workload mpc_bnn = BASELINE.json configs[4]: the receding-horizon loop
+    of examples/mpc_animation.py:29-39 on cartpole with the BNN dynamics model,
+    horizon 50, 256 restarts x 200 control steps, 11-alpha schedule
+    (ilqr.py:116), one GPU.  A step = one control step of all restarts:
+    `iLQRController.forward(mpc=True)` (ilqr.py:318-362: reset the
+    regularisation, one fit iteration from the measured state, emit U[0], shift
+    the plan); the plant is the true cartpole model (the reference steps a gym
+    env; no env on the GPU box).  Reported eager and, where the controller
+    supports it, with every round replayed as a captured hipGraph."""
     import pddp_amd
-    from pddp_amd import _native
+    from pddp_amd.examples import cartpole
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    world, rank, dev = init_ranks()
+    B = args.batch or 256
+    N = args.horizon or 50
+    K = args.steps if args.steps != 30 else 200
+    W = args.warmup if args.warmup != 5 else 3
+    P = 100
+    CM = cartpole.CartpoleDynamicsModel
+    enc = pddp_amd.StateEncoding.DEFAULT
+    ienc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
+    iu = torch.triu_indices(4, 4)
+    tri = (0.1 * torch.eye(4))[iu[0], iu[1]].to(dev)  # var 1e-2: chol = 0.1 I
+
+    def run(graph):
+        torch.manual_seed(0)
+        model = bnn_dynamics_model_factory(
+            4, 1, [200, 200], CM.angular_indices, CM.non_angular_indices)(
+                n_particles=P).to(dev).eval()
+        with torch.no_grad():  # untrained network: keep its dynamics gentle
+            model.model.out.weight.mul_(0.05)
+            model.model.out.bias.mul_(0.05)
+        cost = cartpole.CartpoleCost().to(dev)
+        plant = CM(0.1).to(dev)
+        ctrl = pddp_amd.controllers.iLQRController(
+            None, model, cost, graph=graph,
+            model_opts={"use_predicted_std": False,
+                        "infer_noise_variables": True})
+        u_min, u_max = torch.tensor([-10.0]), torch.tensor([10.0])
+        g = torch.Generator().manual_seed(rank)
+        ctrl._U_nominal = (0.1 * torch.randn(B, N, 1, generator=g)).to(dev)
+        x = (torch.tensor([0.0, 0.0, 3.14159, 0.0]) +
+             1e-2 * torch.randn(B, 4, generator=g)).to(dev)
+        rounds = [0]
+
+        def on_iteration(*a):
+            rounds[0] += 1
+
+        def control_step(x):
+            z = torch.cat([x, tri.expand(B, -1)], -1)
+            u = ctrl(z, 0, enc, mpc=True, u_min=u_min, u_max=u_max,
+                     on_iteration=on_iteration)
+            with torch.no_grad():
+                return plant(x, u.clamp(-10.0, 10.0), 0, ienc)
+
+        for _ in range(W):
+            x = control_step(x)
+        torch.cuda.synchronize(dev)
+        rounds[0] = 0
+        t0 = time.perf_counter()
+        for _ in range(K):
+            x = control_step(x)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        return dt, rounds[0] / K, getattr(ctrl._solver.plugin,
+                                          "last_derivs_path", None), \
+            bool(torch.isfinite(x).all())
+
+    dt, rps, path, finite = run(False)
+    res = {"eager": {"ms_per_control_step": dt / K * 1e3,
+                     "rounds_per_control_step": rps}}
+    try:
+        dtg, rpsg, _, fg = run(True)
+        res["graph"] = {"ms_per_control_step": dtg / K * 1e3,
+                        "rounds_per_control_step": rpsg}
+        if dtg < dt:
+            dt = dtg
+    except Exception as e:  # (reported, not hidden)
+        res["graph"] = {"error": repr(e)[:200]}
+    out = {
+        "metric": "mpc_restart_control_steps_per_sec", "value": B * K / dt,
+        "unit": "restart-control-steps/s", "n_gpus": world, "steps": K,
+        "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[4]: MPC receding-horizon loop, "
+                        "cartpole BNN [200,200] P=%d DEFAULT encoding n=14, "
+                        "horizon %d, %d restarts x %d control steps, 11 "
+                        "alphas, bounds +-10, random-init network weights"
+                        % (P, N, B, K),
+            "restarts": B, "horizon": N, "control_steps": K,
+            "modes": res, "derivative_path": path, "state_finite": finite},
+        "roofline": None, "cpu_baseline": None,
+    }
+    if rank == 0:
+        print(json.dumps(out))
+
+
+class EventPool(object):
+    """HIP event pairs attached to single dispatches (pddp_attach_events /
+    pddp_riccati_backward_timed): elapsed(start, stop) is the kernel's own
+    duration on the stream it was launched on."""
+
+    def __init__(self, lib):
+        self.lib, self.pairs = lib, []
+
+    def pair(self):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        self.lib.pddp_event_create(ctypes.byref(a))
+        self.lib.pddp_event_create(ctypes.byref(b))
+        self.pairs.append((a, b))
+        return a, b
+
+    def durations(self):
+        """Seconds per pair, in creation order; destroys the events."""
+        out = []
+        for a, b in self.pairs:
+            ms = ctypes.c_float()
+            self.lib.pddp_event_elapsed_ms(a, b, ctypes.byref(ms))
+            out.append(ms.value * 1e-3)
+            self.lib.pddp_event_destroy(a)
+            self.lib.pddp_event_destroy(b)
+        self.pairs = []
+        return out
+
+
+def make_cartpole_solver(B, N, dtype, device, seed, variant=0):
+    import pddp_amd
     from pddp_amd.controllers.solver import ILQRSolver
     from pddp_amd.examples import cartpole
-    from pddp_amd.parallel import gather_best_rollout
-
-    dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    B, N = args.batch, args.horizon
     enc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
     model, cost = cartpole.CartpoleDynamicsModel(0.1), cartpole.CartpoleCost()
     prob = model.native_problem(enc, cost)
@@ -290,93 +469,206 @@ def main():
     bound = 10.0
     u_min = torch.full((m,), -bound, dtype=dtype)
     u_max = torch.full((m,), bound, dtype=dtype)
-    s = ILQRSolver(prob, B, N, dtype, device, u_min, u_max)
-    g = torch.Generator().manual_seed(rank)
+    s = ILQRSolver(prob, B, N, dtype, device, u_min, u_max,
+                   kernel_variant=variant)
+    g = torch.Generator().manual_seed(seed)
     z0 = (1e-2 * torch.randn(B, n, generator=g, dtype=torch.float64)).to(dtype)
     U = (0.1 * torch.randn(B, N, m, generator=g, dtype=torch.float64)).to(dtype)
-    s.set_nominal(z0.to(device), U.to(device))
+    s._keep = prob
+    return s, z0.to(device), U.to(device), bound
 
+
+def sweep_point(lib, B, N, dtype, device, variant, rounds=12, cold=False,
+                solver=None):
+    """One extra roofline point of the backward sweep: `rounds` rounds of the
+    fit loop from a fresh nominal with events on the sweep's dispatch (warm: the
+    records were just written by the previous launch - the fit loop's own
+    condition), or, `cold`, the sweep alone with > 512 MB written through the
+    caches before every launch."""
+    if solver is None:
+        s, z0, U, _ = make_cartpole_solver(B, N, dtype, device, 0, variant)
+    else:
+        s, z0, U = solver
+    s.set_nominal(z0, U)
+    for _ in range(3):
+        s.round(5e-6, 1e10, 1 << 30)
+    pool = EventPool(lib)
+    if cold:
+        flush = torch.empty(768 << 20, dtype=torch.uint8, device=device)
+        for i in range(rounds):
+            flush.fill_(i)
+            s.backward(active=s.active, variant=s.kernel_variant,
+                       events=pool.pair())
+        del flush
+    else:
+        for _ in range(rounds):
+            s.round(5e-6, 1e10, 1 << 30, backward_events=pool.pair())
+    torch.cuda.synchronize(device)
+    live = int(s.active.sum().item())
+    d = np.array(pool.durations())
+    itemsize = 4 if dtype == torch.float32 else 8
+    nbytes = live * algorithmic_bytes_per_trajectory(N, s.n, s.m, itemsize, True)
+    return {"batch": B, "horizon": N,
+            "dtype": "f32" if dtype == torch.float32 else "f64",
+            "cache": "cold (768 MB written between launches)" if cold else
+                     "as in the fit loop",
+            "avg_launch_us": float(d.mean()) * 1e6,
+            "min_launch_us": float(d.min()) * 1e6,
+            "algorithmic_bytes_per_launch": nbytes,
+            "achieved": nbytes / float(d.mean()) / 1e9,
+            "frac": nbytes / float(d.mean()) / 1e9 / HBM_PEAK_GBS}
+
+
+def search_accept_bytes(B, N, n, m, A, S, itemsize, accepted_share=1.0):
+    """Algorithmic bytes of the fused line search + accept + records launch:
+    reads the nominal (Z, U) and the gains; writes the A candidate rollouts and
+    their costs; for an accepted trajectory reads the winning rollout back,
+    writes it as the new nominal, copies the gains (self._K) and writes the
+    derivative records + stage costs of the new nominal."""
+    zu = (N + 1) * n + N * m
+    gains = N * (m + m * n)
+    per = zu + gains + A * zu + A
+    per_acc = 2 * zu + 2 * gains + (N + 1) * (S + 1)
+    return itemsize * B * (per + accepted_share * per_acc)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=None,
+                    help="repetitions of the timed region (default 5; 1 for "
+                         "the BNN workloads)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch trajectories per GPU; strong: --batch "
+                         "trajectories in total, sharded over the GPUs")
+    ap.add_argument("--workload", default="cartpole",
+                    choices=["cartpole", "cartpole_bnn", "double_cartpole_bnn",
+                             "mpc_bnn"],
+                    help="cartpole = BASELINE configs[1] (the headline line); "
+                         "cartpole_bnn = configs[2]; double_cartpole_bnn = "
+                         "configs[3]'s problem with the reference's BNN model; "
+                         "mpc_bnn = configs[4]")
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--horizon", type=int, default=None)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-points", action="store_true",
+                    help="skip the extra roofline points (B = 16384, fp64, "
+                         "cold cache)")
+    ap.add_argument("--kernel-variant", type=int, default=0,
+                    help="backward kernel (include/pddp_hip.h): 0 auto")
+    args = ap.parse_args()
+    launch_ranks_if_asked(args)
+    if args.workload == "mpc_bnn":
+        return bench_mpc_bnn(args)
+    if args.workload != "cartpole":
+        return bench_bnn(args)
+
+    import torch.distributed as dist
+    world, rank, device = init_ranks()
+    from pddp_amd import _native
+    from pddp_amd.parallel import gather_best_rollout, shard_bounds
+
+    dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    N = args.horizon or 100
+    total = args.batch or 4096
+    if args.scaling == "strong":
+        lo, hi = shard_bounds(total, rank, world)
+        B = hi - lo
+    else:
+        B, lo = total, rank * total
+    s, z0, U, bound = make_cartpole_solver(B, N, dtype, device, rank,
+                                           args.kernel_variant)
+    n, m = s.n, s.m
     lib = _native.lib()
     K, W = args.steps, args.warmup
+    R = args.repeats or 5
     n_iter = 1 << 30  # the fit loop never runs out inside the benchmark
+    seen = ranks_seen(world, device)
 
-    def one_round(ev=None):
-        # the product's round (ILQRSolver.round): records of fresh nominals,
-        # sweep (events attached to its own dispatch: the kernel's duration),
-        # fused line search + accept + records of the accepted nominals
-        s.round(5e-6, 1e10, n_iter, variant=args.kernel_variant,
-                backward_events=ev)
+    pool_sweep, pool_search = EventPool(lib), EventPool(lib)
+    reps = []
+    for _ in range(R):
+        # every repetition times the same K rounds from the same nominal
+        s.set_nominal(z0, U)
+        for _ in range(W):
+            s.round(5e-6, 1e10, n_iter)
+        s.n_live.zero_()
+        live0 = int(s.active.sum().item())
+        ev = [(pool_sweep.pair(), pool_search.pair()) for _ in range(K)]
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            # the product's round (ILQRSolver.round): records of fresh
+            # nominals, sweep, fused line search + accept + records of the
+            # accepted nominals; events ride on the two dispatches themselves
+            s.round(5e-6, 1e10, n_iter, backward_events=ev[i][0],
+                    search_events=ev[i][1])
+        if world > 1:  # the one exchange of the path: best rollout over RCCL
+            gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        # units processed: attempts actually made (live trajectories per round)
+        liveK = int(s.active.sum().item())
+        cum_live = int(s.n_live.sum().item())  # sum over rounds of live-after
+        attempted = live0 + cum_live - liveK   # sum over rounds of live-before
+        total_attempted = attempted
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            t = torch.tensor([attempted], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            total_attempted = int(t.item())
+        reps.append({"elapsed": elapsed, "attempted": attempted,
+                     "total_attempted": total_attempted,
+                     "live": [live0, liveK]})
 
-    for _ in range(W):
-        one_round()
-    torch.cuda.synchronize(device)
-    events = []
-    for _ in range(K):
-        a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        lib.pddp_event_create(ctypes.byref(a))
-        lib.pddp_event_create(ctypes.byref(b))
-        events.append((a, b))
-    s.n_live.zero_()
-    live0 = int(s.active.sum().item())
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(K):
-        one_round(events[i])
-    if world > 1:  # the one exchange of the path: best rollout over RCCL
-        lo = rank * B
-        Jb, idx, Zb, Ub = gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
-    torch.cuda.synchronize(device)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    order = sorted(range(R), key=lambda i: reps[i]["elapsed"])
+    med = reps[order[R // 2]]
+    elapsed, total_attempted = med["elapsed"], med["total_attempted"]
+    attempted_all = sum(r["attempted"] for r in reps)
 
-    # units processed: attempts actually made (live trajectories per round)
-    liveK = int(s.active.sum().item())
-    cum_live = int(s.n_live.sum().item())    # sum over rounds of live-after
-    attempted = live0 + cum_live - liveK     # sum over rounds of live-before
-    total_attempted = attempted
-    if world > 1:
-        t = torch.tensor([attempted], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        total_attempted = int(t.item())
-
-    durs = []
-    for a, b in events:
-        ms = ctypes.c_float()
-        lib.pddp_event_elapsed_ms(a, b, ctypes.byref(ms))
-        durs.append(ms.value * 1e-3)
-        lib.pddp_event_destroy(a)
-        lib.pddp_event_destroy(b)
     itemsize = 4 if dtype == torch.float32 else 8
     per_traj = algorithmic_bytes_per_trajectory(N, n, m, itemsize, True)
-    avg_dur = float(np.mean(durs))
-    # every timed launch swept `attempted / K` trajectories on average
-    achieved = (attempted / K) * per_traj / avg_dur / 1e9
+    d_sweep = np.array(pool_sweep.durations())
+    d_search = np.array(pool_search.durations())
+    launches = R * K
+    # every timed launch swept `attempted_all / launches` trajectories on average
+    sweep_bytes = attempted_all / launches * per_traj
+    achieved = sweep_bytes / float(d_sweep.mean()) / 1e9
+    search_bytes = search_accept_bytes(attempted_all / launches, N, n, m,
+                                       int(s.A), s.lay.stride, itemsize)
 
-    # HBM traffic of the same kernel from rocprofv3 PMC passes (FETCH_SIZE and
+    # HBM traffic of the same kernels from rocprofv3 PMC passes (FETCH_SIZE and
     # WRITE_SIZE cannot share a pass, and counters cannot be read from inside
     # this process): taken from the committed summary of the profiled run of
     # this very command, see profiles/.
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath) and B == 4096 and N == 100 and args.dtype == "f32":
+    traffic, traffic_search = None, None
+    for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", tname)
+        if not (os.path.exists(tpath) and B == 4096 and N == 100
+                and args.dtype == "f32"):
+            continue
         try:
             with open(tpath) as fh:
                 for kname, v in json.load(fh)["kernels"].items():
+                    t = {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                         "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / "
+                                   "WRITE_SIZE, 2*FETCH+WRITE)" % tname}
                     if "riccati" in kname:
-                        traffic = {"hbm_bytes_per_launch":
-                                   v["hbm_bytes_per_launch"],
-                                   "source": "profiles/r01_pmc_traffic.json "
-                                             "(rocprofv3 --pmc FETCH_SIZE / "
-                                             "WRITE_SIZE, 2*FETCH+WRITE)"}
+                        traffic = t
+                    elif "line_search" in kname:
+                        traffic_search = t
+            break
         except (OSError, KeyError, ValueError):
-            traffic = None
+            traffic = traffic_search = None
 
     out = None
     if rank == 0:
@@ -389,10 +681,14 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
+            "rccl_ranks_seen": seen,
+            "repeats": R,
+            "ms_per_step_min": reps[order[0]]["elapsed"] / K * 1e3,
+            "ms_per_step_all": [r["elapsed"] / K * 1e3 for r in reps],
             "config": {
                 "workload": "BASELINE.json configs[1]: cartpole n=4 m=1, "
                             "known-dynamics iLQR, horizon=%d, batch=%d "
@@ -403,29 +699,50 @@ def main():
                                    "derivative records when its nominal "
                                    "changed + backward sweep + line search + "
                                    "accept",
+                "value_definition": "median of %d repetitions of the timed "
+                                    "region (each: set_nominal, %d warm-up "
+                                    "rounds, %d timed rounds)" % (R, W, K),
                 "batched_iterations_per_s": K / elapsed,
                 "trajectory_timesteps_per_s": total_attempted * N / elapsed,
-                "live_trajectories_start_end": [live0, liveK],
+                "live_trajectories_start_end": med["live"],
                 "backward_kernel_variant": args.kernel_variant,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "backward Riccati sweep",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "avg_launch_us": avg_dur * 1e6,
-                "min_launch_us": float(np.min(durs)) * 1e6,
-                "algorithmic_bytes_per_launch": (attempted / K) * per_traj,
+                "avg_launch_us": float(d_sweep.mean()) * 1e6,
+                "median_launch_us": float(np.median(d_sweep)) * 1e6,
+                "min_launch_us": float(d_sweep.min()) * 1e6,
+                "launches_timed": int(launches),
+                "algorithmic_bytes_per_launch": sweep_bytes,
                 "traffic": traffic,
-                # what the memory system allows for this transfer with no
-                # arithmetic at all (tools/probe/record_stream_probe.hip on a
-                # cold cache, B = 4096, N = 100, fp32): informational
-                "transfer_only_us": ({"plain_coalesced_read": 27.9,
-                                      "this_kernels_streaming_pattern": 33.0,
-                                      "source": "profiles/r01_record_stream_probe.txt"}
-                                     if (B == 4096 and N == 100 and
-                                         args.dtype == "f32") else None),
+                "other_kernels": [{
+                    "bound": "hbm",
+                    "kernel": "fused line search + accept + records "
+                              "(line_search_lds_kernel<.., FUSED>)",
+                    "avg_launch_us": float(d_search.mean()) * 1e6,
+                    "min_launch_us": float(d_search.min()) * 1e6,
+                    "algorithmic_bytes_per_launch": search_bytes,
+                    "achieved": search_bytes / float(d_search.mean()) / 1e9,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": search_bytes / float(d_search.mean()) / 1e9 /
+                            HBM_PEAK_GBS,
+                    "traffic": traffic_search,
+                }],
             },
         }
+        if world == 1 and not args.no_points and B == 4096 and N == 100 and \
+                args.dtype == "f32":
+            # the points that defeat the caches, in the line
+            out["roofline"]["points"] = [
+                sweep_point(lib, B, N, dtype, device, args.kernel_variant,
+                            cold=True, solver=(s, z0, U)),
+                sweep_point(lib, 16384, N, torch.float32, device,
+                            args.kernel_variant),
+                sweep_point(lib, 4096, N, torch.float64, device,
+                            args.kernel_variant),
+            ]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline("cartpole", 0.1, N, bound)
         else:

@@ -428,6 +428,11 @@ int pddp_event_create(void** ev);
 int pddp_event_record(void* ev, void* stream);
 int pddp_event_elapsed_ms(void* start, void* stop, float* ms); /* syncs stop */
 int pddp_event_destroy(void* ev);
+/* Attaches (start, stop) to the NEXT kernel this host thread launches through
+ * any pddp_* entry point: the events then time that kernel from its own start
+ * to its own end (what rocprofv3 --kernel-trace reports), without the
+ * stream's dispatch gaps.  One-shot; (NULL, NULL) detaches. */
+int pddp_attach_events(void* start, void* stop);
 
 #ifdef __cplusplus
 }

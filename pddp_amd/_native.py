@@ -83,6 +83,7 @@ _SIGS = {
     "pddp_event_record": [_P, _P],
     "pddp_event_elapsed_ms": [_P, _P, _P],
     "pddp_event_destroy": [_P],
+    "pddp_attach_events": [_P, _P],
 }
 _TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
           "pddp_riccati_backward_timed",

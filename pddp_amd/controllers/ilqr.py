@@ -47,13 +47,17 @@ def _native_problem(model, cost, encoding):
 
 
 def _make_solver(model, cost, encoding, B, N, n, dtype, device, u_min, u_max,
-                 alphas, model_opts=None, cost_opts=None, force_plugin=False):
+                 alphas, model_opts=None, cost_opts=None, force_plugin=False,
+                 kernel_variant=0, exact=False):
     problem = None if force_plugin else _native_problem(model, cost, encoding)
     if problem is not None:
-        return ILQRSolver(problem, B, N, dtype, device, u_min, u_max, alphas)
-    plugin = TorchProblem(model, cost, encoding, model_opts, cost_opts)
-    return ILQRSolver(None, B, N, dtype, device, u_min, u_max, alphas,
-                      plugin=plugin, n=n, m=model.action_size)
+        s = ILQRSolver(problem, B, N, dtype, device, u_min, u_max, alphas)
+    else:
+        plugin = TorchProblem(model, cost, encoding, model_opts, cost_opts)
+        s = ILQRSolver(None, B, N, dtype, device, u_min, u_max, alphas,
+                       plugin=plugin, n=n, m=model.action_size)
+    s.kernel_variant = s.exact_variant() if exact else int(kernel_variant)
+    return s
 
 
 def _as_batch(t, ndim_single):
@@ -70,12 +74,19 @@ class iLQRController(Controller):
     `env.get_state()`)."""
 
     def __init__(self, env, model, cost, model_opts={}, cost_opts={},
-                 force_plugin=False, graph=False, **kwargs):
-        """`graph=True` replays each round as one captured hipGraph (native
-        sample problems only; see ILQRSolver.capture_round)."""
+                 force_plugin=False, graph=False, exact=False,
+                 kernel_variant=0, **kwargs):
+        """`graph=True` replays each round as one captured hipGraph (see
+        ILQRSolver.capture_round).  `exact=True` runs the fp32 backward sweep
+        on the IEEE-division twin of the kernel `auto` picks (the default fp32
+        kernels use v_rcp / v_sqrt; measured error identical, see
+        profiles/r02_sweep_error_stats.json); `kernel_variant` selects a sweep
+        kernel by number (include/pddp_hip.h)."""
         super(iLQRController, self).__init__()
         self._force_plugin = force_plugin
         self._graph = graph
+        self._exact = bool(exact)
+        self._kernel_variant = int(kernel_variant)
         self.env = env
         self.cost = cost
         self.model = model
@@ -104,17 +115,22 @@ class iLQRController(Controller):
         if s is None or getattr(s, "_key", None) != key:
             s = _make_solver(self.model, self.cost, encoding, B, N, n, dtype,
                              device, u_min, u_max, alphas, self._model_opts,
-                             self._cost_opts, self._force_plugin)
+                             self._cost_opts, self._force_plugin,
+                             self._kernel_variant, self._exact)
             s._key = key
             self._solver = s
         return s
 
     def _export(self, s):
+        # independent tensors cross the public API, like the reference's
+        # `Z_new[:, amin].detach()` (ilqr.py:167-169): the solver (cached per
+        # key) overwrites its buffers in the next fit / MPC step
         k, K = s.gain_views(accepted=True)
         if self._batched:
-            self._Z_nominal, self._U_nominal, self._K = s.Z, s.U, K
+            Z, U, K = s.Z.clone(), s.U.clone(), K.clone()
         else:
-            self._Z_nominal, self._U_nominal, self._K = s.Z[0], s.U[0], K[0]
+            Z, U, K = s.Z[0].clone(), s.U[0].clone(), K[0].clone()
+        self._Z_nominal, self._U_nominal, self._K = Z, U, K
         self._mu = float(s.mu[0])
         self._delta = float(s.delta[0])
 
@@ -129,15 +145,15 @@ class iLQRController(Controller):
             if on_iteration is None:
                 return
             if self._batched:
-                on_iteration(s.iter.cpu() - 1, s.state.cpu(), s.Z.detach(),
-                             s.U.detach(), s.J_opt.detach())
+                on_iteration(s.iter.cpu() - 1, s.state.cpu(), s.Z.clone(),
+                             s.U.clone(), s.J_opt.clone())
             else:
                 it = int(s.iter[0]) - 1
                 st = iLQRState(int(s.state[0]))
                 if st == iLQRState.ACCEPTED and int(s.active[0]):
                     it -= 1  # the counter already points at the next step()
-                on_iteration(it, st, s.Z[0].detach(), s.U[0].detach(),
-                             s.J_opt[0].detach())
+                on_iteration(it, st, s.Z[0].clone(), s.U[0].clone(),
+                             s.J_opt[0].clone())
         s.fit(n_iterations, tol, max_reg, on_round,
               graph=self._graph and s.plugin is None)
 
@@ -257,6 +273,27 @@ def Q(F_z, F_u, L_z, L_u, L_zz, L_uz, L_uu, V_z, V_zz):
     return Q_z, Q_u, Q_zz, Q_uz, Q_uu
 
 
+
+def _views_of_record(owner, B, N, n, m, dtype, lay, tensors, batched):
+    """True when ALL seven derivative tensors are the untouched views
+    `forward()` handed out of `owner.rec` (same storage offset, shape and
+    strides): only then may `backward` stream the record buffer as it is.  A
+    caller who replaced any of them (say `L_uu + reg I`) gets the pack path."""
+    rec = owner.rec
+    if rec.shape != (B, N + 1, lay.stride) or rec.dtype != dtype:
+        return False
+    ref = owner.record_views()
+    if not batched:
+        ref = tuple(t[0] for t in ref)
+    for got, want in zip(tensors, ref):
+        if (got.dtype != want.dtype or got.device != want.device
+                or got.data_ptr() != want.data_ptr()
+                or tuple(got.shape) != tuple(want.shape)
+                or tuple(got.stride()) != tuple(want.stride())):
+            return False
+    return True
+
+
 _STATUS_MSG = {1: "non-positive definite matrix",
                2: "non-positive definite matrix (Cholesky failed)",
                3: "BoxQP failed"}
@@ -278,12 +315,9 @@ def backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu, reg=0.0,
     dtype, device = F_z.dtype, F_z.device
     lay = _native.record_layout(n, m)
     owner = _REC_OWNERS.get(F_z.data_ptr())
-    isz = F_z.element_size()
-    zero_copy = (
-        owner is not None and owner.rec.shape == (B, N + 1, lay.stride)
-        and owner.rec.dtype == dtype
-        and L_zz.data_ptr() == owner.rec.data_ptr() + lay.o_Lzz * isz
-        and L_z.data_ptr() == owner.rec.data_ptr() + lay.o_Lz * isz)
+    zero_copy = owner is not None and _views_of_record(
+        owner, B, N, n, m, dtype, lay,
+        (F_z, F_u, L_z, L_u, L_zz, L_uz, L_uu), batched)
     bounded = u_min is not None and u_max is not None
     if zero_copy:
         rec = owner.rec

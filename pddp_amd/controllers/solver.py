@@ -24,6 +24,20 @@ from ..utils.encoding import StateEncoding
 BRANCH_EIG, BRANCH_CHOLESKY = 0, 1
 
 
+def _on_device(fn):
+    """The C ABI takes a stream handle and launches on the CURRENT device: a
+    solver that lives on another GPU makes its device current for the call."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kwargs):
+        if torch.cuda.current_device() == self.device.index:
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(self.device):
+            return fn(self, *args, **kwargs)
+    return wrapped
+
+
 def fit_alphas(dtype, device):
     """ilqr.py:282 (the schedule `fit` actually uses)."""
     return (1.025 ** (-torch.arange(10.0, dtype=torch.float64) ** 2)).to(
@@ -38,7 +52,8 @@ def mpc_alphas(dtype, device):
 class ILQRSolver(object):
 
     def __init__(self, problem, B, N, dtype, device, u_min=None, u_max=None,
-                 alphas=None, branch=BRANCH_EIG, plugin=None, n=None, m=None):
+                 alphas=None, branch=BRANCH_EIG, plugin=None, n=None, m=None,
+                 kernel_variant=0):
         """`problem`: ctypes PddpProblem of a sample problem (everything in
         HIP), or None together with `plugin` (plugin.TorchProblem) and the
         encoded state / action sizes `n`, `m`: derivatives and the line search
@@ -54,8 +69,13 @@ class ILQRSolver(object):
         if self.device.type != "cuda":
             raise _native.NativeError(
                 "ILQRSolver needs a GPU device (no CPU fallback)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lay = _native.record_layout(self.n, self.m)
         self.branch = branch
+        # backward-sweep kernel of round(): 0 = auto (f32: approximate
+        # v_rcp / v_sqrt kernels), `exact_variant()` = the IEEE-division twins
+        self.kernel_variant = int(kernel_variant)
         opts = dict(dtype=dtype, device=self.device)
         B, N, n, m = self.B, self.N, self.n, self.m
         S, gs = self.lay.stride, self.lay.gain_stride
@@ -118,10 +138,26 @@ class ILQRSolver(object):
         m, n = self.m, self.n
         return g[..., :m], g[..., m:].unflatten(-1, (m, n))
 
+    def exact_variant(self, branch=None, bounded=True):
+        """The variant number (include/pddp_hip.h) of the kernel `auto` would
+        pick, with IEEE division / square root instead of v_rcp / v_sqrt."""
+        branch = self.branch if branch is None else branch
+        bounded = bounded and self.u_min is not None
+        if self.dtype != torch.float32:
+            return 0  # the f64 kernels are IEEE throughout
+        if self.n == 4 and self.m == 1:
+            if bounded and self.B <= 16384:
+                return 12 if branch == BRANCH_EIG else 8
+            return 6
+        if self.m == 1 and self.n <= 30:
+            return 14
+        return 0  # generic kernel: IEEE throughout
+
     # -- kernels --------------------------------------------------------------
     def _s(self):
         return _native.stream_handle(self.device)
 
+    @_on_device
     def set_nominal(self, z0, U):
         """ilqr.py:274-277: new nominal controls, regularisation reset."""
         self.z0.copy_(z0.reshape(self.B, self.n))
@@ -139,6 +175,7 @@ class ILQRSolver(object):
         self.active.fill_(1)
         self.fresh.fill_(1)
 
+    @_on_device
     def nominal_rollout(self, mask=None):
         if self.plugin is not None:
             return self.plugin.rollout(self)
@@ -147,6 +184,7 @@ class ILQRSolver(object):
                      self.N, p(self.z0), p(self.U), p(self.u_min),
                      p(self.u_max), p(mask), p(self.Z), self._s())
 
+    @_on_device
     def derivs(self, mask=None, set_state=True):
         if self.plugin is not None:
             return self.plugin.derivs(self, mask, set_state)
@@ -156,6 +194,7 @@ class ILQRSolver(object):
                      p(mask), p(self.rec), p(self.L), p(self.J_opt),
                      p(self.state) if set_state else None, self._s())
 
+    @_on_device
     def backward(self, active=None, reg=None, branch=None, bounded=True,
                  variant=0, events=None):
         """variant: 0 auto, 1 generic kernel, 2 / 3 specialised n=4 kernel
@@ -176,6 +215,7 @@ class ILQRSolver(object):
             _native.call("pddp_riccati_backward_timed", self.dtype, *args,
                          events[0], events[1])
 
+    @_on_device
     def line_search(self, active=None, use_status=True):
         if self.plugin is not None:
             return self.plugin.line_search(self, active, use_status)
@@ -186,6 +226,7 @@ class ILQRSolver(object):
                      p(self.bwd_status) if use_status else None, p(self.Zc),
                      p(self.Uc), p(self.Jc), self._s())
 
+    @_on_device
     def accept(self, tol, max_reg, n_iterations):
         p = _native.ptr
         _native.call("pddp_accept", self.dtype, self.B, self.N, self.n, self.m,
@@ -196,6 +237,7 @@ class ILQRSolver(object):
                      p(self.delta), p(self.state), p(self.iter),
                      p(self.active), p(self.fresh), p(self.n_live), self._s())
 
+    @_on_device
     def search_accept(self, tol, max_reg, n_iterations):
         """Line search + accept + derivative records of the new nominals in
         one launch (pddp_search_accept_*).  False when the fused kernel does
@@ -214,22 +256,27 @@ class ILQRSolver(object):
         self._fused = rc == 0
         return self._fused
 
-    def round(self, tol=5e-6, max_reg=1e10, n_iterations=50, variant=0,
-              backward_events=None):
+    def round(self, tol=5e-6, max_reg=1e10, n_iterations=50, variant=None,
+              backward_events=None, always_derivs=False, search_events=None):
         """One attempt of every live trajectory (no host sync): derivative
         records of the trajectories whose nominal is new, backward sweep, and
         - fused into one launch where the problem allows - line search,
         accept / regularisation schedule and the records of the accepted
         nominals (so the first call is a no-op from the second round on)."""
-        if self._derivs_due or not self._fused:
+        if variant is None:
+            variant = self.kernel_variant
+        if self._derivs_due or not self._fused or always_derivs:
             self.derivs(mask=self.fresh)
             self._derivs_due = False
         self.backward(active=self.active, variant=variant,
                       events=backward_events)
+        if search_events is not None:  # (bench.py: times the fused launch)
+            _native.lib().pddp_attach_events(*search_events)
         if not self.search_accept(tol, max_reg, n_iterations):
             self.line_search(active=self.active)
             self.accept(tol, max_reg, n_iterations)
 
+    @_on_device
     def capture_round(self, tol=5e-6, max_reg=1e10, n_iterations=50):
         """Captures round() - five kernel launches and a memset, all on
         device-resident state - into a hipGraph; `replay_round()` then issues
@@ -239,16 +286,21 @@ class ILQRSolver(object):
             raise _native.NativeError(
                 "graph capture needs the native problem kernels; plugin "
                 "models run autograd inside a round")
-        key = (float(tol), float(max_reg), int(n_iterations))
+        key = (float(tol), float(max_reg), int(n_iterations),
+               self.kernel_variant)
         if self._graph is not None and self._graph[0] == key:
             return self._graph[1]
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            self.round(tol, max_reg, n_iterations)
+            # the masked records launch is always part of the graph (a no-op
+            # when no nominal is fresh): a replay after set_nominal() must not
+            # sweep the previous nominal's records
+            self.round(tol, max_reg, n_iterations, always_derivs=True)
         self._graph = (key, graph)
         return graph
 
+    @_on_device
     def replay_round(self):
         self._graph[1].replay()
 

@@ -302,11 +302,11 @@ static int bnn_jvp_check(const pddp_bnn_jvp* s) {
 int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
   if (s->D <= 4)
-    hipLaunchKernelGGL((pddp::bnn_jvp_features_kernel<4>),
+    PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<4>),
                        dim3((s->B * s->P + 7) / 8), dim3(64), 0,
                        (hipStream_t)stream, *s);
   else
-    hipLaunchKernelGGL((pddp::bnn_jvp_features_kernel<6>),
+    PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<6>),
                        dim3((s->B * s->P + 7) / 8), dim3(64), 0,
                        (hipStream_t)stream, *s);
   return pddp::launch_status();
@@ -316,10 +316,10 @@ int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
   if (!s->net_out || !s->F_z || !s->F_u) return PDDP_E_BADARG;
   if (pddp_bnn_jvp_group(s->D, s->m) == 16)
-    hipLaunchKernelGGL((pddp::bnn_jvp_moments_kernel<16, 4>), dim3(s->B),
+    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<16, 4>), dim3(s->B),
                        dim3(64), 0, (hipStream_t)stream, *s);
   else
-    hipLaunchKernelGGL((pddp::bnn_jvp_moments_kernel<32, 6>), dim3(s->B),
+    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<32, 6>), dim3(s->B),
                        dim3(64), 0, (hipStream_t)stream, *s);
   return pddp::launch_status();
 }

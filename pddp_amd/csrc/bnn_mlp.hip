@@ -306,27 +306,33 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
 
 template <int H, int W1S, int JVP = 0>
 static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
-  static int cus = 0;  // queried once: hipGetDeviceProperties costs ms
-  if (cus == 0) {
-    int dev = 0;
+  // per device (a process may drive several GPUs): CU count queried once -
+  // hipGetDeviceProperties costs ms - and the > 64 KB dynamic-LDS opt-in,
+  // which is a per-device function attribute
+  constexpr int kMaxDev = 16;
+  static int cus_of[kMaxDev] = {};
+  static bool attr_set[kMaxDev] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev)
+    return PDDP_E_UNSUPPORTED;
+  if (cus_of[dev] == 0) {
     hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess &&
-           hipGetDeviceProperties(&prop, dev) == hipSuccess)
-              ? prop.multiProcessorCount
-              : 256;
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess
+                      ? prop.multiProcessorCount
+                      : 256;
   }
+  const int cus = cus_of[dev];
   const int ntiles = (a.R + kMlpTile - 1) / kMlpTile;
   const int grid = ntiles < cus ? ntiles : cus;  // persistent: one per CU
   constexpr size_t lds = sizeof(float) * bnn_mlp_lds_floats<H, W1S>();
-  static bool attr_set = false;
-  if (!attr_set) {  // more than 64 KB of dynamic LDS needs the opt-in
+  if (!attr_set[dev]) {  // more than 64 KB of dynamic LDS needs the opt-in
     const hipError_t e = hipFuncSetAttribute(
         (const void*)bnn_mlp_kernel<H, W1S, JVP>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((bnn_mlp_kernel<H, W1S, JVP>), dim3(grid),
+  PDDP_LAUNCH((bnn_mlp_kernel<H, W1S, JVP>), dim3(grid),
                      dim3(kMlpThreads), lds, st, a);
   return launch_status();
 }

@@ -286,7 +286,7 @@ extern "C" int pddp_bnn_moment_step_f32(const pddp_bnn_step* s, void* stream) {
       s->n_non < 0 || s->n_non + s->n_ang != s->D ||
       s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D)
     return PDDP_E_UNSUPPORTED;
-  hipLaunchKernelGGL(pddp::bnn_moment_step_kernel, dim3(s->B * s->A), dim3(64),
+  PDDP_LAUNCH(pddp::bnn_moment_step_kernel, dim3(s->B * s->A), dim3(64),
                      0, (hipStream_t)stream, *s);
   return pddp::launch_status();
 }

@@ -77,7 +77,7 @@ static int accept_impl(int B, int N, int n, int m, int A, const T* Zc,
   AcceptArgs<T> a{B, N, n, m, A, Zc, Uc, Jc, gains, bwd_status, tol, max_reg,
                   n_iterations, Z, U, gains_acc, J_opt, mu, delta, state, iter,
                   active, fresh, n_live};
-  hipLaunchKernelGGL((accept_kernel<T>), dim3(B), dim3(kAcceptThreads), 0,
+  PDDP_LAUNCH((accept_kernel<T>), dim3(B), dim3(kAcceptThreads), 0,
                      (hipStream_t)stream, a);
   return launch_status();
 }
@@ -138,7 +138,7 @@ static int pack_impl(int B, int N, int n, int m, const T* F_z, const T* F_u,
   const size_t total = (size_t)B * (N + 1) * lay.stride;
   int blocks = (int)((total + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL((pack_kernel<T>), dim3(blocks), dim3(256), 0,
+  PDDP_LAUNCH((pack_kernel<T>), dim3(blocks), dim3(256), 0,
                      (hipStream_t)stream, a);
   return launch_status();
 }
@@ -234,6 +234,10 @@ int pddp_event_elapsed_ms(void* start, void* stop, float* ms) {
 }
 int pddp_event_destroy(void* ev) {
   return (int)hipEventDestroy((hipEvent_t)ev);
+}
+int pddp_attach_events(void* start, void* stop) {
+  pddp::launch_events() = {(hipEvent_t)start, (hipEvent_t)stop};
+  return 0;
 }
 
 }  // extern "C"

@@ -570,14 +570,14 @@ static int launch_rollout(const pddp_problem& p, RolloutArgs<T> a,
                           hipStream_t st) {
   const ProblemT<T> P = convert_problem<T>(p);
   const int blocks = (a.B + kWave - 1) / kWave;
-  hipLaunchKernelGGL((nominal_rollout_kernel<T, MODEL>), dim3(blocks),
+  PDDP_LAUNCH((nominal_rollout_kernel<T, MODEL>), dim3(blocks),
                      dim3(kWave), 0, st, P, a);
   return launch_status();
 }
 template <typename T, int MODEL>
 static int launch_derivs(const pddp_problem& p, DerivArgs<T> a, hipStream_t st) {
   const ProblemT<T> P = convert_problem<T>(p);
-  hipLaunchKernelGGL((derivs_kernel<T, MODEL>), dim3(a.B), dim3(kDerivThreads),
+  PDDP_LAUNCH((derivs_kernel<T, MODEL>), dim3(a.B), dim3(kDerivThreads),
                      0, st, P, a);
   return launch_status();
 }
@@ -591,18 +591,18 @@ static int launch_line_search(const pddp_problem& p, LineSearchArgs<T> a,
   const size_t lds = 4 * per * sizeof(T);
   if (a.A <= 16 && lds <= 64 * 1024) {  // nominal data staged in LDS
     if (4 * lds <= 64 * 1024)
-      hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, false, 4>),
+      PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, false, 4>),
                          dim3((a.B + 15) / 16), dim3(kWave * 4), 4 * lds, st, P,
                          a, AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
     else
-      hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, false, 1>),
+      PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, false, 1>),
                          dim3((a.B + 3) / 4), dim3(kWave), lds, st, P, a,
                          AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
     return launch_status();
   }
   const int total = a.B * a.A;
   const int blocks = (total + kWave - 1) / kWave;
-  hipLaunchKernelGGL((line_search_kernel<T, MODEL>), dim3(blocks), dim3(kWave),
+  PDDP_LAUNCH((line_search_kernel<T, MODEL>), dim3(blocks), dim3(kWave),
                      0, st, P, a);
   return launch_status();
 }
@@ -628,11 +628,11 @@ static int launch_search_accept(const pddp_problem& p, SearchAcceptArgs<T> a,
   a.ac.n = D::n;
   a.ac.m = D::m;
   if (4 * lds <= 64 * 1024)
-    hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, true, 4>),
+    PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 4>),
                        dim3((a.ls.B + 15) / 16), dim3(kWave * 4), 4 * lds, st, P,
                        a.ls, a.ac, a.rec, a.L);
   else
-    hipLaunchKernelGGL((line_search_lds_kernel<T, MODEL, true, 1>),
+    PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 1>),
                        dim3((a.ls.B + 3) / 4), dim3(kWave), lds, st, P, a.ls,
                        a.ac, a.rec, a.L);
   return launch_status();

@@ -221,9 +221,9 @@ extern "C" int pddp_qr_cost_derivs_f32(const pddp_qr_cost* s, void* stream) {
   const dim3 grid(s->B * (s->N + 1)), block(64);
   hipStream_t st = (hipStream_t)stream;
   switch (s->D) {
-    case 2: hipLaunchKernelGGL(pddp::qr_cost_derivs_kernel<2>, grid, block, 0, st, *s); break;
-    case 4: hipLaunchKernelGGL(pddp::qr_cost_derivs_kernel<4>, grid, block, 0, st, *s); break;
-    case 6: hipLaunchKernelGGL(pddp::qr_cost_derivs_kernel<6>, grid, block, 0, st, *s); break;
+    case 2: PDDP_LAUNCH(pddp::qr_cost_derivs_kernel<2>, grid, block, 0, st, *s); break;
+    case 4: PDDP_LAUNCH(pddp::qr_cost_derivs_kernel<4>, grid, block, 0, st, *s); break;
+    case 6: PDDP_LAUNCH(pddp::qr_cost_derivs_kernel<6>, grid, block, 0, st, *s); break;
     default: return PDDP_E_UNSUPPORTED;
   }
   return pddp::launch_status();

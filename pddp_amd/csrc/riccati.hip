@@ -219,7 +219,7 @@ int pddp_boxqp_m1_f32(int count, const float* x0, const float* Q,
   if (count <= 0 || !x0 || !Q || !c || !lower || !upper || !x || !result ||
       !free_mask)
     return PDDP_E_BADARG;
-  hipLaunchKernelGGL((pddp::n4::boxqp1_kernel<float, false>),
+  PDDP_LAUNCH((pddp::n4::boxqp1_kernel<float, false>),
                      dim3((count + 3) / 4), dim3(pddp::kWave), 0,
                      (hipStream_t)stream, count, x0, Q, c, lower, upper, x,
                      result, free_mask);
@@ -232,7 +232,7 @@ int pddp_boxqp_m1_f64(int count, const double* x0, const double* Q,
   if (count <= 0 || !x0 || !Q || !c || !lower || !upper || !x || !result ||
       !free_mask)
     return PDDP_E_BADARG;
-  hipLaunchKernelGGL((pddp::n4::boxqp1_kernel<double, false>),
+  PDDP_LAUNCH((pddp::n4::boxqp1_kernel<double, false>),
                      dim3((count + 3) / 4), dim3(pddp::kWave), 0,
                      (hipStream_t)stream, count, x0, Q, c, lower, upper, x,
                      result, free_mask);

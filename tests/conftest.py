@@ -23,3 +23,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The fp32 comparisons record what they measured (test_gpu_parity.STATS);
+    with PDDP_DUMP_STATS=<path> the rows are written out as JSON - the source
+    of profiles/r02_fp32_parity_rows.json."""
+    path = os.environ.get("PDDP_DUMP_STATS")
+    mod = sys.modules.get("test_gpu_parity")
+    if path and mod is not None and getattr(mod, "STATS", None):
+        import json
+        with open(path, "w") as fh:
+            json.dump(mod.STATS, fh)

@@ -19,9 +19,62 @@ MEAN0 = {"cartpole": [0, 0, 0, 0], "pendulum": [0, 0],
          "double_cartpole": [0, 0, np.pi, 0, np.pi, 0],
          "rendezvous": [-10, -10, 10, 10, 0, -5, 5, 0]}
 TDT = {"f64": torch.float64, "f32": torch.float32}
-# fp32 tolerance: parity is graded in fp64; fp32 drift over a
-# horizon is ~1e-5 on K (eig + BoxQP branch) in the reference itself.
-TOL = {"f64": 1e-9, "f32": 5e-3}
+# fp64 is held to 1e-9 everywhere.  fp32 bounds are DATA-DRIVEN: the sweep is a
+# recursion through a discontinuous BoxQP whose conditioning (not the kernel)
+# sets the fp32 error - the oracle's own IEEE fp32 run, in the reference's
+# operation order, is 1.5e-4 (median) / 1e-3 (p99) away from its fp64 run on
+# k for the eig-clamp branch at reg = 1e-3 and 6e-7 / 2e-6 on the Cholesky
+# branch (profiles/r02_sweep_error_stats.json).  So an fp32 kernel is judged
+# by (a) its error against the fp64 oracle relative to the fp32 oracle's error
+# against the same fp64 oracle, and (b) counted status / clamp-pattern flips.
+TOL = {"f64": 1e-9}
+# single-trajectory comparisons (small samples: the ratio of two draws from a
+# heavy-tailed error distribution is noisy): error vs the fp64 oracle at most
+# F32_RATIO x the fp32 oracle's own on the same trajectory, or below the floor
+# of the branch - the well-conditioned Cholesky branches 2e-5; the eig-clamp
+# branches 1e-3 = the fp32 oracle's own p99 against fp64 on the bench
+# distribution (8.8e-4 at reg = 1e-3, 3.1e-3 at reg = 1).  Of 1865 rows
+# measured on the MI355X (profiles/r02_fp32_parity_rows.json) the largest HIP
+# error outside the ratio is 5.5e-4 (eig-clamp) / 2.2e-5 (Cholesky).  The
+# sharp statement is test_sweep_variants_vs_oracle_many_trajectories.
+import os  # noqa: E402
+F32_RATIO = float(os.environ.get("PDDP_F32_RATIO", 8.0))  # (override: survey)
+F32_FLOOR = {0: 1e-3, 1: 3e-5}  # by gain branch (0 eig-clamp, 1 Cholesky)
+STATS = []  # rows recorded by the fp32 comparisons (dumped by conftest)
+
+
+def _f32_ok(e_hip64, e_o64, branch):
+    return e_hip64 <= max(F32_RATIO * e_o64, F32_FLOOR[int(bool(branch))])
+
+
+def _backward64(args, kw):
+    """The fp64 oracle on the same (fp32-valued) inputs cast up: the yardstick
+    of every fp32 gain comparison."""
+    d = lambda a: np.asarray(a, np.float64) if isinstance(a, np.ndarray) else a
+    return orc.load(np.float64).backward(
+        *[d(a) for a in args], **{k: d(v) for k, v in kw.items()})
+
+
+def _check_gains(dtype, kb, Kb, kr, Kr, args, kw, **ctx):
+    """HIP gains (kb, Kb) against the oracle's (kr, Kr) of the same dtype.
+    fp64: 1e-9.  fp32: error against the fp64 oracle on the same inputs at
+    most F32_RATIO x the fp32 oracle's own (or F32_FLOOR); False when the fp64
+    oracle fails on these inputs (nothing to compare)."""
+    if dtype == "f64":
+        ek, eK = rel_err(kb, kr), rel_err(Kb, Kr)
+        assert ek < TOL[dtype] and eK < TOL[dtype], (ctx, ek, eK)
+        return True
+    k64, K64, st64 = _backward64(args, kw)
+    if st64 != 0:
+        return False
+    row = dict(ctx, k_hip=rel_err(kb, k64), k_o32=rel_err(kr, k64),
+               K_hip=rel_err(Kb, K64), K_o32=rel_err(Kr, K64),
+               k_hip_o32=rel_err(kb, kr), K_hip_o32=rel_err(Kb, Kr))
+    STATS.append(row)
+    branch = kw.get("V_zz_reg", False)
+    assert _f32_ok(row["k_hip"], row["k_o32"], branch), row
+    assert _f32_ok(row["K_hip"], row["K_o32"], branch), row
+    return True
 
 
 def _setup(problem, dtype, B, N, seed=0):
@@ -121,7 +174,8 @@ def test_backward_vs_oracle(problem, dtype, variant):
     s.derivs(set_state=False)
     o = orc.load(np_dtype(dtype))
     fwd = [o.forward(op, z0[b], U[b], u_min, u_max) for b in range(B)]
-    checked = 0
+    names = ("F_z", "F_u", "L_z", "L_u", "L_zz", "L_uz", "L_uu")
+    checked = flips = cases = 0
     for branch, bounded in ((0, False), (0, True), (1, False), (1, True)):
         if variant in (14, 15):
             pass  # all four branches
@@ -141,21 +195,23 @@ def test_backward_vs_oracle(problem, dtype, variant):
                 kw = dict(reg=reg, V_zz_reg=bool(branch))
                 if bounded:
                     kw.update(u_min=u_min, u_max=u_max, U=U[b])
-                kr, Kr, st = o.backward(f["F_z"], f["F_u"], f["L_z"], f["L_u"],
-                                        f["L_zz"], f["L_uz"], f["L_uu"], **kw)
+                kr, Kr, st = o.backward(*[f[nm] for nm in names], **kw)
+                cases += 1
                 if dtype == "f32" and (st == 0) != (status[b] == 0):
-                    continue  # knife-edge PD test in float
+                    flips += 1  # knife-edge PD test in float: counted below
+                    continue
                 assert (st == 0) == (status[b] == 0), (branch, bounded, reg, b)
-                if st == 0:
-                    assert status[b] == 0
-                    ek = rel_err(k[b].cpu().numpy(), kr)
-                    eK = rel_err(K[b].cpu().numpy(), Kr)
-                    assert ek < TOL[dtype] and eK < TOL[dtype], (
-                        branch, bounded, reg, b, ek, eK)
-                    checked += 1
-                else:
+                if st != 0:
                     assert status[b] == st
+                    continue
+                checked += _check_gains(
+                    dtype, k[b].cpu().numpy(), K[b].cpu().numpy(), kr, Kr,
+                    [f[nm] for nm in names], kw, test="backward_vs_oracle",
+                    problem=problem, variant=variant, branch=branch,
+                    bounded=bounded, reg=reg, b=b)
     assert checked >= 20
+    # fp32 status flips against the fp32 oracle: counted, at most 2.5 %
+    assert flips <= max(1, cases // 40), (flips, cases)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -166,9 +222,10 @@ def test_backward_vs_reference_golden(problem, dtype):
     against the reference's own outputs."""
     from pddp_amd.controllers.ilqr import backward
     g = load(problem, dtype=dtype)
+    g64 = load(problem, dtype="f64")
     td = TDT[dtype]
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda")
-    n_ok = 0
+    n_ok = n_flip = 0
     for tag in tags(problem):
         f = {nm: cu(g["%s/fwd_bounded/%s" % (tag, nm)]) for nm in FWD_NAMES}
         U = cu(g[tag + "/U"])
@@ -187,17 +244,36 @@ def test_backward_vs_reference_golden(problem, dtype):
                 except RuntimeError:
                     got_ok = 0
                 if dtype == "f32" and ok != got_ok:
+                    n_flip += 1  # knife-edge PD test in float: counted below
                     continue
                 assert ok == got_ok, key
                 if ok:
                     assert k.dtype == td
-                    # 1e-5 relative: the north star's bar, on the reference's
-                    # own numbers (fp64); fp32 a few 1e-4 over 100 steps
-                    tol = 1e-8 if dtype == "f64" else 2e-3
-                    assert rel_err(k.cpu().numpy(), g[key + "/k"]) < tol, key
-                    assert rel_err(K.cpu().numpy(), g[key + "/K"]) < tol, key
+                    kb, Kb = k.cpu().numpy(), K.cpu().numpy()
+                    if dtype == "f64":
+                        # the north star's bar is 1e-5 on the reference's own
+                        # numbers; held to 1e-8
+                        assert rel_err(kb, g[key + "/k"]) < 1e-8, key
+                        assert rel_err(Kb, g[key + "/K"]) < 1e-8, key
+                    elif int(g64[key + "/ok"]):
+                        # fp32: against the reference's fp64 run, no further
+                        # off than F32_RATIO x the reference's own fp32 run
+                        row = dict(
+                            test="reference_golden", problem=problem, key=key,
+                            k_hip=rel_err(kb, g64[key + "/k"]),
+                            k_o32=rel_err(g[key + "/k"], g64[key + "/k"]),
+                            K_hip=rel_err(Kb, g64[key + "/K"]),
+                            K_o32=rel_err(g[key + "/K"], g64[key + "/K"]),
+                            k_hip_o32=rel_err(kb, g[key + "/k"]),
+                            K_hip_o32=rel_err(Kb, g[key + "/K"]))
+                        STATS.append(row)
+                        assert _f32_ok(row["k_hip"], row["k_o32"],
+                                       branch in "CD"), row
+                        assert _f32_ok(row["K_hip"], row["K_o32"],
+                                       branch in "CD"), row
                     n_ok += 1
     assert n_ok >= 12
+    assert n_flip <= 2, n_flip  # of 48 (tag, branch, reg) cases
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -334,14 +410,18 @@ def test_full_size_batch_invariance(dtype):
     o = orc.load(np_dtype(dtype))
     k, K = s.gain_views()
     st = s.bwd_status.cpu().numpy()
-    for b in (0, 5, 777, 2049, 4095):
+    sample = np.random.RandomState(1).choice(B, 64, replace=False)
+    for b in [0, 4095] + sample.tolist():  # >= 64 oracle rows
         f = o.forward(op, z0[b], U[b], u_min, u_max)
         kr, Kr, sr = o.backward(f["F_z"], f["F_u"], f["L_z"], f["L_u"],
                                 f["L_zz"], f["L_uz"], f["L_uu"], reg=1.0,
                                 u_min=u_min, u_max=u_max, U=U[b])
         assert sr == st[b] == 0
-        assert rel_err(k[b].cpu().numpy(), kr) < TOL[dtype]
-        assert rel_err(K[b].cpu().numpy(), Kr) < TOL[dtype]
+        _check_gains(dtype, k[b].cpu().numpy(), K[b].cpu().numpy(), kr, Kr,
+                     [f[nm] for nm in ("F_z", "F_u", "L_z", "L_u", "L_zz",
+                                       "L_uz", "L_uu")],
+                     dict(reg=1.0, u_min=u_min, u_max=u_max, U=U[b]),
+                     test="full_size", b=b)
     # a few full rounds: J_opt is monotone non-increasing per trajectory
     s.reset_controller_state()
     J_prev = None
@@ -670,12 +750,15 @@ def test_backward_ragged_shapes(B, N, dtype, problem):
                     kw.update(u_min=u_min, u_max=u_max, U=U[b])
                 kr, Kr, sr = o.backward(f["F_z"], f["F_u"], f["L_z"], f["L_u"],
                                         f["L_zz"], f["L_uz"], f["L_uu"], **kw)
-                if dtype == "f32" and (sr == 0) != (st[b] == 0):
-                    continue
+                # (reg = 1: no knife-edge PD tests, fp32 statuses agree too)
                 assert (sr == 0) == (st[b] == 0), (variant, branch, bounded, b)
                 if sr == 0:
-                    assert rel_err(k[b].cpu().numpy(), kr) < TOL[dtype]
-                    assert rel_err(K[b].cpu().numpy(), Kr) < TOL[dtype]
+                    _check_gains(
+                        dtype, k[b].cpu().numpy(), K[b].cpu().numpy(), kr, Kr,
+                        [f[nm] for nm in ("F_z", "F_u", "L_z", "L_u", "L_zz",
+                                          "L_uz", "L_uu")], kw,
+                        test="ragged", problem=problem, variant=variant,
+                        branch=branch, bounded=bounded, B=B, N=N, b=b)
 
 
 ALL_ENCODINGS = ["FULL_COVARIANCE_MATRIX", "UPPER_TRIANGULAR_CHOLESKY",
@@ -785,8 +868,11 @@ def test_backward_large_state_vs_oracle(n, m, dtype):
                 kr, Kr, sr = o.backward(F_z[b], F_u[b], L_z[b], L_u[b],
                                         L_zz[b], L_uz[b], L_uu[b], **okw)
                 assert sr == 0 and int(st[b]) == 0, (V_zz_reg, bounded, reg, b)
-                assert rel_err(k[b].cpu().numpy(), kr) < TOL[dtype]
-                assert rel_err(K[b].cpu().numpy(), Kr) < TOL[dtype]
+                _check_gains(dtype, k[b].cpu().numpy(), K[b].cpu().numpy(), kr,
+                             Kr, [F_z[b], F_u[b], L_z[b], L_u[b], L_zz[b],
+                                  L_uz[b], L_uu[b]], okw, test="large_state",
+                             n=n, m=m, V_zz_reg=V_zz_reg, bounded=bounded,
+                             reg=reg, b=b)
 
 
 def test_graph_replay_equals_eager_rounds():
@@ -1159,46 +1245,128 @@ def test_qr_cost_native_derivatives_vs_autograd_path(problem):
                        rb[..., lay.o_Fz:lay.o_Fz + n * n])
 
 
-@pytest.mark.parametrize("dtype,variants", [("f64", (6, 8, 12)),
-                                            ("f32", (7, 9, 13, 15))])
-def test_sweep_variants_vs_oracle_many_trajectories(dtype, variants):
-    """Every n = 4 sweep kernel on 384 cartpole trajectories of the bench's
-    distribution (N = 100, bounds +-10, eig-clamp + BoxQP branch, two
-    regularisations) against the oracle, trajectory by trajectory: status and
-    gains.  fp32 compares where the oracle's own fp32 run succeeds; the sweep is
-    a 100-step recursion through a discontinuous BoxQP, so fp32 trajectories
-    whose clamped / free pattern flips under rounding are allowed for (counted,
-    bounded to a small share)."""
+def _dist(x):
+    x = np.asarray(x, np.float64)
+    return (float(np.median(x)), float(np.percentile(x, 99)), float(x.max()))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_sweep_variants_vs_oracle_many_trajectories(dtype):
+    """Every sweep kernel `auto` can select for n = 4 (and the A/B twins) on
+    384 cartpole trajectories of the bench's distribution (N = 100, bounds
+    +-10), all four gain branches, two regularisations, trajectory by
+    trajectory against the oracle: status and gains.
+
+    fp64: 1e-9 on every trajectory, statuses identical.
+
+    fp32 (what bench.py times: variant 13 = riccati_n4_pipe_kernel<float,
+    true> with v_rcp / v_sqrt; 9, 7, 15 for the other branches): the sweep is a
+    100-step recursion through a discontinuous BoxQP, so the yardstick is the
+    fp64 oracle and the reference point is what IEEE fp32 arithmetic in the
+    reference's operation order (the fp32 oracle) loses against it.  Asserted
+    per (variant, branch, reg): status flips and clamp-pattern flips against
+    the fp32 oracle <= 1 %; median and p99 of the relative error of k and K
+    against the fp64 oracle within 2x / 2.5x of the fp32 oracle's own; and on
+    the well-conditioned Cholesky branches the north star's absolute bar:
+    median <= 1e-5 on k, max <= 1e-5 on K.  Measured distributions:
+    profiles/r02_sweep_error_stats.json."""
     B, N = 384, 100
     s, op, z0, U, u_min, u_max = _setup("cartpole", dtype, B, N, seed=5)
     s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
     s.derivs(mask=s.fresh)
     o = orc.load(np_dtype(dtype))
+    o64 = orc.load(np.float64)
+    names = ("F_z", "F_u", "L_z", "L_u", "L_zz", "L_uz", "L_uu")
     fwd = [o.forward(op, z0[b], U[b], u_min, u_max) for b in range(B)]
-    for reg in (1e-3, 1.0):
-        ref = []
-        for b in range(B):
-            f = fwd[b]
-            ref.append(o.backward(f["F_z"], f["F_u"], f["L_z"], f["L_u"],
-                                  f["L_zz"], f["L_uz"], f["L_uu"], reg=reg,
-                                  u_min=u_min, u_max=u_max, U=U[b]))
-        regv = torch.full((B,), reg, dtype=torch.float64, device="cuda")
-        for variant in variants:
-            s.gains.zero_()
-            s.backward(reg=regv, variant=variant)
-            k, K = s.gain_views()
-            k, K = k.cpu().numpy(), K.cpu().numpy()
-            st = s.bwd_status.cpu().numpy()
-            off = 0
+    f64 = dtype == "f64"
+    plan = (  # branch, bounded, variants (f64 | f32)
+        (0, True, (6, 8, 12) if f64 else (2, 7, 9, 12, 13, 15)),
+        (1, True, (6, 8) if f64 else (7, 8, 9, 15)),
+        (0, False, (6,) if f64 else (6, 7, 15)),
+        (1, False, (6,) if f64 else (6, 7, 15)))
+    compared = 0
+    for branch, bounded, variants in plan:
+        for reg in (1e-3, 1.0):
+            kw = dict(reg=reg, V_zz_reg=bool(branch))
+            ref, ref64 = [], []
             for b in range(B):
-                kr, Kr, sr = ref[b]
-                if dtype == "f64":
-                    assert (sr == 0) == (st[b] == 0), (variant, reg, b)
-                if sr != 0 or st[b] != 0:
+                kwb = dict(kw)
+                if bounded:
+                    kwb.update(u_min=u_min, u_max=u_max, U=U[b])
+                args = [fwd[b][nm] for nm in names]
+                ref.append(o.backward(*args, **kwb))
+                ref64.append(ref[-1] if f64 else o64.backward(*args, **kwb))
+            good = [b for b in range(B)
+                    if ref[b][2] == 0 and ref64[b][2] == 0]
+            if not f64 and good:
+                base_k = _dist([rel_err(ref[b][0], ref64[b][0]) for b in good])
+                base_K = _dist([rel_err(ref[b][1], ref64[b][1]) for b in good])
+            regv = torch.full((B,), reg, dtype=torch.float64, device="cuda")
+            for variant in variants:
+                s.gains.zero_()
+                s.backward(reg=regv, branch=branch, bounded=bounded,
+                           variant=variant)
+                k, K = s.gain_views()
+                k, K = k.cpu().numpy(), K.cpu().numpy()
+                st = s.bwd_status.cpu().numpy()
+                ctx = (variant, branch, bounded, reg)
+                flips = sum((ref[b][2] == 0) != (st[b] == 0) for b in range(B))
+                if f64:
+                    assert flips == 0, ctx
+                    for b in good:
+                        e = max(rel_err(k[b], ref[b][0]),
+                                rel_err(K[b], ref[b][1]))
+                        assert e < TOL[dtype], (ctx, b, e)
+                    compared += len(good)
                     continue
-                e = max(rel_err(k[b], kr), rel_err(K[b], Kr))
-                if dtype == "f64":
-                    assert e < TOL[dtype], (variant, reg, b, e)
-                elif e >= TOL[dtype]:
-                    off += 1
-            assert off <= B // 20, (variant, reg, off)
+                assert flips <= B // 100, (ctx, flips)
+                ek, eK, pattern = [], [], 0
+                for b in good:
+                    if st[b] != 0:
+                        continue
+                    za = np.all(K[b] == 0, axis=(-1, -2))  # clamped steps
+                    zb = np.all(ref[b][1] == 0, axis=(-1, -2))
+                    if not np.array_equal(za, zb):
+                        pattern += 1
+                        continue
+                    ek.append(rel_err(k[b], ref64[b][0]))
+                    eK.append(rel_err(K[b], ref64[b][1]))
+                assert pattern <= B // 100, (ctx, pattern)
+                if not ek:
+                    continue
+                dk, dK = _dist(ek), _dist(eK)
+                STATS.append(dict(test="many_trajectories", variant=variant,
+                                  branch=branch, bounded=bounded, reg=reg,
+                                  n=len(ek), status_flips=int(flips),
+                                  pattern_flips=pattern, k_med_p99_max=dk,
+                                  K_med_p99_max=dK, o32_k_med_p99_max=base_k,
+                                  o32_K_med_p99_max=base_K))
+                for got, base in ((dk, base_k), (dK, base_K)):
+                    assert got[0] <= 2.0 * base[0] + 1e-7, (ctx, got, base)
+                    assert got[1] <= 2.5 * base[1] + 1e-6, (ctx, got, base)
+                if branch == 1 and reg == 1.0:
+                    assert dk[0] <= 1e-5 and dK[2] <= 1e-5, (ctx, dk, dK)
+                compared += len(ek)
+    assert compared >= 4 * B
+
+
+def test_bench_two_ranks_over_rccl():
+    """`python bench.py --gpus 2` starts two ranks itself and runs the RCCL
+    exchange inside the timed region; needs two GPUs."""
+    import json
+    import os
+    import subprocess
+    import sys
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (the driver's multi-GPU box)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run(
+        [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+         "--steps", "5", "--warmup", "2", "--repeats", "2", "--batch", "512",
+         "--no-cpu-baseline", "--no-points"], env=env, capture_output=True,
+        text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2

@@ -204,6 +204,23 @@ def test_best_rollout_all_gather_two_ranks(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+def test_bench_gpus_flag_is_honoured():
+    """`bench.py --gpus N` never silently runs another world size: a torchrun
+    environment of a different size, or fewer visible devices than asked,
+    exits non-zero before anything touches the GPU."""
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "WORLD_SIZE" in out.stderr
+    if torch.cuda.device_count() < 2:
+        env = {k: v for k, v in os.environ.items()
+               if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        out = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 2 and "device(s) visible" in out.stderr
+
+
 def test_best_rollout_single_process():
     from pddp_amd.parallel import gather_best_rollout
     J = torch.tensor([3.0, float("inf"), 1.5])
