@@ -376,13 +376,10 @@ def bench_mpc_bnn(args):
              1e-2 * torch.randn(B, 4, generator=g)).to(dev)
         rounds = [0]
 
-        def on_iteration(*a):
-            rounds[0] += 1
-
         def control_step(x):
             z = torch.cat([x, tri.expand(B, -1)], -1)
-            u = ctrl(z, 0, enc, mpc=True, u_min=u_min, u_max=u_max,
-                     on_iteration=on_iteration)
+            u = ctrl(z, 0, enc, mpc=True, u_min=u_min, u_max=u_max)
+            rounds[0] += ctrl._last_rounds
             with torch.no_grad():
                 return plant(x, u.clamp(-10.0, 10.0), 0, ienc)
 

@@ -144,6 +144,14 @@ int pddp_pack_records_f64(int B, int N, int n, int m, const double* F_z,
                           const double* L_uz, const double* L_uu,
                           const double* U, double* rec, void* stream);
 
+/* Trajectory cost J[b] = sum_t L[b][t] (ilqr.py:484 `L.sum()`), summed in t
+ * order by one lane per trajectory: the result does not depend on the
+ * trajectory's position in the batch.  L [B][count], J [B]. */
+int pddp_sum_stage_costs_f32(int B, int count, const float* L, float* J,
+                             void* stream);
+int pddp_sum_stage_costs_f64(int B, int count, const double* L, double* J,
+                             void* stream);
+
 /* ---- ilqr.py:393-486 forward(): derivative rollout for the sample
  * problems (analytic; replaces utils/evaluation.py:134-288 autograd) ------ */
 /* Nominal rollout Z[b][0] = z0[b], Z[b][t+1] = model(Z[b][t], clamp(U[b][t]))

@@ -101,6 +101,7 @@ class iLQRController(Controller):
         self._K = None
         self._solver = None
         self._batched = False
+        self._last_rounds = 0  # rounds of the last fit / MPC step
 
     # -- solver plumbing ------------------------------------------------------
     def _get_solver(self, B, N, n, dtype, device, encoding, u_min, u_max,
@@ -118,6 +119,7 @@ class iLQRController(Controller):
                              self._cost_opts, self._force_plugin,
                              self._kernel_variant, self._exact)
             s._key = key
+            s.graph_rollout = bool(self._graph)
             self._solver = s
         return s
 
@@ -154,8 +156,8 @@ class iLQRController(Controller):
                     it -= 1  # the counter already points at the next step()
                 on_iteration(it, st, s.Z[0].clone(), s.U[0].clone(),
                              s.J_opt[0].clone())
-        s.fit(n_iterations, tol, max_reg, on_round,
-              graph=self._graph and s.plugin is None)
+        self._last_rounds = s.fit(n_iterations, tol, max_reg, on_round,
+                                  graph=self._graph and s.graph_ok())
 
     # -- reference API ----------------------------------------------------------
     def fit(self, U, encoding=StateEncoding.DEFAULT, n_iterations=50, tol=5e-6,

@@ -102,9 +102,20 @@ class TorchProblem(object):
         J = J.reshape(B, n, n + m)
         return J[:, :, :n], J[:, :, n:]
 
-    def derivs(self, s, mask=None, set_state=True):
-        """Fills s.rec, s.L, s.J_opt (and resets s.state) for masked rows."""
-        if mask is not None and not bool(mask.any()):
+    @torch.no_grad()
+    def capture_ok(self, s):
+        """True when a whole round is HIP launches and sync-free torch ops
+        (native BNN rollout, forward-mode Jacobians, hyper-dual cost
+        derivatives): the round can then be captured into hipGraphs
+        (ILQRSolver.capture_round)."""
+        return (self._bnn_native_ok(s) and self._bnn_jvp_ok(s)
+                and self._qr_cost_native_ok(s))
+
+    def derivs(self, s, mask=None, set_state=True, in_graph=False):
+        """Fills s.rec, s.L, s.J_opt (and resets s.state) for masked rows.
+        `in_graph`: no host synchronisation at all (stream capture): the
+        caller knows some nominal is fresh; rows are blended by the mask."""
+        if not in_graph and mask is not None and not bool(mask.any()):
             # a round of retries only (ilqr.py:125-139 with a larger mu): every
             # nominal is unchanged, so are its records.  One host sync, against
             # a derivative rollout of the whole batch.
@@ -155,20 +166,23 @@ class TorchProblem(object):
         _native.call("pddp_pack_records", s.dtype, B, N, n, m, p(F_z), p(F_u),
                      p(L_z), p(L_u), p(L_zz), p(L_uz), p(L_uu),
                      p(s.U.contiguous()), p(rec), s._s())
-        J = L.sum(-1)
+        J = torch.empty(B, **opts)  # L.sum() (ilqr.py:484), in t order
+        _native.call("pddp_sum_stage_costs", s.dtype, B, N + 1, p(L), p(J),
+                     s._s())
         if mask is None:
             s.rec.copy_(rec)
             s.L.copy_(L)
             s.J_opt.copy_(J)
             if set_state:
                 s.state.zero_()
-        else:
+        else:  # (torch.where: no nonzero(), so no host sync)
             sel = mask.bool()
-            s.rec[sel] = rec[sel]
-            s.L[sel] = L[sel]
-            s.J_opt[sel] = J[sel]
+            s.rec.copy_(torch.where(sel.view(B, 1, 1), rec, s.rec))
+            s.L.copy_(torch.where(sel.view(B, 1), L, s.L))
+            s.J_opt.copy_(torch.where(sel, J, s.J_opt))
             if set_state:
-                s.state[sel] = 0
+                s.state.copy_(torch.where(sel, torch.zeros_like(s.state),
+                                          s.state))
 
     # -- fused BNN rollout: csrc/bnn_rollout.hip + csrc/bnn_mlp.hip -------------
     def _qr_cost_native_ok(self, s):

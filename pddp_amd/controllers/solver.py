@@ -112,7 +112,9 @@ class ILQRSolver(object):
         # attempt" since the last reset (bench.py's unit accounting; the fit
         # loop itself looks at `active`)
         self.n_live = torch.zeros(256, **i32)
-        self._graph = None  # (key, torch.cuda.CUDAGraph) of one round
+        self._graph = None  # (key, graph of a round [, round without derivs])
+        self._rollout_graph = None
+        self.graph_rollout = False  # nominal rollout of a plugin as a hipGraph
         self._fused = None  # None: untried, True / False: fused kernel applies
         self._derivs_due = True
         self._pp = None if problem is None else ctypes.addressof(problem)
@@ -178,6 +180,18 @@ class ILQRSolver(object):
     @_on_device
     def nominal_rollout(self, mask=None):
         if self.plugin is not None:
+            if self.graph_rollout and self.plugin.capture_ok(self):
+                # the N + 1 moment-step / network launch pairs of the nominal
+                # rollout as one hipGraph (z0, U, Z are solver-owned buffers)
+                if self._rollout_graph is None:
+                    self.plugin.rollout(self)  # warm: caches, attributes
+                    torch.cuda.synchronize(self.device)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self.plugin.rollout(self)
+                    self._rollout_graph = g
+                self._rollout_graph.replay()
+                return
             return self.plugin.rollout(self)
         p = _native.ptr
         _native.call("pddp_nominal_rollout", self.dtype, self._pp, self.B,
@@ -185,9 +199,9 @@ class ILQRSolver(object):
                      p(self.u_max), p(mask), p(self.Z), self._s())
 
     @_on_device
-    def derivs(self, mask=None, set_state=True):
+    def derivs(self, mask=None, set_state=True, in_graph=False):
         if self.plugin is not None:
-            return self.plugin.derivs(self, mask, set_state)
+            return self.plugin.derivs(self, mask, set_state, in_graph)
         p = _native.ptr
         _native.call("pddp_derivs", self.dtype, self._pp, self.B, self.N,
                      p(self.Z), p(self.U), p(self.u_min), p(self.u_max),
@@ -276,33 +290,74 @@ class ILQRSolver(object):
             self.line_search(active=self.active)
             self.accept(tol, max_reg, n_iterations)
 
+    def graph_ok(self):
+        """A round can be captured: native sample problem, or a plugin whose
+        round is all HIP launches and sync-free torch ops (the BNN path)."""
+        return self.plugin is None or self.plugin.capture_ok(self)
+
+    _STATE = ("Z", "U", "rec", "L", "J_opt", "gains", "gains_acc", "Jc",
+              "bwd_status", "state", "iter", "mu", "delta", "active", "fresh",
+              "n_live")
+
     @_on_device
     def capture_round(self, tol=5e-6, max_reg=1e10, n_iterations=50):
-        """Captures round() - five kernel launches and a memset, all on
-        device-resident state - into a hipGraph; `replay_round()` then issues
-        it with one launch.  For the launch-bound regime: small batches and
-        the receding-horizon loop (BASELINE.json configs[4])."""
-        if self.plugin is not None:
+        """Captures round() - a fixed launch sequence on device-resident state
+        - into a hipGraph; `replay_round()` then issues it with one launch.
+        For the launch-bound regime: small batches and the receding-horizon
+        loop (BASELINE.json configs[4]).
+
+        Native sample problems: one graph (the masked records launch is part
+        of it).  Plugin (BNN) rounds: two graphs sharing one memory pool - the
+        round with the derivative rollout (every record recomputed, rows
+        blended by the `fresh` mask) and the round of retries only (ilqr.py
+        :125-139 with a larger mu: nominals, hence records, unchanged); fit()
+        picks one per round from the counts it reads back anyway."""
+        if not self.graph_ok():
             raise _native.NativeError(
-                "graph capture needs the native problem kernels; plugin "
-                "models run autograd inside a round")
+                "graph capture needs a round without host synchronisation: "
+                "this plugin runs autograd / torch fallbacks inside a round")
         key = (float(tol), float(max_reg), int(n_iterations),
                self.kernel_variant)
         if self._graph is not None and self._graph[0] == key:
             return self._graph[1]
         torch.cuda.synchronize(self.device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            # the masked records launch is always part of the graph (a no-op
-            # when no nominal is fresh): a replay after set_nominal() must not
-            # sweep the previous nominal's records
-            self.round(tol, max_reg, n_iterations, always_derivs=True)
-        self._graph = (key, graph)
-        return graph
+        if self.plugin is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                # the masked records launch is always part of the graph (a
+                # no-op when no nominal is fresh): a replay after
+                # set_nominal() must not sweep the previous nominal's records
+                self.round(tol, max_reg, n_iterations, always_derivs=True)
+            self._graph = (key, graph, None)
+            return graph
+        # warm-up outside the capture (noise caches, masks, per-kernel
+        # attributes, allocator) on a snapshot of the solver's state
+        snap = {k: getattr(self, k).clone() for k in self._STATE}
+        self._plugin_round(tol, max_reg, n_iterations, True, False)
+        for k, v in snap.items():
+            getattr(self, k).copy_(v)
+        torch.cuda.synchronize(self.device)
+        g_full = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_full):
+            self._plugin_round(tol, max_reg, n_iterations, True, True)
+        g_retry = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_retry, pool=g_full.pool()):
+            self._plugin_round(tol, max_reg, n_iterations, False, True)
+        self._graph = (key, g_full, g_retry)
+        return g_full
+
+    def _plugin_round(self, tol, max_reg, n_iterations, with_derivs, in_graph):
+        if with_derivs:
+            self.derivs(mask=self.fresh, in_graph=in_graph)
+        self.backward(active=self.active, variant=self.kernel_variant)
+        self.line_search(active=self.active)
+        self.accept(tol, max_reg, n_iterations)
 
     @_on_device
-    def replay_round(self):
-        self._graph[1].replay()
+    def replay_round(self, with_derivs=True):
+        g = self._graph[1] if (with_derivs or self._graph[2] is None) \
+            else self._graph[2]
+        g.replay()
 
     def fit(self, n_iterations=50, tol=5e-6, max_reg=1e10, on_round=None,
             max_rounds=None, graph=False, rounds_per_sync=1):
@@ -313,10 +368,13 @@ class ILQRSolver(object):
         on the device, so the result does not depend on it)."""
         if graph:
             self.capture_round(tol, max_reg, n_iterations)
+            if self.plugin is not None:
+                rounds_per_sync = 1  # which graph comes next is read back
         rounds = 0
+        need_derivs = True
         while True:
             if graph:
-                self.replay_round()
+                self.replay_round(need_derivs)
             else:
                 self.round(tol, max_reg, n_iterations)
             rounds += 1
@@ -326,6 +384,11 @@ class ILQRSolver(object):
                 break
             if rounds % rounds_per_sync:
                 continue
-            if int(self.active.sum().item()) == 0:  # the one host sync
+            # the one host sync: live trajectories, and (plugin graphs) whether
+            # any nominal changed
+            live, fresh = torch.stack([self.active.sum(),
+                                       self.fresh.sum()]).tolist()
+            need_derivs = fresh > 0
+            if live == 0:
                 break
         return rounds

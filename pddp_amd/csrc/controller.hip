@@ -143,6 +143,29 @@ static int pack_impl(int B, int N, int n, int m, const T* F_z, const T* F_u,
   return launch_status();
 }
 
+// J[b] = L[b][0] + ... + L[b][count-1] in index order: the trajectory cost of
+// ilqr.py:484 (`L.sum()`) with a summation order that does not depend on the
+// trajectory's position in the batch (a library row reduction does not
+// promise that; duplicated trajectories must stay bit-identical)
+template <typename T>
+__global__ __launch_bounds__(256) void row_sum_kernel(int B, int count,
+                                                      const T* L, T* J) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const T* row = L + (size_t)b * count;
+  T acc = T(0);
+  for (int t = 0; t < count; ++t) acc += row[t];
+  J[b] = acc;
+}
+
+template <typename T>
+static int row_sum_impl(int B, int count, const T* L, T* J, void* stream) {
+  if (B <= 0 || count <= 0 || !L || !J) return PDDP_E_BADARG;
+  PDDP_LAUNCH((row_sum_kernel<T>), dim3((B + 255) / 256), dim3(256), 0,
+              (hipStream_t)stream, B, count, L, J);
+  return launch_status();
+}
+
 }  // namespace pddp
 
 extern "C" {
@@ -215,6 +238,15 @@ int pddp_pack_records_f64(int B, int N, int n, int m, const double* F_z,
                           const double* U, double* rec, void* stream) {
   return pddp::pack_impl<double>(B, N, n, m, F_z, F_u, L_z, L_u, L_zz, L_uz,
                                  L_uu, U, rec, stream);
+}
+
+int pddp_sum_stage_costs_f32(int B, int count, const float* L, float* J,
+                             void* stream) {
+  return pddp::row_sum_impl<float>(B, count, L, J, stream);
+}
+int pddp_sum_stage_costs_f64(int B, int count, const double* L, double* J,
+                             void* stream) {
+  return pddp::row_sum_impl<double>(B, count, L, J, stream);
 }
 
 int pddp_event_create(void** ev) {

@@ -112,3 +112,31 @@ def test_bnn_fit_reduces_loss_and_keeps_api():
     model.resample()
     assert model.eps_in == {} and model.output == {}
     assert all(d.noise is None for d in model.model.drops)
+
+
+def test_bnn_real_size_rollout_matches_reference_f64():
+    """The torch model at [200, 200] x 100 particles, float64 on the CPU,
+    against the reference's float64 rollout with the same weights and noise
+    (tests/golden/bnn_cartpole_real_size.npz; the HIP kernels are held to the
+    same fixture in test_gpu_parity)."""
+    from pddp_amd import StateEncoding
+    from pddp_amd.examples.cartpole import CartpoleDynamicsModel as CM
+    from pddp_amd.models.bnn import (bnn_dynamics_model_factory,
+                                     load_reference_state)
+    g = np.load(os.path.join(GOLDEN_DIR, "bnn_cartpole_real_size.npz"))
+    P, H = int(g["P"]), int(g["H"])
+    model = bnn_dynamics_model_factory(
+        4, 1, [H, H], CM.angular_indices, CM.non_angular_indices)(
+            n_particles=P).double().eval()
+    load_reference_state(model, {k[len("state/"):]: g[k] for k in g.files
+                                 if k.startswith("state/")})
+    for r in range(g["z0"].shape[0]):
+        model.output = {}
+        z = torch.from_numpy(g["z0"][r]).double()
+        U = torch.from_numpy(g["U"][r]).double()
+        ref = g["f64/%d/fwd/Z" % r]
+        for i in range(U.shape[0]):
+            z = model(z, U[i].clamp(-10.0, 10.0), i, StateEncoding.DEFAULT,
+                      **OPTS).detach()
+            assert np.allclose(z.numpy(), ref[i + 1], rtol=1e-8,
+                               atol=1e-10), (r, i)

@@ -1370,3 +1370,317 @@ def test_bench_two_ranks_over_rccl():
     assert out.returncode == 0, out.stdout + out.stderr
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2
+
+
+def _bnn_real_size_run():
+    """Runs the HIP BNN path (native nominal rollout, forward-mode Jacobians,
+    hyper-dual cost derivatives, moment-step line search around the fused
+    network kernel) on the inputs of tests/golden/bnn_cartpole_real_size.npz and
+    returns rows {what, r, hip_vs_f64, hip_vs_f32, ref32_vs_f64}."""
+    import os
+    import pddp_amd
+    from golden_util import GOLDEN_DIR
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.examples import cartpole
+    from pddp_amd.models.bnn import (bnn_dynamics_model_factory,
+                                     load_reference_state)
+    g = np.load(os.path.join(GOLDEN_DIR, "bnn_cartpole_real_size.npz"))
+    CM = cartpole.CartpoleDynamicsModel
+    P, H, N = int(g["P"]), int(g["H"]), int(g["N"])
+    model = bnn_dynamics_model_factory(
+        4, 1, [H, H], CM.angular_indices, CM.non_angular_indices)(
+            n_particles=P).float().eval()
+    load_reference_state(model, {k[len("state/"):]: g[k] for k in g.files
+                                 if k.startswith("state/")})
+    model = model.cuda()
+    model.eps_in = {k: v.cuda() for k, v in model.eps_in.items()}
+    for d in model.model.drops:
+        d.noise = d.noise.cuda()
+    cost = cartpole.CartpoleCost().cuda()
+    enc = pddp_amd.StateEncoding.DEFAULT
+    opts = {"use_predicted_std": False, "infer_noise_variables": True}
+    plugin = TorchProblem(model, cost, enc, opts, {})
+    R = g["z0"].shape[0]
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().cuda()
+    s = ILQRSolver(None, R, N, torch.float32, "cuda", cu(g["u_min"]),
+                   cu(g["u_max"]), cu(g["alphas"]), plugin=plugin, n=14, m=1)
+    s.set_nominal(cu(g["z0"]), cu(g["U"]))  # native nominal rollout
+    s.derivs()
+    path = dict(plugin.last_derivs_path)
+    views = dict(zip(("F_z", "F_u", "L_z", "L_u", "L_zz", "L_uz", "L_uu"),
+                     s.record_views()))
+    views["Z"], views["L"] = s.Z, s.L
+    rows = []
+
+    def add(what, r, got, key):
+        a32, a64 = g["f32/%d/%s" % (r, key)], g["f64/%d/%s" % (r, key)]
+        rows.append(dict(what=what, r=r, hip_vs_f64=rel_err(got, a64),
+                         hip_vs_f32=rel_err(got, a32),
+                         ref32_vs_f64=rel_err(a32, a64)))
+    for r in range(R):
+        for nm in ("Z", "F_z", "F_u", "L", "L_z", "L_u", "L_zz", "L_uu"):
+            add(nm, r, views[nm][r].cpu().numpy(), "fwd/" + nm)
+        assert float(views["L_uz"][r].abs().max()) == 0.0 == float(
+            np.abs(g["f64/%d/fwd/L_uz" % r]).max())
+    # the line search on the reference's own gains
+    for r in range(R):
+        s.gains[r, :, :1] = cu(g["f32/%d/k" % r])
+        s.gains[r, :, 1:] = cu(g["f32/%d/K" % r]).reshape(N, 14)
+        s.Z[r] = cu(g["f32/%d/fwd/Z" % r])
+    s.line_search(use_status=False)
+    Zc = s.Zc.permute(0, 1, 2, 3).cpu().numpy()  # [R][N+1][A][n]
+    Uc = s.Uc.cpu().numpy()
+    Jc = s.Jc.cpu().numpy()
+    for r in range(R):
+        add("Z_new", r, Zc[r], "ls/Z_new")
+        add("U_new", r, Uc[r], "ls/U_new")
+        add("J", r, Jc[r], "ls/J")
+    rows.append(dict(what="path", path=path))
+    return rows
+
+
+def test_bnn_hip_kernels_vs_reference_real_size():
+    """The HIP BNN kernels at the size configs[2] runs them ([200, 200] hidden,
+    100 particles, cartpole DEFAULT encoding n = 14, float32) DIRECTLY against
+    the reference's outputs (tests/golden/bnn_cartpole_real_size.npz: `forward`
+    ilqr.py:393-486 with modules.py:287-386 + evaluation.py:242-288,
+    `_control_law` / `_trajectory_cost` ilqr.py:678-791, captured in float32
+    and - same weights and noise cast up - float64):
+
+      * pddp_bnn_moment_step_f32 + pddp_bnn_mlp_f32: nominal rollout Z and the
+        10-candidate line search (Z_new, U_new, J) on the reference's gains;
+      * pddp_bnn_jvp_features / pddp_bnn_mlp_jvp / pddp_bnn_jvp_moments: F_z,
+        F_u; pddp_qr_cost_derivs_f32: L, L_z, L_u, L_zz, L_uu.
+
+    Bar: the north star's 1e-5 against the float64 reference for everything
+    (measured on the MI355X: Jacobians 1.3e-6 .. 4.9e-6 where the reference's
+    own float32 run is 3e-7 .. 2.9e-6 off; everything else <= 3e-7, held to
+    2e-6)."""
+    rows = _bnn_real_size_run()
+    assert rows[-1]["path"] == {"dynamics": "hip", "cost": "hip"}
+    seen = set()
+    for r in rows[:-1]:
+        tol = 1e-5 if r["what"] in ("F_z", "F_u") else 2e-6
+        assert r["hip_vs_f64"] <= tol, r
+        assert r["hip_vs_f32"] <= tol, r
+        seen.add(r["what"])
+    assert seen == {"Z", "F_z", "F_u", "L", "L_z", "L_u", "L_zz", "L_uu",
+                    "Z_new", "U_new", "J"}
+
+
+def _bnn_mpc_controller(B, N, graph, P=100, H=200, seed=0):
+    import pddp_amd
+    from pddp_amd.examples import cartpole
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    torch.manual_seed(seed)
+    CM = cartpole.CartpoleDynamicsModel
+    model = bnn_dynamics_model_factory(
+        4, 1, [H, H], CM.angular_indices, CM.non_angular_indices)(
+            n_particles=P).cuda().eval()
+    with torch.no_grad():  # untrained network: keep its dynamics gentle
+        model.model.out.weight.mul_(0.05)
+        model.model.out.bias.mul_(0.05)
+    cost = cartpole.CartpoleCost().cuda()
+    ctrl = pddp_amd.controllers.iLQRController(
+        None, model, cost, graph=graph,
+        model_opts={"use_predicted_std": False, "infer_noise_variables": True})
+    g = torch.Generator().manual_seed(seed + 1)
+    ctrl._U_nominal = (0.1 * torch.randn(B, N, 1, generator=g)).cuda()
+    x = (torch.tensor([0.0, 0.0, 3.14159, 0.0]) +
+         1e-2 * torch.randn(B, 4, generator=g)).cuda()
+    return ctrl, CM(0.1).cuda(), x
+
+
+def test_bnn_mpc_graph_replay_equals_eager():
+    """BASELINE.json configs[4] (shortened): the receding-horizon loop of
+    examples/mpc_animation.py:29-39 on the cartpole BNN ([200, 200], 100
+    particles, DEFAULT encoding), horizon 50, 256 restarts x 5 control steps,
+    `iLQRController.forward(mpc=True)` (ilqr.py:318-362).  With graph=True the
+    nominal rollout and every round (with / without the derivative rollout)
+    are hipGraph replays: actions, plans, gains and round counts must equal
+    the eager run bit for bit (same kernels, same order, same buffers);
+    duplicated restarts stay bit-identical; states stay finite."""
+    import pddp_amd
+    B, N, steps = 256, 50, 5
+    enc = pddp_amd.StateEncoding.DEFAULT
+    ienc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
+    iu = torch.triu_indices(4, 4)
+    tri = (0.1 * torch.eye(4))[iu[0], iu[1]].cuda()
+    u_min, u_max = torch.tensor([-10.0]), torch.tensor([10.0])
+    runs = {}
+    for graph in (False, True):
+        ctrl, plant, x = _bnn_mpc_controller(B, N, graph)
+        x[255], x[100] = x[0], x[7]          # duplicated restarts
+        ctrl._U_nominal[255] = ctrl._U_nominal[0]
+        ctrl._U_nominal[100] = ctrl._U_nominal[7]
+        us, rounds = [], []
+        for _ in range(steps):
+            z = torch.cat([x, tri.expand(B, -1)], -1)
+            u = ctrl(z, 0, enc, mpc=True, u_min=u_min, u_max=u_max)
+            rounds.append(ctrl._last_rounds)
+            us.append(u.clone())
+            with torch.no_grad():
+                x = plant(x, u.clamp(-10.0, 10.0), 0, ienc)
+        s = ctrl._solver
+        assert s.plugin.last_derivs_path == {"dynamics": "hip", "cost": "hip"}
+        assert (s._graph is not None) == graph
+        assert (s._rollout_graph is not None) == graph
+        runs[graph] = (torch.stack(us), rounds, ctrl._U_nominal.clone(),
+                       ctrl._K.clone(), x.clone())
+    (ue, re_, Ue, Ke, xe), (ug, rg, Ug, Kg, xg) = runs[False], runs[True]
+    assert re_ == rg, (re_, rg)
+    assert torch.equal(ue, ug) and torch.equal(Ue, Ug)
+    assert torch.equal(Ke, Kg) and torch.equal(xe, xg)
+    assert torch.isfinite(xe).all() and torch.isfinite(ue).all()
+    for a, b in ((0, 255), (7, 100)):
+        assert torch.equal(ue[:, a], ue[:, b]) and torch.equal(Ue[a], Ue[b])
+
+
+def _bnn_problem(problem, B, N, seed=0):
+    """The BNN workloads of bench.py (configs[2] / configs[3]'s problem):
+    [200, 200] hidden, 100 particles, DEFAULT encoding, float32, bounded."""
+    import pddp_amd
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    torch.manual_seed(0)
+    if problem == "cartpole":
+        from pddp_amd.examples import cartpole as ex
+        CM, cost_cls = ex.CartpoleDynamicsModel, ex.CartpoleCost
+        mean0, bound = [0.0, 0.0, 3.14159, 0.0], 10.0
+    else:
+        from pddp_amd.examples import double_cartpole as ex
+        CM, cost_cls = ex.DoubleCartpoleDynamicsModel, ex.DoubleCartpoleCost
+        mean0, bound = [0.0, 0.0, 3.14159, 0.0, 3.14159, 0.0], 20.0
+    D, m = CM.state_size, 1
+    n = D + D * (D + 1) // 2
+    model = bnn_dynamics_model_factory(
+        D, m, [200, 200], CM.angular_indices, CM.non_angular_indices)(
+            n_particles=100).cuda().eval()
+    with torch.no_grad():  # untrained weights: keep the dynamics gentle
+        model.model.out.weight.mul_(0.05)
+        model.model.out.bias.mul_(0.05)
+    cost = cost_cls().cuda()
+    enc = pddp_amd.StateEncoding.DEFAULT
+    opts = {"use_predicted_std": False, "infer_noise_variables": True}
+    g = torch.Generator().manual_seed(seed)
+    mean = torch.tensor(mean0)
+    z0 = torch.stack([pddp_amd.GaussianVariable(
+        mean + 1e-2 * torch.randn(D, generator=g),
+        var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).cuda()
+    U = (0.1 * torch.randn(B, N, m, generator=g)).cuda()
+
+    def solver(model_, cost_, rows, dtype):
+        plugin = TorchProblem(model_, cost_, enc, opts, {})
+        return ILQRSolver(None, rows, N, dtype, "cuda", torch.tensor([-bound]),
+                          torch.tensor([bound]), fit_alphas(dtype, "cuda"),
+                          plugin=plugin, n=n, m=m)
+    return model, cost, z0, U, solver
+
+
+def _float64_twin(model, cost):
+    """The same network, masks and particle noise, computed by the torch ops
+    of pddp_amd.models.bnn in float64 (that path is pinned to the reference's
+    goldens at 1e-9: test_bnn.py, test_bnn_ilqr_fit_vs_reference_golden)."""
+    import copy
+    m64 = copy.deepcopy(model).double()
+    m64.eps_in = {k: v.double() for k, v in model.eps_in.items()}
+    m64.output = {}
+    return m64, copy.deepcopy(cost).double()
+
+
+@pytest.mark.parametrize("problem,B,N", [("cartpole", 4096, 100),
+                                         ("double_cartpole", 1024, 150)])
+def test_full_size_bnn_round(problem, B, N):
+    """BASELINE.json configs[2] (cartpole BNN, B = 4096, N = 100) and one GPU's
+    shard of configs[3] (double-cartpole BNN - the reference has no GP -
+    B = 1024, N = 150, n = 27) at FULL size, one round of the fit loop on the
+    HIP path (native rollout, forward-mode Jacobians, hyper-dual cost
+    derivatives, matrix-core sweep, moment-step line search, accept):
+
+      1. duplicated trajectories are bit-identical (position / neighbour
+         independence) in records, gains, candidate costs and decisions;
+      2. 64 sampled trajectories re-run as a batch of 64 on the same kernels
+         give bit-identical records, gains and candidate costs;
+      3. the same 64 against the float64 torch path (autograd Jacobians,
+         evaluation.py:242-288 style; torch line search): nominal rollout and
+         derivative records, and the line search's costs under the HIP gains
+         - then the accept decision wherever the float64 margin between the
+         best two step sizes is not a rounding matter."""
+    model, cost, z0, U, solver = _bnn_problem(problem, B, N)
+    dup = [(0, B - 1), (17, B // 2), (1000 % B, 1001 % B)]
+    for a, b in dup:
+        z0[b], U[b] = z0[a], U[a]
+    s = solver(model, cost, B, torch.float32)
+    s.set_nominal(z0, U)
+    s.round(n_iterations=50)
+    torch.cuda.synchronize()
+    assert s.plugin.last_derivs_path == {"dynamics": "hip", "cost": "hip"}
+    assert int((s.bwd_status != 0).sum()) == 0
+    for a, b in dup:
+        for t in (s.rec, s.gains, s.Jc, s.J_opt, s.U, s.state, s.mu):
+            assert torch.equal(t[a], t[b]), (a, b)
+    assert torch.isfinite(s.Jc).all()
+    # ---- 2. the sample as its own small batch, same kernels
+    sample = np.random.RandomState(2).choice(B, 64, replace=False)
+    sample[:2] = (0, B - 1)
+    idx = torch.from_numpy(sample).cuda()
+    full = {k: getattr(s, k)[idx].clone()
+            for k in ("rec", "gains", "Jc", "Z", "J_opt", "state")}
+    full["Z0"] = z0[idx].clone()
+    rec_full = s.rec[idx].clone()
+    s2 = solver(model, cost, 64, torch.float32)
+    s2.set_nominal(z0[idx], U[idx])
+    Z_nom = s2.Z.clone()
+    s2.derivs(mask=s2.fresh)
+    rec_small = s2.rec.clone()
+    s2.backward(active=s2.active)
+    s2.line_search(active=s2.active)
+    # (the full batch's records were overwritten for accepted trajectories by
+    # nothing: plugin rounds re-derive at the NEXT round; rec is the one swept)
+    assert torch.equal(rec_small, rec_full)
+    assert torch.equal(s2.gains, full["gains"])
+    assert torch.equal(s2.Jc, full["Jc"])
+    # ---- 3. float64 torch path on the sample
+    m64, c64 = _float64_twin(model, cost)
+    s3 = solver(m64, c64, 64, torch.float64)
+    s3.set_nominal(z0[idx].double(), U[idx].double())
+    assert rel_err(Z_nom.cpu().numpy(), s3.Z.cpu().numpy()) < 2e-5
+    s3.derivs(mask=s3.fresh)
+    assert s3.plugin.last_derivs_path == {"dynamics": "autograd",
+                                          "cost": "autograd"}
+    lay, n, m = s3.lay, s3.n, s3.m
+    worst = {}
+    # each derivative as ONE matrix in (z | u): the Jacobian [F_z | F_u] (with
+    # the gentle random network |F_u| ~ 1e-3 |F_z|), the gradient, the Hessian
+    for name, blocks in (
+            ("F_zu", ((lay.o_Fz, n * n), (lay.o_Fu, n * m))),
+            ("L_zu", ((lay.o_Lz, n), (lay.o_Lu, m))),
+            ("L_zuzu", ((lay.o_Lzz, n * n), (lay.o_Luz, m * n),
+                        (lay.o_Luu, m * m)))):
+        a = np.concatenate([rec_small[..., o:o + c].cpu().numpy()
+                            for o, c in blocks], -1)
+        b = np.concatenate([s3.rec[..., o:o + c].cpu().numpy()
+                            for o, c in blocks], -1)
+        worst[name] = rel_err(a, b)
+        # measured on the MI355X: Jacobian 6.4e-5 / 6.5e-5 (at N = 8, against
+        # the reference itself: 5e-6 - a 100 / 150 step float32 rollout
+        # compounds it), gradient and Hessian of the cost 4e-7
+        assert worst[name] < (2e-4 if name == "F_zu" else 1e-5), (name, worst)
+    s3.gains.copy_(s2.gains.double())
+    s3.bwd_status.zero_()
+    s3.line_search(active=s3.active)
+    J32, J64 = s2.Jc.cpu().numpy(), s3.Jc.cpu().numpy()
+    assert rel_err(J32, J64) < 1e-5, rel_err(J32, J64)  # (measured: 3e-7)
+    # decisions: same best step size wherever float64 separates the two best
+    # candidates by more than the float32 error of J
+    srt = np.sort(J64, axis=1)
+    clear = (srt[:, 1] - srt[:, 0]) > 2e-5 * np.abs(srt[:, 0])
+    assert clear.sum() >= 16
+    assert np.array_equal(J32.argmin(1)[clear], J64.argmin(1)[clear])
+    STATS.append(dict(test="full_size_bnn_round", problem=problem, B=B, N=N,
+                      records_vs_float64=worst,
+                      J_vs_float64=rel_err(J32, J64),
+                      clear_decisions=int(clear.sum())))

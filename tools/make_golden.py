@@ -364,12 +364,125 @@ def capture_bnn():
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
 
 
+def capture_bnn_real_size():
+    """The BNN at the size BASELINE.json configs[2] runs it - hidden [200, 200],
+    100 particles, cartpole, DEFAULT encoding (n = 14) - through the reference's
+    own `forward` (ilqr.py:393-486: moment-matched nominal rollout,
+    batch_eval_dynamics Jacobians evaluation.py:242-288, cost derivatives),
+    `backward` (ilqr.py:529-674), `_control_law` + `_trajectory_cost`
+    (ilqr.py:678-791) in float32 (the reference's default dtype, what the HIP
+    BNN kernels compute in) AND in float64 with the very same weights, dropout
+    noise and particle noise cast up (the yardstick for fp32 error).  A few
+    trajectories, horizon 8."""
+    from pddp.models.bnn import bnn_dynamics_model_factory
+    from pddp.examples.cartpole import CartpoleDynamicsModel as CM
+    from pddp.examples.cartpole import CartpoleCost
+    torch.manual_seed(11)
+    P, D, m, H, N, R = 100, 4, 1, 200, 8, 3
+    enc = StateEncoding.DEFAULT
+    opts = {"use_predicted_std": False, "infer_noise_variables": True}
+    cls = bnn_dynamics_model_factory(D, m, [H, H], CM.angular_indices,
+                                     CM.non_angular_indices)
+    m32 = cls(n_particles=P).eval()
+    with torch.no_grad():  # untrained network: moderate dynamics
+        m32.model.fc_out.weight.mul_(0.1)
+        m32.model.fc_out.bias.mul_(0.1)
+    m32.X_mean.data = 0.1 * torch.randn(6)
+    m32.X_std.data = 0.5 + torch.rand(6)
+    m32.X_std_inv.data = m32.X_std.reciprocal()
+    m32.dX_mean.data = 0.05 * torch.randn(D)
+    m32.dX_std.data = 0.2 + 0.3 * torch.rand(D)
+    m32.dX_std_inv.data = m32.dX_std.reciprocal()
+    # inputs: R trajectories around the hanging-down start
+    z0s, Us = [], []
+    for r in range(R):
+        mean = torch.tensor([0.0, 0.0, math.pi, 0.0]) + 0.05 * torch.randn(D)
+        z0s.append(GaussianVariable(
+            mean, var=1e-2 * torch.ones(D)).encode(enc).detach())
+        Us.append(0.3 * torch.randn(N, m))
+    # one call draws the dropout masks and eps_in[0]; they are then reused
+    m32(z0s[0], Us[0][0], 0, enc, **opts)
+    m32.output = {}
+    store = {"P": np.array(P), "H": np.array(H), "N": np.array(N),
+             "z0": np.stack([np_(z) for z in z0s]),
+             "U": np.stack([np_(u) for u in Us]),
+             "alphas": np_(ALPHAS_FIT()), "u_min": np.array([-10.0]),
+             "u_max": np.array([10.0]), "reg": np.array(1.0)}
+    for name, mod in m32.model.named_children():
+        if hasattr(mod, "noise") and name.startswith("drop"):
+            store["state/%s.noise" % name] = np_(mod.noise)
+            store["state/%s.logit_p" % name] = np_(mod.logit_p)
+            store["state/%s.temperature" % name] = np_(mod.temperature)
+        if hasattr(mod, "weight"):
+            store["state/%s.weight" % name] = np_(mod.weight)
+            store["state/%s.bias" % name] = np_(mod.bias)
+    for nm in ("X_mean", "X_std", "X_std_inv", "dX_mean", "dX_std",
+               "dX_std_inv"):
+        store["state/" + nm] = np_(getattr(m32, nm))
+    store["state/eps_in/0"] = np_(m32.eps_in[0])
+    # the float64 twin: identical parameter and noise VALUES
+    m64 = cls(n_particles=P).double().eval()
+    with torch.no_grad():
+        for (n_a, p_a), (n_b, p_b) in zip(m32.named_parameters(),
+                                          m64.named_parameters()):
+            assert n_a == n_b
+            p_b.data = p_a.data.double()
+        for name, mod in m64.model.named_children():
+            if hasattr(mod, "noise") and name.startswith("drop"):
+                # same uniform draws; the concrete mask is recomputed from
+                # them in float64 (CDropout.forward only redraws when it has
+                # no mask of the right shape, modules.py:563-568)
+                mod.noise.data = getattr(m32.model, name).noise.data.double()
+                mod._update_concrete_noise(mod.noise)
+    for nm in ("X_mean", "X_std", "X_std_inv", "dX_mean", "dX_std",
+               "dX_std_inv"):
+        getattr(m64, nm).data = getattr(m32, nm).data.double()
+    m64.eps_in = {0: m32.eps_in[0].double()}
+    for tag, model, dt in (("f32", m32, torch.float32),
+                           ("f64", m64, torch.float64)):
+        cost = CartpoleCost().to(dt)
+        u_min = torch.tensor([-10.0], dtype=dt)
+        u_max = torch.tensor([10.0], dtype=dt)
+        for r in range(R):
+            model.output = {}
+            model.eps_in = {0: model.eps_in[0]}
+            z0, U = z0s[r].to(dt), Us[r].to(dt)
+            out = forward(z0, U.clone(), model, cost, enc, True, opts, {},
+                          u_min, u_max)
+            names = ("Z", "F_z", "F_u", "L", "L_z", "L_u", "L_zz", "L_uz",
+                     "L_uu")
+            for nm, t in zip(names, out):
+                store["%s/%d/fwd/%s" % (tag, r, nm)] = np_(t)
+            k, K = backward(*out, reg=1.0, u_min=u_min, u_max=u_max, U=U)
+            store["%s/%d/k" % (tag, r)] = np_(k)
+            store["%s/%d/K" % (tag, r)] = np_(K)
+            # the line search is fed the float32 run's gains in both dtypes:
+            # it is the rollout kernels that are being pinned, not the sweep
+            k_in = torch.from_numpy(store["f32/%d/k" % r]).to(dt)
+            K_in = torch.from_numpy(store["f32/%d/K" % r]).to(dt)
+            Z_in = torch.from_numpy(store["f32/%d/fwd/Z" % r]).to(dt)
+            alphas = ALPHAS_FIT().to(dt)
+            model.output = {}
+            Zn, Un = _control_law(model, Z_in, U, k_in, K_in, alphas, enc,
+                                  opts, u_min, u_max)
+            J = _trajectory_cost(cost, Zn, Un, enc, {})
+            store["%s/%d/ls/Z_new" % (tag, r)] = np_(Zn)
+            store["%s/%d/ls/U_new" % (tag, r)] = np_(Un)
+            store["%s/%d/ls/J" % (tag, r)] = np_(J)
+    path = os.path.join(OUT, "bnn_cartpole_real_size.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
     if "--bnn-only" in sys.argv:
         capture_bnn()
+        return
+    if "--bnn-real-size" in sys.argv:
+        capture_bnn_real_size()
         return
     if "--default-only" in sys.argv:
         capture_problem("cartpole", "default", torch.float64, [5, 25],
@@ -389,6 +502,7 @@ def main():
     capture_problem("cartpole", "default", torch.float64, [5, 25], with_fit=12)
     capture_problem("pendulum", "default", torch.float64, [5, 25], with_fit=12)
     capture_bnn()
+    capture_bnn_real_size()
 
 
 if __name__ == "__main__":
