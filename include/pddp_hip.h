@@ -97,10 +97,12 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  * 6 / 7 with every step split over two wavefronts (bounded problems only),
  * 10 / 11 = 6 / 7 in workgroups of four wavefronts, 12 / 13 = 8 / 9 with the
  * BoxQP chain decoupled from the value update (bounded eig-clamp branch only).
- * Auto: n=4/m=1 bounded f32, up to 16384 trajectories -> 13 (eig-clamp branch)
- * or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64).  14 / 15: the f32
- * matrix-core kernels for n <= 30, m = 1 (IEEE / approximate division; auto for
- * those shapes other than n = 4). */
+ * 16 / 17: four lanes per trajectory, sixteen trajectories per wavefront
+ * (IEEE / approximate division; all four branches; f32 and f64).
+ * Auto for n=4/m=1: f32 from 8192 trajectories on -> 17; bounded f32 below that
+ * -> 13 (eig-clamp branch) or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64).
+ * 14 / 15: the f32 matrix-core kernels for n <= 30, m = 1 (IEEE / approximate
+ * division; auto for those shapes other than n = 4). */
 int pddp_riccati_backward_variant_f32(int B, int N, int n, int m,
                                       const float* rec, const float* u_min,
                                       const float* u_max, const double* reg,

@@ -9,6 +9,16 @@
 
 namespace pddp {
 
+// riccati_quad.hip (its own translation unit: compiled without SLP pairing)
+int launch_n4_quad_f32(const RiccatiArgs<float>& a, hipStream_t st, bool fast);
+int launch_n4_quad_f64(const RiccatiArgs<double>& a, hipStream_t st, bool fast);
+static int launch_n4_quad(const RiccatiArgs<float>& a, hipStream_t st, bool f) {
+  return launch_n4_quad_f32(a, st, f);
+}
+static int launch_n4_quad(const RiccatiArgs<double>& a, hipStream_t st, bool f) {
+  return launch_n4_quad_f64(a, st, f);
+}
+
 template <typename T, int NMAX, int M>
 static int launch_generic(const RiccatiArgs<T>& a, hipStream_t st) {
   PDDP_LAUNCH((riccati_generic_kernel<T, NMAX, M>), dim3(a.B), dim3(kWave), 0,
@@ -57,8 +67,9 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          10 / 11 = 6 / 7 in workgroups of four wavefronts,
   //          12 / 13 = 8 / 9 with the BoxQP chain decoupled from the value
   //          update (riccati_n4_pipe.hpp; bounded eig-clamp branch only);
-  //          auto: bounded f32, up to 16384 trajectories -> 13 (eig-clamp
-  //          branch) or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64)
+  //          auto: f32 from 8192 trajectories on -> 17; bounded f32 below
+  //          that -> 13 (eig-clamp branch) or 9 (Cholesky branch); otherwise
+  //          7 (f32) / 6 (f64)
   //          14 / 15: the matrix-core kernels for n <= 30, m = 1, fp32
   //          (riccati_mfma16.hpp / riccati_mfma32.hpp; IEEE / approximate
   //          division) - auto for those shapes other than n = 4
@@ -74,9 +85,21 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
     }
   }
   if (variant >= 2 && !(n == 4 && m == 1)) return PDDP_E_UNSUPPORTED;
+  //          16 / 17: four lanes per trajectory, sixteen trajectories per
+  //          wavefront (riccati_n4_quad.hpp; IEEE / approximate division),
+  //          all four branches
+  if (variant == 16 || variant == 17)
+    return launch_n4_quad(a, st, variant == 17);
   if (variant < 0 || variant > 13 || variant == 4 || variant == 5)
     return PDDP_E_BADARG;
 
+  if (variant == 0 && n == 4 && m == 1 && sizeof(T) == 4 && B >= 8192) {
+    // large batches: four lanes per trajectory (riccati_n4_quad.hpp) - a
+    // third of the issue slots per trajectory-step of the kernels below; from
+    // 8192 trajectories on it is the fastest on every branch (measured:
+    // 64 / 66 / 86 us at B = 8192 / 12288 / 16384 against 69 / 90 / 131)
+    return launch_n4_quad(a, st, true);
+  }
   if (variant == 0 && n == 4 && m == 1 && u_min != nullptr && B <= 16384) {
     // latency-bound batches: the two-wavefront kernels
     // (f32 only: with f64 the one-wave line search that follows is placed

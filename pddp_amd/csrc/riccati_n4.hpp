@@ -208,6 +208,27 @@ PDDP_DEV int group_min(int m) {
   return min(m, dppi<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(m));
 }
 
+// the same two reductions over a group of GW lanes (16: a DPP row; 4: a quad)
+template <int GW>
+PDDP_DEV int gmin(int m) {
+  if constexpr (GW == 16) {
+    return group_min(m);
+  } else {
+    static_assert(GW == 4, "");
+    m = min(m, dppi<(2 | (3 << 2) | (0 << 4) | (1 << 6))>(m));
+    return min(m, dppi<(1 | (0 << 2) | (3 << 4) | (2 << 6))>(m));
+  }
+}
+template <int GW, typename T>
+PDDP_DEV T gsum(T x) {
+  if constexpr (GW == 16) {
+    return group_sum(x);
+  } else {
+    static_assert(GW == 4, "");
+    return sum_cols(opaque(x));
+  }
+}
+
 // Scalar BoxQP (m = 1): the reference's projected-Newton loop
 // (utils/constraint.py:150-266) with its exit codes and its possibly stale
 // `free` flag.  Every lane of the 16-lane group holds the same scalars.
@@ -224,7 +245,7 @@ PDDP_DEV int group_min(int m) {
 // (:212-228) happens exactly once, and the Newton point -potrs(c, U) is
 // loop-invariant.
 // `lstep0` = T(0.6^l) for this lane (l = lane % 16); later rounds read LDS.
-template <typename T, bool FAST>
+template <typename T, bool FAST, int GW = 16>
 struct BoxQp1 {
   static constexpr T kMinGrad = T(1e-8), kTol = T(1e-8), kArmijo = T(0.1);
   T Q, c, lo, hi;           // the problem
@@ -273,19 +294,19 @@ struct BoxQp1 {
   PDDP_DEV void tail(T lstep0, const T* ls_tail, int l) {
     int nsel = 0;
     if (__any(!found)) {
-      for (int nb = 0;; nb += 16) {
+      for (int nb = 0;; nb += GW) {
         const int n = nb + l;
-        const T st = (nb == 0) ? lstep0 : ls_tail[n];
+        const T st = (nb == 0) ? lstep0 : ls_tail[n < kLsSteps ? n : kLsSteps - 1];
         const T xn = clampq<FAST>(x + st * search, lo, hi);
         const T fn = obj(xn);
         const bool ok = !(div_<FAST>(fn - old_f, st * sdotg) < kArmijo) ||
                         (n >= kLs.n_fail);
-        const int m = group_min(ok ? n : 0x7fffffff);
+        const int m = gmin<GW>(ok ? n : 0x7fffffff);
         const bool hit = (m != 0x7fffffff) && !found;
         // broadcast the winner's (xn, fn): exactly one lane contributes, the
         // others add zeros, so the butterfly sums are exact
-        const T xw = group_sum((n == m) ? xn : T(0));
-        const T fw = group_sum((n == m) ? fn : T(0));
+        const T xw = gsum<GW>((n == m) ? xn : T(0));
+        const T fw = gsum<GW>((n == m) ? fn : T(0));
         xc = hit ? xw : xc;
         fc = hit ? fw : fc;
         nsel = hit ? m : nsel;
@@ -350,7 +371,7 @@ struct BoxQp1 {
   }
 
   PDDP_DEV int finish(T lstep0, const T* ls_tail, int lane) {
-    const int l = lane & 15;
+    const int l = lane & (GW - 1);
     tail(lstep0, ls_tail, l);
     for (int it = 1; it < 100; ++it) {
       if (!__any(result == 0)) break;
@@ -361,10 +382,10 @@ struct BoxQp1 {
   }
 };
 
-template <typename T, bool FAST>
+template <typename T, bool FAST, int GW = 16>
 PDDP_DEV int boxqp1(T x0, T Q, T c, T lo, T hi, T lstep0, const T* ls_tail,
                     int lane, T& x_out, T& U_out, bool& free_out) {
-  BoxQp1<T, FAST> qp;
+  BoxQp1<T, FAST, GW> qp;
   qp.begin(x0, Q, c, lo, hi);
   const int res = qp.finish(lstep0, ls_tail, lane);
   x_out = qp.x;
@@ -383,6 +404,9 @@ template <typename T, bool FAST>
 struct QpClosed {
   T x, U, inv;  // minimiser; sqrt(Q) (IEEE) or 1 / Q (FAST)
   bool free_, fail, slow;
+#ifdef PDDP_QP_STATS
+  int dbg;  // why: bit 0 done0, 1 Armijo / guard failed, 2 live on a bound, ...
+#endif
 
   // All flag logic below is written with the eager `&` / `|` on bools: with
   // `&&` / `||` the compiler builds exec-mask branches around the compares.
@@ -432,6 +456,11 @@ struct QpClosed {
     const bool live1 = !(conv | ncl1 | (abs_(g1) < kMinGrad));
     const T x2 = clampq<FAST>(x1 + (newton - x1), lo, hi);
     slow = !done0 & (!(pass0 | guard) | (live1 & on_bound1));
+#ifdef PDDP_QP_STATS
+    dbg = (done0 ? 1 : 0) | ((!done0 & !(pass0 | guard)) ? 2 : 0) |
+          ((!done0 & live1 & on_bound1) ? 4 : 0) | (on_bound1 ? 8 : 0) |
+          ((!done0 & !pass0 & guard) ? 16 : 0) | (!(sdotg < T(0)) ? 32 : 0);
+#endif
     x = done0 ? xs : (live1 ? x2 : x1);
     free_ = (done0 & !ncl0) | (!done0 & (conv | !ncl1));
   }
@@ -448,15 +477,15 @@ struct SlowQpOut {
   T x, U;
   int result_free;  // result * 2 + free
 };
-template <typename T, bool FAST>
+template <typename T, bool FAST, int GW = 16>
 __device__ __noinline__ SlowQpOut<T> boxqp1_outlined(T x0, T Q, T c, T lo,
                                                      T hi, T lstep0,
                                                      const T* ls_tail,
                                                      int lane) {
   SlowQpOut<T> o;
   bool fr;
-  const int res =
-      boxqp1<T, FAST>(x0, Q, c, lo, hi, lstep0, ls_tail, lane, o.x, o.U, fr);
+  const int res = boxqp1<T, FAST, GW>(x0, Q, c, lo, hi, lstep0, ls_tail, lane,
+                                      o.x, o.U, fr);
   o.result_free = res * 2 + (fr ? 1 : 0);
   return o;
 }

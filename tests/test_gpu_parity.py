@@ -151,7 +151,8 @@ def test_derivative_records_vs_oracle(problem, dtype):
         assert np.array_equal(got_U, U[b])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 12, 13, 14, 15])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 12, 13, 14, 15,
+                                     16, 17])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", PROBLEMS)
 def test_backward_vs_oracle(problem, dtype, variant):
@@ -165,9 +166,9 @@ def test_backward_vs_oracle(problem, dtype, variant):
             pytest.skip("variants 14 / 15 = fp32 matrix-core kernel, m = 1")
     elif variant >= 2 and problem != "cartpole":
         pytest.skip("variants >= 2 are the n=4/m=1 kernel")
-    if variant in (3, 7, 9, 13) and dtype != "f32":
-        pytest.skip("variants 3 / 7 / 9 / 13 = f32 kernels with approximate "
-                    "division")
+    if variant in (3, 7, 9, 13, 17) and dtype != "f32":
+        pytest.skip("variants 3 / 7 / 9 / 13 / 17 = f32 kernels with "
+                    "approximate division")
     B, N = 5, 40
     s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N)
     s.nominal_rollout()
@@ -177,7 +178,7 @@ def test_backward_vs_oracle(problem, dtype, variant):
     names = ("F_z", "F_u", "L_z", "L_u", "L_zz", "L_uz", "L_uu")
     checked = flips = cases = 0
     for branch, bounded in ((0, False), (0, True), (1, False), (1, True)):
-        if variant in (14, 15):
+        if variant in (14, 15, 16, 17):
             pass  # all four branches
         elif variant >= 8 and not bounded:
             continue
@@ -727,11 +728,11 @@ def test_backward_ragged_shapes(B, N, dtype, problem):
     active = torch.ones(B, dtype=torch.uint8, device="cuda")
     if B > 2:
         active[1] = 0
-    for variant in ((0, 1, 2, 8, 12) if problem == "cartpole" else (0, 1)):
+    for variant in ((0, 1, 2, 8, 12, 16) if problem == "cartpole" else (0, 1)):
         for branch, bounded in ((0, True), (0, False), (1, True), (1, False)):
-            if variant >= 8 and not bounded:
+            if variant in (8, 12) and not bounded:
                 continue
-            if variant >= 12 and branch != 0:
+            if variant == 12 and branch != 0:
                 continue
             regv = torch.full((B,), 1.0, dtype=torch.float64, device="cuda")
             s.gains.fill_(float("nan"))
@@ -1280,10 +1281,10 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
     fwd = [o.forward(op, z0[b], U[b], u_min, u_max) for b in range(B)]
     f64 = dtype == "f64"
     plan = (  # branch, bounded, variants (f64 | f32)
-        (0, True, (6, 8, 12) if f64 else (2, 7, 9, 12, 13, 15)),
-        (1, True, (6, 8) if f64 else (7, 8, 9, 15)),
-        (0, False, (6,) if f64 else (6, 7, 15)),
-        (1, False, (6,) if f64 else (6, 7, 15)))
+        (0, True, (6, 8, 12, 16) if f64 else (2, 7, 9, 12, 13, 15, 16, 17)),
+        (1, True, (6, 8, 16) if f64 else (7, 8, 9, 15, 16, 17)),
+        (0, False, (6, 16) if f64 else (6, 7, 15, 16, 17)),
+        (1, False, (6, 16) if f64 else (6, 7, 15, 16, 17)))
     compared = 0
     for branch, bounded, variants in plan:
         for reg in (1e-3, 1.0):
