@@ -98,7 +98,8 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  * 10 / 11 = 6 / 7 in workgroups of four wavefronts, 12 / 13 = 8 / 9 with the
  * BoxQP chain decoupled from the value update (bounded eig-clamp branch only).
  * 16 / 17: four lanes per trajectory, sixteen trajectories per wavefront
- * (IEEE / approximate division; all four branches; f32 and f64).
+ * (IEEE / approximate division; all four branches; f32 and f64); 18 = 16 with
+ * every BoxQP through the reference's loop (bounded branches).
  * Auto for n=4/m=1: f32 from 8192 trajectories on -> 17; bounded f32 below that
  * -> 13 (eig-clamp branch) or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64).
  * 14 / 15: the f32 matrix-core kernels for n <= 30, m = 1 (IEEE / approximate
@@ -129,6 +130,24 @@ int pddp_boxqp_m1_f64(int count, const double* x0, const double* Q,
                       const double* c, const double* lower,
                       const double* upper, double* x, int32_t* result,
                       uint8_t* free_mask, void* stream);
+
+/* ---- utils/constraint.py:150-266 boxqp() for m <= 4 action dimensions ------ */
+/* `count` independent QPs  min 0.5 x^T Q x + c^T x  s.t. lower <= x <= upper,
+ * warm-started at x0; the routine the generic sweep calls (csrc/gains.hpp),
+ * one lane per problem.  x0, c, lower, upper, x [count][m]; Q [count][m][m];
+ * result [count] (constraint.py:23-32); free_mask [count][m] (1 = free, the
+ * possibly stale set of constraint.py:191-204); Ufree [count][m][m] = upper
+ * Cholesky factor of the free block with identity rows / columns in place of
+ * the clamped dimensions (the reference returns the compacted block).
+ * PDDP_E_UNSUPPORTED for m > 4. */
+int pddp_boxqp_f32(int count, int m, const float* x0, const float* Q,
+                   const float* c, const float* lower, const float* upper,
+                   float* x, int32_t* result, float* Ufree,
+                   uint8_t* free_mask, void* stream);
+int pddp_boxqp_f64(int count, int m, const double* x0, const double* Q,
+                   const double* c, const double* lower, const double* upper,
+                   double* x, int32_t* result, double* Ufree,
+                   uint8_t* free_mask, void* stream);
 
 /* Packs reference-layout tensors (what ilqr.py:393-486 forward() returns,
  * with a leading batch axis) into records, for plugin models whose

@@ -263,8 +263,13 @@ _LIB = None
 
 
 def load(dtype=np.float64):
+    """PDDP_ORACLE_LIB=<path> loads another build of the same oracle (the
+    sanitizer build: `make -C oracle asan`, see tests/test_host_cpu.py)."""
     global _LIB
     if _LIB is None:
-        build()
-        _LIB = ctypes.CDLL(LIB_PATH)
+        path = os.environ.get("PDDP_ORACLE_LIB")
+        if not path:
+            build()
+            path = LIB_PATH
+        _LIB = ctypes.CDLL(path)
     return Oracle(_LIB, dtype)

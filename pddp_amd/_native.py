@@ -63,6 +63,7 @@ _SIGS = {
     "pddp_riccati_backward_timed": [c_int] * 4 + [_P] * 4 + [c_int] +
                                    [_P] * 4 + [c_int, _P, _P],
     "pddp_boxqp_m1": [c_int] + [_P] * 9,
+    "pddp_boxqp": [c_int, c_int] + [_P] * 10,
     "pddp_pack_records": [c_int] * 4 + [_P] * 10,
     "pddp_sum_stage_costs": [c_int, c_int, _P, _P, _P],
     "pddp_nominal_rollout": [_P, c_int, c_int] + [_P] * 7,
@@ -88,7 +89,7 @@ _SIGS = {
 }
 _TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
           "pddp_riccati_backward_timed",
-          "pddp_boxqp_m1", "pddp_pack_records", "pddp_sum_stage_costs",
+          "pddp_boxqp_m1", "pddp_boxqp", "pddp_pack_records", "pddp_sum_stage_costs",
           "pddp_nominal_rollout",
           "pddp_derivs",
           "pddp_line_search", "pddp_search_accept", "pddp_accept")

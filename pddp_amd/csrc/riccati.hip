@@ -10,13 +10,17 @@
 namespace pddp {
 
 // riccati_quad.hip (its own translation unit: compiled without SLP pairing)
-int launch_n4_quad_f32(const RiccatiArgs<float>& a, hipStream_t st, bool fast);
-int launch_n4_quad_f64(const RiccatiArgs<double>& a, hipStream_t st, bool fast);
-static int launch_n4_quad(const RiccatiArgs<float>& a, hipStream_t st, bool f) {
-  return launch_n4_quad_f32(a, st, f);
+int launch_n4_quad_f32(const RiccatiArgs<float>& a, hipStream_t st, bool fast,
+                       bool loop_always);
+int launch_n4_quad_f64(const RiccatiArgs<double>& a, hipStream_t st, bool fast,
+                       bool loop_always);
+static int launch_n4_quad(const RiccatiArgs<float>& a, hipStream_t st, bool f,
+                          bool loop_always = false) {
+  return launch_n4_quad_f32(a, st, f, loop_always);
 }
-static int launch_n4_quad(const RiccatiArgs<double>& a, hipStream_t st, bool f) {
-  return launch_n4_quad_f64(a, st, f);
+static int launch_n4_quad(const RiccatiArgs<double>& a, hipStream_t st, bool f,
+                          bool loop_always = false) {
+  return launch_n4_quad_f64(a, st, f, loop_always);
 }
 
 template <typename T, int NMAX, int M>
@@ -88,8 +92,11 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          16 / 17: four lanes per trajectory, sixteen trajectories per
   //          wavefront (riccati_n4_quad.hpp; IEEE / approximate division),
   //          all four branches
+  //          18: variant 16 with every BoxQP through the reference's loop
+  //          (bounded branches; the closed form's A/B twin)
   if (variant == 16 || variant == 17)
     return launch_n4_quad(a, st, variant == 17);
+  if (variant == 18) return launch_n4_quad(a, st, false, true);
   if (variant < 0 || variant > 13 || variant == 4 || variant == 5)
     return PDDP_E_BADARG;
 
@@ -134,9 +141,78 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   return PDDP_E_UNSUPPORTED;
 }
 
+// Stand-alone batched BoxQP for m <= 4 (utils/constraint.py:150-266): one lane
+// per problem, the routine of the generic sweep kernel (gains.hpp `boxqp`).
+template <typename T, int M>
+__global__ __launch_bounds__(kWave) void boxqp_kernel(
+    int count, const T* x0, const T* Q, const T* c, const T* lower,
+    const T* upper, T* x, int32_t* result, T* Ufree, uint8_t* free_mask) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= count) return;
+  T x0r[M], Qr[M * M], cr[M], lo[M], hi[M], xr[M], U[M * M];
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    x0r[i] = x0[(size_t)p * M + i];
+    cr[i] = c[(size_t)p * M + i];
+    lo[i] = lower[(size_t)p * M + i];
+    hi[i] = upper[(size_t)p * M + i];
+  }
+#pragma unroll
+  for (int i = 0; i < M * M; ++i) Qr[i] = Q[(size_t)p * M * M + i];
+  unsigned free_bits = 0u;
+  const int res = boxqp<T, M>(x0r, Qr, cr, lo, hi, xr, U, free_bits);
+#pragma unroll
+  for (int i = 0; i < M; ++i) {
+    x[(size_t)p * M + i] = xr[i];
+    free_mask[(size_t)p * M + i] = (free_bits >> i) & 1u;
+  }
+#pragma unroll
+  for (int i = 0; i < M * M; ++i) Ufree[(size_t)p * M * M + i] = U[i];
+  result[p] = res;
+}
+
+template <typename T>
+static int boxqp_impl(int count, int m, const T* x0, const T* Q, const T* c,
+                      const T* lower, const T* upper, T* x, int32_t* result,
+                      T* Ufree, uint8_t* free_mask, void* stream) {
+  if (count <= 0 || m <= 0 || !x0 || !Q || !c || !lower || !upper || !x ||
+      !result || !Ufree || !free_mask)
+    return PDDP_E_BADARG;
+  const dim3 grid((count + kWave - 1) / kWave), block(kWave);
+  hipStream_t st = (hipStream_t)stream;
+#define PDDP_BOXQP_CASE(M)                                                   \
+  case M:                                                                    \
+    PDDP_LAUNCH((boxqp_kernel<T, M>), grid, block, 0, st, count, x0, Q, c,   \
+                lower, upper, x, result, Ufree, free_mask);                  \
+    return launch_status();
+  switch (m) {
+    PDDP_BOXQP_CASE(1)
+    PDDP_BOXQP_CASE(2)
+    PDDP_BOXQP_CASE(3)
+    PDDP_BOXQP_CASE(4)
+  }
+#undef PDDP_BOXQP_CASE
+  return PDDP_E_UNSUPPORTED;
+}
+
 }  // namespace pddp
 
 extern "C" {
+
+int pddp_boxqp_f32(int count, int m, const float* x0, const float* Q,
+                   const float* c, const float* lower, const float* upper,
+                   float* x, int32_t* result, float* Ufree,
+                   uint8_t* free_mask, void* stream) {
+  return pddp::boxqp_impl<float>(count, m, x0, Q, c, lower, upper, x, result,
+                                 Ufree, free_mask, stream);
+}
+int pddp_boxqp_f64(int count, int m, const double* x0, const double* Q,
+                   const double* c, const double* lower, const double* upper,
+                   double* x, int32_t* result, double* Ufree,
+                   uint8_t* free_mask, void* stream) {
+  return pddp::boxqp_impl<double>(count, m, x0, Q, c, lower, upper, x, result,
+                                  Ufree, free_mask, stream);
+}
 
 #ifdef PDDP_PIPE_TIMING
 int pddp_debug_pipe_wait(unsigned long long* out, int reset) {

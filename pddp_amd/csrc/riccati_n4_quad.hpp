@@ -227,7 +227,10 @@ struct QuadGeom {
   static constexpr int SLOT = NI * GS;               // scalars per ring slot
 };
 
-template <typename T, bool CHOL, bool BOUNDED, bool FAST, int R, int WPB>
+// LOOP: every BoxQP through the reference's loop (boxqp1_wave) - the exact
+// A/B twin of the closed form, and the test vehicle of the fall-back.
+template <typename T, bool CHOL, bool BOUNDED, bool FAST, int R, int WPB,
+          bool LOOP = false>
 __global__ __launch_bounds__(kWave * WPB) void riccati_n4_quad_kernel(
     RiccatiArgs<T> a) {
   using G = QuadGeom<T>;
@@ -535,9 +538,10 @@ __global__ __launch_bounds__(kWave * WPB) void riccati_n4_quad_kernel(
     // run again with the loop's result.
     tail();
     if constexpr (BOUNDED) {
-      if (__builtin_expect(PDDP_Q4_SLOWTEST(qc.slow && alive), 0)) {
+      const bool slow = (LOOP || qc.slow) && alive;
+      if (__builtin_expect(PDDP_Q4_SLOWTEST(slow), 0)) {
         // one slow trajectory at a time on the whole wavefront (boxqp1_wave)
-        unsigned long long todo = __ballot(qc.slow && alive && q == 0);
+        unsigned long long todo = __ballot(slow && q == 0);
         const T lo_b = umin - w.Un, hi_b = umax - w.Un;
         while (todo != 0) {
           const int src = __builtin_ctzll(todo);
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(kWave * WPB) void riccati_n4_quad_kernel(
 // (one per SIMD of a CU by construction).
 template <typename T>
 static int launch_n4_quad(const RiccatiArgs<T>& a, hipStream_t st,
-                          bool fast_math) {
+                          bool fast_math, bool loop_always = false) {
   constexpr int R = 8;
   using G = n4q::QuadGeom<T>;
   const bool bounded = a.u_min != nullptr;
@@ -597,6 +601,18 @@ static int launch_n4_quad(const RiccatiArgs<T>& a, hipStream_t st,
   const size_t lds1 = (size_t)R * G::SLOT * sizeof(T);
   // (four f64 rings would not fit the CU's 160 KB of LDS)
   const bool four = waves > 256 && 4 * lds1 <= 150 * 1024;
+  if (loop_always) {  // IEEE, bounded, one wave per workgroup
+    if (!bounded) return PDDP_E_UNSUPPORTED;
+    auto k0 = n4q::riccati_n4_quad_kernel<T, false, true, false, R, 1, true>;
+    auto k1 = n4q::riccati_n4_quad_kernel<T, true, true, false, R, 1, true>;
+    auto kern = chol ? k1 : k0;
+    const hipError_t e = hipFuncSetAttribute(
+        (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+        (int)lds1);
+    if (e != hipSuccess) return (int)e;
+    PDDP_LAUNCH(kern, dim3(waves), dim3(kWave), lds1, st, a);
+    return launch_status();
+  }
 #define PDDP_Q4_LAUNCH(C, Bd, F)                                              \
   do {                                                                        \
     if (four) {                                                               \

@@ -8,12 +8,12 @@
 namespace pddp {
 
 int launch_n4_quad_f32(const RiccatiArgs<float>& a, hipStream_t st,
-                       bool fast_math) {
-  return launch_n4_quad<float>(a, st, fast_math);
+                       bool fast_math, bool loop_always) {
+  return launch_n4_quad<float>(a, st, fast_math, loop_always);
 }
 int launch_n4_quad_f64(const RiccatiArgs<double>& a, hipStream_t st,
-                       bool fast_math) {
-  return launch_n4_quad<double>(a, st, fast_math);
+                       bool fast_math, bool loop_always) {
+  return launch_n4_quad<double>(a, st, fast_math, loop_always);
 }
 
 }  // namespace pddp

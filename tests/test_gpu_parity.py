@@ -152,7 +152,7 @@ def test_derivative_records_vs_oracle(problem, dtype):
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 12, 13, 14, 15,
-                                     16, 17])
+                                     16, 17, 18])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", PROBLEMS)
 def test_backward_vs_oracle(problem, dtype, variant):
@@ -181,7 +181,7 @@ def test_backward_vs_oracle(problem, dtype, variant):
         if variant in (14, 15, 16, 17):
             pass  # all four branches
         elif variant >= 8 and not bounded:
-            continue
+            continue  # (18: the quad kernel with the BoxQP loop on every step)
         if variant in (12, 13) and branch != 0:
             continue  # the decoupled kernel is the eig-clamp + BoxQP branch
         for reg in (0.0, 1e-6, 1.0, 100.0):
@@ -474,6 +474,77 @@ def test_boxqp_m1_vs_oracle(dtype):
             n_exact += int(free[i] == fr[0])
     # the (possibly stale) free flag agrees except on float knife edges
     assert n_exact >= (n - 50 if dtype == "f64" else int(0.97 * n))
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_boxqp_vs_reference_golden_and_oracle(dtype):
+    """`pddp_amd.utils.constraint.boxqp` (constraint.py:150-266) as a callable
+    for D in {1, 2, 4}: the reference's own unit cases (tests/golden/boxqp.npz:
+    interior, at-bound, warm-started, indefinite) un-batched with the
+    reference's return tuple, then random batches against the oracle."""
+    import os
+    from golden_util import GOLDEN_DIR
+    from pddp_amd.utils.constraint import boxqp
+    nd, td = np_dtype(dtype), TDT[dtype]
+    g = np.load(os.path.join(GOLDEN_DIR, "boxqp.npz"))
+    cu = lambda a: torch.from_numpy(np.asarray(a, nd)).cuda()
+    dims = set()
+    for i in range(int(g["n_cases"])):
+        k = "case%d/" % i
+        if g[k + "Q"].dtype != nd:
+            continue  # (each case was captured in one dtype)
+        D = g[k + "x0"].shape[0]
+        dims.add(D)
+        x, result, Uf, free = boxqp(cu(g[k + "x0"]), cu(g[k + "Q"]),
+                                    cu(g[k + "c"]), cu(g[k + "lower"]),
+                                    cu(g[k + "upper"]))
+        assert x.dtype == td and isinstance(result, int)
+        rr = int(g[k + "result"])
+        if dtype == "f64":
+            assert result == rr, (i, result, rr)
+        else:
+            assert (result >= 1) == (rr >= 1), (i, result, rr)
+        if rr >= 1:
+            tol = 1e-9 if dtype == "f64" else 2e-4
+            assert rel_err(x.cpu().numpy(), g[k + "x"]) < tol, i
+            if dtype == "f64":
+                assert np.array_equal(free.cpu().numpy(), g[k + "free"]), i
+                nf = int(g[k + "free"].sum())
+                assert tuple(Uf.shape) == (nf, nf)
+    assert dims >= {1, 2, 4}
+    # random batches, D = 2, 3, 4, one lane per problem
+    o = orc.load(nd)
+    rng = np.random.RandomState(9)
+    for D in (2, 3, 4):
+        n = 600
+        A = rng.randn(n, D, D)
+        Q = A @ A.transpose(0, 2, 1) + 0.1 * np.eye(D)
+        Q[:20] -= 3.0 * np.eye(D)               # indefinite ones
+        c = rng.randn(n, D) * np.exp(rng.uniform(-2, 3, (n, 1)))
+        lo = -np.exp(rng.uniform(-2, 2, (n, D)))
+        hi = np.exp(rng.uniform(-2, 2, (n, D)))
+        x0 = rng.randn(n, D)
+        x0[20:60] = hi[20:60]                   # warm start on the bound
+        arrs = [a.astype(nd) for a in (x0, Q, c, lo, hi)]
+        x, result, U, free = boxqp(*[torch.from_numpy(a).cuda() for a in arrs])
+        assert x.shape == (n, D) and U.shape == (n, D, D)
+        x, result = x.cpu().numpy(), result.cpu().numpy()
+        free = free.cpu().numpy()
+        same_free = 0
+        for i in range(n):
+            xr, rr, _, fr = o.boxqp(*[a[i] for a in arrs])
+            if dtype == "f64":
+                assert result[i] == rr, (D, i, result[i], rr)
+            else:
+                assert (result[i] >= 1) == (rr >= 1), (D, i)
+            if rr >= 1:
+                tol = 1e-9 if dtype == "f64" else 2e-4
+                assert np.abs(x[i] - xr).max() <= tol * max(
+                    1.0, np.abs(xr).max()), (D, i)
+                same_free += int(np.array_equal(free[i], fr))
+            else:
+                same_free += 1
+        assert same_free >= (n if dtype == "f64" else int(0.97 * n))
 
 
 def test_mpc_steps_vs_oracle():
@@ -1281,8 +1352,9 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
     fwd = [o.forward(op, z0[b], U[b], u_min, u_max) for b in range(B)]
     f64 = dtype == "f64"
     plan = (  # branch, bounded, variants (f64 | f32)
-        (0, True, (6, 8, 12, 16) if f64 else (2, 7, 9, 12, 13, 15, 16, 17)),
-        (1, True, (6, 8, 16) if f64 else (7, 8, 9, 15, 16, 17)),
+        (0, True, (6, 8, 12, 16, 18) if f64 else
+         (2, 7, 9, 12, 13, 15, 16, 17, 18)),
+        (1, True, (6, 8, 16, 18) if f64 else (7, 8, 9, 15, 16, 17, 18)),
         (0, False, (6, 16) if f64 else (6, 7, 15, 16, 17)),
         (1, False, (6, 16) if f64 else (6, 7, 15, 16, 17)))
     compared = 0

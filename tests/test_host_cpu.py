@@ -204,6 +204,28 @@ def test_best_rollout_all_gather_two_ranks(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+def test_oracle_under_address_and_ub_sanitizers():
+    """SURVEY 5 (sanitizers run on the CPU side): the oracle's golden suite
+    re-run in a child interpreter against the -fsanitize=address,undefined
+    build of the same C restatement; any report aborts the child."""
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"],
+                          capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("no libasan in this toolchain")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"),
+                           "asan"])
+    lib = os.path.join(ROOT, "oracle", "_build", "libpddp_oracle_asan.so")
+    env = dict(os.environ, LD_PRELOAD=asan, PDDP_ORACLE_LIB=lib,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    out = subprocess.run(
+        [sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider",
+         os.path.join(ROOT, "tests", "test_oracle_golden.py")],
+        env=env, capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "passed" in out.stdout
+
+
 def test_bench_gpus_flag_is_honoured():
     """`bench.py --gpus N` never silently runs another world size: a torchrun
     environment of a different size, or fewer visible devices than asked,
