@@ -1757,3 +1757,39 @@ def test_full_size_bnn_round(problem, B, N):
                       records_vs_float64=worst,
                       J_vs_float64=rel_err(J32, J64),
                       clear_decisions=int(clear.sum())))
+
+
+@pytest.mark.parametrize("example", ["pendulum", "cartpole", "double_cartpole",
+                                     "experiment", "mpc_animation"])
+def test_headless_example_flows(example):
+    """The reference's example scripts (examples/pendulum.py, cartpole.py,
+    double_cartpole.py, experiment.py, mpc_animation.py) run headless through
+    pddp_amd
+    (tools/run_example.py: same objects and call sequences, plotting dropped):
+    one PDDP trial with a short iLQR / 10 receding-horizon control steps, a
+    valid terminal state, finite costs, the HIP derivative path."""
+    import os
+    import sys
+    from pddp_amd.controllers.ilqr import iLQRState
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import run_example
+    if example == "mpc_animation":
+        out = run_example.run_mpc_animation(steps=10)
+        assert out["actions"].shape == (10, 1)
+        assert torch.isfinite(out["actions"]).all()
+        assert (out["actions"].abs() <= 10.0).all()
+        assert all(p.shape == (26, 4) and torch.isfinite(p).all()
+                   for p in out["plans"])
+        assert torch.isfinite(out["final_state"]).all()
+        return
+    out = run_example.run_pddp(example, trials=1, iterations=3,
+                               train_iters=60, particles=100,
+                               problem="PENDULUM")
+    assert iLQRState(int(out["state"])) in list(iLQRState)
+    N = 25 if example == "experiment" else \
+        run_example.PDDP_FLOWS[example]["N"]
+    assert out["U"].shape[0] == N and out["Z"].shape[0] == N + 1
+    assert len(out["J_hist"]) >= 1 and np.all(np.isfinite(out["J_hist"]))
+    assert torch.isfinite(out["final_state"]).all()
+    assert out["derivs_path"] == {"dynamics": "hip", "cost": "hip"}
