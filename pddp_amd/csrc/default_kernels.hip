@@ -1,0 +1,572 @@
+// default_kernels.hip - the sample problems (cartpole, pendulum, double
+// cartpole) under StateEncoding.DEFAULT = UPPER_TRIANGULAR_CHOLESKY:
+// z = mean (D) | triu(upper Cholesky factor U of the covariance, U^T U = C),
+// n = D + D (D + 1) / 2 = 14 / 5 / 27.
+//
+//   dynamics   the example models step the MEAN with the closed-form
+//              accelerations and carry the input VARIANCE unchanged,
+//              re-encoded as a diagonal covariance:
+//              z' = encode(f(mean, u), V = diag(U^T U))
+//              (pddp/examples/cartpole/model.py:108,141, pendulum/model.py
+//              :84-119, double_cartpole/model.py:100-195), where encode()
+//              takes the jittered Cholesky of diag(V)
+//              (utils/encoding.py:99-141,536-564): chol'_ii = sqrt(V_i + 1e-12)
+//   cost       QRCost on the moment-matched angle augmentation of (mean, C)
+//              (pddp/costs/quadratic.py:60-99, examples/*/cost.py,
+//              utils/angular.py:47-84,161-248)
+//
+// Three kernels behind the ordinary problem entry points
+// (pddp_nominal_rollout_*, pddp_derivs_*, pddp_line_search_*), selected by
+// pddp_problem.encoding:
+//   nominal rollout  one lane per trajectory (ilqr.py:457-468)
+//   records          one 64-lane workgroup per (trajectory, step): the cost's
+//                    value / gradient / Hessian by hyper-dual numbers, one
+//                    lane per pair (i <= j) of the n + m inputs, written
+//                    straight into the record; the dynamics Jacobian in
+//                    closed form: [dmean'/dmean | 0; 0 | dchol'/dchol] with
+//                    d sqrt(V_i + j) / dU[k][i] = U[k][i] / sqrt(V_i + j)
+//                    (what the reference gets from autograd,
+//                    utils/evaluation.py:134-288)
+//   line search      one lane per (trajectory, step size): ilqr.py:677-723
+//                    _control_law + :764-791 _trajectory_cost
+// float and double; the cost is written once over a number type (plain T for
+// values, HDual<T> for derivatives).
+#include "models.hpp"
+#include "problem_args.hpp"
+
+namespace pddp {
+
+PDDP_DEV float exp_(float x) { return expf(x); }
+PDDP_DEV double exp_(double x) { return exp(x); }
+
+template <typename T>
+struct HDual {  // hyper-dual number: value, d/dx_i, d/dx_j, d2/dx_i dx_j
+  T v, a, b, ab;
+};
+template <typename T> PDDP_DEV HDual<T> operator+(HDual<T> x, HDual<T> y) { return {x.v + y.v, x.a + y.a, x.b + y.b, x.ab + y.ab}; }
+template <typename T> PDDP_DEV HDual<T> operator-(HDual<T> x, HDual<T> y) { return {x.v - y.v, x.a - y.a, x.b - y.b, x.ab - y.ab}; }
+template <typename T> PDDP_DEV HDual<T> operator-(HDual<T> x) { return {-x.v, -x.a, -x.b, -x.ab}; }
+template <typename T> PDDP_DEV HDual<T> operator*(HDual<T> x, HDual<T> y) {
+  return {x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b,
+          x.ab * y.v + x.a * y.b + x.b * y.a + x.v * y.ab};
+}
+template <typename T> PDDP_DEV HDual<T> operator*(T s, HDual<T> x) { return {s * x.v, s * x.a, s * x.b, s * x.ab}; }
+template <typename T> PDDP_DEV HDual<T> operator-(HDual<T> x, T s) { return {x.v - s, x.a, x.b, x.ab}; }
+template <typename T> PDDP_DEV HDual<T> exp_(HDual<T> x) {
+  const T e = exp_(x.v);
+  return {e, e * x.a, e * x.b, e * (x.ab + x.a * x.b)};
+}
+PDDP_DEV void sincos_lib(float x, float& s, float& c) { sincosf(x, &s, &c); }
+PDDP_DEV void sincos_lib(double x, double& s, double& c) { sincos(x, &s, &c); }
+template <typename T> PDDP_DEV void sincos_x(T x, T& s, T& c) { sincos_lib(x, s, c); }
+template <typename T> PDDP_DEV void sincos_x(HDual<T> x, HDual<T>& s, HDual<T>& c) {
+  T sv, cv;
+  sincos_lib(x.v, sv, cv);
+  s = {sv, cv * x.a, cv * x.b, cv * x.ab - sv * x.a * x.b};
+  c = {cv, -sv * x.a, -sv * x.b, -sv * x.ab - cv * x.a * x.b};
+}
+template <typename T> PDDP_DEV T val(T x) { return x; }
+template <typename T> PDDP_DEV T val(HDual<T> x) { return x.v; }
+template <typename X, typename T> PDDP_DEV X lift(T v) {
+  if constexpr (sizeof(X) == sizeof(T)) return v;
+  else return X{v, T(0), T(0), T(0)};
+}
+
+// shape of a sample problem under the DEFAULT encoding
+template <int MODEL>
+struct DefDims {
+  using M = ModelDims<MODEL>;
+  static constexpr int D = M::n, m = M::m, na = M::na, nang = M::n_ang;
+  static constexpr int nn = na - 2 * nang;      // non-angular rows come first
+  static constexpr int n = D + D * (D + 1) / 2;  // encoded size
+  static constexpr int non(int r) { return M::col[r]; }
+  static constexpr int ang(int a) { return M::col[nn + 2 * a]; }
+};
+
+// the jittered upper Cholesky only decides which trace the cost sees
+// (encoding.py:536-564: jitter 1e-12, 1e-11, ... <= 10, else the diagonal)
+template <typename T, int NA>
+PDDP_DEV T chol_jitter_of(const T (&C)[NA][NA]) {
+  double jit = 1e-12;
+  while (jit <= 10.0) {
+    T U[NA][NA];
+    bool ok = true;
+    for (int i = 0; i < NA && ok; ++i)
+      for (int j = i; j < NA; ++j) {
+        T s = C[i][j] + (i == j ? (T)jit : T(0));
+        for (int q = 0; q < i; ++q) s -= U[q][i] * U[q][j];
+        if (i == j) {
+          if (!(s > T(0))) { ok = false; break; }
+          U[i][i] = sqrt_(s);
+        } else {
+          U[i][j] = s / U[i][i];
+        }
+      }
+    if (ok) return (T)jit;
+    jit *= 10.0;
+  }
+  return T(-1);
+}
+
+// l(z, u) on the augmented Gaussian moments; X = T (value) or HDual<T>.
+// mu [D], U [D][D] upper factor (lower part ignored), u [m] (clamped).
+template <typename X, typename T, int MODEL>
+PDDP_DEV X qr_cost_default(const ProblemT<T>& P,
+                           const X (&mu)[DefDims<MODEL>::D],
+                           const X (&U)[DefDims<MODEL>::D][DefDims<MODEL>::D],
+                           const X (&u)[DefDims<MODEL>::m], bool terminal) {
+  using G = DefDims<MODEL>;
+  constexpr int D = G::D, m = G::m, na = G::na, nn = G::nn, nang = G::nang;
+  constexpr int LQ = PDDP_MAX_AUG, LR = PDDP_MAX_ACTION;
+  const T* Q = terminal ? P.Qt : P.Q;
+  X C[D][D];  // U^T U
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = r; c < D; ++c) {
+      X v = lift<X>(T(0));
+#pragma unroll
+      for (int kx = 0; kx <= r; ++kx) v = v + U[kx][r] * U[kx][c];
+      C[r][c] = v;
+      C[c][r] = v;
+    }
+  T Cav[na][na];
+#pragma unroll
+  for (int r = 0; r < na; ++r)
+#pragma unroll
+    for (int c = 0; c < na; ++c) Cav[r][c] = T(0);
+  X Ma[na];
+  X tr = lift<X>(T(0)), trd = lift<X>(T(0));  // sum Ca_ij Q_ji; sum Ca_ii Q_ii
+  auto put = [&](int r, int c, X v) {  // every entry is written once
+    Cav[r][c] = val(v);
+    tr = tr + Q[c * LQ + r] * v;
+    if (r == c) trd = trd + Q[r * LQ + r] * v;
+  };
+#pragma unroll
+  for (int r = 0; r < nn; ++r) {
+    Ma[r] = mu[G::non(r)];
+#pragma unroll
+    for (int c = 0; c < nn; ++c) put(r, c, C[G::non(r)][G::non(c)]);
+  }
+#pragma unroll
+  for (int a1 = 0; a1 < nang; ++a1) {
+    const int i1 = G::ang(a1);
+    const X m1 = mu[i1], v1 = C[i1][i1];
+    const X damp = exp_(T(-0.5) * v1);
+    X s1, c1;
+    sincos_x(m1, s1, c1);
+    const X Es = damp * s1, Ec = damp * c1;
+    const int r = nn + 2 * a1;
+    Ma[r] = Es;
+    Ma[r + 1] = Ec;
+#pragma unroll
+    for (int a2 = 0; a2 < nang; ++a2) {
+      const int i2 = G::ang(a2);
+      const X m2 = mu[i2], v2 = C[i2][i2], cij = C[i1][i2];
+      const X lq = T(-0.5) * (v1 + v2), qq = exp_(lq);
+      const X ep = exp_(lq + cij) - qq, em = exp_(lq - cij) - qq;
+      X sd, cd, ss, cs;
+      sincos_x(m1 - m2, sd, cd);
+      sincos_x(m1 + m2, ss, cs);
+      const int cc = nn + 2 * a2;
+      put(r, cc, T(0.5) * (ep * cd - em * cs));          // sin, sin
+      put(r + 1, cc + 1, T(0.5) * (ep * cd + em * cs));  // cos, cos
+      const X sc = T(0.5) * (ep * sd + em * ss);         // sin_1, cos_2
+      put(r, cc + 1, sc);
+      put(cc + 1, r, sc);
+    }
+#pragma unroll
+    for (int c = 0; c < nn; ++c) {
+      const X col = C[G::non(c)][i1];
+      put(c, r, col * Ec);         // Cov(x, sin)
+      put(c, r + 1, -(col * Es));  // Cov(x, cos)
+      put(r, c, col * Ec);
+      put(r + 1, c, -(col * Es));
+    }
+  }
+  const T jit = chol_jitter_of<T, na>(Cav);
+  X cost = lift<X>(T(0));
+#pragma unroll
+  for (int c = 0; c < na; ++c) {
+    X row = lift<X>(T(0));
+#pragma unroll
+    for (int r = 0; r < na; ++r) row = row + Q[r * LQ + c] * (Ma[r] - P.goal[r]);
+    cost = cost + row * (Ma[c] - P.goal[c]);
+  }
+  if (!terminal) {
+#pragma unroll
+    for (int c = 0; c < m; ++c) {
+      X row = lift<X>(T(0));
+#pragma unroll
+      for (int r = 0; r < m; ++r)
+        row = row + P.R[r * LR + c] * (u[r] - P.ugoal[r]);
+      cost = cost + row * (u[c] - P.ugoal[c]);
+    }
+  }
+  if (jit >= T(0)) {
+    T trq = T(0);
+#pragma unroll
+    for (int r = 0; r < na; ++r) trq += Q[r * LQ + r];
+    cost = cost + tr + lift<X>(jit * trq);  // tr(Q (Ca + jitter I))
+  } else {
+    cost = cost + trd;  // encode()'s diagonal fall-back
+  }
+  return cost;
+}
+
+// z [n] -> mean [D], upper factor U [D][D] (zeros below the diagonal)
+template <typename T, int D>
+PDDP_DEV void unpack_state(const T* z, T (&mean)[D], T (&U)[D][D]) {
+#pragma unroll
+  for (int c = 0; c < D; ++c) mean[c] = z[c];
+  int o = D;
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      if (c >= r) U[r][c] = z[o++];
+      else U[r][c] = T(0);
+    }
+}
+
+// one model step: mean' = f(mean, u); chol' = diag(sqrt(V_i + 1e-12)),
+// V_i = sum_k U[k][i]^2   (encode(mean', V = decode_var(z)))
+template <typename T, int MODEL>
+PDDP_DEV void step_default(const ProblemT<T>& P,
+                           T (&mean)[DefDims<MODEL>::D],
+                           T (&U)[DefDims<MODEL>::D][DefDims<MODEL>::D],
+                           const T (&u)[DefDims<MODEL>::m]) {
+  constexpr int D = DefDims<MODEL>::D;
+  T next[D];
+  const Trig<T, MODEL> tr = trig_of<T, MODEL>(mean);
+  dynamics<T, MODEL, false>(P, mean, u, tr, next, nullptr, nullptr);
+  T sd[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) {
+    T v = T(0);
+#pragma unroll
+    for (int k = 0; k <= i; ++k) v += U[k][i] * U[k][i];  // pow(2).sum(-2)
+    sd[i] = sqrt_(v + (T)1e-12);
+  }
+#pragma unroll
+  for (int r = 0; r < D; ++r) {
+    mean[r] = next[r];
+#pragma unroll
+    for (int c = 0; c < D; ++c) U[r][c] = (r == c) ? sd[r] : T(0);
+  }
+}
+
+template <typename T, int D>
+PDDP_DEV void pack_state(const T (&mean)[D], const T (&U)[D][D], T* z) {
+#pragma unroll
+  for (int c = 0; c < D; ++c) z[c] = mean[c];
+  int o = D;
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = r; c < D; ++c) z[o++] = U[r][c];
+}
+
+// --------------------------------------------------------------------------
+// nominal rollout: one lane per trajectory
+// --------------------------------------------------------------------------
+template <typename T, int MODEL>
+__global__ __launch_bounds__(kWave) void rollout_default_kernel(
+    ProblemT<T> P, RolloutArgs<T> a) {
+  using G = DefDims<MODEL>;
+  constexpr int D = G::D, m = G::m, n = G::n;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.B) return;
+  if (a.mask != nullptr && a.mask[b] == 0) return;
+  const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
+  T mean[D], U[D][D], zz[n];
+  T* Zb = a.Z + (size_t)b * (a.N + 1) * n;
+  const T* Ub = a.U + (size_t)b * a.N * m;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    zz[j] = a.z0[(size_t)b * n + j];
+    Zb[j] = zz[j];
+  }
+  unpack_state<T, D>(zz, mean, U);
+  for (int t = 0; t < a.N; ++t) {
+    T u[m];
+#pragma unroll
+    for (int j = 0; j < m; ++j) {
+      u[j] = Ub[t * m + j];
+      if (bounded) u[j] = clamp1(u[j], a.u_min[j], a.u_max[j]);
+    }
+    step_default<T, MODEL>(P, mean, U, u);
+    pack_state<T, D>(mean, U, zz);
+#pragma unroll
+    for (int j = 0; j < n; ++j) Zb[(size_t)(t + 1) * n + j] = zz[j];
+  }
+}
+
+// --------------------------------------------------------------------------
+// derivative records: one workgroup per (trajectory, step)
+// --------------------------------------------------------------------------
+template <typename T, int MODEL>
+__global__ __launch_bounds__(kWave) void derivs_default_kernel(
+    ProblemT<T> P, DerivArgs<T> a) {
+  using G = DefDims<MODEL>;
+  constexpr int D = G::D, m = G::m, n = G::n;
+  constexpr RecLayout lay(n, m);
+  constexpr int S = lay.stride;
+  __shared__ T sFx[D * D], sFu[D * m], sSd[D];
+  const int lane = threadIdx.x;
+  const int N = a.N;
+  const int bt = blockIdx.x;  // (trajectory, step), step N = terminal
+  const int b = bt / (N + 1), t = bt - b * (N + 1);
+  if (a.mask != nullptr && a.mask[b] == 0) return;
+  const bool terminal = (t == N);
+  const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
+  const T* z = a.Z + ((size_t)b * (N + 1) + t) * n;
+  T* w = a.rec + ((size_t)b * (N + 1) + t) * S;
+  T mean[D], U[D][D], un[m], u[m];
+  {
+    T zz[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) zz[j] = z[j];
+    unpack_state<T, D>(zz, mean, U);
+  }
+#pragma unroll
+  for (int r = 0; r < m; ++r) {
+    un[r] = terminal ? T(0) : a.U[((size_t)b * N + t) * m + r];
+    // derivatives AT the clamped action (ilqr.py:461-462)
+    u[r] = (bounded && !terminal) ? clamp1(un[r], a.u_min[r], a.u_max[r])
+                                  : un[r];
+  }
+  // ---- the dynamics' Jacobian blocks, by lane 0 (closed form)
+  if (lane == 0) {
+    T next[D], Fx[D * D], Fu[D * m];
+    if (!terminal) {
+      const Trig<T, MODEL> tr = trig_of<T, MODEL>(mean);
+      dynamics<T, MODEL, true>(P, mean, u, tr, next, Fx, Fu);
+    }
+#pragma unroll
+    for (int j = 0; j < D * D; ++j) sFx[j] = terminal ? T(0) : Fx[j];
+#pragma unroll
+    for (int j = 0; j < D * m; ++j) sFu[j] = terminal ? T(0) : Fu[j];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      T v = T(0);
+#pragma unroll
+      for (int k = 0; k <= i; ++k) v += U[k][i] * U[k][i];
+      sSd[i] = sqrt_(v + (T)1e-12);
+    }
+  }
+  // ---- the cost by hyper-dual numbers: one lane per pair (i <= j)
+  const int d = n + (terminal ? 0 : m);
+  const int npairs = d * (d + 1) / 2;
+  for (int q = lane; q < npairs; q += kWave) {
+    int i = 0, rem = q;  // pair q -> (i, j), i <= j, row-major upper triangle
+    while (rem >= d - i) { rem -= d - i; ++i; }
+    const int j = i + rem;
+    using X = HDual<T>;
+    auto in = [&](int kx, T v) {
+      return X{v, kx == i ? T(1) : T(0), kx == j ? T(1) : T(0), T(0)};
+    };
+    X mu_[D], U_[D][D], u_[m];
+#pragma unroll
+    for (int c = 0; c < D; ++c) mu_[c] = in(c, mean[c]);
+    {
+      int o = D;
+#pragma unroll
+      for (int r = 0; r < D; ++r)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          if (c >= r) { U_[r][c] = in(o, U[r][c]); ++o; }
+          else U_[r][c] = lift<X>(T(0));
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < m; ++r) u_[r] = in(n + r, u[r]);
+    const X cost = qr_cost_default<X, T, MODEL>(P, mu_, U_, u_, terminal);
+    if (q == 0) a.L[(size_t)b * (N + 1) + t] = cost.v;
+    if (i == j) {
+      if (i < n) w[lay.oLz + i] = cost.a;
+      else w[lay.oLu + (i - n)] = cost.a;
+    }
+    if (j < n) {
+      w[lay.oLzz + i * n + j] = cost.ab;
+      w[lay.oLzz + j * n + i] = cost.ab;
+    } else if (i < n) {
+      w[lay.oLuz + (j - n) * n + i] = cost.ab;
+    } else {
+      w[lay.oLuu + (i - n) * m + (j - n)] = cost.ab;
+      w[lay.oLuu + (j - n) * m + (i - n)] = cost.ab;
+    }
+  }
+  __syncthreads();
+  // ---- F_z = [dmean'/dmean 0; 0 dchol'/dchol], F_u, the action-side blocks of
+  // the terminal record, the un-clamped nominal action, padding
+  for (int e = lane; e < n * n; e += kWave) {
+    const int r = e / n, c = e - r * n;
+    T v = T(0);
+    if (!terminal) {
+      if (r < D && c < D) {
+        v = sFx[r * D + c];
+      } else if (r >= D && c >= D) {
+        // encoded row r = upper-triangle entry (ri, rj); only the diagonal
+        // entries of chol' are non-zero functions of the input
+        int ri = 0, o = r - D;
+        while (o >= D - ri) { o -= D - ri; ++ri; }
+        const int rj = ri + o;
+        int ci = 0, oc = c - D;
+        while (oc >= D - ci) { oc -= D - ci; ++ci; }
+        const int cj = ci + oc;
+        // d sqrt(V_i + j) / dU[k][i] = U[k][i] / sqrt(V_i + j)
+        if (ri == rj && cj == ri) v = z[c] / sSd[ri];
+      }
+    }
+    w[lay.oFz + e] = v;
+  }
+  for (int e = lane; e < n * m; e += kWave) {
+    const int r = e / m, c = e - r * m;
+    w[lay.oFu + e] = (!terminal && r < D) ? sFu[r * m + c] : T(0);
+  }
+  if (terminal) {
+    for (int e = lane; e < m * n; e += kWave) w[lay.oLuz + e] = T(0);
+    for (int e = lane; e < m * m; e += kWave) w[lay.oLuu + e] = T(0);
+    if (lane < m) w[lay.oLu + lane] = T(0);
+  }
+  if (lane < m) w[lay.oU + lane] = un[lane];
+  for (int e = lay.oU + m + lane; e < S; e += kWave) w[e] = T(0);
+}
+
+// J[b] = sum_t L[b][t] in t order (+ the state reset of pddp_derivs_*)
+template <typename T>
+__global__ __launch_bounds__(256) void cost_sum_default_kernel(
+    int B, int count, const T* L, const uint8_t* mask, T* J, int32_t* state) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  if (mask != nullptr && mask[b] == 0) return;
+  const T* row = L + (size_t)b * count;
+  T acc = T(0);
+  for (int t = 0; t < count; ++t) acc += row[t];
+  J[b] = acc;
+  if (state != nullptr) state[b] = PDDP_STATE_UNDEFINED;
+}
+
+// --------------------------------------------------------------------------
+// line search: one lane per (trajectory, step size)
+// --------------------------------------------------------------------------
+template <typename T, int MODEL>
+__global__ __launch_bounds__(kWave) void line_search_default_kernel(
+    ProblemT<T> P, LineSearchArgs<T> a) {
+  using G = DefDims<MODEL>;
+  constexpr int D = G::D, m = G::m, n = G::n;
+  constexpr int GS = m + m * n;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.B * a.A) return;
+  const int b = idx / a.A, ai = idx - b * a.A;
+  if (a.active != nullptr && a.active[b] == 0) return;
+  if (a.bwd_status != nullptr && a.bwd_status[b] != 0) return;
+  const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
+  const int N = a.N;
+  const T alpha = a.alphas[ai];
+  const T* Zb = a.Z + (size_t)b * (N + 1) * n;
+  const T* Ub = a.U + (size_t)b * N * m;
+  const T* Gb = a.gains + (size_t)b * N * GS;
+  T* Zci = a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
+  T* Uci = a.Uc + ((size_t)b * N * a.A + ai) * m;
+  const size_t zstep = (size_t)a.A * n, ustep = (size_t)a.A * m;
+
+  T zz[n], mean[D], U[D][D];
+#pragma unroll
+  for (int j = 0; j < n; ++j) zz[j] = Zb[j];  // Z_new[0] = Z[0]  (ilqr.py:690)
+  unpack_state<T, D>(zz, mean, U);
+  T J = T(0);
+  for (int t = 0; t < N; ++t) {
+    T u[m];
+#pragma unroll
+    for (int r = 0; r < m; ++r) {
+      T du = alpha * Gb[t * GS + r];  // alpha * k[i]              (ilqr.py:708)
+      T s = T(0);
+#pragma unroll
+      for (int c = 0; c < n; ++c)
+        s += (zz[c] - Zb[(size_t)t * n + c]) * Gb[t * GS + m + r * n + c];
+      du = du + s;  // + dz K^T                                    (ilqr.py:710)
+      const T v = Ub[t * m + r] + du;
+      u[r] = bounded ? clamp_nan(v, a.u_min[r], a.u_max[r]) : v;
+    }
+#pragma unroll
+    for (int j = 0; j < n; ++j) Zci[(size_t)t * zstep + j] = zz[j];
+#pragma unroll
+    for (int j = 0; j < m; ++j) Uci[(size_t)t * ustep + j] = u[j];
+    J += qr_cost_default<T, T, MODEL>(P, mean, U, u, false);
+    step_default<T, MODEL>(P, mean, U, u);
+    pack_state<T, D>(mean, U, zz);
+  }
+#pragma unroll
+  for (int j = 0; j < n; ++j) Zci[(size_t)N * zstep + j] = zz[j];
+  T u0[m];
+#pragma unroll
+  for (int r = 0; r < m; ++r) u0[r] = T(0);
+  J += qr_cost_default<T, T, MODEL>(P, mean, U, u0, true);
+  a.Jc[idx] = J;  // L.sum(0) + l_f                                (ilqr.py:789)
+}
+
+// --------------------------------------------------------------------------
+// launchers (called from problem_kernels.hip when problem.encoding is DEFAULT)
+// --------------------------------------------------------------------------
+static int check_default(const pddp_problem& p) {
+  if (p.encoding != PDDP_ENC_UPPER_TRIANGULAR_CHOLESKY)
+    return PDDP_E_UNSUPPORTED;
+  switch (p.model) {
+    case PDDP_MODEL_CARTPOLE:
+    case PDDP_MODEL_DOUBLE_CARTPOLE:
+    case PDDP_MODEL_PENDULUM:
+      return 0;  // (rendezvous carries the full covariance: plugin path)
+  }
+  return PDDP_E_UNSUPPORTED;
+}
+
+#define PDDP_DEFAULT_DISPATCH(CALL)                                          \
+  switch (p.model) {                                                         \
+    case PDDP_MODEL_CARTPOLE: { constexpr int MODEL = PDDP_MODEL_CARTPOLE; CALL; } break; \
+    case PDDP_MODEL_PENDULUM: { constexpr int MODEL = PDDP_MODEL_PENDULUM; CALL; } break; \
+    default: { constexpr int MODEL = PDDP_MODEL_DOUBLE_CARTPOLE; CALL; } break; \
+  }
+
+template <typename T>
+int default_rollout(const pddp_problem& p, RolloutArgs<T> a, hipStream_t st) {
+  if (int rc = check_default(p)) return rc;
+  const ProblemT<T> P = convert_problem<T>(p);
+  const dim3 grid((a.B + kWave - 1) / kWave), block(kWave);
+  PDDP_DEFAULT_DISPATCH(
+      PDDP_LAUNCH((rollout_default_kernel<T, MODEL>), grid, block, 0, st, P, a))
+  return launch_status();
+}
+template <typename T>
+int default_derivs(const pddp_problem& p, DerivArgs<T> a, hipStream_t st) {
+  if (int rc = check_default(p)) return rc;
+  const ProblemT<T> P = convert_problem<T>(p);
+  const dim3 grid(a.B * (a.N + 1)), block(kWave);
+  PDDP_DEFAULT_DISPATCH(
+      PDDP_LAUNCH((derivs_default_kernel<T, MODEL>), grid, block, 0, st, P, a))
+  if (int rc = launch_status()) return rc;
+  PDDP_LAUNCH((cost_sum_default_kernel<T>), dim3((a.B + 255) / 256), dim3(256),
+              0, st, a.B, a.N + 1, (const T*)a.L, a.mask, a.J, a.state);
+  return launch_status();
+}
+template <typename T>
+int default_line_search(const pddp_problem& p, LineSearchArgs<T> a,
+                        hipStream_t st) {
+  if (int rc = check_default(p)) return rc;
+  const ProblemT<T> P = convert_problem<T>(p);
+  const int total = a.B * a.A;
+  const dim3 grid((total + kWave - 1) / kWave), block(kWave);
+  PDDP_DEFAULT_DISPATCH(PDDP_LAUNCH((line_search_default_kernel<T, MODEL>),
+                                    grid, block, 0, st, P, a))
+  return launch_status();
+}
+
+template int default_rollout<float>(const pddp_problem&, RolloutArgs<float>, hipStream_t);
+template int default_rollout<double>(const pddp_problem&, RolloutArgs<double>, hipStream_t);
+template int default_derivs<float>(const pddp_problem&, DerivArgs<float>, hipStream_t);
+template int default_derivs<double>(const pddp_problem&, DerivArgs<double>, hipStream_t);
+template int default_line_search<float>(const pddp_problem&, LineSearchArgs<float>, hipStream_t);
+template int default_line_search<double>(const pddp_problem&, LineSearchArgs<double>, hipStream_t);
+
+}  // namespace pddp

@@ -6,6 +6,7 @@
 //                      (parallel over trajectory AND time step)
 //   line search       ilqr.py:677-723 _control_law + :764-791 _trajectory_cost
 #include "models.hpp"
+#include "problem_args.hpp"
 #include "accept.hpp"
 #include "riccati_n4.hpp"  // DPP helpers of the 16-lane groups
 
@@ -14,16 +15,6 @@ namespace pddp {
 // --------------------------------------------------------------------------
 // nominal rollout: one lane per trajectory
 // --------------------------------------------------------------------------
-template <typename T>
-struct RolloutArgs {
-  int B, N;
-  const T* z0;
-  const T* U;
-  const T* u_min;
-  const T* u_max;
-  const uint8_t* mask;
-  T* Z;
-};
 
 template <typename T, int MODEL>
 __global__ __launch_bounds__(kWave) void nominal_rollout_kernel(
@@ -149,19 +140,6 @@ PDDP_DEV T record_of(const ProblemT<T>& P, const T* z, const T* un,
   return l;
 }
 
-template <typename T>
-struct DerivArgs {
-  int B, N;
-  const T* Z;
-  const T* U;
-  const T* u_min;
-  const T* u_max;
-  const uint8_t* mask;
-  T* rec;
-  T* L;
-  T* J;
-  int32_t* state;
-};
 
 constexpr int kDerivThreads = 64;
 
@@ -224,28 +202,6 @@ __global__ __launch_bounds__(kDerivThreads) void derivs_kernel(
 // --------------------------------------------------------------------------
 // line search: one lane per (trajectory, alpha) candidate
 // --------------------------------------------------------------------------
-template <typename T>
-struct LineSearchArgs {
-  int B, N, A;
-  const T* Z;
-  const T* U;
-  const T* gains;
-  const T* alphas;
-  const T* u_min;
-  const T* u_max;
-  const uint8_t* active;
-  const int32_t* bwd_status;
-  // Candidates are laid out time-major, Zc [B][N+1][A][n], Uc [B][N][A][m]:
-  // the A lanes of a trajectory then write ONE contiguous segment per step
-  // (160 B for cartpole) instead of A scattered 16-B pieces of A different
-  // rows.  Measured on gfx950 (rocprofv3 WRITE_SIZE): candidate-major cost
-  // 152 MB of HBM writes per launch for 82 MB of data and a third of the
-  // kernel's time; the accept kernel's strided read of the one winning row is
-  // 12x smaller than what this saves.
-  T* Zc;
-  T* Uc;
-  T* Jc;
-};
 
 template <typename T, int MODEL>
 __global__ __launch_bounds__(kWave) void line_search_kernel(
@@ -638,6 +594,19 @@ static int launch_search_accept(const pddp_problem& p, SearchAcceptArgs<T> a,
   return launch_status();
 }
 
+// default_kernels.hip: the same three operations under the DEFAULT (upper-
+// triangular Cholesky) encoding, selected by pddp_problem.encoding
+template <typename T>
+int default_rollout(const pddp_problem& p, RolloutArgs<T> a, hipStream_t st);
+template <typename T>
+int default_derivs(const pddp_problem& p, DerivArgs<T> a, hipStream_t st);
+template <typename T>
+int default_line_search(const pddp_problem& p, LineSearchArgs<T> a,
+                        hipStream_t st);
+static bool is_default_encoding(const pddp_problem* p) {
+  return p != nullptr && p->encoding == PDDP_ENC_UPPER_TRIANGULAR_CHOLESKY;
+}
+
 static int check_problem(const pddp_problem* p) {
   if (p == nullptr) return PDDP_E_BADARG;
   if (p->encoding != PDDP_ENC_IGNORE_UNCERTAINTY) return PDDP_E_UNSUPPORTED;
@@ -668,9 +637,11 @@ static int nominal_rollout_impl(const pddp_problem* p, int B, int N,
                                 const T* z0, const T* U, const T* u_min,
                                 const T* u_max, const uint8_t* mask, T* Z,
                                 void* stream) {
-  if (int rc = check_problem(p)) return rc;
   if (B <= 0 || N <= 0 || !z0 || !U || !Z) return PDDP_E_BADARG;
   RolloutArgs<T> a{B, N, z0, U, u_min, u_max, mask, Z};
+  if (is_default_encoding(p))
+    return default_rollout<T>(*p, a, (hipStream_t)stream);
+  if (int rc = check_problem(p)) return rc;
   PDDP_DISPATCH_MODEL(launch_rollout, T, p, a, (hipStream_t)stream)
 }
 
@@ -679,9 +650,11 @@ static int derivs_impl(const pddp_problem* p, int B, int N, const T* Z,
                        const T* U, const T* u_min, const T* u_max,
                        const uint8_t* mask, T* rec, T* L, T* J, int32_t* state,
                        void* stream) {
-  if (int rc = check_problem(p)) return rc;
   if (B <= 0 || N <= 0 || !Z || !U || !rec || !L || !J) return PDDP_E_BADARG;
   DerivArgs<T> a{B, N, Z, U, u_min, u_max, mask, rec, L, J, state};
+  if (is_default_encoding(p))
+    return default_derivs<T>(*p, a, (hipStream_t)stream);
+  if (int rc = check_problem(p)) return rc;
   PDDP_DISPATCH_MODEL(launch_derivs, T, p, a, (hipStream_t)stream)
 }
 
@@ -691,12 +664,14 @@ static int line_search_impl(const pddp_problem* p, int B, int N, int A,
                             const T* alphas, const T* u_min, const T* u_max,
                             const uint8_t* active, const int32_t* bwd_status,
                             T* Zc, T* Uc, T* Jc, void* stream) {
-  if (int rc = check_problem(p)) return rc;
   if (B <= 0 || N <= 0 || A <= 0 || !Z || !U || !gains || !alphas || !Zc ||
       !Uc || !Jc)
     return PDDP_E_BADARG;
   LineSearchArgs<T> a{B, N, A, Z, U, gains, alphas, u_min, u_max, active,
                       bwd_status, Zc, Uc, Jc};
+  if (is_default_encoding(p))
+    return default_line_search<T>(*p, a, (hipStream_t)stream);
+  if (int rc = check_problem(p)) return rc;
   PDDP_DISPATCH_MODEL(launch_line_search, T, p, a, (hipStream_t)stream)
 }
 

@@ -28,8 +28,16 @@ class AugmentedQRCost(QRCost):
 
 
 def build_problem(name, model, cost, encoding, param_names):
-    """Flattens a sample (model, cost) pair into include/pddp_problem.h."""
-    if encoding != StateEncoding.IGNORE_UNCERTAINTY:
+    """Flattens a sample (model, cost) pair into include/pddp_problem.h: the
+    problems the HIP kernels evaluate in closed form - every sample problem
+    under IGNORE_UNCERTAINTY (csrc/problem_kernels.hip) and cartpole, pendulum,
+    double cartpole under DEFAULT = UPPER_TRIANGULAR_CHOLESKY
+    (csrc/default_kernels.hip; rendezvous carries a full covariance there and
+    stays on the plugin path).  None otherwise."""
+    if encoding == StateEncoding.UPPER_TRIANGULAR_CHOLESKY:
+        if name == "rendezvous":
+            return None
+    elif encoding != StateEncoding.IGNORE_UNCERTAINTY:
         return None
     if not isinstance(cost, AugmentedQRCost) or \
             cost.model_class is not type(model):

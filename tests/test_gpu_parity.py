@@ -627,7 +627,9 @@ def test_default_encoding_vs_reference_golden(problem):
     """StateEncoding.DEFAULT (upper-triangular Cholesky, n = 14 / 5) through
     the reference-signature API - forward, backward (zero-copy records, generic
     HIP sweep), _control_law + costs, and a full fit - against the reference's
-    own outputs (fp64 goldens)."""
+    own outputs (fp64 goldens).  All of it on the native path
+    (csrc/default_kernels.hip: closed-form dynamics Jacobian, hyper-dual cost
+    derivatives, line-search kernel) - asserted below."""
     import pddp_amd
     from pddp_amd import StateEncoding
     from pddp_amd.controllers.ilqr import _control_law, backward, forward
@@ -688,6 +690,85 @@ def test_default_encoding_vs_reference_golden(problem):
     assert int(state) == int(g["fit_bounded/state"])
     assert rel_err(U.cpu().numpy(), g["fit_bounded/U"]) < 1e-5
     assert rel_err(ctrl._K.cpu().numpy(), g["fit_bounded/K"]) < 1e-5
+    # no plugin: problem kernels only
+    assert ctrl._solver.plugin is None and ctrl._solver.problem is not None
+    assert ctrl._solver.problem.encoding == int(enc)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("problem", ["cartpole", "pendulum",
+                                     "double_cartpole"])
+def test_default_encoding_native_vs_plugin_path(problem, dtype):
+    """The native DEFAULT-encoding kernels (csrc/default_kernels.hip) against
+    the plugin path on the same inputs - replicated-input autograd Jacobians
+    and Hessians through the torch model / cost, torch line search
+    (controllers/plugin.py; pinned to the reference's goldens by
+    tests/test_host_cpu.py and, for cartpole / pendulum, by the test above):
+    nominal rollout, every derivative, the candidates and their costs.  Covers
+    double cartpole (n = 27, no golden captured) and float32."""
+    import pddp_amd
+    from pddp_amd.controllers.ilqr import _make_solver
+    mod = getattr(pddp_amd.examples, problem)
+    td = TDT[dtype]
+    model = [getattr(mod, n) for n in dir(mod) if n.endswith("DynamicsModel")
+             and n != "DynamicsModel"][0](DT[problem]).to(td).cuda()
+    cost = [getattr(mod, n) for n in dir(mod) if n.endswith("Cost")
+            and n != "AugmentedQRCost"][0]().to(td).cuda()
+    enc = pddp_amd.StateEncoding.DEFAULT
+    D, m = model.state_size, model.action_size
+    n = D + D * (D + 1) // 2
+    B, N = 5, 12
+    g = torch.Generator().manual_seed(4)
+    mean = torch.tensor(MEAN0[problem], dtype=torch.float64)
+    rows = []
+    for b in range(B):
+        A = 0.1 * torch.randn(D, D, generator=g, dtype=torch.float64)
+        C = A.t() @ A + 1e-2 * torch.eye(D, dtype=torch.float64)
+        rows.append(pddp_amd.GaussianVariable(
+            mean + 0.05 * torch.randn(D, generator=g, dtype=torch.float64),
+            covar=C).encode(enc))  # (a FULL upper factor at t = 0)
+    z0 = torch.stack(rows).to(td).cuda()
+    U = (0.5 * torch.randn(B, N, m, generator=g, dtype=torch.float64)).to(
+        td).cuda()
+    bound = BOUND[problem]
+    u_min, u_max = torch.tensor([-bound]), torch.tensor([bound])
+    sols = []
+    for force in (False, True):
+        s = _make_solver(model, cost, enc, B, N, n, td, "cuda", u_min, u_max,
+                         None, force_plugin=force)
+        assert (s.plugin is not None) == force
+        if force:  # the independent path: no HIP cost / dynamics kernels
+            s.plugin.use_native_cost = False
+        s.set_nominal(z0, U)
+        s.derivs()
+        s.gains.copy_(sols[0].gains if sols else
+                      0.05 * torch.randn(s.gains.shape, generator=g,
+                                         dtype=torch.float64).to(td).cuda())
+        s.line_search(use_status=False)
+        sols.append(s)
+    a, b = sols
+    assert b.plugin.last_derivs_path == {"dynamics": "autograd",
+                                         "cost": "autograd"}
+    tol = 1e-9 if dtype == "f64" else 2e-4
+    assert rel_err(a.Z.cpu().numpy(), b.Z.cpu().numpy()) < tol
+    lay = a.lay
+    for name, o, cnt in (("F_z", lay.o_Fz, n * n), ("F_u", lay.o_Fu, n * m),
+                         ("L_z", lay.o_Lz, n), ("L_u", lay.o_Lu, m),
+                         ("L_zz", lay.o_Lzz, n * n), ("L_uz", lay.o_Luz, m * n),
+                         ("L_uu", lay.o_Luu, m * m), ("U", lay.o_U, m)):
+        x = a.rec[..., o:o + cnt].cpu().numpy()
+        y = b.rec[..., o:o + cnt].cpu().numpy()
+        scale = max(np.abs(y).max(), 1.0)
+        assert np.abs(x - y).max() <= tol * scale, (name, np.abs(x - y).max())
+    assert rel_err(a.L.cpu().numpy(), b.L.cpu().numpy()) < tol
+    assert rel_err(a.J_opt.cpu().numpy(), b.J_opt.cpu().numpy()) < tol
+    T = 8  # stable prefix of possibly diverging candidates
+    assert rel_err(a.Zc[:, :T].cpu().numpy(), b.Zc[:, :T].cpu().numpy()) < tol
+    assert rel_err(a.Uc[:, :T].cpu().numpy(), b.Uc[:, :T].cpu().numpy()) < tol
+    Ja, Jb = a.Jc.cpu().numpy(), b.Jc.cpu().numpy()
+    fin = np.isfinite(Jb) & (np.abs(Jb) < 1e6)
+    assert fin.sum() >= B and np.allclose(Ja[fin], Jb[fin],
+                                          rtol=1e-7 if dtype == "f64" else 1e-3)
 
 
 def test_bnn_ilqr_fit_vs_reference_golden():
