@@ -31,6 +31,12 @@
 //                    _control_law + :764-791 _trajectory_cost
 // float and double; the cost is written once over a number type (plain T for
 // values, HDual<T> for derivatives).
+//
+// The same kernels, templated on the encoding, serve VARIANCE_ONLY
+// (z = mean | var) and STANDARD_DEVIATION_ONLY (z = mean | std), n = 2 D: the
+// covariance is diag(var), the dynamics carry var unchanged (std: sqrt(std^2)),
+// the augmented state keeps variances only (angular.py:87-158), so the
+// cost's trace term is sum_i Q_ii Var_a[i] (no Cholesky, no jitter).
 #include "models.hpp"
 #include "problem_args.hpp"
 
@@ -72,16 +78,50 @@ template <typename X, typename T> PDDP_DEV X lift(T v) {
   else return X{v, T(0), T(0), T(0)};
 }
 
-// shape of a sample problem under the DEFAULT encoding
-template <int MODEL>
+// shape of a sample problem under a Gaussian encoding ENC (PDDP_ENC_*)
+constexpr int kChol = PDDP_ENC_UPPER_TRIANGULAR_CHOLESKY;
+constexpr int kVar = PDDP_ENC_VARIANCE_ONLY;
+constexpr int kStd = PDDP_ENC_STANDARD_DEVIATION_ONLY;
+template <int MODEL, int ENC = kChol>
 struct DefDims {
   using M = ModelDims<MODEL>;
   static constexpr int D = M::n, m = M::m, na = M::na, nang = M::n_ang;
   static constexpr int nn = na - 2 * nang;      // non-angular rows come first
-  static constexpr int n = D + D * (D + 1) / 2;  // encoded size
+  static constexpr int NO = ENC == kChol ? D * (D + 1) / 2 : D;
+  static constexpr int n = D + NO;               // encoded size
   static constexpr int non(int r) { return M::col[r]; }
   static constexpr int ang(int a) { return M::col[nn + 2 * a]; }
+  // position of U[k][i] (k <= i) among the row-major upper-triangle entries
+  static constexpr int tri(int k, int i) {
+    return k * D - k * (k - 1) / 2 + (i - k);
+  }
 };
+
+// covariance of the state from the encoding's second block
+template <typename X, int MODEL, int ENC>
+PDDP_DEV void covar_of(const X (&oth)[DefDims<MODEL, ENC>::NO],
+                       X (&C)[DefDims<MODEL, ENC>::D][DefDims<MODEL, ENC>::D]) {
+  using G = DefDims<MODEL, ENC>;
+  constexpr int D = G::D;
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = r; c < D; ++c) {
+      if constexpr (ENC == kChol) {  // U^T U
+        X v = oth[G::tri(0, r)] * oth[G::tri(0, c)];
+#pragma unroll
+        for (int kx = 1; kx <= r; ++kx)
+          v = v + oth[G::tri(kx, r)] * oth[G::tri(kx, c)];
+        C[r][c] = v;
+        C[c][r] = v;
+      } else {
+        X v = oth[r] - oth[r];  // zero of the number type
+        if (r == c) v = (ENC == kVar) ? oth[r] : oth[r] * oth[r];
+        C[r][c] = v;
+        C[c][r] = v;
+      }
+    }
+}
 
 // the jittered upper Cholesky only decides which trace the cost sees
 // (encoding.py:536-564: jitter 1e-12, 1e-11, ... <= 10, else the diagonal)
@@ -109,27 +149,19 @@ PDDP_DEV T chol_jitter_of(const T (&C)[NA][NA]) {
 }
 
 // l(z, u) on the augmented Gaussian moments; X = T (value) or HDual<T>.
-// mu [D], U [D][D] upper factor (lower part ignored), u [m] (clamped).
-template <typename X, typename T, int MODEL>
+// mu [D], oth [NO] the encoding's second block, u [m] (clamped).
+template <typename X, typename T, int MODEL, int ENC>
 PDDP_DEV X qr_cost_default(const ProblemT<T>& P,
-                           const X (&mu)[DefDims<MODEL>::D],
-                           const X (&U)[DefDims<MODEL>::D][DefDims<MODEL>::D],
-                           const X (&u)[DefDims<MODEL>::m], bool terminal) {
-  using G = DefDims<MODEL>;
+                           const X (&mu)[DefDims<MODEL, ENC>::D],
+                           const X (&oth)[DefDims<MODEL, ENC>::NO],
+                           const X (&u)[DefDims<MODEL, ENC>::m],
+                           bool terminal) {
+  using G = DefDims<MODEL, ENC>;
   constexpr int D = G::D, m = G::m, na = G::na, nn = G::nn, nang = G::nang;
   constexpr int LQ = PDDP_MAX_AUG, LR = PDDP_MAX_ACTION;
   const T* Q = terminal ? P.Qt : P.Q;
-  X C[D][D];  // U^T U
-#pragma unroll
-  for (int r = 0; r < D; ++r)
-#pragma unroll
-    for (int c = r; c < D; ++c) {
-      X v = lift<X>(T(0));
-#pragma unroll
-      for (int kx = 0; kx <= r; ++kx) v = v + U[kx][r] * U[kx][c];
-      C[r][c] = v;
-      C[c][r] = v;
-    }
+  X C[D][D];
+  covar_of<X, MODEL, ENC>(oth, C);
   T Cav[na][na];
 #pragma unroll
   for (int r = 0; r < na; ++r)
@@ -184,7 +216,8 @@ PDDP_DEV X qr_cost_default(const ProblemT<T>& P,
       put(r + 1, c, -(col * Es));
     }
   }
-  const T jit = chol_jitter_of<T, na>(Cav);
+  // variance-only encodings: the augmented state keeps diag(Ca) only
+  const T jit = ENC == kChol ? chol_jitter_of<T, na>(Cav) : T(-1);
   X cost = lift<X>(T(0));
 #pragma unroll
   for (int c = 0; c < na; ++c) {
@@ -214,80 +247,65 @@ PDDP_DEV X qr_cost_default(const ProblemT<T>& P,
   return cost;
 }
 
-// z [n] -> mean [D], upper factor U [D][D] (zeros below the diagonal)
-template <typename T, int D>
-PDDP_DEV void unpack_state(const T* z, T (&mean)[D], T (&U)[D][D]) {
-#pragma unroll
-  for (int c = 0; c < D; ++c) mean[c] = z[c];
-  int o = D;
-#pragma unroll
-  for (int r = 0; r < D; ++r)
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-      if (c >= r) U[r][c] = z[o++];
-      else U[r][c] = T(0);
-    }
-}
-
-// one model step: mean' = f(mean, u); chol' = diag(sqrt(V_i + 1e-12)),
-// V_i = sum_k U[k][i]^2   (encode(mean', V = decode_var(z)))
-template <typename T, int MODEL>
+// one model step on (mean, other): mean' = f(mean, u); the second block is
+// encode(mean', V = decode_var(z)):
+//   Cholesky   chol' = diag(sqrt(V_i + 1e-12)), V_i = sum_k U[k][i]^2
+//   variance   var' = var            standard deviation   std' = sqrt(std^2)
+template <typename T, int MODEL, int ENC>
 PDDP_DEV void step_default(const ProblemT<T>& P,
-                           T (&mean)[DefDims<MODEL>::D],
-                           T (&U)[DefDims<MODEL>::D][DefDims<MODEL>::D],
-                           const T (&u)[DefDims<MODEL>::m]) {
-  constexpr int D = DefDims<MODEL>::D;
+                           T (&mean)[DefDims<MODEL, ENC>::D],
+                           T (&oth)[DefDims<MODEL, ENC>::NO],
+                           const T (&u)[DefDims<MODEL, ENC>::m]) {
+  using G = DefDims<MODEL, ENC>;
+  constexpr int D = G::D;
   T next[D];
   const Trig<T, MODEL> tr = trig_of<T, MODEL>(mean);
   dynamics<T, MODEL, false>(P, mean, u, tr, next, nullptr, nullptr);
-  T sd[D];
+  if constexpr (ENC == kChol) {
+    T sd[D];
 #pragma unroll
-  for (int i = 0; i < D; ++i) {
-    T v = T(0);
+    for (int i = 0; i < D; ++i) {
+      T v = T(0);
 #pragma unroll
-    for (int k = 0; k <= i; ++k) v += U[k][i] * U[k][i];  // pow(2).sum(-2)
-    sd[i] = sqrt_(v + (T)1e-12);
+      for (int k = 0; k <= i; ++k)
+        v += oth[G::tri(k, i)] * oth[G::tri(k, i)];  // pow(2).sum(-2)
+      sd[i] = sqrt_(v + (T)1e-12);
+    }
+#pragma unroll
+    for (int j = 0; j < G::NO; ++j) oth[j] = T(0);
+#pragma unroll
+    for (int i = 0; i < D; ++i) oth[G::tri(i, i)] = sd[i];
+  } else if constexpr (ENC == kStd) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) oth[i] = sqrt_(oth[i] * oth[i]);
   }
 #pragma unroll
-  for (int r = 0; r < D; ++r) {
-    mean[r] = next[r];
-#pragma unroll
-    for (int c = 0; c < D; ++c) U[r][c] = (r == c) ? sd[r] : T(0);
-  }
-}
-
-template <typename T, int D>
-PDDP_DEV void pack_state(const T (&mean)[D], const T (&U)[D][D], T* z) {
-#pragma unroll
-  for (int c = 0; c < D; ++c) z[c] = mean[c];
-  int o = D;
-#pragma unroll
-  for (int r = 0; r < D; ++r)
-#pragma unroll
-    for (int c = r; c < D; ++c) z[o++] = U[r][c];
+  for (int r = 0; r < D; ++r) mean[r] = next[r];
 }
 
 // --------------------------------------------------------------------------
 // nominal rollout: one lane per trajectory
 // --------------------------------------------------------------------------
-template <typename T, int MODEL>
+template <typename T, int MODEL, int ENC>
 __global__ __launch_bounds__(kWave) void rollout_default_kernel(
     ProblemT<T> P, RolloutArgs<T> a) {
-  using G = DefDims<MODEL>;
-  constexpr int D = G::D, m = G::m, n = G::n;
+  using G = DefDims<MODEL, ENC>;
+  constexpr int D = G::D, m = G::m, n = G::n, NO = G::NO;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= a.B) return;
   if (a.mask != nullptr && a.mask[b] == 0) return;
   const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
-  T mean[D], U[D][D], zz[n];
+  T mean[D], oth[NO];
   T* Zb = a.Z + (size_t)b * (a.N + 1) * n;
   const T* Ub = a.U + (size_t)b * a.N * m;
 #pragma unroll
-  for (int j = 0; j < n; ++j) {
-    zz[j] = a.z0[(size_t)b * n + j];
-    Zb[j] = zz[j];
-  }
-  unpack_state<T, D>(zz, mean, U);
+  for (int j = 0; j < D; ++j) mean[j] = a.z0[(size_t)b * n + j];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) oth[j] = a.z0[(size_t)b * n + D + j];
+#pragma unroll
+  for (int j = 0; j < D; ++j) Zb[j] = mean[j];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) Zb[D + j] = oth[j];
   for (int t = 0; t < a.N; ++t) {
     T u[m];
 #pragma unroll
@@ -295,21 +313,22 @@ __global__ __launch_bounds__(kWave) void rollout_default_kernel(
       u[j] = Ub[t * m + j];
       if (bounded) u[j] = clamp1(u[j], a.u_min[j], a.u_max[j]);
     }
-    step_default<T, MODEL>(P, mean, U, u);
-    pack_state<T, D>(mean, U, zz);
+    step_default<T, MODEL, ENC>(P, mean, oth, u);
 #pragma unroll
-    for (int j = 0; j < n; ++j) Zb[(size_t)(t + 1) * n + j] = zz[j];
+    for (int j = 0; j < D; ++j) Zb[(size_t)(t + 1) * n + j] = mean[j];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) Zb[(size_t)(t + 1) * n + D + j] = oth[j];
   }
 }
 
 // --------------------------------------------------------------------------
 // derivative records: one workgroup per (trajectory, step)
 // --------------------------------------------------------------------------
-template <typename T, int MODEL>
+template <typename T, int MODEL, int ENC>
 __global__ __launch_bounds__(kWave) void derivs_default_kernel(
     ProblemT<T> P, DerivArgs<T> a) {
-  using G = DefDims<MODEL>;
-  constexpr int D = G::D, m = G::m, n = G::n;
+  using G = DefDims<MODEL, ENC>;
+  constexpr int D = G::D, m = G::m, n = G::n, NO = G::NO;
   constexpr RecLayout lay(n, m);
   constexpr int S = lay.stride;
   __shared__ T sFx[D * D], sFu[D * m], sSd[D];
@@ -322,13 +341,11 @@ __global__ __launch_bounds__(kWave) void derivs_default_kernel(
   const bool bounded = a.u_min != nullptr && a.u_max != nullptr;
   const T* z = a.Z + ((size_t)b * (N + 1) + t) * n;
   T* w = a.rec + ((size_t)b * (N + 1) + t) * S;
-  T mean[D], U[D][D], un[m], u[m];
-  {
-    T zz[n];
+  T mean[D], oth[NO], un[m], u[m];
 #pragma unroll
-    for (int j = 0; j < n; ++j) zz[j] = z[j];
-    unpack_state<T, D>(zz, mean, U);
-  }
+  for (int j = 0; j < D; ++j) mean[j] = z[j];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) oth[j] = z[D + j];
 #pragma unroll
   for (int r = 0; r < m; ++r) {
     un[r] = terminal ? T(0) : a.U[((size_t)b * N + t) * m + r];
@@ -349,10 +366,15 @@ __global__ __launch_bounds__(kWave) void derivs_default_kernel(
     for (int j = 0; j < D * m; ++j) sFu[j] = terminal ? T(0) : Fu[j];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-      T v = T(0);
+      if constexpr (ENC == kChol) {
+        T v = T(0);
 #pragma unroll
-      for (int k = 0; k <= i; ++k) v += U[k][i] * U[k][i];
-      sSd[i] = sqrt_(v + (T)1e-12);
+        for (int k = 0; k <= i; ++k)
+          v += oth[G::tri(k, i)] * oth[G::tri(k, i)];
+        sSd[i] = sqrt_(v + (T)1e-12);
+      } else {
+        sSd[i] = sqrt_(oth[i] * oth[i]);
+      }
     }
   }
   // ---- the cost by hyper-dual numbers: one lane per pair (i <= j)
@@ -366,22 +388,14 @@ __global__ __launch_bounds__(kWave) void derivs_default_kernel(
     auto in = [&](int kx, T v) {
       return X{v, kx == i ? T(1) : T(0), kx == j ? T(1) : T(0), T(0)};
     };
-    X mu_[D], U_[D][D], u_[m];
+    X mu_[D], oth_[NO], u_[m];
 #pragma unroll
     for (int c = 0; c < D; ++c) mu_[c] = in(c, mean[c]);
-    {
-      int o = D;
 #pragma unroll
-      for (int r = 0; r < D; ++r)
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          if (c >= r) { U_[r][c] = in(o, U[r][c]); ++o; }
-          else U_[r][c] = lift<X>(T(0));
-        }
-    }
+    for (int c = 0; c < NO; ++c) oth_[c] = in(D + c, oth[c]);
 #pragma unroll
     for (int r = 0; r < m; ++r) u_[r] = in(n + r, u[r]);
-    const X cost = qr_cost_default<X, T, MODEL>(P, mu_, U_, u_, terminal);
+    const X cost = qr_cost_default<X, T, MODEL, ENC>(P, mu_, oth_, u_, terminal);
     if (q == 0) a.L[(size_t)b * (N + 1) + t] = cost.v;
     if (i == j) {
       if (i < n) w[lay.oLz + i] = cost.a;
@@ -398,8 +412,8 @@ __global__ __launch_bounds__(kWave) void derivs_default_kernel(
     }
   }
   __syncthreads();
-  // ---- F_z = [dmean'/dmean 0; 0 dchol'/dchol], F_u, the action-side blocks of
-  // the terminal record, the un-clamped nominal action, padding
+  // ---- F_z = [dmean'/dmean 0; 0 dother'/dother], F_u, the action-side blocks
+  // of the terminal record, the un-clamped nominal action, padding
   for (int e = lane; e < n * n; e += kWave) {
     const int r = e / n, c = e - r * n;
     T v = T(0);
@@ -407,16 +421,22 @@ __global__ __launch_bounds__(kWave) void derivs_default_kernel(
       if (r < D && c < D) {
         v = sFx[r * D + c];
       } else if (r >= D && c >= D) {
-        // encoded row r = upper-triangle entry (ri, rj); only the diagonal
-        // entries of chol' are non-zero functions of the input
-        int ri = 0, o = r - D;
-        while (o >= D - ri) { o -= D - ri; ++ri; }
-        const int rj = ri + o;
-        int ci = 0, oc = c - D;
-        while (oc >= D - ci) { oc -= D - ci; ++ci; }
-        const int cj = ci + oc;
-        // d sqrt(V_i + j) / dU[k][i] = U[k][i] / sqrt(V_i + j)
-        if (ri == rj && cj == ri) v = z[c] / sSd[ri];
+        if constexpr (ENC == kChol) {
+          // encoded row r = upper-triangle entry (ri, rj); only the diagonal
+          // entries of chol' are non-zero functions of the input:
+          // d sqrt(V_i + j) / dU[k][i] = U[k][i] / sqrt(V_i + j)
+          int ri = 0, o = r - D;
+          while (o >= D - ri) { o -= D - ri; ++ri; }
+          const int rj = ri + o;
+          int ci = 0, oc = c - D;
+          while (oc >= D - ci) { oc -= D - ci; ++ci; }
+          const int cj = ci + oc;
+          if (ri == rj && cj == ri) v = z[c] / sSd[ri];
+        } else if constexpr (ENC == kVar) {
+          v = (r == c) ? T(1) : T(0);          // var' = var
+        } else {
+          if (r == c) v = z[c] / sSd[c - D];   // d sqrt(s^2) / ds
+        }
       }
     }
     w[lay.oFz + e] = v;
@@ -451,11 +471,11 @@ __global__ __launch_bounds__(256) void cost_sum_default_kernel(
 // --------------------------------------------------------------------------
 // line search: one lane per (trajectory, step size)
 // --------------------------------------------------------------------------
-template <typename T, int MODEL>
+template <typename T, int MODEL, int ENC>
 __global__ __launch_bounds__(kWave) void line_search_default_kernel(
     ProblemT<T> P, LineSearchArgs<T> a) {
-  using G = DefDims<MODEL>;
-  constexpr int D = G::D, m = G::m, n = G::n;
+  using G = DefDims<MODEL, ENC>;
+  constexpr int D = G::D, m = G::m, n = G::n, NO = G::NO;
   constexpr int GS = m + m * n;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= a.B * a.A) return;
@@ -472,10 +492,11 @@ __global__ __launch_bounds__(kWave) void line_search_default_kernel(
   T* Uci = a.Uc + ((size_t)b * N * a.A + ai) * m;
   const size_t zstep = (size_t)a.A * n, ustep = (size_t)a.A * m;
 
-  T zz[n], mean[D], U[D][D];
+  T mean[D], oth[NO];
 #pragma unroll
-  for (int j = 0; j < n; ++j) zz[j] = Zb[j];  // Z_new[0] = Z[0]  (ilqr.py:690)
-  unpack_state<T, D>(zz, mean, U);
+  for (int j = 0; j < D; ++j) mean[j] = Zb[j];  // Z_new[0] = Z[0] (ilqr.py:690)
+#pragma unroll
+  for (int j = 0; j < NO; ++j) oth[j] = Zb[D + j];
   T J = T(0);
   for (int t = 0; t < N; ++t) {
     T u[m];
@@ -483,35 +504,41 @@ __global__ __launch_bounds__(kWave) void line_search_default_kernel(
     for (int r = 0; r < m; ++r) {
       T du = alpha * Gb[t * GS + r];  // alpha * k[i]              (ilqr.py:708)
       T s = T(0);
+      const T* Kr = Gb + t * GS + m + r * n;
+      const T* zr = Zb + (size_t)t * n;
 #pragma unroll
-      for (int c = 0; c < n; ++c)
-        s += (zz[c] - Zb[(size_t)t * n + c]) * Gb[t * GS + m + r * n + c];
+      for (int c = 0; c < D; ++c) s += (mean[c] - zr[c]) * Kr[c];
+#pragma unroll
+      for (int c = 0; c < NO; ++c) s += (oth[c] - zr[D + c]) * Kr[D + c];
       du = du + s;  // + dz K^T                                    (ilqr.py:710)
       const T v = Ub[t * m + r] + du;
       u[r] = bounded ? clamp_nan(v, a.u_min[r], a.u_max[r]) : v;
     }
 #pragma unroll
-    for (int j = 0; j < n; ++j) Zci[(size_t)t * zstep + j] = zz[j];
+    for (int j = 0; j < D; ++j) Zci[(size_t)t * zstep + j] = mean[j];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) Zci[(size_t)t * zstep + D + j] = oth[j];
 #pragma unroll
     for (int j = 0; j < m; ++j) Uci[(size_t)t * ustep + j] = u[j];
-    J += qr_cost_default<T, T, MODEL>(P, mean, U, u, false);
-    step_default<T, MODEL>(P, mean, U, u);
-    pack_state<T, D>(mean, U, zz);
+    J += qr_cost_default<T, T, MODEL, ENC>(P, mean, oth, u, false);
+    step_default<T, MODEL, ENC>(P, mean, oth, u);
   }
 #pragma unroll
-  for (int j = 0; j < n; ++j) Zci[(size_t)N * zstep + j] = zz[j];
+  for (int j = 0; j < D; ++j) Zci[(size_t)N * zstep + j] = mean[j];
+#pragma unroll
+  for (int j = 0; j < NO; ++j) Zci[(size_t)N * zstep + D + j] = oth[j];
   T u0[m];
 #pragma unroll
   for (int r = 0; r < m; ++r) u0[r] = T(0);
-  J += qr_cost_default<T, T, MODEL>(P, mean, U, u0, true);
+  J += qr_cost_default<T, T, MODEL, ENC>(P, mean, oth, u0, true);
   a.Jc[idx] = J;  // L.sum(0) + l_f                                (ilqr.py:789)
 }
 
 // --------------------------------------------------------------------------
-// launchers (called from problem_kernels.hip when problem.encoding is DEFAULT)
+// launchers (called from problem_kernels.hip for the Gaussian encodings)
 // --------------------------------------------------------------------------
 static int check_default(const pddp_problem& p) {
-  if (p.encoding != PDDP_ENC_UPPER_TRIANGULAR_CHOLESKY)
+  if (p.encoding != kChol && p.encoding != kVar && p.encoding != kStd)
     return PDDP_E_UNSUPPORTED;
   switch (p.model) {
     case PDDP_MODEL_CARTPOLE:
@@ -522,11 +549,26 @@ static int check_default(const pddp_problem& p) {
   return PDDP_E_UNSUPPORTED;
 }
 
-#define PDDP_DEFAULT_DISPATCH(CALL)                                          \
+#define PDDP_DEFAULT_ENC(...)                                                \
+  switch (p.encoding) {                                                      \
+    case kChol: { constexpr int ENC = kChol; __VA_ARGS__; } break;             \
+    case kVar: { constexpr int ENC = kVar; __VA_ARGS__; } break;               \
+    default: { constexpr int ENC = kStd; __VA_ARGS__; } break;                 \
+  }
+#define PDDP_DEFAULT_DISPATCH(...)                                           \
   switch (p.model) {                                                         \
-    case PDDP_MODEL_CARTPOLE: { constexpr int MODEL = PDDP_MODEL_CARTPOLE; CALL; } break; \
-    case PDDP_MODEL_PENDULUM: { constexpr int MODEL = PDDP_MODEL_PENDULUM; CALL; } break; \
-    default: { constexpr int MODEL = PDDP_MODEL_DOUBLE_CARTPOLE; CALL; } break; \
+    case PDDP_MODEL_CARTPOLE: {                                              \
+      constexpr int MODEL = PDDP_MODEL_CARTPOLE;                             \
+      PDDP_DEFAULT_ENC(__VA_ARGS__)                                            \
+    } break;                                                                 \
+    case PDDP_MODEL_PENDULUM: {                                              \
+      constexpr int MODEL = PDDP_MODEL_PENDULUM;                             \
+      PDDP_DEFAULT_ENC(__VA_ARGS__)                                            \
+    } break;                                                                 \
+    default: {                                                               \
+      constexpr int MODEL = PDDP_MODEL_DOUBLE_CARTPOLE;                      \
+      PDDP_DEFAULT_ENC(__VA_ARGS__)                                            \
+    } break;                                                                 \
   }
 
 template <typename T>
@@ -534,8 +576,8 @@ int default_rollout(const pddp_problem& p, RolloutArgs<T> a, hipStream_t st) {
   if (int rc = check_default(p)) return rc;
   const ProblemT<T> P = convert_problem<T>(p);
   const dim3 grid((a.B + kWave - 1) / kWave), block(kWave);
-  PDDP_DEFAULT_DISPATCH(
-      PDDP_LAUNCH((rollout_default_kernel<T, MODEL>), grid, block, 0, st, P, a))
+  PDDP_DEFAULT_DISPATCH(PDDP_LAUNCH((rollout_default_kernel<T, MODEL, ENC>),
+                                    grid, block, 0, st, P, a))
   return launch_status();
 }
 template <typename T>
@@ -543,8 +585,8 @@ int default_derivs(const pddp_problem& p, DerivArgs<T> a, hipStream_t st) {
   if (int rc = check_default(p)) return rc;
   const ProblemT<T> P = convert_problem<T>(p);
   const dim3 grid(a.B * (a.N + 1)), block(kWave);
-  PDDP_DEFAULT_DISPATCH(
-      PDDP_LAUNCH((derivs_default_kernel<T, MODEL>), grid, block, 0, st, P, a))
+  PDDP_DEFAULT_DISPATCH(PDDP_LAUNCH((derivs_default_kernel<T, MODEL, ENC>),
+                                    grid, block, 0, st, P, a))
   if (int rc = launch_status()) return rc;
   PDDP_LAUNCH((cost_sum_default_kernel<T>), dim3((a.B + 255) / 256), dim3(256),
               0, st, a.B, a.N + 1, (const T*)a.L, a.mask, a.J, a.state);
@@ -557,7 +599,7 @@ int default_line_search(const pddp_problem& p, LineSearchArgs<T> a,
   const ProblemT<T> P = convert_problem<T>(p);
   const int total = a.B * a.A;
   const dim3 grid((total + kWave - 1) / kWave), block(kWave);
-  PDDP_DEFAULT_DISPATCH(PDDP_LAUNCH((line_search_default_kernel<T, MODEL>),
+  PDDP_DEFAULT_DISPATCH(PDDP_LAUNCH((line_search_default_kernel<T, MODEL, ENC>),
                                     grid, block, 0, st, P, a))
   return launch_status();
 }

@@ -604,7 +604,9 @@ template <typename T>
 int default_line_search(const pddp_problem& p, LineSearchArgs<T> a,
                         hipStream_t st);
 static bool is_default_encoding(const pddp_problem* p) {
-  return p != nullptr && p->encoding == PDDP_ENC_UPPER_TRIANGULAR_CHOLESKY;
+  return p != nullptr && (p->encoding == PDDP_ENC_UPPER_TRIANGULAR_CHOLESKY ||
+                          p->encoding == PDDP_ENC_VARIANCE_ONLY ||
+                          p->encoding == PDDP_ENC_STANDARD_DEVIATION_ONLY);
 }
 
 static int check_problem(const pddp_problem* p) {

@@ -31,10 +31,13 @@ def build_problem(name, model, cost, encoding, param_names):
     """Flattens a sample (model, cost) pair into include/pddp_problem.h: the
     problems the HIP kernels evaluate in closed form - every sample problem
     under IGNORE_UNCERTAINTY (csrc/problem_kernels.hip) and cartpole, pendulum,
-    double cartpole under DEFAULT = UPPER_TRIANGULAR_CHOLESKY
-    (csrc/default_kernels.hip; rendezvous carries a full covariance there and
-    stays on the plugin path).  None otherwise."""
-    if encoding == StateEncoding.UPPER_TRIANGULAR_CHOLESKY:
+    double cartpole under DEFAULT = UPPER_TRIANGULAR_CHOLESKY, VARIANCE_ONLY and
+    STANDARD_DEVIATION_ONLY (csrc/default_kernels.hip; rendezvous carries a
+    full covariance there and stays on the plugin path, as does
+    FULL_COVARIANCE_MATRIX).  None otherwise."""
+    if encoding in (StateEncoding.UPPER_TRIANGULAR_CHOLESKY,
+                    StateEncoding.VARIANCE_ONLY,
+                    StateEncoding.STANDARD_DEVIATION_ONLY):
         if name == "rendezvous":
             return None
     elif encoding != StateEncoding.IGNORE_UNCERTAINTY:

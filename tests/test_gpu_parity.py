@@ -695,11 +695,15 @@ def test_default_encoding_vs_reference_golden(problem):
     assert ctrl._solver.problem.encoding == int(enc)
 
 
+@pytest.mark.parametrize("enc_name", ["UPPER_TRIANGULAR_CHOLESKY",
+                                      "VARIANCE_ONLY",
+                                      "STANDARD_DEVIATION_ONLY"])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", ["cartpole", "pendulum",
                                      "double_cartpole"])
-def test_default_encoding_native_vs_plugin_path(problem, dtype):
-    """The native DEFAULT-encoding kernels (csrc/default_kernels.hip) against
+def test_default_encoding_native_vs_plugin_path(problem, dtype, enc_name):
+    """The native Gaussian-encoding kernels (csrc/default_kernels.hip: DEFAULT =
+    upper-triangular Cholesky, VARIANCE_ONLY, STANDARD_DEVIATION_ONLY) against
     the plugin path on the same inputs - replicated-input autograd Jacobians
     and Hessians through the torch model / cost, torch line search
     (controllers/plugin.py; pinned to the reference's goldens by
@@ -714,9 +718,9 @@ def test_default_encoding_native_vs_plugin_path(problem, dtype):
              and n != "DynamicsModel"][0](DT[problem]).to(td).cuda()
     cost = [getattr(mod, n) for n in dir(mod) if n.endswith("Cost")
             and n != "AugmentedQRCost"][0]().to(td).cuda()
-    enc = pddp_amd.StateEncoding.DEFAULT
+    enc = pddp_amd.StateEncoding[enc_name]
     D, m = model.state_size, model.action_size
-    n = D + D * (D + 1) // 2
+    n = pddp_amd.utils.encoding.infer_encoded_state_size(D, enc)
     B, N = 5, 12
     g = torch.Generator().manual_seed(4)
     mean = torch.tensor(MEAN0[problem], dtype=torch.float64)
