@@ -100,7 +100,7 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  * 16 / 17: four lanes per trajectory, sixteen trajectories per wavefront
  * (IEEE / approximate division; all four branches; f32 and f64); 18 = 16 with
  * every BoxQP through the reference's loop (bounded branches).
- * Auto for n=4/m=1: f32 from 8192 trajectories on -> 17; bounded f32 below that
+ * Auto for n=4/m=1: f32 from 12288 trajectories on -> 17; bounded f32 below that
  * -> 13 (eig-clamp branch) or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64).
  * 14 / 15: the f32 matrix-core kernels for n <= 30, m = 1 (IEEE / approximate
  * division; auto for those shapes other than n = 4). */

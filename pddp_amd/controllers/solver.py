@@ -148,7 +148,7 @@ class ILQRSolver(object):
         if self.dtype != torch.float32:
             return 0  # the f64 kernels are IEEE throughout
         if self.n == 4 and self.m == 1:
-            if self.B >= 8192:
+            if self.B >= 12288:
                 return 16
             if bounded:
                 return 12 if branch == BRANCH_EIG else 8

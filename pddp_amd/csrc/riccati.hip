@@ -71,7 +71,7 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          10 / 11 = 6 / 7 in workgroups of four wavefronts,
   //          12 / 13 = 8 / 9 with the BoxQP chain decoupled from the value
   //          update (riccati_n4_pipe.hpp; bounded eig-clamp branch only);
-  //          auto: f32 from 8192 trajectories on -> 17; bounded f32 below
+  //          auto: f32 from 12288 trajectories on -> 17; bounded f32 below
   //          that -> 13 (eig-clamp branch) or 9 (Cholesky branch); otherwise
   //          7 (f32) / 6 (f64)
   //          14 / 15: the matrix-core kernels for n <= 30, m = 1, fp32
@@ -100,11 +100,13 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   if (variant < 0 || variant > 13 || variant == 4 || variant == 5)
     return PDDP_E_BADARG;
 
-  if (variant == 0 && n == 4 && m == 1 && sizeof(T) == 4 && B >= 8192) {
+  if (variant == 0 && n == 4 && m == 1 && sizeof(T) == 4 && B >= 12288) {
     // large batches: four lanes per trajectory (riccati_n4_quad.hpp) - a
-    // third of the issue slots per trajectory-step of the kernels below; from
-    // 8192 trajectories on it is the fastest on every branch (measured:
-    // 64 / 66 / 86 us at B = 8192 / 12288 / 16384 against 69 / 90 / 131)
+    // third of the issue slots per trajectory-step of the kernels below.
+    // Measured inside the fit loop (bench.py --batch B): 66 / 90 / 98 us at
+    // B = 8192 / 12288 / 16384 against 67 / 92 / 128 for the kernels below
+    // (alone on records that sit in the Infinity Cache: 64 / 66 / 86 against
+    // 69 / 90 / 131)
     return launch_n4_quad(a, st, true);
   }
   if (variant == 0 && n == 4 && m == 1 && u_min != nullptr && B <= 16384) {

@@ -38,6 +38,8 @@
 // f^T (V + reg I) F = f^T V F + reg f^T F.
 #pragma once
 
+#include <cstdlib>
+
 #include "riccati_n4.hpp"
 
 #ifdef PDDP_Q4_NOSLOW  // timing experiment: never take the loop fall-back
@@ -599,8 +601,16 @@ static int launch_n4_quad(const RiccatiArgs<T>& a, hipStream_t st,
   const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
   const int waves = (a.B + 15) / 16;
   const size_t lds1 = (size_t)R * G::SLOT * sizeof(T);
-  // (four f64 rings would not fit the CU's 160 KB of LDS)
-  const bool four = waves > 256 && 4 * lds1 <= 150 * 1024;
+  // wavefronts per workgroup: as many as keep at least one workgroup on every
+  // CU (256) and fit the CU's 160 KB of LDS - 512 waves as 128 workgroups of
+  // four left half the chip idle (B = 8192: 81 against 66 us; B = 12288 runs
+  // 89 us as 192 workgroups of four, 94 us as 384 of two)
+  int wpb = waves >= 768 ? 4 : (waves >= 512 ? 2 : 1);
+  while (wpb > 1 && (size_t)wpb * lds1 > 150 * 1024) wpb /= 2;
+  if (const char* e = getenv("PDDP_QUAD_WPB")) {  // (A/B measurements)
+    const int w = atoi(e);
+    if (w == 1 || w == 2 || w == 4) wpb = w;
+  }
   if (loop_always) {  // IEEE, bounded, one wave per workgroup
     if (!bounded) return PDDP_E_UNSUPPORTED;
     auto k0 = n4q::riccati_n4_quad_kernel<T, false, true, false, R, 1, true>;
@@ -613,24 +623,21 @@ static int launch_n4_quad(const RiccatiArgs<T>& a, hipStream_t st,
     PDDP_LAUNCH(kern, dim3(waves), dim3(kWave), lds1, st, a);
     return launch_status();
   }
+#define PDDP_Q4_GO(C, Bd, F, W)                                               \
+  do {                                                                        \
+    auto kern = n4q::riccati_n4_quad_kernel<T, C, Bd, F, R, W>;               \
+    const hipError_t e = hipFuncSetAttribute(                                 \
+        (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+        (int)(W * lds1));                                                     \
+    if (e != hipSuccess) return (int)e;                                       \
+    PDDP_LAUNCH(kern, dim3((waves + W - 1) / W), dim3(kWave * W), W * lds1,   \
+                st, a);                                                       \
+  } while (0)
 #define PDDP_Q4_LAUNCH(C, Bd, F)                                              \
   do {                                                                        \
-    if (four) {                                                               \
-      auto kern = n4q::riccati_n4_quad_kernel<T, C, Bd, F, R, 4>;             \
-      const hipError_t e = hipFuncSetAttribute(                               \
-          (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-          (int)(4 * lds1));                                                   \
-      if (e != hipSuccess) return (int)e;                                     \
-      PDDP_LAUNCH(kern, dim3((waves + 3) / 4), dim3(kWave * 4), 4 * lds1, st, \
-                  a);                                                         \
-    } else {                                                                  \
-      auto kern = n4q::riccati_n4_quad_kernel<T, C, Bd, F, R, 1>;             \
-      const hipError_t e = hipFuncSetAttribute(                               \
-          (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,      \
-          (int)lds1);                                                         \
-      if (e != hipSuccess) return (int)e;                                     \
-      PDDP_LAUNCH(kern, dim3(waves), dim3(kWave), lds1, st, a);               \
-    }                                                                         \
+    if (wpb == 4) PDDP_Q4_GO(C, Bd, F, 4);                                    \
+    else if (wpb == 2) PDDP_Q4_GO(C, Bd, F, 2);                               \
+    else PDDP_Q4_GO(C, Bd, F, 1);                                             \
   } while (0)
 #define PDDP_Q4_BRANCH(F)                                                     \
   do {                                                                        \
@@ -646,6 +653,7 @@ static int launch_n4_quad(const RiccatiArgs<T>& a, hipStream_t st,
   else PDDP_Q4_BRANCH(false);
 #undef PDDP_Q4_BRANCH
 #undef PDDP_Q4_LAUNCH
+#undef PDDP_Q4_GO
   return launch_status();
 }
 

@@ -277,9 +277,17 @@ def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
 
         def fit(self, X, U, dX, n_iter=500, batch_size=128, reg_scale=1.0,
                 learning_rate=1e-4, likelihood=gaussian_log_likelihood,
-                resample=True, normalize=True, quiet=False, **kw):
+                resample=True, normalize=True, quiet=False, graph=None, **kw):
             """Maximum-likelihood training with the dropout regulariser
-            (modules.py:131-198): Adam(amsgrad), shuffled mini-batches."""
+            (modules.py:131-198): Adam(amsgrad), shuffled mini-batches.
+
+            `graph` (default: on for CUDA data): one training step - gather of
+            the mini-batch, forward with freshly drawn concrete-dropout masks,
+            likelihood + regulariser, backward, Adam - is captured once into a
+            hipGraph and replayed per full mini-batch; a trailing partial
+            batch of an epoch (another shape) runs eagerly on the same
+            optimizer state.  The network is small: a step is ~60 launches of
+            a few microseconds each, i.e. launch-bound."""
             Xa = (augment_state(X, angular_indices, non_angular_indices)
                   if angular else X)
             X_ = torch.cat([Xa, U], dim=-1).detach()
@@ -293,26 +301,64 @@ def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
                 self.dX_std = dX.std(0)
                 self.dX_std_inv = self.dX_std.reciprocal()
             params = [p for p in self.parameters() if p.requires_grad]
-            opt = torch.optim.Adam(params, learning_rate, amsgrad=True)
+            use_graph = X_.is_cuda if graph is None else bool(graph)
+            use_graph = use_graph and X_.is_cuda
+            if not resample and N % min(batch_size, N) != 0:
+                # held masks are re-drawn (python side) whenever the batch
+                # shape changes: a trailing partial batch would leave the
+                # captured step on the masks of the previous epoch
+                use_graph = False
+            opt = torch.optim.Adam(params, learning_rate, amsgrad=True,
+                                   capturable=use_graph)
             self.train()
+            log_dX_std = self.dX_std.log()
+
+            def step(idx):
+                opt.zero_grad(set_to_none=True)
+                out = self.model((X_[idx] - self.X_mean) * self.X_std_inv,
+                                 resample=resample)
+                mean, log_std = out.split([state_size, state_size], -1)
+                mean = mean * self.dX_std + self.dX_mean
+                log_std = log_std + log_dX_std
+                loss = -likelihood(dX[idx], mean, log_std.exp()).mean()
+                loss = loss + reg_scale * self.model.regularization() / N
+                loss.backward()
+                opt.step()
+
+            full = min(batch_size, N)
+            static_idx, captured, warm = None, None, 0
+            if use_graph:
+                static_idx = torch.zeros(full, dtype=torch.long,
+                                         device=X_.device)
             it = 0
             while it < n_iter:
                 perm = torch.randperm(N, device=X_.device)
                 for s0 in range(0, N, batch_size):
                     idx = perm[s0:s0 + batch_size]
-                    opt.zero_grad()
-                    out = self.model((X_[idx] - self.X_mean) * self.X_std_inv,
-                                     resample=resample)
-                    mean, log_std = out.split([state_size, state_size], -1)
-                    mean = mean * self.dX_std + self.dX_mean
-                    log_std = log_std + self.dX_std.log()
-                    loss = -likelihood(dX[idx], mean, log_std.exp()).mean()
-                    loss = loss + reg_scale * self.model.regularization() / N
-                    loss.backward()
-                    opt.step()
+                    if not use_graph or idx.shape[0] != full:
+                        step(idx)
+                    elif captured is None and warm < 3:
+                        # the first full batches run eagerly on a side stream
+                        # (allocator / autograd warm-up before the capture;
+                        # they are ordinary training steps)
+                        side = torch.cuda.Stream(device=X_.device)
+                        side.wait_stream(torch.cuda.current_stream(X_.device))
+                        with torch.cuda.stream(side):
+                            static_idx.copy_(idx)
+                            step(static_idx)
+                        torch.cuda.current_stream(X_.device).wait_stream(side)
+                        warm += 1
+                    else:
+                        static_idx.copy_(idx)
+                        if captured is None:
+                            captured = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(captured):
+                                step(static_idx)
+                        captured.replay()
                     it += 1
                     if it >= n_iter:
                         break
+            self.last_fit_used_graph = captured is not None
             return self
 
         def forward(self, X, u, i, resample=False, use_predicted_std=False,

@@ -1878,3 +1878,50 @@ def test_headless_example_flows(example):
     assert len(out["J_hist"]) >= 1 and np.all(np.isfinite(out["J_hist"]))
     assert torch.isfinite(out["final_state"]).all()
     assert out["derivs_path"] == {"dynamics": "hip", "cost": "hip"}
+
+
+def test_bnn_training_graph_equals_eager():
+    """BNN training (modules.py:131-198) with each step replayed as a captured
+    hipGraph: with the dropout noise held fixed (resample=False) and the same
+    seed, the graph path and the eager path walk the same mini-batches through
+    the same kernels and must end at the same parameters; with fresh noise per
+    step (the reference's default) the graph path still learns."""
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    torch.manual_seed(0)
+    X = torch.randn(300, 3).cuda()      # 300 = 2 full batches of 128 + 44
+    U = torch.randn(300, 1).cuda()
+    dX = 0.1 * X + 0.2 * U
+    cls = bnn_dynamics_model_factory(3, 1, [32, 32])
+    finals = {}
+    for graph in (False, True):
+        torch.manual_seed(1)
+        model = cls(n_particles=10).cuda()
+        torch.manual_seed(2)
+        # (256 rows = two full batches: held masks keep their shape)
+        model.fit(X[:256], U[:256], dX[:256], n_iter=40, learning_rate=1e-2,
+                  resample=False, quiet=True, graph=graph)
+        assert model.last_fit_used_graph == graph
+        finals[graph] = [p.detach().clone() for p in model.parameters()]
+    for a, b in zip(finals[False], finals[True]):
+        # (the capturable Adam keeps its step count and bias corrections in
+        # device tensors: float rounding differs from the eager optimizer's
+        # python scalars; 40 steps at lr = 1e-2 move weights by ~0.3)
+        assert torch.allclose(a, b, rtol=1e-2, atol=2e-3), \
+            float((a - b).abs().max())
+
+    def nll(model):
+        model.eval()
+        out = model.model((torch.cat([X, U], -1) - model.X_mean)
+                          * model.X_std_inv)
+        mean, log_std = out.split([3, 3], -1)
+        mean = mean * model.dX_std + model.dX_mean
+        log_std = log_std + model.dX_std.log()
+        d = (mean - dX) / log_std.exp()
+        return float((0.5 * d ** 2 + log_std).sum(-1).mean())
+    torch.manual_seed(3)
+    model = cls(n_particles=10).cuda()
+    model.fit(X, U, dX, n_iter=1, quiet=True)
+    before = nll(model)
+    model.fit(X, U, dX, n_iter=300, learning_rate=1e-2, quiet=True)
+    assert model.last_fit_used_graph
+    assert nll(model) < before - 0.5

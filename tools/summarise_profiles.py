@@ -71,6 +71,8 @@ for p in sorted(glob.glob("gpurun_out/%s_bench*.json" % tag)):
 json.dump(points, open(os.path.join(out, "%s_bench_points.json" % tag), "w"),
           indent=1)
 for k, d in points.items():
+    if not d.get("roofline"):
+        continue
     print(k, round(d["ms_per_step"], 4), "ms/step; sweep",
           round(d["roofline"]["avg_launch_us"], 1), "us, frac",
           round(d["roofline"]["frac"], 4), "value", int(d["value"]))
