@@ -100,8 +100,12 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  * 16 / 17: four lanes per trajectory, sixteen trajectories per wavefront
  * (IEEE / approximate division; all four branches; f32 and f64); 18 = 16 with
  * every BoxQP through the reference's loop (bounded branches).
- * Auto for n=4/m=1: f32 from 12288 trajectories on -> 17; bounded f32 below that
- * -> 13 (eig-clamp branch) or 9 (Cholesky branch); otherwise 7 (f32) / 6 (f64).
+ * 20 / 21: the quad mapping over three wavefronts of a workgroup - record
+ * producer, matrices, scalars (IEEE / approximate division; bounded eig-clamp
+ * branch only; f32 and f64); 22 / 23 = 20 / 21 without the mirrored Qzz row.
+ * Auto for n=4/m=1: bounded eig-clamp branch below 16384 (f32) / 8193 (f64)
+ * trajectories -> 21 / 20; f32 from 12288 trajectories on -> 17; bounded
+ * Cholesky branch f32 below that -> 9; otherwise 7 (f32) / 6 (f64).
  * 14 / 15: the f32 matrix-core kernels for n <= 30, m = 1 (IEEE / approximate
  * division; auto for those shapes other than n = 4). */
 int pddp_riccati_backward_variant_f32(int B, int N, int n, int m,

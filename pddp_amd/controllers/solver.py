@@ -148,10 +148,12 @@ class ILQRSolver(object):
         if self.dtype != torch.float32:
             return 0  # the f64 kernels are IEEE throughout
         if self.n == 4 and self.m == 1:
+            if bounded and branch == BRANCH_EIG and self.B < 16384:
+                return 20
             if self.B >= 12288:
                 return 16
             if bounded:
-                return 12 if branch == BRANCH_EIG else 8
+                return 8
             return 6
         if self.m == 1 and self.n <= 30:
             return 14

