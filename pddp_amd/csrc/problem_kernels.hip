@@ -309,15 +309,27 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
 // one wave per SIMD of a CU whatever the dispatcher did before - with
 // one-wave workgroups the placement of 1024 of them on 1024 SIMDs depended on
 // the previous kernel's shape (measured: +13 us after a 128-thread kernel).
-template <typename T, int MODEL, bool FUSED, int WPB>
-__global__ __launch_bounds__(kWave * WPB) void line_search_lds_kernel(
+//
+// H = 2 (FUSED only): a HELPER wavefront per rollout wavefront.  The rollouts
+// are a dependent chain that one wave per SIMD runs as fast as it can be run;
+// the tail is the opposite - every (trajectory, step) record of the accepted
+// nominals is ~770 independent instructions - and a wave that has a SIMD to
+// itself issues at half the SIMD's rate.  The helper (same four trajectories,
+// same LDS slice) helps with the staging, sleeps at a barrier through the
+// rollouts, and takes every other row of the tail.
+template <typename T, int MODEL, bool FUSED, int WPB, int H = 1>
+__global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
     ProblemT<T> P, LineSearchArgs<T> a, AcceptArgs<T> c, T* rec, T* Lout) {
   using D = ModelDims<MODEL>;
   constexpr int n = D::n, m = D::m;
   constexpr int GS = m + m * n;
+  static_assert(H == 1 || (H == 2 && FUSED), "");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __shared__ int sh_dec[WPB][4][2];  // H = 2: {amin_out, fresh} per trajectory
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x >> 6;
+  const int wave_all = threadIdx.x >> 6;
+  const int wave = H == 1 ? wave_all : wave_all % WPB;
+  const int hid = H == 1 ? 0 : wave_all / WPB;  // 0 rollout wave, 1 helper
   const int grp = lane >> 4, ai = lane & 15;
   const int N = a.N;
   const int per = (N + 1) * n + N * m + N * GS;  // scalars per trajectory
@@ -328,6 +340,7 @@ __global__ __launch_bounds__(kWave * WPB) void line_search_lds_kernel(
   for (int g = 0; g < 4; ++g) {
     const int bg = b0 + g;
     if (bg >= a.B) break;
+    if (H == 2 && (g & 1) != hid) continue;  // the pair splits the copies
     if (a.active != nullptr && a.active[bg] == 0) continue;
     T* dst = smem + (size_t)g * per;
     const T* zs = a.Z + (size_t)bg * (N + 1) * n;
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(kWave * WPB) void line_search_lds_kernel(
     if (attempted && ai == 0) acc_in = accept_load(c, b);
   }
   T Jmine = T(0);
-  if (run) {
+  if (run && hid == 0) {
     const T alpha = a.alphas[ai];
     const int idx = b * a.A + ai;
     T* Zci = a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
@@ -430,18 +443,31 @@ __global__ __launch_bounds__(kWave * WPB) void line_search_lds_kernel(
 
     // ---- accept / reject, mu schedule, masks: lane 0 of the group
     int amin_out = -1, fresh_i = 0;
-    if (attempted && ai == 0) {
+    if (attempted && ai == 0 && hid == 0) {
       bool fr;
       amin_out = accept_decide(c, b, acc_in, amin, J_new, fr);
       fresh_i = fr ? 1 : 0;
     }
     amin_out = __shfl(amin_out, lane & 48);
     fresh_i = __shfl(fresh_i, lane & 48);
-    if (!__any(amin_out >= 0)) return;
-    // the candidate rows written above are read back below, by this same
-    // wavefront: workgroup scope (an agent-scope fence writes back the XCD's
-    // whole L2 on gfx950 - measured: +40 us per launch)
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if constexpr (H == 1) {
+      if (!__any(amin_out >= 0)) return;
+      // the candidate rows written above are read back below, by this same
+      // wavefront: workgroup scope (an agent-scope fence writes back the
+      // XCD's whole L2 on gfx950 - measured: +40 us per launch)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    } else {
+      // hand the decisions (and, through the workgroup-scope fence, the
+      // candidate rows) to the helper wave
+      if (hid == 0 && ai == 0) {
+        sh_dec[wave][grp][0] = amin_out;
+        sh_dec[wave][grp][1] = fresh_i;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __syncthreads();
+      amin_out = sh_dec[wave][grp][0];
+      fresh_i = sh_dec[wave][grp][1];
+    }
     if (amin_out >= 0) {
       // nominal <- winning candidate; self._K <- K            (ilqr.py:167-169)
       constexpr RecLayout lay(n, m);
@@ -458,18 +484,20 @@ __global__ __launch_bounds__(kWave * WPB) void line_search_lds_kernel(
       const T* G = c.gains + (size_t)b * N * GS;
       T* Ga = c.gains_acc + (size_t)b * N * GS;
       T zc[n], uc[m];
+      const int t_first = ai + 16 * hid;  // rows t_first, t_first + 16 H, ...
       {
-        const int tu = ai < N ? ai : 0;
+        const int tz = t_first <= N ? t_first : N;
+        const int tu = t_first < N ? t_first : 0;
 #pragma unroll
-        for (int j = 0; j < n; ++j) zc[j] = srcz[(size_t)ai * zstep + j];
+        for (int j = 0; j < n; ++j) zc[j] = srcz[(size_t)tz * zstep + j];
 #pragma unroll
         for (int j = 0; j < m; ++j) uc[j] = srcu[(size_t)tu * ustep + j];
       }
 #pragma unroll 1
-      for (int t = ai; t <= N; t += 16) {
+      for (int t = t_first; t <= N; t += 16 * H) {
         T zn_[n], un_[m];
         {
-          const int t2 = t + 16;
+          const int t2 = t + 16 * H;
           const int tz = t2 <= N ? t2 : N, tu = t2 < N ? t2 : 0;
 #pragma unroll
           for (int j = 0; j < n; ++j) zn_[j] = srcz[(size_t)tz * zstep + j];
@@ -503,16 +531,35 @@ __global__ __launch_bounds__(kWave * WPB) void line_search_lds_kernel(
 #pragma unroll
         for (int j = 0; j < m; ++j) uc[j] = un_[j];
       }
-      group_copy(Ga, G, N * GS, ai);
-      if (fresh_i) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (ai == 0) {
-          T Jacc = T(0);
-          for (int t = 0; t <= N; ++t) Jacc += Ls[t];  // L.sum(), in t order
-          c.J_opt[b] = Jacc;
-          c.fresh[b] = 0;  // its records are up to date
+      if constexpr (H == 1) {
+        group_copy(Ga, G, N * GS, ai);
+      } else {  // each wave of the pair copies half of the gains
+        const int half = (N * GS + 1) / 2;
+        const int off = hid * half;
+        const int cnt = hid == 0 ? half : N * GS - half;
+        group_copy(Ga + off, G + off, cnt, ai);
+      }
+      if constexpr (H == 1) {
+        if (fresh_i) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (ai == 0) {
+            T Jacc = T(0);
+            for (int t = 0; t <= N; ++t) Jacc += Ls[t];  // L.sum(), in t order
+            c.J_opt[b] = Jacc;
+            c.fresh[b] = 0;  // its records are up to date
+          }
         }
+      }
+    }
+    if constexpr (H == 2) {
+      __syncthreads();  // both waves' stage costs Ls[t] are in LDS
+      if (amin_out >= 0 && fresh_i && hid == 0 && ai == 0) {
+        const T* Ls = smem + (size_t)grp * per;
+        T Jacc = T(0);
+        for (int t = 0; t <= N; ++t) Jacc += Ls[t];  // L.sum(), in t order
+        c.J_opt[b] = Jacc;
+        c.fresh[b] = 0;  // its records are up to date
       }
     }
   }
@@ -584,8 +631,9 @@ static int launch_search_accept(const pddp_problem& p, SearchAcceptArgs<T> a,
   a.ac.n = D::n;
   a.ac.m = D::m;
   if (4 * lds <= 64 * 1024)
-    PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 4>),
-                       dim3((a.ls.B + 15) / 16), dim3(kWave * 4), 4 * lds, st, P,
+    // four rollout waves (one per SIMD of a CU) + their four helpers
+    PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 4, 2>),
+                       dim3((a.ls.B + 15) / 16), dim3(kWave * 8), 4 * lds, st, P,
                        a.ls, a.ac, a.rec, a.L);
   else
     PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 1>),
