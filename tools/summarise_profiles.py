@@ -16,39 +16,50 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = "profiles"
 os.makedirs(out, exist_ok=True)
 
-src = newest("gpurun_out/%s_stats/*/*kernel_stats.csv" % tag)
-with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w") as f:
-    w = csv.writer(f)
-    cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage",
-            "MinNs", "MaxNs", "StdDev"]
-    w.writerow(cols)
-    for r in csv.DictReader(open(src)):
-        w.writerow([r["Name"][:110]] + [r[c] for c in cols[1:]])
+def stats_and_traffic(suffix, workload, extra_args):
+    """kernel-trace stats + the FETCH / WRITE passes of one bench command."""
+    try:
+        src = newest("gpurun_out/%s_stats%s/*/*kernel_stats.csv" % (tag, suffix))
+    except ValueError:
+        return
+    name = "%s%s" % (tag, suffix)
+    with open(os.path.join(out, "%s_kernel_stats.csv" % name), "w") as f:
+        w = csv.writer(f)
+        cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage",
+                "MinNs", "MaxNs", "StdDev"]
+        w.writerow(cols)
+        for r in csv.DictReader(open(src)):
+            w.writerow([r["Name"][:110]] + [r[c] for c in cols[1:]])
+    traffic = {}
+    for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        f = newest("gpurun_out/%s_pmc_%s%s/*/*counter_collection.csv"
+                   % (tag, kind, suffix))
+        acc = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "pddp" in r["Kernel_Name"]:
+                acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(
+                    float(r["Counter_Value"]))
+        for k, v in acc.items():
+            traffic.setdefault(k, {})[ctr + "_KB_avg"] = sum(v) / len(v)
+            traffic[k][ctr + "_launches"] = len(v)
+    for k, v in traffic.items():
+        fe = v.get("FETCH_SIZE_KB_avg", 0.0) * 1024
+        wr = v.get("WRITE_SIZE_KB_avg", 0.0) * 1024
+        # gfx950: FETCH_SIZE counts 1/2 of a wide (16 B/lane) streaming read
+        v["hbm_bytes_per_launch"] = 2 * fe + wr
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | "
+                          "WRITE_SIZE (separate passes) -- python3 bench.py "
+                          "--steps 10 --warmup 2 --no-cpu-baseline" + extra_args,
+               "formula": "2*FETCH_SIZE + WRITE_SIZE, KB = 1024 B "
+                          "(MI355X_MICROARCH.md, HBM section)",
+               "workload": workload, "kernels": traffic},
+              open(os.path.join(out, "%s_pmc_traffic.json" % name), "w"),
+              indent=1)
 
-traffic = {}
-for kind, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    f = newest("gpurun_out/%s_pmc_%s/*/*counter_collection.csv" % (tag, kind))
-    acc = collections.defaultdict(list)
-    for r in csv.DictReader(open(f)):
-        if "pddp" in r["Kernel_Name"]:
-            acc[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(
-                float(r["Counter_Value"]))
-    for k, v in acc.items():
-        traffic.setdefault(k, {})[ctr + "_KB_avg"] = sum(v) / len(v)
-        traffic[k][ctr + "_launches"] = len(v)
-for k, v in traffic.items():
-    fe = v.get("FETCH_SIZE_KB_avg", 0.0) * 1024
-    wr = v.get("WRITE_SIZE_KB_avg", 0.0) * 1024
-    # gfx950: FETCH_SIZE counts 1/2 of a wide (16 B/lane) streaming read
-    v["hbm_bytes_per_launch"] = 2 * fe + wr
-json.dump({"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE "
-                      "(separate passes) -- python3 bench.py --steps 10 "
-                      "--warmup 2 --no-cpu-baseline",
-           "formula": "2*FETCH_SIZE + WRITE_SIZE, KB = 1024 B "
-                      "(MI355X_MICROARCH.md, HBM section)",
-           "workload": "cartpole n=4 m=1 N=100 B=4096 fp32, bounds +-10",
-           "kernels": traffic},
-          open(os.path.join(out, "%s_pmc_traffic.json" % tag), "w"), indent=1)
+
+stats_and_traffic("", "cartpole n=4 m=1 N=100 B=4096 fp32, bounds +-10", "")
+stats_and_traffic("_B16384", "cartpole n=4 m=1 N=100 B=16384 fp32, bounds +-10",
+                  " --batch 16384")
 
 f = newest("gpurun_out/%s_pmc_sq/*/*counter_collection.csv" % tag)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
