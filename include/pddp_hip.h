@@ -106,8 +106,10 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  * Auto for n=4/m=1: bounded eig-clamp branch below 16384 (f32) / 8193 (f64)
  * trajectories -> 21 / 20; f32 from 12288 trajectories on -> 17; bounded
  * Cholesky branch f32 below that -> 9; otherwise 7 (f32) / 6 (f64).
- * 14 / 15: the f32 matrix-core kernels for n <= 30, m = 1 (IEEE / approximate
- * division; auto for those shapes other than n = 4). */
+ * 14 / 15: the matrix-core kernels for n <= 30, m = 1 (IEEE / approximate
+ * division; auto for those shapes other than n = 4); f64: n <= 14 on the f64
+ * matrix cores, variant 14 only (15 and n > 14: PDDP_E_UNSUPPORTED; auto then
+ * takes the generic kernel). */
 int pddp_riccati_backward_variant_f32(int B, int N, int n, int m,
                                       const float* rec, const float* u_min,
                                       const float* u_max, const double* reg,

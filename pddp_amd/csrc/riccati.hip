@@ -92,14 +92,17 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          (riccati_mfma16.hpp / riccati_mfma32.hpp; IEEE / approximate
   //          division) - auto for those shapes other than n = 4
   //          (n = 15 .. 30: the 32x32-tile form, riccati_mfma32.hpp)
+  //          fp64: the 16x16 form (n <= 14) on the f64 matrix cores, IEEE
+  //          division (variant 14; auto for those shapes)
   if (variant == 14 || variant == 15 ||
-      (variant == 0 && sizeof(T) == 4 && m == 1 && n != 4 && n <= 30)) {
+      (variant == 0 && m == 1 && n != 4 && n <= (sizeof(T) == 4 ? 30 : 14))) {
+    if (m != 1) return PDDP_E_UNSUPPORTED;
     if constexpr (sizeof(T) == 4) {
-      if (m != 1) return PDDP_E_UNSUPPORTED;
-      return n <= 14 ? launch_mfma16(a, st, variant != 14)
+      return n <= 14 ? launch_mfma16<T>(a, st, variant != 14)
                      : launch_mfma32(a, st, variant != 14);
     } else {
-      return PDDP_E_UNSUPPORTED;
+      if (variant == 15 || n > 14) return PDDP_E_UNSUPPORTED;
+      return launch_mfma16<T>(a, st, false);
     }
   }
   if (variant >= 2 && !(n == 4 && m == 1)) return PDDP_E_UNSUPPORTED;

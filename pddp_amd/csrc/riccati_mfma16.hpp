@@ -1,6 +1,6 @@
-// riccati_mfma16.hpp - backward Riccati sweep for n + 1 <= 15, m = 1 in fp32 on
-// the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32, bitwise an fmaf
-// chain), both gain branches (eig clamp ilqr.py:629-672, V_zz-regularised
+// riccati_mfma16.hpp - backward Riccati sweep for n + 1 <= 15, m = 1 on the
+// matrix cores: fp32 (v_mfma_f32_16x16x4_f32: exact f32, bitwise an fmaf
+// chain) and fp64 (v_mfma_f64_16x16x4_f64), both gain branches (eig clamp ilqr.py:629-672, V_zz-regularised
 // Cholesky :587-625), bounded or not.  The DEFAULT
 // (Cholesky) encoding of cartpole is n = 14: BASELINE.json configs[2]'s sweep,
 // 744 MB per launch at B = 4096, N = 100.
@@ -27,6 +27,9 @@
 //   V' = sym(Q_zz) + c Q_uz^T Q_uz,  V_z' = Q_z + Q_uz^T w
 // (c, w from the scalar BoxQP; riccati_n4_pipe.hpp).  Records stream HBM -> LDS
 // by full-wave LDS-DMA, R slots ahead.
+// fp64: the f64 instruction's C/D layout puts row g + 4 r (not 4 g + r) in
+// register r of lane group g; with the k-slab of MFMA r taken as k = g + 4 r
+// everything above holds unchanged (`Tile<T>::row`).
 #pragma once
 
 #include "riccati_n4_split.hpp"
@@ -35,21 +38,56 @@ namespace pddp {
 namespace m16 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kWaves = 4;  // independent trajectories (wavefronts) per workgroup
 constexpr int kRing = 4;   // record slots in flight per wavefront
+constexpr int kMaxDma = 4; // LDS-DMA instructions per record (64 x 16 B each)
 
-template <bool BOUNDED, bool FAST, bool CHOL>
+// the 16x16x4 instruction of each type: accumulator vector, the matrix row
+// (= k-slab) held by register r of lane group g, and where row n sits
+template <typename T> struct Tile;
+template <> struct Tile<float> {
+  using Acc = f32x4;
+  PDDP_DEV static int row(int g, int r) { return 4 * g + r; }
+  PDDP_DEV static int group_of(int k) { return k >> 2; }
+  PDDP_DEV static int reg_of(int k) { return k & 3; }
+  PDDP_DEV static Acc mma(float x, float y, Acc c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, c, 0, 0, 0);
+  }
+  PDDP_DEV static float read_lane(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+  }
+};
+template <> struct Tile<double> {
+  using Acc = f64x4;
+  PDDP_DEV static int row(int g, int r) { return g + 4 * r; }
+  PDDP_DEV static int group_of(int k) { return k & 3; }
+  PDDP_DEV static int reg_of(int k) { return k >> 2; }
+  PDDP_DEV static Acc mma(double x, double y, Acc c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, c, 0, 0, 0);
+  }
+  PDDP_DEV static double read_lane(double v, int l) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)b, l);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  }
+};
+
+template <typename T, bool BOUNDED, bool FAST, bool CHOL>
 __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
-    RiccatiArgs<float> a, int slot_words, int ndma) {
-  using T = float;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+    RiccatiArgs<T> a, int slot_words, int ndma) {
+  using TL = Tile<T>;
+  using Acc = typename TL::Acc;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
   // per wave: kRing record slots, the 16x16 transpose tile; shared: step sizes
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int per_wave = kRing * slot_words + 256;
-  float* ring = smem + wave * per_wave;
-  float* tile = ring + kRing * slot_words;
-  float* ls_tail = smem + kWaves * per_wave;
+  T* ring = smem + wave * per_wave;
+  T* tile = ring + kRing * slot_words;
+  T* ls_tail = smem + kWaves * per_wave;
   if constexpr (BOUNDED) {
     for (int q = threadIdx.x; q < n4::kLsSteps; q += kWave * kWaves)
       ls_tail[q] = (T)n4::kLs.v[q];
@@ -72,7 +110,7 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
   int oF[4], oL[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int k = 4 * g + r;  // F~ row / L~ row
+    const int k = TL::row(g, r);  // F~ row / L~ row
     oF[r] = (k < n) ? (j < n ? lay.oFz + k * n + j
                              : (j == n ? lay.oFu + k : -1))
                     : -1;
@@ -92,22 +130,26 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
   // i.e. + reg f^T F~ (row n of F~^T F~): this lane's share needs f[4g + r]
   int oFf[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) oFf[r] = (4 * g + r < n) ? lay.oFu + 4 * g + r : -1;
+  for (int r = 0; r < 4; ++r)
+    oFf[r] = (TL::row(g, r) < n) ? lay.oFu + TL::row(g, r) : -1;
 
   // ---- record DMA: chunk q of 16 bytes -> lane q % 64 of instruction q / 64
   const char* rec_b = reinterpret_cast<const char*>(
       a.rec + (size_t)b * (size_t)(N + 1) * S);
-  const int chunks = S / 4;  // S is a multiple of 4 words
+  const int chunks = S * (int)sizeof(T) / 16;  // S is a multiple of 4 words
   // (padding lanes past the record re-load an early chunk into the slot's pad)
-  const uint32_t qoff0 = (uint32_t)(lane % chunks) * 16u;
-  const uint32_t qoff1 = (uint32_t)((lane + kWave) % chunks) * 16u;
+  uint32_t qoff[kMaxDma];
+#pragma unroll
+  for (int i = 0; i < kMaxDma; ++i)
+    qoff[i] = (uint32_t)((lane + i * kWave) % chunks) * 16u;
   auto dma = [&](int slot, int t) {
     const int tt = t < 0 ? 0 : t;
     const uint32_t base = (uint32_t)tt * (uint32_t)(S * sizeof(T));
     const uint32_t lbase =
         __builtin_amdgcn_readfirstlane(n4::lds_addr(ring + slot * slot_words));
-    n4::lds_dma16(rec_b, base + qoff0, lbase);
-    if (ndma == 2) n4::lds_dma16(rec_b, base + qoff1, lbase + kWave * 16);
+#pragma unroll
+    for (int i = 0; i < kMaxDma; ++i)
+      if (i < ndma) n4::lds_dma16(rec_b, base + qoff[i], lbase + i * kWave * 16);
   };
 
   // ---- terminal value function in the accumulator layout (ilqr.py:581-583)
@@ -116,7 +158,7 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
     const T* term = a.rec + ((size_t)b * (size_t)(N + 1) + N) * S;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int k = 4 * g + r;
+      const int k = TL::row(g, r);
       V[r] = (k < n && j < n) ? term[lay.oLzz + k * n + j] : T(0);
       Vz[r] = (k < n) ? term[lay.oLz + k] : T(0);
     }
@@ -131,8 +173,12 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
   for (int t = N - 1; t >= 0; --t) {
     // record t has landed once at most (kRing - 1) younger {DMA x ndma, store}
     // groups are outstanding; counted waits need immediates: ndma is 1 or 2
-    if (ndma == 1) n4::wait_vmcnt<(kRing - 1) * 2>();
-    else n4::wait_vmcnt<(kRing - 1) * 3>();
+    switch (ndma) {
+      case 1: n4::wait_vmcnt<(kRing - 1) * 2>(); break;
+      case 2: n4::wait_vmcnt<(kRing - 1) * 3>(); break;
+      case 3: n4::wait_vmcnt<(kRing - 1) * 4>(); break;
+      default: n4::wait_vmcnt<(kRing - 1) * 5>(); break;
+    }
     const T* R = ring + slot * slot_words;
     T Fa[4], La[4];
 #pragma unroll
@@ -155,34 +201,35 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
     }
 
     // ---- X = V F~ ; X[:, 15] = V_z
-    f32x4 X = {0.f, 0.f, 0.f, 0.f};
+    Acc X = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      X = __builtin_amdgcn_mfma_f32_16x16x4f32(V[r], Fa[r], X, 0, 0, 0);
+    for (int r = 0; r < 4; ++r) X = TL::mma(V[r], Fa[r], X);
 #pragma unroll
     for (int r = 0; r < 4; ++r) X[r] = (j == 15) ? Vz[r] : X[r];
     // ---- Q~ = L~ + F~^T X
-    f32x4 Q = {La[0], La[1], La[2], La[3]};
-    Q = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[0], X[0], Q, 0, 0, 0);
-    Q = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[1], X[1], Q, 0, 0, 0);
-    Q = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[2], X[2], Q, 0, 0, 0);
-    Q = __builtin_amdgcn_mfma_f32_16x16x4f32(Fa[3], X[3], Q, 0, 0, 0);
+    Acc Q = {La[0], La[1], La[2], La[3]};
+    Q = TL::mma(Fa[0], X[0], Q);
+    Q = TL::mma(Fa[1], X[1], Q);
+    Q = TL::mma(Fa[2], X[2], Q);
+    Q = TL::mma(Fa[3], X[3], Q);
 
-    // row n = 4 gn + rn of Q~ is (Q_uz | Q_uu | Q_u at column 15)
-    const int gn = n >> 2, rn = n & 3;
+    // row n (register rn of lane group gn) of Q~ is (Q_uz | Q_uu | Q_u at
+    // column 15)
+    const int gn = TL::group_of(n), rn = TL::reg_of(n);
     const T rowv = rn == 0 ? Q[0] : (rn == 1 ? Q[1] : (rn == 2 ? Q[2] : Q[3]));
-    const T Quu = __int_as_float(
-        __builtin_amdgcn_readlane(__float_as_int(rowv), gn * 16 + n));
-    const T Qu = __int_as_float(
-        __builtin_amdgcn_readlane(__float_as_int(rowv), gn * 16 + 15));
+    const T Quu = TL::read_lane(rowv, gn * 16 + n);
+    const T Qu = TL::read_lane(rowv, gn * 16 + 15);
     // the regularised row (Q_uz_reg | Q_uu_reg) of the Cholesky branch
     const T rowg = CHOL ? rowv + reg * ffrow : rowv;
-    const T Quug = CHOL ? __int_as_float(__builtin_amdgcn_readlane(
-                              __float_as_int(rowg), gn * 16 + n))
-                        : Quu;
+    const T Quug = CHOL ? TL::read_lane(rowg, gn * 16 + n) : Quu;
     // transpose tile: T[col][row] = Q~[row][col]; row 15 (free: n + 1 <= 15)
     // carries Q_uz_reg
-    *reinterpret_cast<f32x4*>(tile + j * 16 + 4 * g) = Q;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<f32x4*>(tile + j * 16 + 4 * g) = Q;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tile[j * 16 + TL::row(g, r)] = Q[r];
+    }
     if constexpr (CHOL) {
       if (g == gn) tile[j * 16 + 15] = rowg;
     }
@@ -221,7 +268,7 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
       sE = n4::div_<FAST>(T(1), qp_Q);  // (E / e) E^T             (ilqr.py:636)
       kt = -(sE * Qu);
       // NaN in k or K raises (ilqr.py:639-640)
-      const bool nanK = (g == (n >> 2)) && (j < n) && (sE * rowg != sE * rowg);
+      const bool nanK = (g == gn) && (j < n) && (sE * rowg != sE * rowg);
       if (!CHOL && (kt != kt || __builtin_amdgcn_ballot_w64(nanK) != 0))
         stt = PDDP_BWD_NAN;
     }
@@ -246,7 +293,7 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
     const T Qg_j = CHOL ? tile[j * 16 + 15] : T(0);  // Q_uz_reg[j]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int k = 4 * g + r;
+      const int k = TL::row(g, r);
       const T QT = tile[k * 16 + j];      // Q~[j][k]
       const T Quz_k = tile[k * 16 + n];   // Q~[n][k]
       const T sym = T(0.5) * (Q[r] + QT);
@@ -257,8 +304,8 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
         V[r] = (k < n && j < n) ? v : T(0);
         Vz[r] = (k < n) ? Q[r] + Quz_k * kt - Qg_k * wz : T(0);
       } else {
-        V[r] = (k < n && j < n) ? __builtin_fmaf(c * Quz_k, Quz_j, sym) : T(0);
-        Vz[r] = (k < n) ? __builtin_fmaf(Quz_k, w, Q[r]) : T(0);  // (lanes j = 15)
+        V[r] = (k < n && j < n) ? n4::fma_(c * Quz_k, Quz_j, sym) : T(0);
+        Vz[r] = (k < n) ? n4::fma_(Quz_k, w, Q[r]) : T(0);  // (lanes j = 15)
       }
     }
     slot = slot + 1 == kRing ? 0 : slot + 1;
@@ -269,33 +316,38 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
 
 }  // namespace m16
 
-// n + 1 <= 15, m = 1, fp32; PDDP_E_UNSUPPORTED otherwise
-static int launch_mfma16(const RiccatiArgs<float>& a, hipStream_t st,
+// n + 1 <= 15, m = 1; PDDP_E_UNSUPPORTED otherwise (fp64: IEEE division only)
+template <typename T>
+static int launch_mfma16(const RiccatiArgs<T>& a, hipStream_t st,
                          bool fast_math) {
   if (a.n + 1 > 15) return PDDP_E_UNSUPPORTED;
   const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
   const RecLayout lay(a.n, 1);
-  const int chunks = lay.stride / 4;
+  const int chunks = lay.stride * (int)sizeof(T) / 16;
   const int ndma = (chunks + kWave - 1) / kWave;
-  if (ndma > 2) return PDDP_E_UNSUPPORTED;
-  const int slot_words = ndma * kWave * 4;
-  const size_t lds = sizeof(float) * ((size_t)m16::kWaves *
-                                          (m16::kRing * slot_words + 256) +
-                                      n4::kLsSteps);
+  if (ndma > m16::kMaxDma) return PDDP_E_UNSUPPORTED;
+  const int slot_words = ndma * kWave * (16 / (int)sizeof(T));
+  const size_t lds = sizeof(T) * ((size_t)m16::kWaves *
+                                      (m16::kRing * slot_words + 256) +
+                                  n4::kLsSteps);
   const dim3 grid((a.B + m16::kWaves - 1) / m16::kWaves),
       block(kWave * m16::kWaves);
   const bool bounded = a.u_min != nullptr;
 #define PDDP_M16(Bd, F)                                                        \
   do {                                                                         \
     if (chol)                                                                  \
-      PDDP_LAUNCH((m16::riccati_mfma16_kernel<Bd, F, true>), grid, block, lds, \
-                  st, a, slot_words, ndma);                                    \
+      PDDP_LAUNCH((m16::riccati_mfma16_kernel<T, Bd, F, true>), grid, block,   \
+                  lds, st, a, slot_words, ndma);                               \
     else                                                                       \
-      PDDP_LAUNCH((m16::riccati_mfma16_kernel<Bd, F, false>), grid, block,     \
+      PDDP_LAUNCH((m16::riccati_mfma16_kernel<T, Bd, F, false>), grid, block,  \
                   lds, st, a, slot_words, ndma);                               \
   } while (0)
-  if (bounded) { if (fast_math) PDDP_M16(true, true); else PDDP_M16(true, false); }
-  else { if (fast_math) PDDP_M16(false, true); else PDDP_M16(false, false); }
+  if constexpr (sizeof(T) == 4) {
+    if (bounded) { if (fast_math) PDDP_M16(true, true); else PDDP_M16(true, false); }
+    else { if (fast_math) PDDP_M16(false, true); else PDDP_M16(false, false); }
+  } else {
+    if (bounded) PDDP_M16(true, false); else PDDP_M16(false, false);
+  }
 #undef PDDP_M16
   return launch_status();
 }
