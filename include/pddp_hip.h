@@ -312,14 +312,13 @@ int pddp_riccati_backward_timed_f64(int B, int N, int n, int m,
  *   Y[r] = W3 relu(M2[p] * (W2 relu(M1[p] * (W1 X[r] + b1)) + b2)) + b3,
  * p = r % P the particle of row r (rows = states x particles, particle
  * fastest).  X [R][in_dim], W1 [H][in_dim], W2 [H][H], W3 [out_dim][H]
- * (torch.nn.Linear layout); M1S = the layer-1 mask parity-split,
- * M1S[p][h][s] = M1[p][2 s + h] ([P][2][H/2]: the order a lane of the kernel
- * consumes it), M2 [P][H] the layer-2 mask as it is (all ones: no dropout);
- * Y [R][out_dim].  in_dim <= 15, out_dim <= 16, H in {64, 128,
+ * (torch.nn.Linear layout); M1, M2 [P][H] the dropout masks of the two hidden
+ * layers as the framework holds them (all ones: no dropout), rows 16-byte
+ * aligned (H a multiple of 4); Y [R][out_dim].  in_dim <= 15, out_dim <= 16, H in {64, 128,
  * 200}; PDDP_E_UNSUPPORTED otherwise (use the library GEMMs then). */
 int pddp_bnn_mlp_f32(int R, int P, int in_dim, int H, int out_dim,
                      const float* X, const float* W1, const float* b1,
-                     const float* M1S, const float* W2, const float* b2,
+                     const float* M1, const float* W2, const float* b2,
                      const float* M2, const float* W3, const float* b3,
                      float* Y, void* stream);
 
@@ -381,7 +380,7 @@ int pddp_bnn_moment_step_f32(const pddp_bnn_step* step, void* stream);
 int pddp_bnn_mlp_jvp_f32(int R, int P, int group, int in_dim, int H,
                          int out_dim, const float* X, const float* W1,
                          const float* b1,
-                         const float* M1S, const float* W2, const float* b2,
+                         const float* M1, const float* W2, const float* b2,
                          const float* M2, const float* W3, const float* b3,
                          float* Y, void* stream);
 

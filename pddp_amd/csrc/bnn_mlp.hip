@@ -17,17 +17,28 @@
 // W2[32 j + i][2 s + h], s < H / 2, exactly the A operand of
 // v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate, bitwise an fmaf chain; the
 // exact-f32 matrix rate of gfx950 is 1/16 of bf16).  The
-// workgroup then streams 32-row tiles:
-//   A  all 512 lanes: layer 1 (in_dim <= 8: plain FMAs) for the tile, written
-//      to LDS transposed, in the order the B operand is read back (one
-//      ds_read_b128 feeds four MFMAs);
-//   B  wavefront j: h2^T[32 units][32 rows] = W2_j . h1^T, 100 MFMAs on one
-//      accumulator tile; bias, mask, ReLU on the accumulator registers; the
-//      result has the data row on the lane and the unit in the register, which
-//      IS the B operand of the next MFMA (k-slot h of step i <-> unit
-//      32 j + (i & 3) + 8 (i >> 2) + 4 h), so layer 3 takes it with W3
-//      permuted to match: 16 more MFMAs, no LDS, no shuffles;
-//   C  the NB partial outputs are summed from LDS, b3 added, rows stored.
+// workgroup then streams 32-row tiles, three stages in flight:
+//   A  wavefront j, tile i + 1: layer 1 of ITS 32 units on the matrix cores
+//      too (K = in_dim | bias slot: 4 or 8 MFMAs, W1 | b1 rows in registers) -
+//      as plain FMAs it was a fifth of the kernel: on gfx950 the f32 MFMA and
+//      the f32 VALU do not overlap, every vector instruction costs the SIMD
+//      ~10 cycles of matrix time (measured by ablation) - mask and ReLU on the
+//      accumulators, to LDS as held: four ds_write_b128;
+//   B  wavefront j, tile i: h2^T[32 units][32 rows] = W2_j . h1^T, 100 MFMAs
+//      on one accumulator tile that starts at the bias; the contraction runs
+//      over the units in the order stage A left them (MFMA step 4 q + e, k-slot
+//      h <-> unit 8 q + 4 h + e: one ds_read_b128 feeds four MFMAs); mask and
+//      ReLU on the accumulator registers, which go to LDS as they are;
+//   C  wavefront NB (the finisher), tile i - 1: layer 3 for ALL blocks on
+//      v_mfma_f32_16x16x4_f32 (16 outputs x 16 rows x 4 units: half the
+//      matrix-pipe time of the 32x32 form for out_dim <= 16), B operand = one
+//      ds_read_b32 per instruction from B's registers-as-written (unit
+//      4 s + kk of block j, row 16 hf + n sits at word n * 4 + kk of a
+//      256-word group: conflict-free), + b3, rows stored.
+// With H = 200 the seven blocks sit 2 / 2 / 2 / 1 on the four SIMDs and the
+// finisher shares the fourth: 208 MFMAs of 64 cycles per SIMD and tile, against
+// 232 when every block ran its own layer 3 (round 1, where a producer wavefront
+// computing all of layer 1 was what the tile waited for - 18 % of the kernel).
 //
 // JVP mode (the derivative rollout, ilqr.py:457-468 through
 // utils/evaluation.py:203-235): rows come in groups of 8, 16 or 32 = one (state,
@@ -52,8 +63,7 @@ struct BnnMlpArgs {
   const float* X;
   const float* W1;
   const float* b1;
-  const float* MT1;  // layer-1 mask, parity-split [P][2][H/2]: M1[p][2 s + h]
-                     // at [p][h][s] - the order a producer lane consumes it
+  const float* MT1;  // layer-1 mask [P][H] (as the framework holds it)
   const float* W2;
   const float* b2;
   const float* MT2;  // layer-2 mask [P][H] (as the framework holds it)
@@ -64,7 +74,7 @@ struct BnnMlpArgs {
 
 constexpr int kMlpThreads = 512;
 constexpr int kMlpTile = 32;     // rows per tile
-constexpr int kMlpW1Max = 16;    // W1 row (<= 15 inputs) | b1, in LDS
+constexpr int kMlpW1Max = 16;    // W1 row (<= 15 inputs) | b1
 constexpr int kMlpMaxOut = 16;
 
 // unit index held by accumulator register r of lane-half h in block j
@@ -74,14 +84,15 @@ PDDP_DEV int unit_of(int j, int r, int h) {
 
 template <int H, int W1S>
 constexpr size_t bnn_mlp_lds_floats() {
-  return 2 * (H / 2) * 64 + H * W1S + 2 * ((H + 31) / 32) * kMlpMaxOut * 32;
+  // two h1^T buffers, two buffers of h2 (1024 words per block)
+  return 2 * (H / 2) * 64 + 2 * ((H + 31) / 32) * 1024;
 }
 
-// kMlpW1Stride: LDS stride of a W1 row | b1 (8: in_dim <= 7, 16: <= 15) - the
-// producer wavefront's work is proportional to it
-// value of the group's first row for this lane's unit set.  G = 16: lane 0 of
-// this lane's 16-lane row (gfx90a+ DPP row_newbcast).  G = 32 (a whole tile is
-// one group): lane 0 for the lanes of half 0, lane 32 for half 1.
+// kMlpW1Stride: inputs | zeros | bias slot of layer 1 (8: in_dim <= 7, 16: <=
+// 15) = twice its MFMA steps.
+// row_first: value of the group's first row for this lane's unit set.  G = 16:
+// lane 0 of this lane's 16-lane row (gfx90a+ DPP row_newbcast).  G = 32 (a
+// whole tile is one group): lane 0 for the lanes of half 0, lane 32 for half 1.
 template <int G>
 PDDP_DEV float row_first(float v) {
   if constexpr (G == 8) {
@@ -105,171 +116,223 @@ PDDP_DEV float row_first(float v) {
 template <int H, int kMlpW1Stride, int kJvpGroup = 0>
 __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   constexpr bool JVP = kJvpGroup != 0;
+  constexpr int G = JVP ? kJvpGroup : 1;  // rows per (state, particle)
   static_assert(kJvpGroup == 0 || kJvpGroup == 8 || kJvpGroup == 16 ||
                     kJvpGroup == 32, "");
   static_assert(H % 8 == 0 && H <= 224, "H: multiple of 8, at most 224");
   constexpr int KS = H / 2;          // MFMA steps of layer 2
+  constexpr int NQ = KS / 4;         // 8-unit chunks of layer 1
   constexpr int NB = (H + 31) / 32;  // 32-unit blocks = consumer wavefronts
-  static_assert(NB < kMlpThreads / 64, "one wavefront is the producer");
-  // LDS (dynamic): two h1^T buffers, W1 | b1, two buffers of partial outputs
+  constexpr int kWavesMlp = kMlpThreads / 64;
+  static_assert(NB < kWavesMlp, "one wavefront is the finisher");
+  static_assert(kWavesMlp == 8, "layer-1 chunks are dealt out modulo 8");
+  // LDS (dynamic): two h1^T buffers, two h2 buffers
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* h1t = lds;                       // [2][KS * 64]
-  float* w1b = h1t + 2 * KS * 64;         // [H][16]
-  float* part = w1b + H * kMlpW1Stride;   // [2][NB * 16 * 32]
-  constexpr int kH1 = KS * 64, kPart = NB * kMlpMaxOut * 32;
+  float* h2b = h1t + 2 * KS * 64;         // [2][NB * 1024]
+  constexpr int kH1 = KS * 64, kH2 = NB * 1024;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int P = a.P, IN = a.in_dim, OUT = a.out_dim, R = a.R;
 
-  for (int o = tid; o < H * kMlpW1Stride; o += kMlpThreads) {
-    const int k = o / kMlpW1Stride, c = o - k * kMlpW1Stride;
-    w1b[o] = c < IN ? a.W1[k * IN + c]
-                    : (c == kMlpW1Stride - 1 ? a.b1[k] : 0.f);
-  }
-  __syncthreads();
-
   const int ntiles = (R + kMlpTile - 1) / kMlpTile;
-  // tiles of this workgroup: blockIdx.x + i * gridDim.x, i < my
+  // tiles of this workgroup: blockIdx.x + i * gridDim.x, i < my (my >= 1: the
+  // grid is never larger than the number of tiles)
   const int my = blockIdx.x < ntiles
                      ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  // LDS only: the tile barrier must not wait for the finisher's row stores
+  auto tile_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
 
-  if (wave >= NB) {
+  if (wave > NB) {
+    // spare wavefronts (H < 200) only keep step
+    tile_barrier();
+    for (int i = 0; i < my; ++i) tile_barrier();
+    return;
+  }
+
+  if (wave == NB) {
     // =====================================================================
-    // producer wavefront(s): layer 1 of tile i + 1 into h1t[(i + 1) & 1] and
-    // the output rows of tile i - 1 from part[(i - 1) & 1], while the
-    // consumers run tile i on the matrix cores.  Lane (row li, half lh)
-    // computes the units k = 2 s + lh, four s at a time (one ds_write_b128).
+    // finisher: layer 3 of tile i - 1 for all blocks while the consumers run
+    // tile i.  A operand: lane (o = l & 15, kk = l >> 4) holds
+    // W3[o][32 j + 4 s + kk]; accumulators: register q of lane (n, kk) =
+    // output 4 kk + q of data row 16 hf + n.
     // =====================================================================
-    const bool first_prod = wave == NB;  // extra wavefronts just keep step
-    auto layer1 = [&](int i) {           // tile index in this workgroup's list
-      if (!first_prod || i >= my) return;
-      const int row = (blockIdx.x + i * gridDim.x) * kMlpTile + li;
-      const bool live = row < R;
-      const int p = live ? (JVP ? (row / (JVP ? kJvpGroup : 1)) % P : row % P) : 0;
-      float x[kMlpW1Stride];
+    const int n16 = lane & 15, kk = lane >> 4;
+    float a3[NB][8];
 #pragma unroll
-      for (int c = 0; c < kMlpW1Stride; ++c)
-        x[c] = (live && c < IN) ? a.X[(size_t)row * IN + c] : 0.f;
-      // multiplies the bias slot (tangent rows carry no bias)
-      x[kMlpW1Stride - 1] =
-          (JVP && (li & ((JVP ? kJvpGroup : 1) - 1)) != 0) ? 0.f : 1.f;
-      f32x4* dst = reinterpret_cast<f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
-      // this lane's KS mask values, contiguous in the parity-split layout:
-      // all requested up front (KS / 4 independent 16-B loads)
-      f32x4 mk[KS / 4];
-      {
-        const f32x4* msrc =
-            reinterpret_cast<const f32x4*>(a.MT1 + ((size_t)p * 2 + lh) * KS);
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
-        for (int q = 0; q < KS / 4; ++q) mk[q] = msrc[q];
+      for (int s = 0; s < 8; ++s) {
+        const int u = 32 * j + 4 * s + kk;
+        const float w3 = a.W3[(size_t)(n16 < OUT ? n16 : 0) * H + (u < H ? u : 0)];
+        a3[j][s] = (u < H && n16 < OUT) ? w3 : 0.f;
       }
+    f32x4 bias;
 #pragma unroll
-      for (int q = 0; q < KS / 4; ++q) {
-        f32x4 v;
+    for (int q = 0; q < 4; ++q)
+      bias[q] = 4 * kk + q < OUT ? a.b3[4 * kk + q] : 0.f;
+    auto layer3 = [&](int t) {
+      const float* hb = h2b + (t & 1) * kH2 + (n16 * 4 + kk);
+      f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int k = 2 * (4 * q + e) + lh;
-          const f32x4* wr =
-              reinterpret_cast<const f32x4*>(w1b + k * kMlpW1Stride);
-          float acc = 0.f;
+      for (int j = 0; j < NB; ++j) {
 #pragma unroll
-          for (int c4 = kMlpW1Stride / 4 - 1; c4 >= 0; --c4) {
-            const f32x4 w = wr[c4];
-            // bias first (last slot), then the inputs: not the accumulation
-            // order of a library GEMM bit for bit (that order is unspecified)
-            acc = __builtin_fmaf(x[4 * c4 + 3], w[3], acc);
-            acc = __builtin_fmaf(x[4 * c4 + 2], w[2], acc);
-            acc = __builtin_fmaf(x[4 * c4 + 1], w[1], acc);
-            acc = __builtin_fmaf(x[4 * c4 + 0], w[0], acc);
-          }
-          if constexpr (JVP) {
-            // linearised at the group's primal row (for which this IS relu)
-            v[e] = (row_first<JVP ? kJvpGroup : 16>(acc) * mk[q][e] > 0.f)
-                       ? acc * mk[q][e] : 0.f;
+        for (int s = 0; s < 8; ++s) {
+          // unit 4 s + kk of the block = register (s >> 1) * 4 + kk of the
+          // consumer's lane half s & 1
+          const int off = ((j * 4 + (s >> 1)) * 64 + (s & 1) * 32) * 4;
+          const float b0 = hb[off], b1 = hb[off + 64];
+          o0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[j][s], b0, o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[j][s], b1, o1, 0, 0, 0);
+        }
+      }
+      const int row0 = (blockIdx.x + t * gridDim.x) * kMlpTile;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int rt = 16 * hf + n16, rr = row0 + rt;
+        f32x4 y = hf == 0 ? o0 : o1;
+        if (!(JVP && (rt & (G - 1)) != 0)) y += bias;  // tangents: no bias
+        if (rr < R) {
+          if ((OUT & 3) == 0) {
+            if (4 * kk < OUT)
+              *reinterpret_cast<f32x4*>(a.Y + (size_t)rr * OUT + 4 * kk) = y;
           } else {
-            v[e] = fmaxf(acc * mk[q][e], 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (4 * kk + q < OUT) a.Y[(size_t)rr * OUT + 4 * kk + q] = y[q];
           }
         }
-        dst[q * 64] = v;
       }
     };
-    auto store_out = [&](int i) {  // sum the blocks' partial outputs, + b3
-      if (!first_prod || i < 0) return;
-      const int row0 = (blockIdx.x + i * gridDim.x) * kMlpTile;
-      const float* pr = part + (i & 1) * kPart;
-      for (int t = lane; t < 32 * OUT; t += 64) {
-        const int rr = row0 + (t & 31), o = t >> 5;
-        float y = (JVP && ((t & 31) & ((JVP ? kJvpGroup : 1) - 1)) != 0)
-                      ? 0.f : a.b3[o];
-#pragma unroll
-        for (int jj = 0; jj < NB; ++jj)
-          y += pr[(jj * kMlpMaxOut + o) * 32 + (t & 31)];
-        if (rr < R) a.Y[(size_t)rr * OUT + o] = y;
-      }
-    };
-    layer1(0);
-    __syncthreads();
+    tile_barrier();
     for (int i = 0; i < my; ++i) {
-      store_out(i - 1);
-      layer1(i + 1);
-      __syncthreads();
+      if (i > 0) layer3(i - 1);
+      tile_barrier();
     }
-    store_out(my - 1);
+    layer3(my - 1);
     return;
   }
 
   // =======================================================================
-  // consumer wavefront j: its 32 units of layer 2 - rows of W2 in registers
-  // for the whole kernel - and its share of layer 3
+  // consumer wavefront j: its 32 units of both hidden layers - rows of W2
+  // (and of W1 | b1) in registers for the whole kernel.  Unit order of the
+  // layer-2 contraction: MFMA step 4 q + e, k-slot h  <->  unit 8 q + 4 h + e,
+  // so that the accumulator registers of layer 1 (unit_of) are written to LDS
+  // as they are and come back as B operands four steps per ds_read_b128.
   // =======================================================================
   const int j = wave;
+  constexpr int KS1 = kMlpW1Stride / 2;  // MFMA steps of layer 1
   float a2[KS];
-  float a3[16], b2r[16];
+  float a1[KS1];
+  float b2r[16];
   {
     const int u = 32 * j + li;  // A operand: row i = li is unit u
     const bool uok = u < H;
-    const float* w2row = a.W2 + (size_t)(uok ? u : 0) * H + lh;
+    const float* w2row = a.W2 + (size_t)(uok ? u : 0) * H + 4 * lh;
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float v = w2row[2 * s];  // (clamped address + select: no branch
-      a2[s] = uok ? v : 0.f;         // per element)
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = w2row[8 * q + e];  // (clamped address + select: no
+        a2[4 * q + e] = uok ? v : 0.f;     // branch per element)
+      }
+    // layer 1: W1 | 0 | b1; MFMA step s, k-slot lh takes input slot
+    // c = W1S - 1 - (2 s + lh): the bias first, then the inputs from the last
+    // to the first (the order of round 1's FMA chain)
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+      const int c = kMlpW1Stride - 1 - (2 * s + lh);
+      const float w = a.W1[(size_t)(uok ? u : 0) * IN + (c < IN ? c : 0)];
+      const float bb = a.b1[uok ? u : 0];
+      a1[s] = !uok ? 0.f : (c < IN ? w : (c == kMlpW1Stride - 1 ? bb : 0.f));
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int n = unit_of(j, r, lh);
-      const int nc = n < H ? n : 0;
-      // layer 3, step r: A[i = li = output][k-slot lh] = W3[li][n]
-      const float w3 = a.W3[(size_t)(li < OUT ? li : 0) * H + nc];
-      const float bb = a.b2[nc];
-      a3[r] = (n < H && li < OUT) ? w3 : 0.f;
+      const float bb = a.b2[n < H ? n : 0];
       b2r[r] = n < H ? bb : 0.f;
     }
   }
-  __syncthreads();  // pairs with the producer's first barrier: h1t[0] ready
-
-  for (int i = 0; i < my; ++i) {
-    const int row0 = (blockIdx.x + i * gridDim.x) * kMlpTile;
-    // mask of layer 2, requested before the MFMAs so that its latency is
-    // theirs: registers 4 g .. 4 g + 3 are the units 32 j + 8 g + 4 lh +
-    // (0..3), one 16-B load of the mask row each (clamped inside the row for
-    // the padded units of the last block, whose weights are zero)
-    const int row = row0 + li;
-    const int p = row < R ? (JVP ? (row / (JVP ? kJvpGroup : 1)) % P : row % P) : 0;
-    f32x4 m2[4];
+  // layer 1 of tile i for this block: inputs requested by l1_load (early),
+  // four MFMAs, mask and ReLU on the accumulators, four ds_write_b128
+  float xin[KS1];
+  f32x4 m1[4];
+  auto masks_of = [&](const float* M, int row, f32x4 (&m)[4]) {
+    // registers 4 g .. 4 g + 3 are the units 32 j + 8 g + 4 lh + (0..3): one
+    // 16-B load of the mask row each (clamped inside the row for the padded
+    // units of the last block, whose weights are zero)
+    const int p = row < R ? (row / G) % P : 0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n0 = 32 * j + 8 * g + 4 * lh;
-      m2[g] = *reinterpret_cast<const f32x4*>(
-          a.MT2 + (size_t)p * H + (n0 + 4 <= H ? n0 : 0));
+      m[g] = *reinterpret_cast<const f32x4*>(
+          M + (size_t)p * H + (n0 + 4 <= H ? n0 : 0));
     }
-    // ---- layer 2 on the matrix cores
+  };
+  auto l1_load = [&](int i) {
+    const int row = (blockIdx.x + i * gridDim.x) * kMlpTile + li;
+    const bool live = row < R;
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+      const int c = kMlpW1Stride - 1 - (2 * s + lh);
+      const float v = a.X[(size_t)(live ? row : 0) * IN + (c < IN ? c : 0)];
+      // the last slot multiplies the bias (tangent rows carry none)
+      xin[s] = c < IN ? (live ? v : 0.f)
+                      : (c == kMlpW1Stride - 1
+                             ? ((JVP && (li & (G - 1)) != 0) ? 0.f : 1.f)
+                             : 0.f);
+    }
+    masks_of(a.MT1, row, m1);
+  };
+  auto layer1 = [&](int i) {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < KS1; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], xin[s], acc, 0, 0, 0);
+    f32x4* dst = reinterpret_cast<f32x4*>(h1t + (i & 1) * kH1) +
+                 (4 * j * 64 + li * 2 + lh);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pre = acc[4 * g + e], mm = m1[g][e];
+        if constexpr (JVP) {
+          // linearised at the group's primal row (for which this IS relu)
+          v[e] = (row_first<JVP ? kJvpGroup : 16>(pre) * mm > 0.f) ? pre * mm : 0.f;
+        } else {
+          v[e] = fmaxf(pre * mm, 0.f);
+        }
+      }
+      if (4 * j + g < NQ) dst[g * 64] = v;  // (wave-uniform)
+    }
+  };
+  l1_load(0);
+  layer1(0);
+  tile_barrier();  // h1t[0] ready
+
+  for (int i = 0; i < my; ++i) {
+    const int row0 = (blockIdx.x + i * gridDim.x) * kMlpTile;
+    const bool nxt = i + 1 < my;
+    if (nxt) l1_load(i + 1);
+    // mask of layer 2, requested before the MFMAs so that its latency is
+    // theirs
+    f32x4 m2[4];
+    masks_of(a.MT2, row0 + li, m2);
+    // ---- layer 2 on the matrix cores; the accumulator starts at the bias
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      acc[r] = (JVP && (li & (G - 1)) != 0) ? 0.f : b2r[r];
     const f32x4* bsrc =
         reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
 #pragma unroll
-    for (int q = 0; q < KS / 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const f32x4 b4 = bsrc[q * 64];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 0], b4[0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 1], b4[1], acc, 0, 0, 0);
@@ -277,30 +340,25 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 3], b4[3], acc, 0, 0, 0);
     }
     // accumulator register r of this lane: unit unit_of(j, r, lh), data row
-    // li - bias, mask, ReLU in place; layer 3 straight from the accumulators
-    f32x16 out = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // li - mask, ReLU in place; to LDS as held (the finisher's reads know the
+    // order)
+    f32x4* hw = reinterpret_cast<f32x4*>(h2b + (i & 1) * kH2) + (j * 4 * 64 + lane);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float h2;
-      if constexpr (JVP) {
-        const float pre =
-            acc[r] + ((li & ((JVP ? kJvpGroup : 1) - 1)) != 0 ? 0.f : b2r[r]);
-        const float mm = m2[r >> 2][r & 3];
-        h2 = (row_first<JVP ? kJvpGroup : 16>(pre) * mm > 0.f) ? pre * mm : 0.f;
-      } else {
-        h2 = fmaxf((acc[r] + b2r[r]) * m2[r >> 2][r & 3], 0.f);
+    for (int g = 0; g < 4; ++g) {
+      f32x4 h2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float pre = acc[4 * g + e], mm = m2[g][e];
+        if constexpr (JVP) {
+          h2[e] = (row_first<JVP ? kJvpGroup : 16>(pre) * mm > 0.f) ? pre * mm : 0.f;
+        } else {
+          h2[e] = fmaxf(pre * mm, 0.f);
+        }
       }
-      out = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[r], h2, out, 0, 0, 0);
+      hw[g * 64] = h2;
     }
-    // out: register r of lane-half lh = output unit (r & 3) + 8 (r >> 2)
-    // + 4 lh of data row li (partial sum over this block's units)
-    float* pw = part + (i & 1) * kPart;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (o < OUT) pw[(j * kMlpMaxOut + o) * 32 + li] = out[r];
-    }
-    __syncthreads();
+    if (nxt) layer1(i + 1);
+    tile_barrier();
   }
 }
 

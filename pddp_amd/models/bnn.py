@@ -157,10 +157,9 @@ class BayesianMLP(torch.nn.Module):
                 and getattr(self, "use_native", True))
 
     def _mask_t(self, k, P, like):
-        """Layer k's mask [P, H] as the kernel wants it (include/pddp_hip.h):
-        layer 0 parity-split [P, 2, H/2], layer 1 as it is.  Same draw as
-        ConcreteDropout.forward on first use; cached until the noise or the
-        dropout parameters change."""
+        """Layer k's mask [P, H] for the kernel (include/pddp_hip.h).  Same
+        draw as ConcreteDropout.forward on first use; cached until the noise
+        or the dropout parameters change."""
         drop = self.drops[k]
         H = self.hidden[k].out_features
         if drop.noise is None or drop.noise.shape != (P, H):
@@ -170,8 +169,6 @@ class BayesianMLP(torch.nn.Module):
         cache = self.__dict__.setdefault("_mask_cache", {})
         if cache.get(k, (None, None))[0] != key:
             m = drop._mask(drop.noise).detach()
-            if k == 0:
-                m = m.reshape(P, H // 2, 2).transpose(1, 2)
             cache[k] = (key, m.contiguous())
         return cache[k][1]
 
