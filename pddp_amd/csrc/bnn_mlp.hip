@@ -90,26 +90,19 @@ constexpr size_t bnn_mlp_lds_floats() {
 
 // kMlpW1Stride: inputs | zeros | bias slot of layer 1 (8: in_dim <= 7, 16: <=
 // 15) = twice its MFMA steps.
-// row_first: value of the group's first row for this lane's unit set.  G = 16:
-// lane 0 of this lane's 16-lane row (gfx90a+ DPP row_newbcast).  G = 32 (a
-// whole tile is one group): lane 0 for the lanes of half 0, lane 32 for half 1.
+// group_first_positive: is `v` of the first row of this lane's group positive?
+// Groups of G data rows are G consecutive lanes of a 32-lane half.  One vector
+// compare; its 64-bit lane mask keeps the bits of the groups' first lanes and
+// a scalar multiply smears each over its G lanes - scalar instructions, which
+// do not take matrix time (a vector instruction does: see above).
 template <int G>
-PDDP_DEV float row_first(float v) {
-  if constexpr (G == 8) {
-    // two groups per 16-lane DPP row: lanes 0-7 take lane 0, lanes 8-15 lane 8
-    const float lo = __int_as_float(__builtin_amdgcn_update_dpp(
-        0, __float_as_int(v), 0x150, 0xf, 0xf, true));
-    const float hi = __int_as_float(__builtin_amdgcn_update_dpp(
-        0, __float_as_int(v), 0x158, 0xf, 0xf, true));
-    return (threadIdx.x & 8) ? hi : lo;
-  } else if constexpr (G == 16) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(
-        0, __float_as_int(v), 0x150, 0xf, 0xf, true));
-  } else {
-    const int lo = __builtin_amdgcn_readlane(__float_as_int(v), 0);
-    const int hi = __builtin_amdgcn_readlane(__float_as_int(v), 32);
-    return __int_as_float((threadIdx.x & 32) ? hi : lo);
-  }
+PDDP_DEV bool group_first_positive(float v) {
+  const unsigned long long b = __builtin_amdgcn_ballot_w64(v > 0.f);
+  constexpr unsigned kFirst = G == 8 ? 0x01010101u : (G == 16 ? 0x00010001u : 1u);
+  constexpr unsigned kSmear = G == 8 ? 0xFFu : (G == 16 ? 0xFFFFu : 0xFFFFFFFFu);
+  const unsigned lo = ((unsigned)b & kFirst) * kSmear;
+  const unsigned hi = ((unsigned)(b >> 32) & kFirst) * kSmear;
+  return __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
 }
 
 // kJvpGroup = rows per (state, particle) in JVP mode (0: plain inference)
@@ -303,8 +296,10 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       for (int e = 0; e < 4; ++e) {
         const float pre = acc[4 * g + e], mm = m1[g][e];
         if constexpr (JVP) {
-          // linearised at the group's primal row (for which this IS relu)
-          v[e] = (row_first<JVP ? kJvpGroup : 16>(pre) * mm > 0.f) ? pre * mm : 0.f;
+          // linearised at the group's primal row (for which this IS relu;
+          // the mask is that of the group's particle, >= 0: where it is zero
+          // the product is)
+          v[e] = group_first_positive<JVP ? kJvpGroup : 16>(pre) ? pre * mm : 0.f;
         } else {
           v[e] = fmaxf(pre * mm, 0.f);
         }
@@ -328,7 +323,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      acc[r] = (JVP && (li & (G - 1)) != 0) ? 0.f : b2r[r];
+      acc[r] = (JVP && (li & (G - 1)) != 0) ? 0.f : b2r[r];  // tangents: no bias
     const f32x4* bsrc =
         reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
 #pragma unroll
@@ -350,7 +345,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       for (int e = 0; e < 4; ++e) {
         const float pre = acc[4 * g + e], mm = m2[g][e];
         if constexpr (JVP) {
-          h2[e] = (row_first<JVP ? kJvpGroup : 16>(pre) * mm > 0.f) ? pre * mm : 0.f;
+          h2[e] = group_first_positive<JVP ? kJvpGroup : 16>(pre) ? pre * mm : 0.f;
         } else {
           h2[e] = fmaxf(pre * mm, 0.f);
         }

@@ -7,6 +7,7 @@ set -u
 TAG=${1:-r02}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+if [ "${2:-}" != "bnn" ]; then
 cd /tmp
 # per-kernel time (kernel trace + stats only)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- \
@@ -40,3 +41,12 @@ timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/
     python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-cpu-baseline --batch 16384 > /dev/null 2>&1
 cd $R
 tail -c 600 gpurun_out/${TAG}_bench.json
+fi
+cd $R
+# the BNN workloads (configs[2], configs[3]'s shard, configs[4]); bench lines only
+if [ "${2:-}" = "bnn" ]; then
+  python3 bench.py --workload cartpole_bnn --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_cartpole_bnn.json
+  python3 bench.py --workload double_cartpole_bnn --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_double_cartpole_bnn.json
+  python3 bench.py --workload mpc_bnn --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_mpc_bnn.json
+  tail -c 400 gpurun_out/${TAG}_bench_mpc_bnn.json
+fi
