@@ -118,7 +118,7 @@ def launch_ranks_if_asked(args):
     if args.gpus <= 1:
         return
     have = torch.cuda.device_count()  # (does not initialise the GPU)
-    if have < args.gpus:
+    if have < args.gpus and not os.environ.get("PDDP_BENCH_ONE_DEVICE"):
         sys.stderr.write("bench.py: --gpus %d but only %d device(s) visible\n"
                          % (args.gpus, have))
         sys.exit(2)
@@ -135,16 +135,24 @@ def launch_ranks_if_asked(args):
 
 def init_ranks():
     """(world, rank, device) from the torchrun environment; RCCL process group
-    when world > 1."""
+    when world > 1.  Rehearsal on a box with one GPU (tests only):
+    PDDP_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and PDDP_BENCH_BACKEND=gloo
+    carries the exchange (RCCL refuses two ranks on one device)."""
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("PDDP_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(
-            "cuda", local_rank))
+        backend = os.environ.get("PDDP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(
+                "cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     return world, rank, torch.device("cuda", local_rank)
 
 

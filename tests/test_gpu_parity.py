@@ -1545,6 +1545,37 @@ def test_bench_two_ranks_over_rccl():
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2
 
 
+@pytest.mark.parametrize("workload,extra", [
+    ("cartpole", ["--batch", "512", "--repeats", "2", "--no-points"]),
+    ("cartpole", ["--batch", "512", "--repeats", "1", "--no-points",
+                  "--scaling", "strong"]),
+    ("double_cartpole_bnn", ["--batch", "16", "--horizon", "6"]),
+])
+def test_bench_two_ranks_rehearsal_on_one_gpu(workload, extra):
+    """The whole multi-rank path of `bench.py --gpus 2` - the launcher, shard
+    bounds, barriers, max-over-ranks timing, the best-rollout exchange inside
+    the timed region - on a box with ONE GPU: both ranks on cuda:0, gloo instead
+    of RCCL (which refuses two ranks on a device).  What the 2-GPU test above
+    adds is RCCL itself."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PDDP_BENCH_ONE_DEVICE="1", PDDP_BENCH_BACKEND="gloo")
+    out = subprocess.run(
+        [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2",
+         "--workload", workload, "--steps", "3", "--warmup", "1",
+         "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True,
+        timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2
+    assert line["value"] > 0 and line["steps"] == 3
+
+
 def _bnn_real_size_run():
     """Runs the HIP BNN path (native nominal rollout, forward-mode Jacobians,
     hyper-dual cost derivatives, moment-step line search around the fused
