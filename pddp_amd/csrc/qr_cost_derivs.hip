@@ -48,32 +48,45 @@ constexpr int kQrMaxAng = 2, kQrMaxM = 2;
 // the jittered upper Cholesky only decides which trace the cost sees
 // (encoding.py:536-564: jitter 1e-12, 1e-11, ... <= 10, else the diagonal)
 template <int NA>
-PDDP_DEV float chol_jitter_of(const float (&C)[NA][NA], int na) {
+PDDP_DEV float chol_jitter_of(const float (&C)[NA][NA]) {
   double jit = 1e-12;
   while (jit <= 10.0) {
     float U[NA][NA];
     bool ok = true;
-    for (int i = 0; i < na && ok; ++i)
-      for (int j = i; j < na; ++j) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+#pragma unroll
+      for (int j = i; j < NA; ++j) {
         float s = C[i][j] + (i == j ? (float)jit : 0.f);
+#pragma unroll
         for (int q = 0; q < i; ++q) s -= U[q][i] * U[q][j];
         if (i == j) {
-          if (!(s > 0.f)) { ok = false; break; }
+          // (a failed pivot ends the reference's attempt; what follows here
+          // is computed on garbage and discarded)
+          if (!(s > 0.f)) ok = false;
           U[i][i] = sqrtf(s);
         } else {
           U[i][j] = s / U[i][i];
         }
       }
+    }
     if (ok) return (float)jit;
     jit *= 10.0;
   }
   return -1.f;
 }
 
-template <int D>
+// D state dimensions of which NANG are angles: every index below is a compile-
+// time constant (the state is permuted to non-angular | angular as it is
+// loaded), so the hyper-dual working set - U, U^T U, the augmented moments -
+// lives in registers.  (Indexed through the runtime `non` / `ang` lists it
+// lived in scratch memory: 149 GB of HBM traffic and 49 ms per launch for the
+// double cartpole, D = 6; 10 ms for cartpole.)
+template <int D, int NANG>
 __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
   constexpr int n = D + D * (D + 1) / 2;
-  constexpr int NA = D + kQrMaxAng;
+  constexpr int NN = D - NANG;       // non-angular dimensions
+  constexpr int NA = NN + 2 * NANG;  // augmented dimensions
   const int lane = threadIdx.x;
   const int N = s.N, m = s.m;
   const int bt = blockIdx.x;  // (trajectory, step), step N = terminal
@@ -81,7 +94,6 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
   const bool terminal = (t == N);
   const int d = n + (terminal ? 0 : m);
   const int npairs = d * (d + 1) / 2;
-  const int nn = s.n_non, nang = s.n_ang, na = nn + 2 * nang;
   const float* z = s.Z + ((size_t)b * (N + 1) + t) * n;
   const float* Q = terminal ? s.Q_term : s.Q;
   float u[kQrMaxM];
@@ -91,7 +103,37 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
       v = clamp1(v, s.u_min[r], s.u_max[r]);  // ilqr.py:461-462
     u[r] = v;
   }
+  // state dimension held at permuted position a
+  int perm[D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) perm[a] = a < NN ? s.non[a] : s.ang[a - NN];
+  // the inputs' values, permuted: mean, and row k of the Cholesky factor at
+  // the permuted columns (zero below the diagonal) with its index in z
+  float zmu[D], zU[D][D];
+  int oU[D][D];
+#pragma unroll
+  for (int a = 0; a < D; ++a) {
+    zmu[a] = z[perm[a]];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const int c = perm[a];
+      // row-major upper triangle: rows 0 .. k - 1 hold D, D - 1, .. entries
+      const int o = D + k * D - (k * (k - 1)) / 2 + (c - k);
+      const bool up = c >= k;
+      oU[k][a] = up ? o : -1;
+      zU[k][a] = up ? z[up ? o : 0] : 0.f;
+    }
+  }
+  float Qr[NA][NA], goal[NA];
+#pragma unroll
+  for (int r = 0; r < NA; ++r) {
+    goal[r] = s.x_goal[r];
+#pragma unroll
+    for (int c = 0; c < NA; ++c) Qr[r][c] = Q[r * NA + c];
+  }
 
+  float jit = 0.f;
+  bool have_jit = false;
   for (int q = lane; q < npairs; q += 64) {
     int i = 0, rem = q;  // pair q -> (i, j), i <= j, row-major upper triangle
     while (rem >= d - i) { rem -= d - i; ++i; }
@@ -99,77 +141,90 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
     auto in = [&](int kx, float v) {
       return HD{v, kx == i ? 1.f : 0.f, kx == j ? 1.f : 0.f, 0.f};
     };
-    HD mu[D], U[D][D];
-    for (int c = 0; c < D; ++c) mu[c] = in(c, z[c]);
-    {
-      int o = D;
-      for (int r = 0; r < D; ++r)
-        for (int c = 0; c < D; ++c) {
-          if (c >= r) { U[r][c] = in(o, z[o]); ++o; }
-          else U[r][c] = hd(0.f);
-        }
+    HD mu[D];
+#pragma unroll
+    for (int a = 0; a < D; ++a) mu[a] = in(perm[a], zmu[a]);
+    HD C[D][D];  // (U^T U) in permuted order; terms in ascending row order
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int c = a; c < D; ++c) C[a][c] = hd(0.f);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      HD row[D];
+#pragma unroll
+      for (int a = 0; a < D; ++a) row[a] = in(oU[k][a], zU[k][a]);
+#pragma unroll
+      for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = a; c < D; ++c) C[a][c] = C[a][c] + row[a] * row[c];
     }
-    HD C[D][D];  // U^T U
-    for (int r = 0; r < D; ++r)
-      for (int c = r; c < D; ++c) {
-        HD v = hd(0.f);
-        for (int kx = 0; kx <= r; ++kx) v = v + U[kx][r] * U[kx][c];
-        C[r][c] = v;
-        C[c][r] = v;
-      }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+      for (int c = 0; c < a; ++c) C[a][c] = C[c][a];
+
     float Cav[NA][NA];
-    for (int r = 0; r < NA; ++r)
-      for (int c = 0; c < NA; ++c) Cav[r][c] = 0.f;
     HD Ma[NA];
     HD tr = hd(0.f), trd = hd(0.f);  // sum Ca_ij Q_ji; sum Ca_ii Q_ii
     auto put = [&](int r, int c, HD v) {  // every entry is written once
       Cav[r][c] = v.v;
-      tr = tr + Q[c * na + r] * v;
-      if (r == c) trd = trd + Q[r * na + r] * v;
+      tr = tr + Qr[c][r] * v;
+      if (r == c) trd = trd + Qr[r][r] * v;
     };
-    for (int r = 0; r < nn; ++r) {
-      Ma[r] = mu[s.non[r]];
-      for (int c = 0; c < nn; ++c) put(r, c, C[s.non[r]][s.non[c]]);
+#pragma unroll
+    for (int r = 0; r < NN; ++r) {
+      Ma[r] = mu[r];
+#pragma unroll
+      for (int c = 0; c < NN; ++c) put(r, c, C[r][c]);
     }
-    for (int a1 = 0; a1 < nang; ++a1) {
-      const int i1 = s.ang[a1];
+#pragma unroll
+    for (int a1 = 0; a1 < NANG; ++a1) {
+      const int i1 = NN + a1;
       const HD m1 = mu[i1], v1 = C[i1][i1];
       const HD damp = exp_(-0.5f * v1);
       HD s1, c1;
       sincos_(m1, s1, c1);
       const HD Es = damp * s1, Ec = damp * c1;
-      const int r = nn + 2 * a1;
+      const int r = NN + 2 * a1;
       Ma[r] = Es;
       Ma[r + 1] = Ec;
-      for (int a2 = 0; a2 < nang; ++a2) {
-        const int i2 = s.ang[a2];
+#pragma unroll
+      for (int a2 = 0; a2 < NANG; ++a2) {
+        const int i2 = NN + a2;
         const HD m2 = mu[i2], v2 = C[i2][i2], cij = C[i1][i2];
         const HD lq = -0.5f * (v1 + v2), qq = exp_(lq);
         const HD ep = exp_(lq + cij) - qq, em = exp_(lq - cij) - qq;
         HD sd, cd, ss, cs;
         sincos_(m1 - m2, sd, cd);
         sincos_(m1 + m2, ss, cs);
-        const int cc = nn + 2 * a2;
+        const int cc = NN + 2 * a2;
         put(r, cc, 0.5f * (ep * cd - em * cs));          // sin, sin
         put(r + 1, cc + 1, 0.5f * (ep * cd + em * cs));  // cos, cos
         const HD sc = 0.5f * (ep * sd + em * ss);        // sin_1, cos_2
         put(r, cc + 1, sc);
         put(cc + 1, r, sc);
       }
-      for (int c = 0; c < nn; ++c) {
-        const HD col = C[s.non[c]][i1];
+#pragma unroll
+      for (int c = 0; c < NN; ++c) {
+        const HD col = C[c][i1];
         put(c, r, col * Ec);        // Cov(x, sin)
         put(c, r + 1, -(col * Es));  // Cov(x, cos)
         put(r, c, col * Ec);
         put(r + 1, c, -(col * Es));
       }
     }
-    const float jit = chol_jitter_of<NA>(Cav, na);
+    if (!have_jit) {  // values only: the same for every pair of this step
+      jit = chol_jitter_of<NA>(Cav);
+      have_jit = true;
+    }
     HD cost = hd(0.f);
-    for (int c = 0; c < na; ++c) {
+#pragma unroll
+    for (int c = 0; c < NA; ++c) {
       HD row = hd(0.f);
-      for (int r = 0; r < na; ++r) row = row + Q[r * na + c] * (Ma[r] - s.x_goal[r]);
-      cost = cost + row * (Ma[c] - s.x_goal[c]);
+#pragma unroll
+      for (int r = 0; r < NA; ++r) row = row + Qr[r][c] * (Ma[r] - goal[r]);
+      cost = cost + row * (Ma[c] - goal[c]);
     }
     if (!terminal) {
       for (int c = 0; c < m; ++c) {
@@ -181,7 +236,8 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
     }
     if (jit >= 0.f) {
       float trq = 0.f;
-      for (int r = 0; r < na; ++r) trq += Q[r * na + r];
+#pragma unroll
+      for (int r = 0; r < NA; ++r) trq += Qr[r][r];
       cost = cost + tr + jit * trq;  // tr(Q (Ca + jitter I))
     } else {
       cost = cost + trd;             // encode()'s diagonal fall-back
@@ -207,6 +263,18 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
   }
 }
 
+template <int D>
+static int launch_qr_cost(const pddp_qr_cost& s, hipStream_t st) {
+  const dim3 grid(s.B * (s.N + 1)), block(64);
+  switch (s.n_ang) {
+    case 0: PDDP_LAUNCH((qr_cost_derivs_kernel<D, 0>), grid, block, 0, st, s); break;
+    case 1: PDDP_LAUNCH((qr_cost_derivs_kernel<D, 1>), grid, block, 0, st, s); break;
+    case 2: PDDP_LAUNCH((qr_cost_derivs_kernel<D, 2>), grid, block, 0, st, s); break;
+    default: return PDDP_E_UNSUPPORTED;
+  }
+  return launch_status();
+}
+
 }  // namespace pddp
 
 extern "C" int pddp_qr_cost_derivs_f32(const pddp_qr_cost* s, void* stream) {
@@ -218,13 +286,11 @@ extern "C" int pddp_qr_cost_derivs_f32(const pddp_qr_cost* s, void* stream) {
   if (s->m < 1 || s->m > pddp::kQrMaxM || s->n_ang < 0 ||
       s->n_ang > pddp::kQrMaxAng || s->n_non < 0 || s->n_non + s->n_ang != s->D)
     return PDDP_E_UNSUPPORTED;
-  const dim3 grid(s->B * (s->N + 1)), block(64);
   hipStream_t st = (hipStream_t)stream;
   switch (s->D) {
-    case 2: PDDP_LAUNCH(pddp::qr_cost_derivs_kernel<2>, grid, block, 0, st, *s); break;
-    case 4: PDDP_LAUNCH(pddp::qr_cost_derivs_kernel<4>, grid, block, 0, st, *s); break;
-    case 6: PDDP_LAUNCH(pddp::qr_cost_derivs_kernel<6>, grid, block, 0, st, *s); break;
-    default: return PDDP_E_UNSUPPORTED;
+    case 2: return pddp::launch_qr_cost<2>(*s, st);
+    case 4: return pddp::launch_qr_cost<4>(*s, st);
+    case 6: return pddp::launch_qr_cost<6>(*s, st);
   }
-  return pddp::launch_status();
+  return PDDP_E_UNSUPPORTED;
 }

@@ -60,6 +60,9 @@ def stats_and_traffic(suffix, workload, extra_args):
 stats_and_traffic("", "cartpole n=4 m=1 N=100 B=4096 fp32, bounds +-10", "")
 stats_and_traffic("_B16384", "cartpole n=4 m=1 N=100 B=16384 fp32, bounds +-10",
                   " --batch 16384")
+stats_and_traffic("_dcbnn", "double cartpole BNN (configs[3] shard): n=27 m=1 "
+                  "N=150 B=1024 fp32, [200,200] x 100 particles",
+                  " --workload double_cartpole_bnn --steps 2 --warmup 1")
 
 f = newest("gpurun_out/%s_pmc_sq/*/*counter_collection.csv" % tag)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
