@@ -1,5 +1,6 @@
 """Common utilities (reference: pddp/utils/__init__.py)."""
-from . import angular, classproperty, constraint, encoding, gaussian_variable
+from . import (angular, autodiff, classproperty, constraint, encoding,
+               evaluation, gaussian_variable, particles, trajectory)
 
-__all__ = ["angular", "classproperty", "constraint", "encoding",
-           "gaussian_variable"]
+__all__ = ["angular", "autodiff", "classproperty", "constraint", "encoding",
+           "evaluation", "gaussian_variable", "particles", "trajectory"]

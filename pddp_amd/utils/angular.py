@@ -54,7 +54,7 @@ def augment_moments(mean, covar, angular_indices, non_angular_indices):
         Cov(sin_i, sin_j) = 0.5 [q (e^c - 1) cos(m_i - m_j) - q (e^-c - 1) cos(m_i + m_j)]
         Cov(cos_i, cos_j) = 0.5 [q (e^c - 1) cos(m_i - m_j) + q (e^-c - 1) cos(m_i + m_j)]
         Cov(sin_i, cos_j) = 0.5 [q (e^c - 1) sin(m_i - m_j) + q (e^-c - 1) sin(m_i + m_j)]
-        Cov(x, sin_i) = C[:, i] E[cos_i],  Cov(x, cos_i) = -C[:, i] E[sin_i]
+        Cov(x, sin_i) = C[i, :] E[cos_i],  Cov(x, cos_i) = -C[i, :] E[sin_i]
     """
     ai, ni = list(angular_indices), list(non_angular_indices)
     na_, nn = len(ai), len(ni)
@@ -84,7 +84,11 @@ def augment_moments(mean, covar, angular_indices, non_angular_indices):
     if nn > 0:
         rows_ni = _take(covar, ni, -2)
         C[..., :nn, :nn] = _take(rows_ni, ni, -1)
-        cols = _take(rows_ni, ai, -1)                  # C[na, angle_i]
+        # C[angle_i, x] as the reference reads it (angular.py:243-245 sums
+        # over the ROW index: with the full-covariance encoding the two
+        # triangles are separate inputs and the partials must land where the
+        # reference's do)
+        cols = _take(_take(covar, ai, -2), ni, -1).transpose(-1, -2)
         cross = mean.new_zeros(*mean.shape[:-1], nn, 2 * na_)
         cross[..., 0::2] = cols * Ma[..., 1::2].unsqueeze(-2)    # x, sin
         cross[..., 1::2] = -cols * Ma[..., 0::2].unsqueeze(-2)   # x, cos

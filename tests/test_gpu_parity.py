@@ -636,14 +636,21 @@ def test_plugin_path_equals_native_path():
     assert torch.allclose(Ka, Kb, rtol=1e-6, atol=1e-8)
 
 
-@pytest.mark.parametrize("problem", ["cartpole", "pendulum"])
-def test_default_encoding_vs_reference_golden(problem):
-    """StateEncoding.DEFAULT (upper-triangular Cholesky, n = 14 / 5) through
-    the reference-signature API - forward, backward (zero-copy records, generic
-    HIP sweep), _control_law + costs, and a full fit - against the reference's
-    own outputs (fp64 goldens).  All of it on the native path
-    (csrc/default_kernels.hip: closed-form dynamics Jacobian, hyper-dual cost
-    derivatives, line-search kernel) - asserted below."""
+@pytest.mark.parametrize("problem,enc_key", [
+    ("cartpole", "default"), ("pendulum", "default"),
+    ("cartpole", "variance"), ("pendulum", "variance"),
+    ("cartpole", "std"), ("pendulum", "std"), ("cartpole", "fullcov")])
+def test_default_encoding_vs_reference_golden(problem, enc_key):
+    """The Gaussian state encodings - DEFAULT (upper-triangular Cholesky, n =
+    14 / 5), VARIANCE_ONLY, STANDARD_DEVIATION_ONLY (n = 8 / 4) and
+    FULL_COVARIANCE_MATRIX (n = 20) - through the reference-signature API:
+    forward, backward (zero-copy records, HIP sweep), _control_law + costs, and
+    a full fit, against the reference's own outputs (fp64 goldens,
+    tools/make_golden.py [--other-encodings]).  All but the full covariance run
+    on the native path (csrc/default_kernels.hip: closed-form dynamics
+    Jacobian, hyper-dual cost derivatives, line-search kernel) - asserted
+    below; the full covariance goes through the plugin path (autograd
+    derivatives, HIP sweep / accept)."""
     import pddp_amd
     from pddp_amd import StateEncoding
     from pddp_amd.controllers.ilqr import _control_law, backward, forward
@@ -654,8 +661,12 @@ def test_default_encoding_vs_reference_golden(problem):
             and n != "AugmentedQRCost"][0]().double().cuda()
     env_cls = [getattr(mod, n) for n in dir(mod) if n.endswith("Env")
                and n != "ModelEnv"][0]
-    g = load(problem, encoding="default")
-    enc = StateEncoding.DEFAULT
+    g = load(problem, encoding=enc_key)
+    enc = {"default": StateEncoding.DEFAULT,
+           "variance": StateEncoding.VARIANCE_ONLY,
+           "std": StateEncoding.STANDARD_DEVIATION_ONLY,
+           "fullcov": StateEncoding.FULL_COVARIANCE_MATRIX}[enc_key]
+    assert int(g["encoding"]) == int(enc)
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     u_min, u_max = cu(g["u_min"]), cu(g["u_max"])
     for tag in ("N5_cos", "N25_cos"):
@@ -704,9 +715,11 @@ def test_default_encoding_vs_reference_golden(problem):
     assert int(state) == int(g["fit_bounded/state"])
     assert rel_err(U.cpu().numpy(), g["fit_bounded/U"]) < 1e-5
     assert rel_err(ctrl._K.cpu().numpy(), g["fit_bounded/K"]) < 1e-5
-    # no plugin: problem kernels only
-    assert ctrl._solver.plugin is None and ctrl._solver.problem is not None
-    assert ctrl._solver.problem.encoding == int(enc)
+    if enc_key == "fullcov":
+        assert ctrl._solver.plugin is not None
+    else:  # no plugin: problem kernels only
+        assert ctrl._solver.plugin is None and ctrl._solver.problem is not None
+        assert ctrl._solver.problem.encoding == int(enc)
 
 
 @pytest.mark.parametrize("enc_name", ["UPPER_TRIANGULAR_CHOLESKY",

@@ -1,0 +1,274 @@
+"""Host-side API contracts a user of the reference relies on, checked on the
+CPU (torch ops only - no kernel is called here): the cost algebra
+(pddp/costs/base.py:AggregateCost), QRCost's expectation under every state
+encoding (pddp/costs/quadratic.py), the autograd helpers and the single-point
+derivative evaluators (pddp/utils/autodiff.py, evaluation.py), particle and
+trajectory helpers.  The behaviours are the ones the reference's own suite
+asserts (tests/costs, tests/utils); the derivative evaluators are additionally
+held to the reference's OUTPUTS through the golden fixtures."""
+import operator
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import pddp_amd
+from pddp_amd import GaussianVariable, StateEncoding
+from pddp_amd.costs import QRCost
+from pddp_amd.utils import autodiff, evaluation, particles, trajectory
+
+from golden_util import DT, load, rel_err
+
+ENCODINGS = [StateEncoding.FULL_COVARIANCE_MATRIX,
+             StateEncoding.UPPER_TRIANGULAR_CHOLESKY,
+             StateEncoding.VARIANCE_ONLY,
+             StateEncoding.STANDARD_DEVIATION_ONLY,
+             StateEncoding.IGNORE_UNCERTAINTY]
+D, M = 5, 2
+
+
+def _random_cost(seed, dtype=torch.float64):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g, dtype=dtype)
+    return QRCost(r(D, D), r(M, M), r(D, D), r(D), r(M)).to(dtype)
+
+
+def _random_state(seed, enc, dtype=torch.float64):
+    g = torch.Generator().manual_seed(100 + seed)
+    mean = torch.randn(D, generator=g, dtype=dtype)
+    A = 0.3 * torch.randn(D, D, generator=g, dtype=dtype)
+    x = GaussianVariable(mean, covar=A @ A.t() + 0.1 * torch.eye(D, dtype=dtype))
+    return x, x.encode(enc)
+
+
+# ---- costs -----------------------------------------------------------------
+@pytest.mark.parametrize("enc", ENCODINGS)
+@pytest.mark.parametrize("terminal", [False, True])
+@pytest.mark.parametrize("op", [operator.add, operator.sub, operator.mul,
+                                operator.truediv, operator.pow])
+def test_cost_algebra_binary(op, terminal, enc):
+    """op(cost_a, cost_b) evaluates to op of the values - for a second cost and
+    for a plain number - is a scalar, and stays differentiable in z and u."""
+    a, b = _random_cost(1), _random_cost(2)
+    _, z = _random_state(3, enc)
+    z = z.detach().requires_grad_()
+    u = None if terminal else torch.randn(M, dtype=torch.float64,
+                                          requires_grad=True)
+    la, lb = a(z, u, 0, terminal, enc), b(z, u, 0, terminal, enc)
+    for other, lo in ((b, lb), (torch.tensor(2.0, dtype=torch.float64),) * 2,
+                      (-0.5, -0.5)):
+        combined = op(a, other)
+        assert isinstance(combined, pddp_amd.costs.Cost)
+        l = combined(z, u, 0, terminal, enc)
+        want = op(la, lo)
+        assert l.shape == torch.Size([])
+        if torch.isnan(want):
+            assert torch.isnan(l)
+            continue
+        assert torch.allclose(l, want, rtol=1e-9)
+        g, = torch.autograd.grad(l, z, retain_graph=True)
+        assert g.shape == z.shape
+        if not terminal:
+            torch.autograd.grad(l, u, retain_graph=True)
+
+
+@pytest.mark.parametrize("enc", ENCODINGS)
+@pytest.mark.parametrize("terminal", [False, True])
+def test_cost_algebra_negation_and_batches(terminal, enc):
+    a = _random_cost(4)
+    _, z = _random_state(5, enc)
+    u = None if terminal else torch.randn(M, dtype=torch.float64)
+    assert torch.allclose((-a)(z, u, 0, terminal, enc),
+                          -a(z, u, 0, terminal, enc))
+    # rows of a batch are evaluated independently
+    Z = torch.stack([_random_state(s, enc)[1] for s in range(4)])
+    U = None if terminal else torch.randn(4, M, dtype=torch.float64)
+    L = (a + a * 2.0)(Z, U, 0, terminal, enc)
+    assert L.shape == (4,)
+    for r in range(4):
+        one = a(Z[r], None if terminal else U[r], 0, terminal, enc)
+        assert torch.allclose(L[r], 3.0 * one, rtol=1e-9)
+
+
+@pytest.mark.parametrize("enc", ENCODINGS)
+@pytest.mark.parametrize("terminal", [False, True])
+def test_qrcost_curvature_and_expectation(terminal, enc):
+    """The Hessian of the expected quadratic cost in the state MEAN is
+    Q + Q^T whatever the encoding carries besides (R + R^T in the action), and
+    with a covariance the value is the quadratic form at the mean plus
+    tr(Q C) (quadratic.py:60-99)."""
+    c = _random_cost(6)
+    x, _ = _random_state(7, enc)
+    mean = x.mean().detach().requires_grad_()
+    z = GaussianVariable(mean, covar=x.covar().detach()).encode(enc)
+    u = None if terminal else torch.randn(M, dtype=torch.float64,
+                                          requires_grad=True)
+    l = c(z, u, 0, terminal, enc)
+    assert l.shape == torch.Size([])
+    Q = c.Q_term if terminal else c.Q
+    l_m = autodiff.grad(l, mean, create_graph=True)
+    assert torch.allclose(autodiff.jacobian(l_m, mean), Q + Q.t(), atol=1e-8)
+    if not terminal:
+        l_u = autodiff.grad(l, u, create_graph=True)
+        assert torch.allclose(autodiff.jacobian(l_u, u), c.R + c.R.t(),
+                              atol=1e-8)
+        assert float(autodiff.jacobian(l_u, mean).detach().abs().max()) < 1e-10
+    dx = mean.detach() - c.x_goal
+    want = dx @ Q @ dx
+    if enc != StateEncoding.IGNORE_UNCERTAINTY:
+        C = x.covar() if enc in (StateEncoding.FULL_COVARIANCE_MATRIX,
+                                 StateEncoding.UPPER_TRIANGULAR_CHOLESKY) \
+            else torch.diag(x.var())
+        want = want + torch.trace(Q @ C)
+    if not terminal:
+        du = u.detach() - c.u_goal
+        want = want + du @ c.R @ du
+    assert torch.allclose(l.detach(), want, rtol=1e-8)
+
+
+@pytest.mark.parametrize("enc", ENCODINGS)
+def test_qrcost_gradcheck(enc):
+    c = _random_cost(8)
+    Z = torch.stack([_random_state(s, enc)[1] for s in range(3)]).detach()
+    Z.requires_grad_()
+    U = torch.randn(3, M, dtype=torch.float64, requires_grad=True)
+    f = lambda Z, U: c(Z, U, 0, False, enc)
+    assert torch.autograd.gradcheck(f, (Z, U))
+    assert torch.autograd.gradgradcheck(f, (Z, U))
+    ft = lambda Z: c(Z, None, 0, True, enc)
+    assert torch.autograd.gradcheck(ft, (Z,))
+
+
+# ---- autodiff ----------------------------------------------------------------
+def test_autodiff_helpers():
+    x = torch.tensor([0.3, -1.2, 2.0], dtype=torch.float64, requires_grad=True)
+    y = torch.stack([x[0] * x[1], x[1].sin(), x[0] ** 2, x[0] * 0 + 1.0])
+    J = autodiff.jacobian(y, x)
+    want = torch.tensor([[-1.2, 0.3, 0.0], [0.0, np.cos(-1.2), 0.0],
+                         [0.6, 0.0, 0.0], [0.0, 0.0, 0.0]], dtype=torch.float64)
+    assert torch.allclose(J, want)
+    # an input the output does not depend on: zeros, not None
+    other = torch.ones(4, dtype=torch.float64, requires_grad=True)
+    g = autodiff.grad(y[0], other)
+    assert g.shape == other.shape and float(g.abs().max()) == 0.0
+    f = lambda X: torch.stack([X[..., 0] * X[..., 1], X[..., 1].sin(),
+                               X[..., 0] ** 2], -1)
+    assert torch.allclose(autodiff.batch_jacobian(f, x.detach()), want[:3])
+    assert torch.allclose(autodiff.batch_jacobian(f, x.detach(), m=3), want[:3])
+    # second derivatives through grad(create_graph=True)
+    h = autodiff.jacobian(autodiff.grad((x ** 3).sum(), x, create_graph=True), x)
+    assert torch.allclose(h, torch.diag(6.0 * x.detach()))
+
+
+# ---- evaluation ----------------------------------------------------------------
+def _sample_problem(problem):
+    mod = getattr(pddp_amd.examples, problem)
+    model = [getattr(mod, n) for n in dir(mod) if n.endswith("DynamicsModel")
+             and n != "DynamicsModel"][0](DT[problem]).double()
+    cost = [getattr(mod, n) for n in dir(mod) if n.endswith("Cost")
+            and n != "AugmentedQRCost"][0]().double()
+    return model, cost
+
+
+@pytest.mark.parametrize("enc", ENCODINGS)
+@pytest.mark.parametrize("problem", ["cartpole", "pendulum"])
+def test_evaluation_loop_and_batch_forms_agree(problem, enc):
+    """evaluation.py's row-by-row and replicate-the-input evaluators return
+    the same values, shapes and None pattern (the reference holds them to
+    1e-3, tests/utils/test_evaluation.py:72-74,112-114)."""
+    model, cost = _sample_problem(problem)
+    Ds, m = model.state_size, model.action_size
+    x = GaussianVariable(0.1 * torch.randn(Ds, dtype=torch.float64),
+                         var=1e-2 * torch.ones(Ds, dtype=torch.float64))
+    z, u = x.encode(enc), torch.randn(m, dtype=torch.float64)
+    n = z.shape[-1]
+    a = evaluation.eval_dynamics(model, z, u, 0, enc)
+    b = evaluation.batch_eval_dynamics(model, z, u, 0, enc)
+    for s, t, shape in zip(a, b, ((n,), (n, n), (n, m))):
+        assert s.shape == shape == t.shape
+        assert torch.allclose(s, t, rtol=1e-9, atol=1e-12)
+    for terminal in (False, True):
+        uu = None if terminal else u
+        a = evaluation.eval_cost(cost, z, uu, 0, terminal, enc)
+        b = evaluation.batch_eval_cost(cost, z, uu, 0, terminal, enc)
+        shapes = ((), (n,), (m,), (n, n), (m, n), (m, m))
+        for k, (s, t) in enumerate(zip(a, b)):
+            if terminal and k in (2, 4, 5):
+                assert s is None and t is None
+                continue
+            assert s.shape == shapes[k] == t.shape
+            assert torch.allclose(s, t, rtol=1e-9, atol=1e-12)
+        # Gauss-Newton option: outer products of the gradient
+        ap = evaluation.eval_cost(cost, z, uu, 0, terminal, enc,
+                                  approximate=True)
+        bp = evaluation.batch_eval_cost(cost, z, uu, 0, terminal, enc,
+                                        approximate=True)
+        assert torch.allclose(ap[3], torch.outer(a[1], a[1]), atol=1e-12)
+        assert torch.allclose(bp[3], ap[3], atol=1e-12)
+        if not terminal:
+            assert torch.allclose(ap[4], torch.outer(a[2], a[1]), atol=1e-12)
+            assert torch.allclose(ap[5], torch.outer(a[2], a[2]), atol=1e-12)
+
+
+@pytest.mark.parametrize("problem,enc_key", [
+    ("cartpole", "default"), ("pendulum", "default"), ("cartpole", "variance"),
+    ("cartpole", "std"), ("cartpole", "fullcov"), ("cartpole", "ignore")])
+def test_evaluators_vs_reference_golden(problem, enc_key):
+    """batch_eval_dynamics / batch_eval_cost at the points of the reference's
+    `forward` (ilqr.py:457-473) against what the reference returned there
+    (fp64 goldens): F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu."""
+    enc = {"default": StateEncoding.DEFAULT,
+           "variance": StateEncoding.VARIANCE_ONLY,
+           "std": StateEncoding.STANDARD_DEVIATION_ONLY,
+           "fullcov": StateEncoding.FULL_COVARIANCE_MATRIX,
+           "ignore": StateEncoding.IGNORE_UNCERTAINTY}[enc_key]
+    model, cost = _sample_problem(problem)
+    g = load(problem, encoding=enc_key)
+    tag = "N5_cos"
+    t_ = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    Z, U = t_(g[tag + "/fwd_bounded/Z"]), t_(g[tag + "/U"])
+    u_min, u_max = t_(g["u_min"]), t_(g["u_max"])
+    N = U.shape[0]
+    for t in range(N):
+        u = torch.min(torch.max(U[t], u_min), u_max)  # ilqr.py:461-462
+        zn, F_z, F_u = evaluation.batch_eval_dynamics(model, Z[t], u, t, enc)
+        assert rel_err(zn.numpy(), g[tag + "/fwd_bounded/Z"][t + 1]) < 1e-10
+        assert rel_err(F_z.numpy(), g[tag + "/fwd_bounded/F_z"][t]) < 1e-9
+        assert rel_err(F_u.numpy(), g[tag + "/fwd_bounded/F_u"][t]) < 1e-9
+        out = evaluation.batch_eval_cost(cost, Z[t], u, t, False, enc)
+        for nm, got in zip(("L", "L_z", "L_u", "L_zz", "L_uz", "L_uu"), out):
+            ref = g["%s/fwd_bounded/%s" % (tag, nm)][t]
+            assert rel_err(got.numpy(), ref) < 1e-9, (t, nm)
+    out = evaluation.batch_eval_cost(cost, Z[N], None, N, True, enc)
+    for nm, k in (("L", 0), ("L_z", 1), ("L_zz", 3)):
+        assert rel_err(out[k].numpy(), g["%s/fwd_bounded/%s" % (tag, nm)][N]) \
+            < 1e-9, nm
+
+
+# ---- particles, trajectories ---------------------------------------------------
+def test_particles_covar_and_trajectory_helpers():
+    x = torch.randn(50, 4, dtype=torch.float64)
+    assert np.allclose(particles.particles_covar(x).numpy(),
+                       np.cov(x.numpy().T), atol=1e-12)
+    xb = torch.randn(50, 3, 4, dtype=torch.float64)  # [particles, batch, D]
+    Cb = particles.particles_covar(xb)
+    assert Cb.shape == (3, 4, 4)
+    for b in range(3):
+        assert np.allclose(Cb[b].numpy(), np.cov(xb[:, b].numpy().T),
+                           atol=1e-12)
+    X = [GaussianVariable(torch.full((3,), float(i)), var=1e-6 * torch.ones(3))
+         for i in range(5)]
+    Mt = trajectory.mean_trajectory(X)
+    assert Mt.shape == (5, 3) and torch.equal(Mt[:, 0], torch.arange(5.0))
+    St = trajectory.sample_trajectory(X)
+    assert St.shape == (5, 3) and float((St - Mt).abs().max()) < 0.1
+    with pytest.raises(ValueError):
+        trajectory.mean_trajectory([])
+    with pytest.raises(ValueError):
+        trajectory.sample_trajectory([])
+    Xs, Us = torch.randn(6, 3), torch.randn(5, 2)
+    X_, dX = trajectory.trajectory_to_training_data(Xs, Us)
+    assert X_.shape == (5, 5) and dX.shape == (5, 3)
+    assert torch.equal(X_[:, :3], Xs[:-1]) and torch.equal(X_[:, 3:], Us)
+    assert torch.equal(dX, Xs[:-1] - Xs[1:])

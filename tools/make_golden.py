@@ -62,6 +62,9 @@ PROBLEMS = {
 ENCODINGS = {
     "ignore": StateEncoding.IGNORE_UNCERTAINTY,
     "default": StateEncoding.DEFAULT,
+    "variance": StateEncoding.VARIANCE_ONLY,
+    "std": StateEncoding.STANDARD_DEVIATION_ONLY,
+    "fullcov": StateEncoding.FULL_COVARIANCE_MATRIX,
 }
 
 ALPHAS_FIT = lambda: 1.025**(-torch.arange(10.0)**2)  # ilqr.py:282
@@ -483,6 +486,16 @@ def main():
         return
     if "--bnn-real-size" in sys.argv:
         capture_bnn_real_size()
+        return
+    if "--other-encodings" in sys.argv:
+        # the remaining Gaussian encodings: fp64, short horizons
+        for enc in ("variance", "std", "fullcov"):
+            capture_problem("cartpole", enc, torch.float64, [5, 25],
+                            with_fit=12)
+        capture_problem("pendulum", "variance", torch.float64, [5, 25],
+                        with_fit=12)
+        capture_problem("pendulum", "std", torch.float64, [5, 25],
+                        with_fit=12)
         return
     if "--default-only" in sys.argv:
         capture_problem("cartpole", "default", torch.float64, [5, 25],
