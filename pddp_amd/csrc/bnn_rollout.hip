@@ -7,7 +7,8 @@
 // angle augmentation for the cost) do per candidate and time step - in the
 // framework that is ~150 small launches per step; here it is one.
 //
-// One wavefront per candidate (b, alpha); lanes own particles.  Step t:
+// Sixteen lanes per candidate (b, alpha), four candidates per wavefront; lanes
+// own particles (up to eight each).  Step t:
 //   X_t = X_{t-1} + net_out * dX_std + dX_mean          (t > 0; modules.py:262)
 //   z_t = encode(mean_p X_t, cov_p X_t)   (t > 0; z_0 is the nominal's start)
 //   u_t = clamp(U_t + alpha k_t + K_t (z_t - Z_t)),  J += l(z_t, u_t)   (t < N)
@@ -18,10 +19,13 @@
 // carried from step to step, which is what X_t above does.
 //
 // The per-candidate algebra (4x4 ... 8x8 Cholesky with the reference's jitter
-// escalation, augmentation moments, quadratic cost) runs on lane 0 out of LDS:
-// it is ~1 kFLOP per step against the network's 8.6 MFLOP, and there are tens
-// of thousands of candidates to fill the machine.
+// escalation, augmentation moments, quadratic cost) runs on the first lane of
+// each group out of LDS: ~1 kFLOP per step against the network's 8.6 MFLOP, but
+// a serial instruction stream that a wavefront issues whether one lane or four
+// are active - hence four candidates per wavefront (round 1 had one: 64-lane
+// reductions, the same serial stream for a quarter of the work).
 #include "pddp_common.hpp"
+#include "models.hpp"  // sincos_, sincos_core: branch-free, ~1 ulp
 
 namespace pddp {
 
@@ -29,9 +33,13 @@ constexpr int kBnnMaxD = 8, kBnnMaxAng = 2, kBnnMaxM = 2;
 constexpr int kBnnMaxNa = kBnnMaxD + kBnnMaxAng;            // augmented size
 constexpr int kBnnMaxN = kBnnMaxD + kBnnMaxD * (kBnnMaxD + 1) / 2;  // 44
 
-PDDP_DEV float wave_sum(float v) {
+constexpr int kBnnGroup = 16;                  // lanes per candidate
+constexpr int kBnnPerWave = 64 / kBnnGroup;    // candidates per wavefront
+constexpr int kBnnMaxPPL = 128 / kBnnGroup;    // particles per lane (P <= 128)
+
+PDDP_DEV float group_sum(float v) {  // over the 16 lanes of a candidate
 #pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  for (int o = kBnnGroup / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
 
@@ -64,30 +72,53 @@ PDDP_DEV float chol_upper_jittered(const float* C, int d, float* U) {
   }
 }
 
+// DT: the state dimension as a compile-time constant (0: taken from the
+// argument).  With it the particle registers x[.][d] are indexed statically;
+// under a runtime D they lived in scratch memory (272 B per lane, 136 scratch
+// instructions) and the kernel waited for them.
+template <int DT>
 __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
-  __shared__ float Ms[kBnnMaxD], Cs[kBnnMaxNa * kBnnMaxNa], Us[kBnnMaxNa * kBnnMaxNa];
-  __shared__ float zs[kBnnMaxN], us[kBnnMaxM];
-  __shared__ float Ma[kBnnMaxNa], Ca[kBnnMaxNa * kBnnMaxNa], Ua[kBnnMaxNa * kBnnMaxNa];
+  constexpr int DX = DT > 0 ? DT : kBnnMaxD;
+  // per candidate: Ms, Cs, Us, zs, us, Ma, Ca, Ua; the stride is odd in banks
+  constexpr int kM2 = kBnnMaxNa * kBnnMaxNa;
+  constexpr int kStride = kBnnMaxD + 4 * kM2 + kBnnMaxN + kBnnMaxM + kBnnMaxNa + 1;
+  static_assert(kStride % 2 == 1, "groups must start in different banks");
+  __shared__ float sm[kBnnPerWave][kStride];
 
-  const int c = blockIdx.x;  // candidate = b * A + ai
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & (kBnnGroup - 1);  // lane of the group
+  const int grp = threadIdx.x / kBnnGroup;
+  const int c = blockIdx.x * kBnnPerWave + grp;    // candidate = b * A + ai
+  if (c >= s.B * s.A) return;
+  float* Ms = sm[grp];
+  float* Cs = Ms + kBnnMaxD;
+  float* Us = Cs + kM2;
+  float* zs = Us + kM2;
+  float* us = zs + kBnnMaxN;
+  float* Ma = us + kBnnMaxM;
+  float* Ca = Ma + kBnnMaxNa;
+  float* Ua = Ca + kM2;
   const int b = c / s.A, ai = c - b * s.A;
+  // (a group that leaves early takes no part in the barriers below: one
+  // wavefront per workgroup, a barrier only orders its LDS traffic)
   if (s.active != nullptr && s.active[b] == 0) return;
   if (s.bwd_status != nullptr && s.bwd_status[b] != 0) return;
-  const int D = s.D, P = s.P, m = s.m, N = s.N, t = s.t;
+  const int D = DT > 0 ? DT : s.D;
+  const int P = s.P, m = s.m, N = s.N, t = s.t;
   const int n = D + D * (D + 1) / 2;
   const int na = s.n_non + 2 * s.n_ang;
   const bool terminal = (t == N);
 
-  // ---- particles of this step (two per lane: P <= 128)
-  float x[2][kBnnMaxD];
-  bool has[2];
+  // ---- particles of this step (up to eight per lane: P <= 128)
+  float x[kBnnMaxPPL][DX];
+  bool has[kBnnMaxPPL];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int p = lane + 64 * q;
+  for (int q = 0; q < kBnnMaxPPL; ++q) {
+    const int p = lane + kBnnGroup * q;
     has[q] = p < P;
     const size_t row = (size_t)c * P + (has[q] ? p : 0);
-    for (int d = 0; d < D; ++d) {
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+      if (d >= D) break;
       float v = s.Xp[row * D + d];
       if (t > 0)  // X + dx, dx = out[:D] * dX_std + dX_mean     (modules.py:262)
         v = v + (s.net_out[row * s.out_dim + d] * s.dX_std[d] + s.dX_mean[d]);
@@ -98,7 +129,8 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
 
   // ---- z_t
   if (t == 0) {
-    if (lane < n) zs[lane] = s.Z[((size_t)b * (N + 1)) * n + lane];
+    for (int k = lane; k < n; k += kBnnGroup)
+      zs[k] = s.Z[((size_t)b * (N + 1)) * n + k];
     __syncthreads();
     if (lane == 0) {  // mean and covariance factor back out of z_0 (cost)
       for (int d = 0; d < D; ++d) Ms[d] = zs[d];
@@ -110,18 +142,28 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
   } else {
     // moments over the particles (modules.py:372-386): mean, then the
     // unbiased covariance of the deviations
-    for (int d = 0; d < D; ++d) {
-      float v = (has[0] ? x[0][d] : 0.f) + (has[1] ? x[1][d] : 0.f);
-      v = wave_sum(v) / (float)P;
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {
+      if (d >= D) break;
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < kBnnMaxPPL; ++q) v += has[q] ? x[q][d] : 0.f;
+      v = group_sum(v) / (float)P;
       if (lane == 0) Ms[d] = v;
-      x[0][d] -= v;  // deviations from here on (features add the mean back)
-      x[1][d] -= v;
+#pragma unroll
+      for (int q = 0; q < kBnnMaxPPL; ++q)
+        x[q][d] -= v;  // deviations from here on (features add the mean back)
     }
-    for (int i = 0; i < D; ++i)
-      for (int j = i; j < D; ++j) {
-        float v = (has[0] ? x[0][i] * x[0][j] : 0.f) +
-                  (has[1] ? x[1][i] * x[1][j] : 0.f);
-        v = wave_sum(v) / (float)(P - 1);
+#pragma unroll
+    for (int i = 0; i < DX; ++i)
+#pragma unroll
+      for (int j = i; j < DX; ++j) {
+        if (j >= D) break;
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < kBnnMaxPPL; ++q)
+          v += has[q] ? x[q][i] * x[q][j] : 0.f;
+        v = group_sum(v) / (float)(P - 1);
         if (lane == 0) {
           Cs[i * kBnnMaxNa + j] = v;
           Cs[j * kBnnMaxNa + i] = v;
@@ -143,14 +185,16 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
         for (int j = i; j < D; ++j) zs[o++] = Us[i * kBnnMaxNa + j];
     }
     __syncthreads();
-    for (int d = 0; d < D; ++d) {  // particles again (Ms is visible now)
-      x[0][d] += Ms[d];
-      x[1][d] += Ms[d];
+#pragma unroll
+    for (int d = 0; d < DX; ++d) {  // particles again (Ms is visible now)
+      if (d >= D) break;
+#pragma unroll
+      for (int q = 0; q < kBnnMaxPPL; ++q) x[q][d] += Ms[d];
     }
   }
   __syncthreads();
-  if (lane < n)
-    s.Zc[(((size_t)b * (N + 1) + t) * s.A + ai) * n + lane] = zs[lane];
+  for (int k = lane; k < n; k += kBnnGroup)
+    s.Zc[(((size_t)b * (N + 1) + t) * s.A + ai) * n + k] = zs[k];
 
   // ---- control law, cost (lane 0)
   if (lane == 0) {
@@ -172,11 +216,14 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     }
     // cost on the angle-augmented moments (examples/*/cost.py, quadratic.py:
     // 60-99, angular.py:161-248).  Covariance as the cost sees it: C = U^T U.
+    // (U is upper triangular: rows k <= min(i, j) only - the skipped terms
+    // are exact zeros; the matrix is symmetric)
     for (int i = 0; i < D; ++i)
-      for (int j = 0; j < D; ++j) {
+      for (int j = i; j < D; ++j) {
         float v = 0.f;
-        for (int k = 0; k < D; ++k) v += Us[k * kBnnMaxNa + i] * Us[k * kBnnMaxNa + j];
+        for (int k = 0; k <= i; ++k) v += Us[k * kBnnMaxNa + i] * Us[k * kBnnMaxNa + j];
         Cs[i * kBnnMaxNa + j] = v;
+        Cs[j * kBnnMaxNa + i] = v;
       }
     const int nn = s.n_non, nang = s.n_ang;
     for (int i = 0; i < na * kBnnMaxNa; ++i) Ca[i] = 0.f;
@@ -189,7 +236,9 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
       const int i1 = s.ang[a1];
       const float m1 = Ms[i1], v1 = Cs[i1 * kBnnMaxNa + i1];
       const float damp = expf(-0.5f * v1);
-      const float Es = damp * sinf(m1), Ec = damp * cosf(m1);
+      float sin1, cos1;
+      sincos_(m1, sin1, cos1);
+      const float Es = damp * sin1, Ec = damp * cos1;
       Ma[nn + 2 * a1] = Es;
       Ma[nn + 2 * a1 + 1] = Ec;
       for (int a2 = 0; a2 < nang; ++a2) {
@@ -198,11 +247,13 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
         const float cij = Cs[i1 * kBnnMaxNa + i2];
         const float lq = -0.5f * (v1 + v2), q = expf(lq);
         const float ep = expf(lq + cij) - q, em = expf(lq - cij) - q;
-        const float dm = m1 - m2, sm = m1 + m2;
+        float sd, cd, ss, cs;
+        sincos_(m1 - m2, sd, cd);
+        sincos_(m1 + m2, ss, cs);
         const int r = nn + 2 * a1, cc = nn + 2 * a2;
-        Ca[r * kBnnMaxNa + cc] = 0.5f * (ep * cosf(dm) - em * cosf(sm));           // sin, sin
-        Ca[(r + 1) * kBnnMaxNa + cc + 1] = 0.5f * (ep * cosf(dm) + em * cosf(sm)); // cos, cos
-        Ca[r * kBnnMaxNa + cc + 1] = 0.5f * (ep * sinf(dm) + em * sinf(sm));       // sin, cos
+        Ca[r * kBnnMaxNa + cc] = 0.5f * (ep * cd - em * cs);            // sin, sin
+        Ca[(r + 1) * kBnnMaxNa + cc + 1] = 0.5f * (ep * cd + em * cs);  // cos, cos
+        Ca[r * kBnnMaxNa + cc + 1] = 0.5f * (ep * sd + em * ss);        // sin, cos
         // (cos_i, sin_j) = (sin_j, cos_i): written when the roles swap
         Ca[(cc + 1) * kBnnMaxNa + r] = Ca[r * kBnnMaxNa + cc + 1];
       }
@@ -234,12 +285,14 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     }
     float tr = 0.f;
     if (jit >= 0.f) {
-      for (int i = 0; i < na; ++i)
-        for (int j = 0; j < na; ++j) {
-          float cij = 0.f;  // (Ua^T Ua)[i][j]
-          for (int k = 0; k < na; ++k) cij += Ua[k * kBnnMaxNa + i] * Ua[k * kBnnMaxNa + j];
-          tr += cij * Q[j * na + i];
-        }
+      // tr(Q Ua^T Ua) with Ua^T Ua = Ca + jitter I: the factor only decides
+      // which jitter the cost sees (as csrc/qr_cost_derivs.hip takes it);
+      // rebuilding the product from Ua was na^3 serial multiply-adds, the
+      // largest single piece of this kernel
+      for (int i = 0; i < na; ++i) {
+        for (int j = 0; j < na; ++j) tr += Ca[i * kBnnMaxNa + j] * Q[j * na + i];
+        tr += jit * Q[i * na + i];
+      }
     } else {  // diagonal fallback of encode(): variances only
       for (int i = 0; i < na; ++i) tr += Ca[i * kBnnMaxNa + i] * Q[i * na + i];
     }
@@ -251,23 +304,47 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
   if (terminal) return;
   __syncthreads();
 
-  // ---- the network's input rows for this candidate's particles
+  // ---- the network's input rows for this candidate's particles: by state
+  // dimension (a static register index) to the feature slot the `non` / `ang`
+  // lists give it - the other way round is a dynamic index into x, i.e.
+  // scratch memory
+  float* frow = s.F + ((size_t)c * P + lane) * s.in_dim;
+  const size_t qstep = (size_t)kBnnGroup * s.in_dim;
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    if (!has[q]) continue;
-    const size_t row = (size_t)c * P + lane + 64 * q;
-    float* f = s.F + row * s.in_dim;
-    int o = 0;
-    for (int i = 0; i < s.n_non; ++i, ++o)
-      f[o] = (x[q][s.non[i]] - s.X_mean[o]) * s.X_std_inv[o];
-    for (int a1 = 0; a1 < s.n_ang; ++a1) {
-      float sn, cs;
-      sincosf(x[q][s.ang[a1]], &sn, &cs);
-      f[o] = (sn - s.X_mean[o]) * s.X_std_inv[o]; ++o;
-      f[o] = (cs - s.X_mean[o]) * s.X_std_inv[o]; ++o;
+  for (int d = 0; d < DX; ++d) {
+    if (d >= D) break;
+    int o = -1, oa = -1;
+    for (int i = 0; i < s.n_non; ++i) o = s.non[i] == d ? i : o;
+    for (int a1 = 0; a1 < s.n_ang; ++a1)
+      oa = s.ang[a1] == d ? s.n_non + 2 * a1 : oa;
+    if (o >= 0) {
+      const float mu = s.X_mean[o], si = s.X_std_inv[o];
+#pragma unroll
+      for (int q = 0; q < kBnnMaxPPL; ++q)
+        if (has[q]) frow[q * qstep + o] = (x[q][d] - mu) * si;
     }
-    for (int r = 0; r < m; ++r, ++o)
-      f[o] = (us[r] - s.X_mean[o]) * s.X_std_inv[o];
+    if (oa >= 0) {
+      const float mu0 = s.X_mean[oa], si0 = s.X_std_inv[oa];
+      const float mu1 = s.X_mean[oa + 1], si1 = s.X_std_inv[oa + 1];
+#pragma unroll
+      for (int q = 0; q < kBnnMaxPPL; ++q) {
+        float sn, cs;  // (a particle beyond 2^30 rad: see sincos_core)
+        sincos_core(x[q][d], sn, cs);
+        if (has[q]) {
+          frow[q * qstep + oa] = (sn - mu0) * si0;
+          frow[q * qstep + oa + 1] = (cs - mu1) * si1;
+        }
+      }
+    }
+  }
+  {
+    const int o0 = s.n_non + 2 * s.n_ang;
+    for (int r = 0; r < m; ++r) {
+      const float v = (us[r] - s.X_mean[o0 + r]) * s.X_std_inv[o0 + r];
+#pragma unroll
+      for (int q = 0; q < kBnnMaxPPL; ++q)
+        if (has[q]) frow[q * qstep + o0 + r] = v;
+    }
   }
 }
 
@@ -286,7 +363,14 @@ extern "C" int pddp_bnn_moment_step_f32(const pddp_bnn_step* s, void* stream) {
       s->n_non < 0 || s->n_non + s->n_ang != s->D ||
       s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D)
     return PDDP_E_UNSUPPORTED;
-  PDDP_LAUNCH(pddp::bnn_moment_step_kernel, dim3(s->B * s->A), dim3(64),
-                     0, (hipStream_t)stream, *s);
+  const int groups = s->B * s->A;
+  const dim3 grid((groups + pddp::kBnnPerWave - 1) / pddp::kBnnPerWave);
+  hipStream_t st = (hipStream_t)stream;
+  switch (s->D) {
+    case 2: PDDP_LAUNCH(pddp::bnn_moment_step_kernel<2>, grid, dim3(64), 0, st, *s); break;
+    case 4: PDDP_LAUNCH(pddp::bnn_moment_step_kernel<4>, grid, dim3(64), 0, st, *s); break;
+    case 6: PDDP_LAUNCH(pddp::bnn_moment_step_kernel<6>, grid, dim3(64), 0, st, *s); break;
+    default: PDDP_LAUNCH(pddp::bnn_moment_step_kernel<0>, grid, dim3(64), 0, st, *s); break;
+  }
   return pddp::launch_status();
 }

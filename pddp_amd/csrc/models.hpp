@@ -90,7 +90,10 @@ struct ModelDims<PDDP_MODEL_RENDEZVOUS> {
 // like the library; finite ones beyond 2^30 take the library's result,
 // computed under one wave-uniform test and selected per lane (a trajectory's
 // result must not depend on its neighbours in the wavefront).
-PDDP_DEV void sincos_(float x, float& s, float& c) {
+// the branch-free part: ~1 ulp for |x| < 2^30, NaN for non-finite arguments;
+// beyond 2^30 (where neighbouring floats are 64 rad and more apart) a finite
+// value in [-1, 1] without meaning
+PDDP_DEV void sincos_core(float x, float& s, float& c) {
   const double xd = (double)x;
   const double kd = __builtin_rint(xd * 0.63661977236758138243);  // 2 / pi
   double rd = __builtin_fma(kd, -1.57079632679489655800e+00, xd);
@@ -109,11 +112,14 @@ PDDP_DEV void sincos_(float x, float& s, float& c) {
   const unsigned cs = (((unsigned)q + 1u) & 2u) << 30;
   s = __uint_as_float(__float_as_uint(swap ? cr : sr) ^ ss);
   c = __uint_as_float(__float_as_uint(swap ? sr : cr) ^ cs);
-  const float ax = fabsf(x);
-  const bool nonfinite = !(ax < __builtin_inff());
+  const bool nonfinite = !(fabsf(x) < __builtin_inff());
   s = nonfinite ? __builtin_nanf("") : s;
   c = nonfinite ? __builtin_nanf("") : c;
-  const bool big = (ax >= 1073741824.0f) & !nonfinite;
+}
+PDDP_DEV void sincos_(float x, float& s, float& c) {
+  sincos_core(x, s, c);
+  const float ax = fabsf(x);
+  const bool big = (ax >= 1073741824.0f) & (ax < __builtin_inff());
   if (__builtin_expect(__any(big), 0)) {
     float sl, cl;
     sincosf(x, &sl, &cl);
