@@ -33,6 +33,7 @@
 // direction of z (G = 16 or 32 lanes per trajectory), each reading its base
 // direction's row and scaling.
 #include "pddp_common.hpp"
+#include "models.hpp"  // sincos_
 
 namespace pddp {
 
@@ -42,7 +43,10 @@ namespace pddp {
 
 constexpr int kNetRows = 8;  // network rows per (state, particle)
 
-template <int kJvpMaxD>
+// EXACT: D == kJvpMaxD, known at compile time - every small matrix below is
+// then indexed statically and lives in registers (under a runtime D they sat in
+// scratch memory: 160 .. 1024 bytes per lane, and the kernels waited for it).
+template <int kJvpMaxD, bool EXACT>
 __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   constexpr int kJvpRows = kNetRows;
   const int lane = threadIdx.x;
@@ -50,7 +54,8 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   const int bp = blockIdx.x * (64 / kJvpRows) + lane / kJvpRows;  // (b, p)
   if (bp >= s.B * s.P) return;
   const int b = bp / s.P;
-  const int D = s.D, m = s.m, n = D + D * (D + 1) / 2;
+  const int D = EXACT ? kJvpMaxD : s.D;
+  const int m = s.m, n = D + D * (D + 1) / 2;
   const float* z = s.Z + ((size_t)b * (s.N + 1) + s.t) * n;
   const float* xp = s.Xp + (size_t)bp * D;
   // eps = (X - mean) U^-1: forward substitution against the upper factor
@@ -68,27 +73,30 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   }
   if (k == 0)
     for (int j = 0; j < D; ++j) s.eps[(size_t)bp * D + j] = eps[j];
-  // row k >= 1: direction mean_{k-1} (k - 1 < D) or u_{k-1-D}
-  float dX[kJvpMaxD];
-  for (int q = 0; q < D; ++q) dX[q] = (k - 1 == q) ? 1.f : 0.f;
+  // row k >= 1: direction mean_{k-1} (k - 1 < D) or u_{k-1-D}.  By state
+  // dimension c (a static index) to the feature slot the `non` / `ang` lists
+  // give it.
   float* f = s.F + ((size_t)bp * kJvpRows + k) * s.in_dim;
-  int o = 0;
-  for (int i = 0; i < s.n_non; ++i, ++o) {
-    const int c = s.non[i];
-    f[o] = k == 0 ? (x[c] - s.X_mean[o]) * s.X_std_inv[o]
-                  : dX[c] * s.X_std_inv[o];
+#pragma unroll
+  for (int c = 0; c < kJvpMaxD; ++c) {
+    if (c >= D) break;
+    const float dXc = (k - 1 == c) ? 1.f : 0.f;
+    int o = -1, oa = -1;
+    for (int i = 0; i < s.n_non; ++i) o = s.non[i] == c ? i : o;
+    for (int a = 0; a < s.n_ang; ++a) oa = s.ang[a] == c ? s.n_non + 2 * a : oa;
+    if (o >= 0)
+      f[o] = k == 0 ? (x[c] - s.X_mean[o]) * s.X_std_inv[o]
+                    : dXc * s.X_std_inv[o];
+    if (oa >= 0) {
+      float sn, cs;
+      sincos_(x[c], sn, cs);
+      f[oa] = k == 0 ? (sn - s.X_mean[oa]) * s.X_std_inv[oa]
+                     : (cs * dXc) * s.X_std_inv[oa];
+      f[oa + 1] = k == 0 ? (cs - s.X_mean[oa + 1]) * s.X_std_inv[oa + 1]
+                         : (-sn * dXc) * s.X_std_inv[oa + 1];
+    }
   }
-  for (int a = 0; a < s.n_ang; ++a) {
-    const int c = s.ang[a];
-    float sn, cs;
-    sincosf(x[c], &sn, &cs);
-    f[o] = k == 0 ? (sn - s.X_mean[o]) * s.X_std_inv[o]
-                  : (cs * dX[c]) * s.X_std_inv[o];
-    ++o;
-    f[o] = k == 0 ? (cs - s.X_mean[o]) * s.X_std_inv[o]
-                  : (-sn * dX[c]) * s.X_std_inv[o];
-    ++o;
-  }
+  int o = s.n_non + 2 * s.n_ang;
   for (int r = 0; r < m; ++r, ++o) {
     // derivatives AT the clamped action (ilqr.py:461-462: the clamp is not
     // differentiated through)
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   }
 }
 
-template <int kJvpRows, int kJvpMaxD>
+template <int kJvpRows, int kJvpMaxD, bool EXACT>
 __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   // one wavefront per trajectory: lane = (particle slice, direction k); the
   // NS = 64 / G slices split the particle loop and meet in xor butterflies
@@ -110,7 +118,8 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   const int slice = lane / kJvpRows;
   const int b = blockIdx.x;
   if (b >= s.B) return;
-  const int D = s.D, P = s.P, m = s.m, n = D + D * (D + 1) / 2;
+  const int D = EXACT ? kJvpMaxD : s.D;
+  const int P = s.P, m = s.m, n = D + D * (D + 1) / 2;
   const int OUT = s.out_dim;
   const float* Y = s.net_out + (size_t)b * P * kNetRows * OUT;
   auto across_slices = [&](float v) {
@@ -187,17 +196,26 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
     double jit = 1e-12;
     while (!ok && jit <= 10.0) {
       ok = true;
-      for (int i = 0; i < D && ok; ++i)
-        for (int j = i; j < D; ++j) {
+      // (no early exit: a failed pivot ends the reference's attempt; what is
+      // computed after it here is garbage that the next attempt overwrites -
+      // the loops stay fully unrolled and Uc in registers)
+#pragma unroll
+      for (int i = 0; i < kJvpMaxD; ++i) {
+        if (i >= D) break;
+#pragma unroll
+        for (int j = i; j < kJvpMaxD; ++j) {
+          if (j >= D) break;
           float v = C[i][j] + (i == j ? (float)jit : 0.f);
+#pragma unroll
           for (int q = 0; q < i; ++q) v -= Uc[q][i] * Uc[q][j];
           if (i == j) {
-            if (!(v > 0.f)) { ok = false; break; }
+            if (!(v > 0.f)) ok = false;
             Uc[i][i] = sqrtf(v);
           } else {
             Uc[i][j] = v / Uc[i][i];
           }
         }
+      }
       jit *= 10.0;
     }
     for (int i = 0; i < D; ++i)
@@ -301,26 +319,37 @@ static int bnn_jvp_check(const pddp_bnn_jvp* s) {
 
 int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
-  if (s->D <= 4)
-    PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<4>),
-                       dim3((s->B * s->P + 7) / 8), dim3(64), 0,
-                       (hipStream_t)stream, *s);
-  else
-    PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<6>),
-                       dim3((s->B * s->P + 7) / 8), dim3(64), 0,
-                       (hipStream_t)stream, *s);
+  const dim3 grid((s->B * s->P + 7) / 8), block(64);
+  hipStream_t st = (hipStream_t)stream;
+  switch (s->D) {
+    case 2: PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<2, true>), grid, block, 0, st, *s); break;
+    case 4: PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<4, true>), grid, block, 0, st, *s); break;
+    case 6: PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<6, true>), grid, block, 0, st, *s); break;
+    default:
+      if (s->D <= 4)
+        PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<4, false>), grid, block, 0, st, *s);
+      else
+        PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<6, false>), grid, block, 0, st, *s);
+  }
   return pddp::launch_status();
 }
 
 int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
   if (!s->net_out || !s->F_z || !s->F_u) return PDDP_E_BADARG;
-  if (pddp_bnn_jvp_group(s->D, s->m) == 16)
-    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<16, 4>), dim3(s->B),
-                       dim3(64), 0, (hipStream_t)stream, *s);
+  const dim3 grid(s->B), block(64);
+  hipStream_t st = (hipStream_t)stream;
+  const bool g16 = pddp_bnn_jvp_group(s->D, s->m) == 16;
+  if (g16 && s->D == 2)
+    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<16, 2, true>), grid, block, 0, st, *s);
+  else if (g16 && s->D == 4)
+    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<16, 4, true>), grid, block, 0, st, *s);
+  else if (g16)
+    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<16, 4, false>), grid, block, 0, st, *s);
+  else if (s->D == 6)
+    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<32, 6, true>), grid, block, 0, st, *s);
   else
-    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<32, 6>), dim3(s->B),
-                       dim3(64), 0, (hipStream_t)stream, *s);
+    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<32, 6, false>), grid, block, 0, st, *s);
   return pddp::launch_status();
 }
 
