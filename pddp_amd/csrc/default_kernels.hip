@@ -131,17 +131,23 @@ PDDP_DEV T chol_jitter_of(const T (&C)[NA][NA]) {
   while (jit <= 10.0) {
     T U[NA][NA];
     bool ok = true;
-    for (int i = 0; i < NA && ok; ++i)
+    // (no early exit: a failed pivot ends the reference's attempt, what is
+    // computed after it is discarded - the loops unroll, U stays in registers)
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+#pragma unroll
       for (int j = i; j < NA; ++j) {
         T s = C[i][j] + (i == j ? (T)jit : T(0));
+#pragma unroll
         for (int q = 0; q < i; ++q) s -= U[q][i] * U[q][j];
         if (i == j) {
-          if (!(s > T(0))) { ok = false; break; }
+          if (!(s > T(0))) ok = false;
           U[i][i] = sqrt_(s);
         } else {
           U[i][j] = s / U[i][i];
         }
       }
+    }
     if (ok) return (T)jit;
     jit *= 10.0;
   }
