@@ -317,3 +317,43 @@ def test_pddp_dataset_helpers():
         xn = model(X[t], U[t], 0, enc)
         assert torch.allclose(xn, X[t + 1], atol=1e-6)
         assert torch.allclose(dX[t], X[t + 1] - X[t])
+
+
+def test_hot_kernels_keep_their_working_set_in_registers():
+    """No scratch memory and no register spills in the kernels the benchmarks
+    run (read from the built library's code-object metadata, tools/
+    kernel_resources.py): a small matrix indexed through a runtime dimension
+    silently moves to scratch - that cost four BNN kernels 2 .. 8x before it
+    was seen.  Kernels known to use scratch are listed."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "tools"))
+    from kernel_resources import kernel_resources
+    rows = kernel_resources()
+    assert len(rows) > 200
+    allowed = (
+        "accept_kernel<",                       # 36 B, one launch per round of the un-fused path
+        "bnn_jvp_features_kernel<6, false>",    # runtime-D fall-backs (D not 2 / 4 / 6)
+        "bnn_jvp_moments_kernel<16, 4, false>",
+        "bnn_jvp_moments_kernel<32, 6, false>",
+        "derivs_default_kernel<double, 2, 1>",  # double cartpole, hyper-dual on 27 inputs
+        "derivs_default_kernel<float, 2, 1>",
+        "line_search_default_kernel<float, 2, 2>",
+        "line_search_kernel<double, 2>",
+        "line_search_lds_kernel<double, 2, true, 4, 2>",
+        "line_search_lds_kernel<double, 4, true, 4, 2>",
+    )
+    bad = [(r["kernel"], r.get("private_segment_fixed_size", 0),
+            r.get("vgpr_spill_count", 0)) for r in rows
+           if (r.get("private_segment_fixed_size", 0) > 0
+               or r.get("vgpr_spill_count", 0) > 0)
+           and not any(a in r["kernel"] for a in allowed)]
+    assert not bad, bad
+    hot = ("riccati_n4_qpipe_kernel<float", "riccati_n4_quad_kernel<float",
+           "line_search_lds_kernel<float, 1, true, 4, 2>",
+           "bnn_mlp_kernel<200", "riccati_mfma16_kernel<", "riccati_mfma32_kernel<",
+           "bnn_moment_step_kernel<4>", "bnn_moment_step_kernel<6>",
+           "bnn_jvp_moments_kernel<16, 4, true>", "qr_cost_derivs_kernel<")
+    for h in hot:
+        assert any(h in r["kernel"] for r in rows), h
