@@ -291,18 +291,21 @@ def bench_bnn(args):
         elapsed, total_attempted = float(tmax[0].item()), int(t[1].item())
     # the dominant kernel, timed alone on torch's current stream (the stream it
     # is launched on): one forward-mode network pass of a time step
-    grp = 8  # rows per (state, particle): the input and D + m <= 7 directions
+    grp = 8  # rows per (state, particle) in memory
+    live = 1 + D + m  # of which in use: the input and the D + m directions
     F = torch.randn(B * P * grp, in_dim, device=dev)
-    model.model._jvp_native(F, P, D, grp)
+    model.model._jvp_native(F, P, D, grp, live=live)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 5
     e0.record()
     for _ in range(reps):
-        model.model._jvp_native(F, P, D, grp)
+        model.model._jvp_native(F, P, D, grp, live=live)
     e1.record()
     torch.cuda.synchronize(dev)
     dur = e0.elapsed_time(e1) * 1e-3 / reps
-    flop = 2.0 * B * P * grp * (in_dim * H + H * H + H * D)
+    # algorithmic: the rows that exist (padding rows of the 32-row tiles - 2 of
+    # 32 with 6 live rows per group - are the kernel's overhead, not work)
+    flop = 2.0 * B * P * live * (in_dim * H + H * H + H * D)
     out = {
         "metric": "pddp_iterations_per_sec", "value": total_attempted / elapsed,
         "unit": "trajectory-iterations/s", "n_gpus": world, "steps": K,
@@ -324,8 +327,10 @@ def bench_bnn(args):
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "fused BNN network, forward-mode (bnn_mlp_kernel<%d, %d, %d>)"
-                      % (H, 8 if in_dim < 8 else 16, grp),
+            "kernel": "fused BNN network, forward-mode (bnn_mlp_kernel<%d, %d, %d, "
+                      "%d>: %d live rows per (state, particle))"
+                      % (H, 8 if in_dim < 8 else 16, grp,
+                         4 if live <= 4 else (6 if live <= 6 else 8), live),
             "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
             "avg_launch_us": dur * 1e6,

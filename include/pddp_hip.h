@@ -383,6 +383,16 @@ int pddp_bnn_mlp_jvp_f32(int R, int P, int group, int in_dim, int H,
                          const float* M1, const float* W2, const float* b2,
                          const float* M2, const float* W3, const float* b3,
                          float* Y, void* stream);
+/* The same with only the first `live` <= group rows of every group in use (the
+ * input row and the 1 + D + m - 1 tangent rows that exist): the other rows are
+ * neither read nor written, and the kernel packs 32 / live whole groups into a
+ * tile instead of 32 / group (group = 8, live <= 4: eight, live <= 6: five). */
+int pddp_bnn_mlp_jvp_live_f32(int R, int P, int group, int live, int in_dim,
+                              int H, int out_dim, const float* X,
+                              const float* W1, const float* b1, const float* M1,
+                              const float* W2, const float* b2, const float* M2,
+                              const float* W3, const float* b3, float* Y,
+                              void* stream);
 
 /* ---- Jacobians F_z, F_u of one moment-matched BNN step (modules.py:287-386
  * under DEFAULT encoding) in forward mode, around pddp_bnn_mlp_jvp_f32:

@@ -77,6 +77,7 @@ _SIGS = {
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
     "pddp_bnn_moment_step_f32": [_P, _P],
     "pddp_bnn_mlp_jvp_f32": [c_int] * 6 + [_P] * 11,
+    "pddp_bnn_mlp_jvp_live_f32": [c_int] * 7 + [_P] * 11,
     "pddp_bnn_jvp_group": [c_int, c_int],
     "pddp_bnn_jvp_features_f32": [_P, _P],
     "pddp_bnn_jvp_moments_f32": [_P, _P],

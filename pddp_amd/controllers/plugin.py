@@ -296,7 +296,7 @@ class TorchProblem(object):
             _native.check(lib.pddp_bnn_jvp_features_f32(ctypes.byref(st),
                                                         stream),
                           "pddp_bnn_jvp_features_f32")
-            Y = mo.model._jvp_native(F, P, D, G)
+            Y = mo.model._jvp_native(F, P, D, G, live=1 + D + s.m)
             st.net_out = p(Y)
             _native.check(lib.pddp_bnn_jvp_moments_f32(ctypes.byref(st),
                                                        stream),

@@ -91,27 +91,41 @@ constexpr size_t bnn_mlp_lds_floats() {
 // kMlpW1Stride: inputs | zeros | bias slot of layer 1 (8: in_dim <= 7, 16: <=
 // 15) = twice its MFMA steps.
 // group_first_positive: is `v` of the first row of this lane's group positive?
-// Groups of G data rows are G consecutive lanes of a 32-lane half.  One vector
+// Groups are L consecutive lanes of a 32-lane half, the first at lane 0 (L need
+// not divide 32: lanes past the last whole group get `false`).  One vector
 // compare; its 64-bit lane mask keeps the bits of the groups' first lanes and
-// a scalar multiply smears each over its G lanes - scalar instructions, which
+// a scalar multiply smears each over its L lanes - scalar instructions, which
 // do not take matrix time (a vector instruction does: see above).
-template <int G>
+template <int L>
 PDDP_DEV bool group_first_positive(float v) {
+  constexpr unsigned first_lanes = [] {
+    unsigned m = 0;
+    for (int g = 0; g < 32 / L; ++g) m |= 1u << (g * L);
+    return m;
+  }();
+  constexpr unsigned smear = L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
   const unsigned long long b = __builtin_amdgcn_ballot_w64(v > 0.f);
-  constexpr unsigned kFirst = G == 8 ? 0x01010101u : (G == 16 ? 0x00010001u : 1u);
-  constexpr unsigned kSmear = G == 8 ? 0xFFu : (G == 16 ? 0xFFFFu : 0xFFFFFFFFu);
-  const unsigned lo = ((unsigned)b & kFirst) * kSmear;
-  const unsigned hi = ((unsigned)(b >> 32) & kFirst) * kSmear;
+  const unsigned lo = ((unsigned)b & first_lanes) * smear;
+  const unsigned hi = ((unsigned)(b >> 32) & first_lanes) * smear;
   return __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
 }
 
-// kJvpGroup = rows per (state, particle) in JVP mode (0: plain inference)
-template <int H, int kMlpW1Stride, int kJvpGroup = 0>
+// kJvpGroup = rows per (state, particle) in memory in JVP mode (0: plain
+// inference); kJvpLive <= kJvpGroup of them are in use (the input row and the
+// tangent rows that exist: 1 + D + m), the rest is padding that is neither
+// read nor written.  A tile takes 32 / kJvpLive whole groups - with cartpole's
+// 6 live rows of 8 that is 5 groups per tile instead of 4: a fifth fewer
+// tiles.
+template <int H, int kMlpW1Stride, int kJvpGroup = 0, int kJvpLive = kJvpGroup>
 __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   constexpr bool JVP = kJvpGroup != 0;
   constexpr int G = JVP ? kJvpGroup : 1;  // rows per (state, particle)
+  constexpr int LIVE = JVP ? kJvpLive : 1;
+  constexpr int GPT = JVP ? kMlpTile / LIVE : kMlpTile;  // groups per tile
+  constexpr int TROWS = GPT * G;                         // memory rows per tile
   static_assert(kJvpGroup == 0 || kJvpGroup == 8 || kJvpGroup == 16 ||
                     kJvpGroup == 32, "");
+  static_assert(kJvpLive >= 0 && kJvpLive <= kJvpGroup, "");
   static_assert(H % 8 == 0 && H <= 224, "H: multiple of 8, at most 224");
   constexpr int KS = H / 2;          // MFMA steps of layer 2
   constexpr int NQ = KS / 4;         // 8-unit chunks of layer 1
@@ -131,7 +145,26 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   const int li = lane & 31, lh = lane >> 5;
   const int P = a.P, IN = a.in_dim, OUT = a.out_dim, R = a.R;
 
-  const int ntiles = (R + kMlpTile - 1) / kMlpTile;
+  const int ntiles = (R + TROWS - 1) / TROWS;
+  // tile row rt (MFMA column) of tile `tile` -> memory row; rows of padding
+  // lanes (past the last whole group) and past R are dead
+  struct RowOf { int mrow, group; bool live, tangent; };
+  auto row_of = [&](int tile, int rt) {
+    RowOf r;
+    if constexpr (!JVP) {
+      r.mrow = tile * kMlpTile + rt;
+      r.group = r.mrow;
+      r.tangent = false;
+      r.live = r.mrow < R;
+    } else {
+      const int g = rt / LIVE, k = rt - g * LIVE;
+      r.group = tile * GPT + g;
+      r.mrow = r.group * G + k;
+      r.tangent = k != 0 || g >= GPT;
+      r.live = g < GPT && r.mrow < R;
+    }
+    return r;
+  };
   // tiles of this workgroup: blockIdx.x + i * gridDim.x, i < my (my >= 1: the
   // grid is never larger than the number of tiles)
   const int my = blockIdx.x < ntiles
@@ -184,13 +217,14 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
           o1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[j][s], b1, o1, 0, 0, 0);
         }
       }
-      const int row0 = (blockIdx.x + t * gridDim.x) * kMlpTile;
+      const int tile = blockIdx.x + t * gridDim.x;
 #pragma unroll
       for (int hf = 0; hf < 2; ++hf) {
-        const int rt = 16 * hf + n16, rr = row0 + rt;
+        const RowOf ro = row_of(tile, 16 * hf + n16);
+        const int rr = ro.mrow;
         f32x4 y = hf == 0 ? o0 : o1;
-        if (!(JVP && (rt & (G - 1)) != 0)) y += bias;  // tangents: no bias
-        if (rr < R) {
+        if (!ro.tangent) y += bias;  // tangents: no bias
+        if (ro.live) {
           if ((OUT & 3) == 0) {
             if (4 * kk < OUT)
               *reinterpret_cast<f32x4*>(a.Y + (size_t)rr * OUT + 4 * kk) = y;
@@ -255,11 +289,11 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   // four MFMAs, mask and ReLU on the accumulators, four ds_write_b128
   float xin[KS1];
   f32x4 m1[4];
-  auto masks_of = [&](const float* M, int row, f32x4 (&m)[4]) {
+  auto masks_of = [&](const float* M, const RowOf& ro, f32x4 (&m)[4]) {
     // registers 4 g .. 4 g + 3 are the units 32 j + 8 g + 4 lh + (0..3): one
     // 16-B load of the mask row each (clamped inside the row for the padded
     // units of the last block, whose weights are zero)
-    const int p = row < R ? (row / G) % P : 0;
+    const int p = ro.live ? ro.group % P : 0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int n0 = 32 * j + 8 * g + 4 * lh;
@@ -268,19 +302,19 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     }
   };
   auto l1_load = [&](int i) {
-    const int row = (blockIdx.x + i * gridDim.x) * kMlpTile + li;
-    const bool live = row < R;
+    const RowOf ro = row_of(blockIdx.x + i * gridDim.x, li);
+    const int row = ro.mrow;
+    const bool live = ro.live;
 #pragma unroll
     for (int s = 0; s < KS1; ++s) {
       const int c = kMlpW1Stride - 1 - (2 * s + lh);
       const float v = a.X[(size_t)(live ? row : 0) * IN + (c < IN ? c : 0)];
       // the last slot multiplies the bias (tangent rows carry none)
       xin[s] = c < IN ? (live ? v : 0.f)
-                      : (c == kMlpW1Stride - 1
-                             ? ((JVP && (li & (G - 1)) != 0) ? 0.f : 1.f)
-                             : 0.f);
+                      : (c == kMlpW1Stride - 1 ? (ro.tangent ? 0.f : 1.f)
+                                               : 0.f);
     }
-    masks_of(a.MT1, row, m1);
+    masks_of(a.MT1, ro, m1);
   };
   auto layer1 = [&](int i) {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -299,7 +333,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
           // linearised at the group's primal row (for which this IS relu;
           // the mask is that of the group's particle, >= 0: where it is zero
           // the product is)
-          v[e] = group_first_positive<JVP ? kJvpGroup : 16>(pre) ? pre * mm : 0.f;
+          v[e] = group_first_positive<JVP ? LIVE : 16>(pre) ? pre * mm : 0.f;
         } else {
           v[e] = fmaxf(pre * mm, 0.f);
         }
@@ -312,18 +346,18 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   tile_barrier();  // h1t[0] ready
 
   for (int i = 0; i < my; ++i) {
-    const int row0 = (blockIdx.x + i * gridDim.x) * kMlpTile;
+    const RowOf ro = row_of(blockIdx.x + i * gridDim.x, li);
     const bool nxt = i + 1 < my;
     if (nxt) l1_load(i + 1);
     // mask of layer 2, requested before the MFMAs so that its latency is
     // theirs
     f32x4 m2[4];
-    masks_of(a.MT2, row0 + li, m2);
+    masks_of(a.MT2, ro, m2);
     // ---- layer 2 on the matrix cores; the accumulator starts at the bias
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-      acc[r] = (JVP && (li & (G - 1)) != 0) ? 0.f : b2r[r];  // tangents: no bias
+      acc[r] = ro.tangent ? 0.f : b2r[r];  // tangents: no bias
     const f32x4* bsrc =
         reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
 #pragma unroll
@@ -345,7 +379,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       for (int e = 0; e < 4; ++e) {
         const float pre = acc[4 * g + e], mm = m2[g][e];
         if constexpr (JVP) {
-          h2[e] = group_first_positive<JVP ? kJvpGroup : 16>(pre) ? pre * mm : 0.f;
+          h2[e] = group_first_positive<JVP ? LIVE : 16>(pre) ? pre * mm : 0.f;
         } else {
           h2[e] = fmaxf(pre * mm, 0.f);
         }
@@ -357,7 +391,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   }
 }
 
-template <int H, int W1S, int JVP = 0>
+template <int H, int W1S, int JVP = 0, int LIVE = JVP>
 static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   // per device (a process may drive several GPUs): CU count queried once -
   // hipGetDeviceProperties costs ms - and the > 64 KB dynamic-LDS opt-in,
@@ -375,25 +409,27 @@ static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
                       : 256;
   }
   const int cus = cus_of[dev];
-  const int ntiles = (a.R + kMlpTile - 1) / kMlpTile;
+  // memory rows per tile: 32, or (32 / LIVE) whole groups of JVP rows
+  constexpr int trows = JVP == 0 ? kMlpTile : (kMlpTile / LIVE) * JVP;
+  const int ntiles = (a.R + trows - 1) / trows;
   const int grid = ntiles < cus ? ntiles : cus;  // persistent: one per CU
   constexpr size_t lds = sizeof(float) * bnn_mlp_lds_floats<H, W1S>();
   if (!attr_set[dev]) {  // more than 64 KB of dynamic LDS needs the opt-in
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)bnn_mlp_kernel<H, W1S, JVP>,
+        (const void*)bnn_mlp_kernel<H, W1S, JVP, LIVE>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set[dev] = true;
   }
-  PDDP_LAUNCH((bnn_mlp_kernel<H, W1S, JVP>), dim3(grid),
+  PDDP_LAUNCH((bnn_mlp_kernel<H, W1S, JVP, LIVE>), dim3(grid),
                      dim3(kMlpThreads), lds, st, a);
   return launch_status();
 }
 
-template <int H, int JVP = 0>
+template <int H, int JVP = 0, int LIVE = JVP>
 static int launch_bnn_mlp(const BnnMlpArgs& a, hipStream_t st) {
-  return a.in_dim < 8 ? launch_bnn_mlp_w<H, 8, JVP>(a, st)
-                      : launch_bnn_mlp_w<H, 16, JVP>(a, st);
+  return a.in_dim < 8 ? launch_bnn_mlp_w<H, 8, JVP, LIVE>(a, st)
+                      : launch_bnn_mlp_w<H, 16, JVP, LIVE>(a, st);
 }
 
 }  // namespace pddp
@@ -421,41 +457,61 @@ int pddp_bnn_mlp_f32(int R, int P, int in_dim, int H, int out_dim,
   return PDDP_E_UNSUPPORTED;
 }
 
-int pddp_bnn_mlp_jvp_f32(int R, int P, int group, int in_dim, int H,
-                         int out_dim, const float* X, const float* W1, const float* b1,
-                         const float* MT1, const float* W2, const float* b2,
-                         const float* MT2, const float* W3, const float* b3,
-                         float* Y, void* stream) {
+static int bnn_mlp_jvp_impl(int R, int P, int group, int live, int in_dim,
+                            int H, int out_dim, const float* X, const float* W1,
+                            const float* b1, const float* MT1, const float* W2,
+                            const float* b2, const float* MT2, const float* W3,
+                            const float* b3, float* Y, void* stream) {
   if (R <= 0 || P <= 0 || in_dim <= 0 || H <= 0 || out_dim <= 0 || !X || !W1 ||
       !b1 || !MT1 || !W2 || !b2 || !MT2 || !W3 || !b3 || !Y)
     return PDDP_E_BADARG;
-  if ((group != 8 && group != 16 && group != 32) || R % group != 0)
+  if ((group != 8 && group != 16 && group != 32) || R % group != 0 ||
+      live < 1 || live > group)
     return PDDP_E_BADARG;
   if (in_dim >= pddp::kMlpW1Max || out_dim > pddp::kMlpMaxOut)
     return PDDP_E_UNSUPPORTED;
   const pddp::BnnMlpArgs a{R, P, in_dim, H, out_dim, X, W1, b1, MT1, W2,
                            b2, MT2, W3, b3, Y};
   hipStream_t st = (hipStream_t)stream;
+#define PDDP_MLP_H(G, L)                                             \
+  switch (H) {                                                       \
+    case 64: return pddp::launch_bnn_mlp<64, G, L>(a, st);           \
+    case 128: return pddp::launch_bnn_mlp<128, G, L>(a, st);         \
+    case 200: return pddp::launch_bnn_mlp<200, G, L>(a, st);         \
+  }                                                                  \
+  return PDDP_E_UNSUPPORTED
   if (group == 8) {
-    switch (H) {
-      case 64: return pddp::launch_bnn_mlp<64, 8>(a, st);
-      case 128: return pddp::launch_bnn_mlp<128, 8>(a, st);
-      case 200: return pddp::launch_bnn_mlp<200, 8>(a, st);
-    }
+    // packed forms: 8 groups of 4 live rows or 5 groups of 6 per tile
+    // (pendulum: 1 + 2 + 1 rows, cartpole: 1 + 4 + 1); anything else runs 4
+    // groups of 8
+    if (live <= 4) { PDDP_MLP_H(8, 4); }
+    if (live <= 6) { PDDP_MLP_H(8, 6); }
+    PDDP_MLP_H(8, 8);
   } else if (group == 16) {
-    switch (H) {
-      case 64: return pddp::launch_bnn_mlp<64, 16>(a, st);
-      case 128: return pddp::launch_bnn_mlp<128, 16>(a, st);
-      case 200: return pddp::launch_bnn_mlp<200, 16>(a, st);
-    }
+    PDDP_MLP_H(16, 16);
   } else {
-    switch (H) {
-      case 64: return pddp::launch_bnn_mlp<64, 32>(a, st);
-      case 128: return pddp::launch_bnn_mlp<128, 32>(a, st);
-      case 200: return pddp::launch_bnn_mlp<200, 32>(a, st);
-    }
+    PDDP_MLP_H(32, 32);
   }
-  return PDDP_E_UNSUPPORTED;
+#undef PDDP_MLP_H
+}
+
+int pddp_bnn_mlp_jvp_f32(int R, int P, int group, int in_dim, int H,
+                         int out_dim, const float* X, const float* W1, const float* b1,
+                         const float* MT1, const float* W2, const float* b2,
+                         const float* MT2, const float* W3, const float* b3,
+                         float* Y, void* stream) {
+  return bnn_mlp_jvp_impl(R, P, group, group, in_dim, H, out_dim, X, W1, b1, MT1,
+                          W2, b2, MT2, W3, b3, Y, stream);
+}
+
+int pddp_bnn_mlp_jvp_live_f32(int R, int P, int group, int live, int in_dim,
+                              int H, int out_dim, const float* X,
+                              const float* W1, const float* b1, const float* MT1,
+                              const float* W2, const float* b2, const float* MT2,
+                              const float* W3, const float* b3, float* Y,
+                              void* stream) {
+  return bnn_mlp_jvp_impl(R, P, group, live, in_dim, H, out_dim, X, W1, b1, MT1,
+                          W2, b2, MT2, W3, b3, Y, stream);
 }
 
 }  // extern "C"

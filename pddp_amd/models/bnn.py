@@ -193,10 +193,12 @@ class BayesianMLP(torch.nn.Module):
         _native.check(rc, "pddp_bnn_mlp_f32")
         return y
 
-    def _jvp_native(self, F, P, out_rows, group=16):
+    def _jvp_native(self, F, P, out_rows, group=16, live=None):
         """Forward-mode pass of csrc/bnn_mlp.hip: F [(states P) group, in_dim],
-        groups of 16 / 32 rows = primal input + tangent rows; returns the first
-        `out_rows` outputs per row (include/pddp_hip.h pddp_bnn_mlp_jvp_f32)."""
+        groups of 8 / 16 / 32 rows = primal input + tangent rows; returns the
+        first `out_rows` outputs per row (include/pddp_hip.h
+        pddp_bnn_mlp_jvp_live_f32).  `live`: rows of a group in use (default:
+        all) - the rest is neither read nor written."""
         from .. import _native
         in_dim = F.shape[-1]
         H = self.hidden[0].out_features
@@ -205,14 +207,14 @@ class BayesianMLP(torch.nn.Module):
         m1, m2 = self._mask_t(0, P, F), self._mask_t(1, P, F)
         c = lambda t: t.detach().contiguous()
         p = _native.ptr
-        rc = _native.lib().pddp_bnn_mlp_jvp_f32(
-            R, P, int(group), in_dim, H, out_rows, p(F),
+        rc = _native.lib().pddp_bnn_mlp_jvp_live_f32(
+            R, P, int(group), int(group if live is None else live), in_dim, H,
+            out_rows, p(F),
             p(c(self.hidden[0].weight)),
             p(c(self.hidden[0].bias)), p(m1), p(c(self.hidden[1].weight)),
             p(c(self.hidden[1].bias)), p(m2), p(c(self.out.weight[:out_rows])),
-            p(c(self.out.bias[:out_rows])), p(Y),
-            _native.stream_handle(F.device))
-        _native.check(rc, "pddp_bnn_mlp_jvp_f32")
+            p(c(self.out.bias[:out_rows])), p(Y), _native.stream_handle(F.device))
+        _native.check(rc, "pddp_bnn_mlp_jvp_live_f32")
         return Y
 
     def forward(self, x, resample=False):
