@@ -73,6 +73,37 @@ if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
         _name, float(_dt), int(_N), float(_bound), float(_seconds), int(_seed)))
     sys.exit(0)
 
+if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-torch-worker":
+    # the second CPU leg: the op-for-op PyTorch-CPU restatement,
+    # one trajectory at a time like the reference, one thread; CPU tensors only
+    os.environ["CUDA_VISIBLE_DEVICES"] = ""
+    os.environ["HIP_VISIBLE_DEVICES"] = ""
+    import torch as _t
+    _t.set_num_threads(1)
+    from oracle import torch_port as _tp
+    import pddp_amd as _pa
+    from pddp_amd.examples import cartpole as _cp
+    _dt, _N, _bound, _seconds = (float(sys.argv[2]), int(sys.argv[3]),
+                                 float(sys.argv[4]), float(sys.argv[5]))
+    _model, _cost = _cp.CartpoleDynamicsModel(_dt), _cp.CartpoleCost()
+    _enc = _pa.StateEncoding.IGNORE_UNCERTAINTY
+    _g = _t.Generator().manual_seed(0)
+    _alphas = 1.025 ** (-_t.arange(10.0) ** 2)
+    _umin, _umax = _t.tensor([-_bound]), _t.tensor([_bound])
+    _n, _t0 = 0, time.perf_counter()
+    while time.perf_counter() - _t0 < _seconds:
+        _z0 = 1e-2 * _t.randn(4, generator=_g)
+        _U = 0.1 * _t.randn(_N, 1, generator=_g)
+        for _ in range(2):
+            try:
+                _U = _tp.iteration(_z0, _U, _model, _cost, _enc, _umin, _umax,
+                                   _alphas, reg=1e-3)[0]
+            except RuntimeError:
+                pass  # (a failed sweep is an attempt too)
+            _n += 1
+    print("%d %.6f" % (_n, time.perf_counter() - _t0))
+    sys.exit(0)
+
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
@@ -189,8 +220,25 @@ def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
         attempts += int(out[0])
         trajs += int(out[1])
         el = max(el, float(out[2]))
+    # second leg: the torch restatement, one thread, a few iterations
+    torch_leg = None
+    try:
+        tout = subprocess.run(
+            [sys.executable, os.path.abspath(__file__),
+             "--cpu-baseline-torch-worker", repr(dt), str(N), repr(bound),
+             repr(min(seconds, 8.0))], stdout=subprocess.PIPE, text=True,
+            timeout=120).stdout.strip().splitlines()[-1].split()
+        torch_leg = {
+            "value": int(tout[0]) / float(tout[1]),
+            "unit": "trajectory-iterations/s", "cores": 1, "kind": "port",
+            "sample": "%s iterations of one cartpole trajectory in %s s, "
+                      "oracle/torch_port.py (op-for-op PyTorch-CPU restatement "
+                      "of the reference's iteration, autograd derivatives, "
+                      "torch.set_num_threads(1), fp32)" % (tout[0], tout[1])}
+    except Exception as e:  # (reported, not hidden)
+        torch_leg = {"error": repr(e)[:200]}
     return {"value": attempts / el, "unit": "trajectory-iterations/s",
-            "cores": workers, "kind": "port",
+            "cores": workers, "kind": "port", "torch_restatement": torch_leg,
             "host_cores": os.cpu_count(), "cgroup_cpu_quota": quota,
             "per_core_value": attempts / el / workers,
             "sample": "%d cartpole trajectories x up to 8 iLQR iterations "
