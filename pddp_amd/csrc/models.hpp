@@ -90,16 +90,8 @@ struct ModelDims<PDDP_MODEL_RENDEZVOUS> {
 // like the library; finite ones beyond 2^30 take the library's result,
 // computed under one wave-uniform test and selected per lane (a trajectory's
 // result must not depend on its neighbours in the wavefront).
-// the branch-free part: ~1 ulp for |x| < 2^30, NaN for non-finite arguments;
-// beyond 2^30 (where neighbouring floats are 64 rad and more apart) a finite
-// value in [-1, 1] without meaning
-PDDP_DEV void sincos_core(float x, float& s, float& c) {
-  const double xd = (double)x;
-  const double kd = __builtin_rint(xd * 0.63661977236758138243);  // 2 / pi
-  double rd = __builtin_fma(kd, -1.57079632679489655800e+00, xd);
-  rd = __builtin_fma(kd, -6.12323399573676603587e-17, rd);
-  const float r = (float)rd;
-  const int q = (int)kd;
+// polynomials on the reduced argument r in [-pi/4, pi/4], quadrant q
+PDDP_DEV void sincos_poly(float r, int q, float& s, float& c) {
   const float z = r * r;
   float ps = __builtin_fmaf(z, -1.9515295891e-4f, 8.3321608736e-3f);
   ps = __builtin_fmaf(z, ps, -1.6666654611e-1f);
@@ -112,6 +104,19 @@ PDDP_DEV void sincos_core(float x, float& s, float& c) {
   const unsigned cs = (((unsigned)q + 1u) & 2u) << 30;
   s = __uint_as_float(__float_as_uint(swap ? cr : sr) ^ ss);
   c = __uint_as_float(__float_as_uint(swap ? sr : cr) ^ cs);
+}
+// the branch-free part: ~1 ulp for |x| < 2^30, NaN for non-finite arguments;
+// beyond 2^30 (where neighbouring floats are 64 rad and more apart) a finite
+// value in [-1, 1] without meaning.  (A float Cody-Waite reduction for
+// |x| < 4096 with this double-precision one kept for larger arguments under a
+// wave-uniform test was measured: the line search got 3 us SLOWER - its
+// diverging candidates take the second path in most wavefronts.)
+PDDP_DEV void sincos_core(float x, float& s, float& c) {
+  const double xd = (double)x;
+  const double kd = __builtin_rint(xd * 0.63661977236758138243);  // 2 / pi
+  double rd = __builtin_fma(kd, -1.57079632679489655800e+00, xd);
+  rd = __builtin_fma(kd, -6.12323399573676603587e-17, rd);
+  sincos_poly((float)rd, (int)kd, s, c);
   const bool nonfinite = !(fabsf(x) < __builtin_inff());
   s = nonfinite ? __builtin_nanf("") : s;
   c = nonfinite ? __builtin_nanf("") : c;
