@@ -366,6 +366,10 @@ typedef struct pddp_bnn_step {
   float* Uc;             /* [B][N][A][m] out */
   float* J;              /* [B A] running cost, in / out */
   float* Jc;             /* [B A] out at t = N */
+  /* use_predicted_std (modules.py:242-262): the standardised normals of step
+   * t - 1, [P][D]; then X_t += exp(net_out[:, D + d] + log dX_std[d]) *
+   * eps_out[p][d] and out_dim >= 2 D.  NULL: the predicted std is not used. */
+  const float* eps_out;
 } pddp_bnn_step;
 int pddp_bnn_moment_step_f32(const pddp_bnn_step* step, void* stream);
 
@@ -432,6 +436,12 @@ typedef struct pddp_bnn_jvp {
   float* Z_next;         /* [B][n] out (moments), nullable */
   float* F_z;            /* [B][N][n][n] out (moments) */
   float* F_u;            /* [B][N][n][m] out (moments) */
+  /* use_predicted_std: standardised normals of step t, [P][D] (moments); the
+   * network rows then carry 2 D outputs (mean | log std).  NULL: unused.
+   * independent_noise != 0: the std is a constant of the differentiation
+   * (modules.py:256-258). */
+  const float* eps_out;
+  int32_t independent_noise;
 } pddp_bnn_jvp;
 int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* step, void* stream);
 int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* step, void* stream);

@@ -174,7 +174,7 @@ class BnnStep(ctypes.Structure):
             "Z", "U", "gains", "alphas", "u_min", "u_max", "active",
             "bwd_status", "Q", "Q_term", "R", "x_goal", "u_goal", "X_mean",
             "X_std_inv", "dX_mean", "dX_std", "net_out", "Xp", "F", "Zc", "Uc",
-            "J", "Jc")])
+            "J", "Jc", "eps_out")])
 
 
 class BnnJvp(ctypes.Structure):
@@ -187,7 +187,8 @@ class BnnJvp(ctypes.Structure):
         [(k, ctypes.c_void_p) for k in (
             "Z", "U", "u_min", "u_max", "X_mean", "X_std_inv", "dX_mean",
             "dX_std", "net_out", "Xp", "Xp_next", "eps", "F", "Z_next", "F_z",
-            "F_u")])
+            "F_u", "eps_out")] +
+        [("independent_noise", ctypes.c_int32)])
 
 
 class QrCost(ctypes.Structure):

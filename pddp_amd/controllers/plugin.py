@@ -281,7 +281,13 @@ class TorchProblem(object):
             st.ang[i] = v
         for i, v in enumerate(non):
             st.non[i] = v
-        st.in_dim, st.out_dim = in_dim, D
+        ups = self._predicted_std()
+        out_rows = 2 * D if ups else D
+        st.in_dim, st.out_dim = in_dim, out_rows
+        st.independent_noise = int(bool(
+            self.model_opts.get("independent_noise", False)))
+        eps_keep = [self._eps_out(i, P, D, opts) for i in range(N)] if ups \
+            else None
         p = _native.ptr
         for name, t in (("X_mean", keep[0]), ("X_std_inv", keep[1]),
                         ("dX_mean", keep[2]), ("dX_std", keep[3]),
@@ -296,8 +302,9 @@ class TorchProblem(object):
             _native.check(lib.pddp_bnn_jvp_features_f32(ctypes.byref(st),
                                                         stream),
                           "pddp_bnn_jvp_features_f32")
-            Y = mo.model._jvp_native(F, P, D, G, live=1 + D + s.m)
+            Y = mo.model._jvp_native(F, P, out_rows, G, live=1 + D + s.m)
             st.net_out = p(Y)
+            st.eps_out = p(eps_keep[t]) if ups else None
             _native.check(lib.pddp_bnn_jvp_moments_f32(ctypes.byref(st),
                                                        stream),
                           "pddp_bnn_jvp_moments_f32")
@@ -321,10 +328,12 @@ class TorchProblem(object):
         if not (hasattr(mo, "eps_in") and hasattr(mo, "n_particles")
                 and hasattr(mo, "angular_indices_")):
             return False
-        opts = dict(use_predicted_std=False, infer_noise_variables=True,
-                    sample_input_distribution=True, resample=False,
-                    independent_noise=False)
+        opts = dict(infer_noise_variables=True,
+                    sample_input_distribution=True, resample=False)
+        free = ("use_predicted_std", "independent_noise")  # either value
         for k, v in self.model_opts.items():
+            if k in free:
+                continue
             if k not in opts or bool(v) != opts[k]:
                 return False
         mc = getattr(co, "model_class", None)
@@ -342,6 +351,19 @@ class TorchProblem(object):
         probe = torch.empty(1, P, mo.model.hidden[0].in_features,
                             dtype=s.dtype, device=s.device)
         return mo.model._native_ok(probe, False)
+
+    def _predicted_std(self):
+        return bool(self.model_opts.get("use_predicted_std", False))
+
+    def _eps_out(self, i, P, D, opts):
+        """Standardised normals of time index i for the predicted std, drawn
+        and cached exactly as the model's own forward does
+        (models/bnn.py forward; modules.py:242-252)."""
+        mo = self.model
+        if i not in mo.eps_out:
+            eps = torch.randn(P, D, **opts)
+            mo.eps_out[i] = (eps - eps.mean(0)) / eps.std(0)
+        return mo.eps_out[i].contiguous()
 
     @torch.no_grad()
     def _line_search_bnn(self, s, active, use_status):
@@ -361,7 +383,9 @@ class TorchProblem(object):
         D, P = mo.state_size, mo.n_particles
         ang, non = mo.angular_indices_, mo.non_angular_indices_
         na = len(non) + 2 * len(ang)
-        in_dim, out_dim = na + m, D  # (the log-std rows of fc_out are unused)
+        ups = self._predicted_std()
+        # (without the predicted std the log-std rows of fc_out are unused)
+        in_dim, out_dim = na + m, (2 * D if ups else D)
         opts = dict(dtype=s.dtype, device=s.device)
         vec = lambda t, k: torch.as_tensor(t).detach().to(**opts).expand(
             k).contiguous()
@@ -405,9 +429,12 @@ class TorchProblem(object):
             setattr(st, name, p(t))
         lib, stream = _native.lib(), _native.stream_handle(s.device)
         out = None
+        eps_keep = [self._eps_out(i, P, D, opts) for i in range(N)] if ups \
+            else None
         for t in range(N + 1):
             st.t = t
             st.net_out = p(out)
+            st.eps_out = p(eps_keep[t - 1]) if ups and t > 0 else None
             _native.check(lib.pddp_bnn_moment_step_f32(ctypes.byref(st),
                                                        stream),
                           "pddp_bnn_moment_step_f32")

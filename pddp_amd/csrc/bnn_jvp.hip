@@ -148,9 +148,25 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   // ---- primal moments (every lane of the group, same arithmetic)
   float M[kJvpMaxD];
   for (int d = 0; d < D; ++d) M[d] = 0.f;
+  // use_predicted_std (modules.py:242-260): + exp(log_std + log dX_std) eps
+  const bool ups = s.eps_out != nullptr;
+  float lsd[kJvpMaxD];
+  for (int d = 0; d < D; ++d) lsd[d] = ups ? logf(sd[d]) : 0.f;
+  auto primal_out = [&](int p, int d, float& stdeps) {
+    const float* y = Y + (size_t)p * kNetRows * OUT;
+    float dx = y[d] * sd[d] + mu[d];
+    stdeps = 0.f;
+    if (ups) {
+      stdeps = expf(y[D + d] + lsd[d]) * s.eps_out[p * D + d];
+      dx = dx + stdeps;
+    }
+    return Xin[p * D + d] + dx;
+  };
   for (int p = slice; p < P; p += NS)
-    for (int d = 0; d < D; ++d)
-      M[d] += Xin[p * D + d] + (Y[(size_t)p * kNetRows * OUT + d] * sd[d] + mu[d]);
+    for (int d = 0; d < D; ++d) {
+      float unused;
+      M[d] += primal_out(p, d, unused);
+    }
   for (int d = 0; d < D; ++d) M[d] = across_slices(M[d]) / (float)P;
 
   // ---- covariance, and this lane's tangent sums
@@ -164,11 +180,15 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
     // tangent of X for the base direction: e_b (mean_b / U_ab), 0 (u); scale
     const float sc = ea < 0 ? 1.f : s.eps[((size_t)b * P + p) * D + ea];
     for (int d = 0; d < D; ++d) {
-      const float out =
-          Xin[p * D + d] + (Y[(size_t)p * kNetRows * OUT + d] * sd[d] + mu[d]);
+      float stdeps;
+      const float out = primal_out(p, d, stdeps);
       dev[d] = out - M[d];
       const float dXd = (yrow >= 1 && yrow <= D && yrow - 1 == d) ? 1.f : 0.f;
-      dout[d] = sc * (dXd + Y[((size_t)p * kNetRows + yrow) * OUT + d] * sd[d]);
+      const float* yt = Y + ((size_t)p * kNetRows + yrow) * OUT;
+      float dnet = yt[d] * sd[d];
+      // d exp(log_std + c) eps = std eps d log_std
+      if (ups && s.independent_noise == 0) dnet = dnet + stdeps * yt[D + d];
+      dout[d] = sc * (dXd + dnet);
       if (k == 0 && s.Xp_next != nullptr)
         s.Xp_next[((size_t)b * P + p) * D + d] = out;
     }
@@ -312,7 +332,8 @@ static int bnn_jvp_check(const pddp_bnn_jvp* s) {
   if (s->D < 1 || s->D > 6 || s->m < 1 || n + s->m > 31 ||
       s->D + s->m > pddp::kNetRows - 1 || s->n_ang < 0 || s->n_ang > 2 ||
       s->n_non < 0 || s->n_non + s->n_ang != s->D ||
-      s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D)
+      s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D ||
+      (s->eps_out != nullptr && s->out_dim < 2 * s->D))
     return PDDP_E_UNSUPPORTED;
   return 0;
 }

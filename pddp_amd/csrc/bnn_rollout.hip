@@ -120,8 +120,13 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     for (int d = 0; d < DX; ++d) {
       if (d >= D) break;
       float v = s.Xp[row * D + d];
-      if (t > 0)  // X + dx, dx = out[:D] * dX_std + dX_mean     (modules.py:262)
-        v = v + (s.net_out[row * s.out_dim + d] * s.dX_std[d] + s.dX_mean[d]);
+      if (t > 0) {  // X + dx, dx = out[:D] * dX_std + dX_mean   (modules.py:262)
+        float dx = s.net_out[row * s.out_dim + d] * s.dX_std[d] + s.dX_mean[d];
+        if (s.eps_out != nullptr)  // + exp(log_std + log dX_std) eps (:242-260)
+          dx = dx + expf(s.net_out[row * s.out_dim + D + d] + logf(s.dX_std[d])) *
+                        s.eps_out[(has[q] ? p : 0) * D + d];
+        v = v + dx;
+      }
       x[q][d] = v;
       if (t > 0 && has[q]) s.Xp[row * D + d] = v;
     }
@@ -361,7 +366,8 @@ extern "C" int pddp_bnn_moment_step_f32(const pddp_bnn_step* s, void* stream) {
   if (s->D < 1 || s->D > pddp::kBnnMaxD || s->m < 1 || s->m > pddp::kBnnMaxM ||
       s->P > 128 || s->n_ang < 0 || s->n_ang > pddp::kBnnMaxAng ||
       s->n_non < 0 || s->n_non + s->n_ang != s->D ||
-      s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D)
+      s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D ||
+      (s->eps_out != nullptr && s->out_dim < 2 * s->D))
     return PDDP_E_UNSUPPORTED;
   const int groups = s->B * s->A;
   const dim3 grid((groups + pddp::kBnnPerWave - 1) / pddp::kBnnPerWave);

@@ -1178,16 +1178,21 @@ def test_bnn_mlp_kernel_vs_torch(rows, P, in_dim, out_dim, H):
     assert e_native < 4 * e_torch + 1e-7, (e_native, e_torch)
 
 
+@pytest.mark.parametrize("model_opts", [{"use_predicted_std": False},
+                                        {"use_predicted_std": True}],
+                         ids=["mean_only", "predicted_std"])
 @pytest.mark.parametrize("problem,H,P", [("cartpole", 64, 30), ("cartpole", 200, 100),
                                          ("pendulum", 64, 40),
                                          ("double_cartpole", 128, 70)])
-def test_bnn_native_line_search_vs_torch_path(problem, H, P):
+def test_bnn_native_line_search_vs_torch_path(problem, H, P, model_opts):
     """The moment-matched line search under a BNN dynamics model as N + 1
     pddp_bnn_moment_step_f32 launches with the fused network kernel in between
     (csrc/bnn_rollout.hip, csrc/bnn_mlp.hip) against the same rollout made of
     torch ops (controllers/plugin.py:line_search, itself pinned to the
     reference by test_bnn_ilqr_fit_vs_reference_golden): candidates' encoded
-    states (mean | Cholesky of the particle covariance), controls and costs."""
+    states (mean | Cholesky of the particle covariance), controls and costs -
+    with and without the predicted standard deviation (modules.py:242-262: the
+    log-std rows of fc_out times the cached standardised normals of the step)."""
     import pddp_amd
     from pddp_amd.controllers.ilqr import fit_alphas
     from pddp_amd.controllers.plugin import TorchProblem
@@ -1212,7 +1217,7 @@ def test_bnn_native_line_search_vs_torch_path(problem, H, P):
     bound = BOUND[problem]
     res = []
     for native in (True, False):
-        plugin = TorchProblem(model, cost, enc, {"use_predicted_std": False}, {})
+        plugin = TorchProblem(model, cost, enc, dict(model_opts), {})
         plugin.use_native_bnn = native
         s = ILQRSolver(None, B, N, torch.float32, "cuda",
                        torch.full((m,), -bound), torch.full((m,), bound),
@@ -1296,12 +1301,16 @@ def test_bnn_mlp_jvp_kernel_vs_float64(groups, P, in_dim, out_dim, H, G, live):
     assert float((fd - ref[:, 1:2]).abs().max()) / scale < 1e-3
 
 
+@pytest.mark.parametrize("model_opts", [
+    {"use_predicted_std": False}, {"use_predicted_std": True},
+    {"use_predicted_std": True, "independent_noise": True}],
+    ids=["mean_only", "predicted_std", "predicted_std_independent"])
 @pytest.mark.parametrize("problem,H,P,B", [("cartpole", 64, 30, 3),
                                            ("cartpole", 200, 100, 2),
                                            ("pendulum", 64, 40, 5),
                                            ("cartpole", 64, 50, 1),
                                            ("double_cartpole", 128, 60, 3)])
-def test_bnn_native_jacobians_vs_autograd_path(problem, H, P, B):
+def test_bnn_native_jacobians_vs_autograd_path(problem, H, P, B, model_opts):
     """F_z, F_u of the moment-matched BNN step in forward mode
     (csrc/bnn_jvp.hip + the network's JVP mode) against autograd over the
     replicated input (controllers/plugin.py:_dyn_derivs, the reference's
@@ -1333,7 +1342,7 @@ def test_bnn_native_jacobians_vs_autograd_path(problem, H, P, B):
     bound = BOUND[problem]
     recs = []
     for native in (True, False):
-        plugin = TorchProblem(model, cost, enc, {"use_predicted_std": False}, {})
+        plugin = TorchProblem(model, cost, enc, dict(model_opts), {})
         plugin.use_native_bnn_jvp = native
         s = ILQRSolver(None, B, N, torch.float32, "cuda",
                        torch.full((m,), -bound), torch.full((m,), bound),
@@ -1691,7 +1700,8 @@ def test_bnn_hip_kernels_vs_reference_real_size():
                     "Z_new", "U_new", "J"}
 
 
-def _bnn_mpc_controller(B, N, graph, P=100, H=200, seed=0):
+def _bnn_mpc_controller(B, N, graph, P=100, H=200, seed=0,
+                        use_predicted_std=False):
     import pddp_amd
     from pddp_amd.examples import cartpole
     from pddp_amd.models.bnn import bnn_dynamics_model_factory
@@ -1706,7 +1716,8 @@ def _bnn_mpc_controller(B, N, graph, P=100, H=200, seed=0):
     cost = cartpole.CartpoleCost().cuda()
     ctrl = pddp_amd.controllers.iLQRController(
         None, model, cost, graph=graph,
-        model_opts={"use_predicted_std": False, "infer_noise_variables": True})
+        model_opts={"use_predicted_std": use_predicted_std,
+                    "infer_noise_variables": True})
     g = torch.Generator().manual_seed(seed + 1)
     ctrl._U_nominal = (0.1 * torch.randn(B, N, 1, generator=g)).cuda()
     x = (torch.tensor([0.0, 0.0, 3.14159, 0.0]) +
@@ -1714,7 +1725,8 @@ def _bnn_mpc_controller(B, N, graph, P=100, H=200, seed=0):
     return ctrl, CM(0.1).cuda(), x
 
 
-def test_bnn_mpc_graph_replay_equals_eager():
+@pytest.mark.parametrize("use_predicted_std", [False, True])
+def test_bnn_mpc_graph_replay_equals_eager(use_predicted_std):
     """BASELINE.json configs[4] (shortened): the receding-horizon loop of
     examples/mpc_animation.py:29-39 on the cartpole BNN ([200, 200], 100
     particles, DEFAULT encoding), horizon 50, 256 restarts x 5 control steps,
@@ -1732,7 +1744,8 @@ def test_bnn_mpc_graph_replay_equals_eager():
     u_min, u_max = torch.tensor([-10.0]), torch.tensor([10.0])
     runs = {}
     for graph in (False, True):
-        ctrl, plant, x = _bnn_mpc_controller(B, N, graph)
+        ctrl, plant, x = _bnn_mpc_controller(
+            B, N, graph, use_predicted_std=use_predicted_std)
         x[255], x[100] = x[0], x[7]          # duplicated restarts
         ctrl._U_nominal[255] = ctrl._U_nominal[0]
         ctrl._U_nominal[100] = ctrl._U_nominal[7]
