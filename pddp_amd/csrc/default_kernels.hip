@@ -32,6 +32,10 @@
 // float and double; the cost is written once over a number type (plain T for
 // values, HDual<T> for derivatives).
 //
+// FULL_COVARIANCE_MATRIX (z = mean | C row-major, n = D + D^2; cartpole and
+// pendulum): C is taken as given - no symmetrisation, so that the partial
+// derivatives land on the entries the reference's formulas read - the dynamics
+// return diag(diag(C)), and the cost's trace needs no factorisation.
 // The same kernels, templated on the encoding, serve VARIANCE_ONLY
 // (z = mean | var) and STANDARD_DEVIATION_ONLY (z = mean | std), n = 2 D: the
 // covariance is diag(var), the dynamics carry var unchanged (std: sqrt(std^2)),
@@ -82,12 +86,14 @@ template <typename X, typename T> PDDP_DEV X lift(T v) {
 constexpr int kChol = PDDP_ENC_UPPER_TRIANGULAR_CHOLESKY;
 constexpr int kVar = PDDP_ENC_VARIANCE_ONLY;
 constexpr int kStd = PDDP_ENC_STANDARD_DEVIATION_ONLY;
+constexpr int kFull = PDDP_ENC_FULL_COVARIANCE_MATRIX;
 template <int MODEL, int ENC = kChol>
 struct DefDims {
   using M = ModelDims<MODEL>;
   static constexpr int D = M::n, m = M::m, na = M::na, nang = M::n_ang;
   static constexpr int nn = na - 2 * nang;      // non-angular rows come first
-  static constexpr int NO = ENC == kChol ? D * (D + 1) / 2 : D;
+  static constexpr int NO =
+      ENC == kChol ? D * (D + 1) / 2 : (ENC == kFull ? D * D : D);
   static constexpr int n = D + NO;               // encoded size
   static constexpr int non(int r) { return M::col[r]; }
   static constexpr int ang(int a) { return M::col[nn + 2 * a]; }
@@ -103,6 +109,15 @@ PDDP_DEV void covar_of(const X (&oth)[DefDims<MODEL, ENC>::NO],
                        X (&C)[DefDims<MODEL, ENC>::D][DefDims<MODEL, ENC>::D]) {
   using G = DefDims<MODEL, ENC>;
   constexpr int D = G::D;
+  if constexpr (ENC == kFull) {
+    // the matrix as given: its two triangles are separate inputs, and which
+    // one a formula reads decides where its partial derivatives land
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c < D; ++c) C[r][c] = oth[r * D + c];
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < D; ++r)
 #pragma unroll
@@ -215,7 +230,8 @@ PDDP_DEV X qr_cost_default(const ProblemT<T>& P,
     }
 #pragma unroll
     for (int c = 0; c < nn; ++c) {
-      const X col = C[G::non(c)][i1];
+      // row = the angle (utils/angular.py:243-245 sums over the row index)
+      const X col = C[i1][G::non(c)];
       put(c, r, col * Ec);         // Cov(x, sin)
       put(c, r + 1, -(col * Es));  // Cov(x, cos)
       put(r, c, col * Ec);
@@ -223,7 +239,9 @@ PDDP_DEV X qr_cost_default(const ProblemT<T>& P,
     }
   }
   // variance-only encodings: the augmented state keeps diag(Ca) only
-  const T jit = ENC == kChol ? chol_jitter_of<T, na>(Cav) : T(-1);
+  // (full covariance: encode() flattens the augmented matrix as it is)
+  const T jit = ENC == kChol ? chol_jitter_of<T, na>(Cav)
+                             : (ENC == kFull ? T(0) : T(-1));
   X cost = lift<X>(T(0));
 #pragma unroll
   for (int c = 0; c < na; ++c) {
@@ -284,6 +302,12 @@ PDDP_DEV void step_default(const ProblemT<T>& P,
   } else if constexpr (ENC == kStd) {
 #pragma unroll
     for (int i = 0; i < D; ++i) oth[i] = sqrt_(oth[i] * oth[i]);
+  } else if constexpr (ENC == kFull) {  // diag(decode_var(z)) as a matrix
+#pragma unroll
+    for (int r = 0; r < D; ++r)
+#pragma unroll
+      for (int c = 0; c < D; ++c)
+        if (r != c) oth[r * D + c] = T(0);
   }
 #pragma unroll
   for (int r = 0; r < D; ++r) mean[r] = next[r];
@@ -378,6 +402,8 @@ __global__ __launch_bounds__(kWave) void derivs_default_kernel(
         for (int k = 0; k <= i; ++k)
           v += oth[G::tri(k, i)] * oth[G::tri(k, i)];
         sSd[i] = sqrt_(v + (T)1e-12);
+      } else if constexpr (ENC == kFull) {
+        sSd[i] = T(1);
       } else {
         sSd[i] = sqrt_(oth[i] * oth[i]);
       }
@@ -438,6 +464,10 @@ __global__ __launch_bounds__(kWave) void derivs_default_kernel(
           while (oc >= D - ci) { oc -= D - ci; ++ci; }
           const int cj = ci + oc;
           if (ri == rj && cj == ri) v = z[c] / sSd[ri];
+        } else if constexpr (ENC == kFull) {
+          // C'[i][i] = C[i][i], every other entry of C' is a constant zero
+          const int ri = (r - D) / D, rj = (r - D) - ri * D;
+          v = (r == c && ri == rj) ? T(1) : T(0);
         } else if constexpr (ENC == kVar) {
           v = (r == c) ? T(1) : T(0);          // var' = var
         } else {
@@ -544,7 +574,12 @@ __global__ __launch_bounds__(kWave) void line_search_default_kernel(
 // launchers (called from problem_kernels.hip for the Gaussian encodings)
 // --------------------------------------------------------------------------
 static int check_default(const pddp_problem& p) {
-  if (p.encoding != kChol && p.encoding != kVar && p.encoding != kStd)
+  if (p.encoding != kChol && p.encoding != kVar && p.encoding != kStd &&
+      p.encoding != kFull)
+    return PDDP_E_UNSUPPORTED;
+  // full covariance: n = D + D^2 = 20 / 6 (cartpole, pendulum); the double
+  // cartpole's 42 stays on the plugin path
+  if (p.encoding == kFull && p.model == PDDP_MODEL_DOUBLE_CARTPOLE)
     return PDDP_E_UNSUPPORTED;
   switch (p.model) {
     case PDDP_MODEL_CARTPOLE:
@@ -557,6 +592,11 @@ static int check_default(const pddp_problem& p) {
 
 #define PDDP_DEFAULT_ENC(...)                                                \
   switch (p.encoding) {                                                      \
+    case kFull: {                                                            \
+      if constexpr (MODEL != PDDP_MODEL_DOUBLE_CARTPOLE) {                   \
+        constexpr int ENC = kFull; __VA_ARGS__;                              \
+      }                                                                      \
+    } break;                                                                 \
     case kChol: { constexpr int ENC = kChol; __VA_ARGS__; } break;             \
     case kVar: { constexpr int ENC = kVar; __VA_ARGS__; } break;               \
     default: { constexpr int ENC = kStd; __VA_ARGS__; } break;                 \

@@ -654,7 +654,8 @@ int default_line_search(const pddp_problem& p, LineSearchArgs<T> a,
 static bool is_default_encoding(const pddp_problem* p) {
   return p != nullptr && (p->encoding == PDDP_ENC_UPPER_TRIANGULAR_CHOLESKY ||
                           p->encoding == PDDP_ENC_VARIANCE_ONLY ||
-                          p->encoding == PDDP_ENC_STANDARD_DEVIATION_ONLY);
+                          p->encoding == PDDP_ENC_STANDARD_DEVIATION_ONLY ||
+                          p->encoding == PDDP_ENC_FULL_COVARIANCE_MATRIX);
 }
 
 static int check_problem(const pddp_problem* p) {

@@ -639,18 +639,17 @@ def test_plugin_path_equals_native_path():
 @pytest.mark.parametrize("problem,enc_key", [
     ("cartpole", "default"), ("pendulum", "default"),
     ("cartpole", "variance"), ("pendulum", "variance"),
-    ("cartpole", "std"), ("pendulum", "std"), ("cartpole", "fullcov")])
+    ("cartpole", "std"), ("pendulum", "std"), ("cartpole", "fullcov"),
+    ("pendulum", "fullcov")])
 def test_default_encoding_vs_reference_golden(problem, enc_key):
     """The Gaussian state encodings - DEFAULT (upper-triangular Cholesky, n =
     14 / 5), VARIANCE_ONLY, STANDARD_DEVIATION_ONLY (n = 8 / 4) and
     FULL_COVARIANCE_MATRIX (n = 20) - through the reference-signature API:
     forward, backward (zero-copy records, HIP sweep), _control_law + costs, and
     a full fit, against the reference's own outputs (fp64 goldens,
-    tools/make_golden.py [--other-encodings]).  All but the full covariance run
-    on the native path (csrc/default_kernels.hip: closed-form dynamics
-    Jacobian, hyper-dual cost derivatives, line-search kernel) - asserted
-    below; the full covariance goes through the plugin path (autograd
-    derivatives, HIP sweep / accept)."""
+    tools/make_golden.py [--other-encodings]).  All of it on the native path
+    (csrc/default_kernels.hip: closed-form dynamics Jacobian, hyper-dual cost
+    derivatives, line-search kernel) - asserted below."""
     import pddp_amd
     from pddp_amd import StateEncoding
     from pddp_amd.controllers.ilqr import _control_law, backward, forward
@@ -715,16 +714,15 @@ def test_default_encoding_vs_reference_golden(problem, enc_key):
     assert int(state) == int(g["fit_bounded/state"])
     assert rel_err(U.cpu().numpy(), g["fit_bounded/U"]) < 1e-5
     assert rel_err(ctrl._K.cpu().numpy(), g["fit_bounded/K"]) < 1e-5
-    if enc_key == "fullcov":
-        assert ctrl._solver.plugin is not None
-    else:  # no plugin: problem kernels only
-        assert ctrl._solver.plugin is None and ctrl._solver.problem is not None
-        assert ctrl._solver.problem.encoding == int(enc)
+    # no plugin: problem kernels only
+    assert ctrl._solver.plugin is None and ctrl._solver.problem is not None
+    assert ctrl._solver.problem.encoding == int(enc)
 
 
 @pytest.mark.parametrize("enc_name", ["UPPER_TRIANGULAR_CHOLESKY",
                                       "VARIANCE_ONLY",
-                                      "STANDARD_DEVIATION_ONLY"])
+                                      "STANDARD_DEVIATION_ONLY",
+                                      "FULL_COVARIANCE_MATRIX"])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", ["cartpole", "pendulum",
                                      "double_cartpole"])
@@ -739,6 +737,8 @@ def test_default_encoding_native_vs_plugin_path(problem, dtype, enc_name):
     double cartpole (n = 27, no golden captured) and float32."""
     import pddp_amd
     from pddp_amd.controllers.ilqr import _make_solver
+    if enc_name == "FULL_COVARIANCE_MATRIX" and problem == "double_cartpole":
+        pytest.skip("n = 42: plugin path only")
     mod = getattr(pddp_amd.examples, problem)
     td = TDT[dtype]
     model = [getattr(mod, n) for n in dir(mod) if n.endswith("DynamicsModel")

@@ -496,6 +496,8 @@ def main():
                         with_fit=12)
         capture_problem("pendulum", "std", torch.float64, [5, 25],
                         with_fit=12)
+        capture_problem("pendulum", "fullcov", torch.float64, [5, 25],
+                        with_fit=12)
         return
     if "--default-only" in sys.argv:
         capture_problem("cartpole", "default", torch.float64, [5, 25],
