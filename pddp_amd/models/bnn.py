@@ -107,20 +107,45 @@ class ConcreteDropout(torch.nn.Module):
         return x * (mask if self.training else mask.detach())
 
 
+class CDropout(ConcreteDropout):
+    """The reference's name and constructor order for concrete dropout
+    (modules.py:494-515)."""
+
+    def __init__(self, temperature=0.1, rate=0.5, reg=1.0, **kwargs):
+        super(CDropout, self).__init__(rate=rate, temperature=temperature,
+                                       reg=reg, binary=False)
+
+
+class BDropout(ConcreteDropout):
+    """Bernoulli dropout with a fixed rate, masks held per particle
+    (modules.py:413-491)."""
+
+    def __init__(self, rate=0.1, reg=1.0, **kwargs):
+        super(BDropout, self).__init__(rate=rate, reg=reg, binary=True)
+
+
 class BayesianMLP(torch.nn.Module):
     """fc -> dropout -> ReLU, ..., fc_out (modules.py:792-864
     `bayesian_model`): Xavier-normal weights with ReLU gain, biases
     U(-0.1, 0.1), concrete dropout with initial keep probability 0.5."""
 
     def __init__(self, in_features, out_features, hidden_features,
-                 initial_p=0.5, binary_dropout=False):
+                 initial_p=0.5, binary_dropout=False, dropout_layers=None):
+        """`dropout_layers`: the reference's keyword (modules.py:803,818-830) -
+        a dropout class or instance, or a list of them, one per hidden layer;
+        default: concrete dropout with keep probability `initial_p`."""
         super(BayesianMLP, self).__init__()
         dims = [in_features] + list(hidden_features)
         self.hidden = torch.nn.ModuleList(
             [torch.nn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:])])
-        self.drops = torch.nn.ModuleList(
-            [ConcreteDropout(rate=initial_p, binary=binary_dropout)
-             for _ in hidden_features])
+        if dropout_layers is None:
+            drops = [ConcreteDropout(rate=initial_p, binary=binary_dropout)
+                     for _ in hidden_features]
+        else:
+            if not isinstance(dropout_layers, (list, tuple)):
+                dropout_layers = [dropout_layers] * len(hidden_features)
+            drops = [d() if isinstance(d, type) else d for d in dropout_layers]
+        self.drops = torch.nn.ModuleList(drops)
         self.out = torch.nn.Linear(dims[-1], out_features)
         gain = torch.nn.init.calculate_gain("relu")
         for lin in list(self.hidden) + [self.out]:
@@ -225,11 +250,24 @@ class BayesianMLP(torch.nn.Module):
         return self.out(x)
 
 
+def bayesian_model(in_features, out_features, hidden_features, **kwargs):
+    """fc -> dropout -> ReLU, ..., fc_out with the reference's initialisation
+    (modules.py:792-864); accepts its `dropout_layers` keyword."""
+    return BayesianMLP(in_features, out_features, hidden_features, **kwargs)
+
+
+BSequential = BayesianMLP  # the container bayesian_model returns (modules.py:744)
+
+
 def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
                                angular_indices=None, non_angular_indices=None,
+                               constrain_min=None, constrain_max=None,
                                particles=False, **kwargs):
     """modules.py:44-398.  Returns a `BNNDynamicsModel` class (or the
-    particle-level model when `particles=True`)."""
+    particle-level model when `particles=True`).  `constrain_min / _max`: the
+    action is squashed into the box before it enters the network
+    (modules.py:78,118-121)."""
+    should_constrain = constrain_min is not None and constrain_max is not None
     angular = angular_indices is not None and non_angular_indices is not None
     aug_size = (infer_augmented_state_size(angular_indices,
                                            non_angular_indices)
@@ -268,6 +306,9 @@ def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
             self.model.resample()
 
         def _features(self, X, u):
+            if should_constrain:
+                from ..utils.constraint import constrain
+                u = constrain(u, constrain_min, constrain_max)
             Xa = (augment_state(X, angular_indices, non_angular_indices)
                   if angular else X)
             P = X.shape[-2]

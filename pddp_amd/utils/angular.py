@@ -27,6 +27,15 @@ def _take(x, indices, dim=-1):
     return x.index_select(dim, _idx(indices, x))
 
 
+def complementary_indices(indices, size):
+    """The indices of range(size) that are not in `indices`, ascending, as a
+    long tensor (reference: angular.py:26-43)."""
+    idx = torch.as_tensor(indices, dtype=torch.long).reshape(-1)
+    keep = torch.ones(size, dtype=torch.bool, device=idx.device)
+    keep[idx] = False
+    return keep.nonzero()[:, 0]
+
+
 def augment_state(x, angular_indices, non_angular_indices):
     """angular.py:251-286"""
     if len(angular_indices) == 0:

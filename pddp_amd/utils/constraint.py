@@ -1,4 +1,5 @@
-"""Control constraints (reference: pddp/utils/constraint.py:146-147 `clamp`,
+"""Control constraints (reference: pddp/utils/constraint.py:35-48 `constrain`,
+:51-143 the `constrain_env` / `constrain_model` decorators, :146-147 `clamp`,
 :150-266 `boxqp`).
 
 The box-constrained QP lives inside the HIP backward sweep (csrc/gains.hpp
@@ -21,14 +22,120 @@ BOXQP_RESULTS = {
 }
 
 
+def constrain(u, min_bounds, max_bounds):
+    """Smooth squash of an unbounded action into the box: the tanh image of u
+    scaled to [min_bounds, max_bounds] (differentiable everywhere)."""
+    half = (max_bounds - min_bounds) / 2.0
+    centre = (max_bounds + min_bounds) / 2.0
+    return half * torch.tanh(u) + centre
+
+
+def constrain_env(min_bounds, max_bounds):
+    """Class decorator: the environment's `apply` squashes its action first."""
+    def decorate(cls):
+        inner = cls.apply
+
+        def apply(self, u):
+            return inner(self, constrain(u, min_bounds, max_bounds))
+        cls.apply = apply
+        return cls
+    return decorate
+
+
+def constrain_model(min_bounds, max_bounds):
+    """Class decorator: the model's `forward` squashes its action first; the
+    instances get `min_bounds` / `max_bounds` parameters and a `constrain`
+    method (constraint.py:83-143; its `min_bounds` parameter is set from the
+    upper bound there - here it holds the lower one)."""
+    def decorate(cls):
+        init, fwd = cls.__init__, cls.forward
+
+        def __init__(self, *args, **kwargs):
+            init(self, *args, **kwargs)
+            P = lambda b: torch.nn.Parameter(
+                torch.as_tensor(b, dtype=torch.get_default_dtype()).expand(
+                    cls.action_size).clone(), requires_grad=False)
+            self.max_bounds, self.min_bounds = P(max_bounds), P(min_bounds)
+
+        def forward(self, z, u, i, encoding=None, **kwargs):
+            u = constrain(u, min_bounds, max_bounds)
+            if encoding is None:
+                return fwd(self, z, u, i, **kwargs)
+            return fwd(self, z, u, i, encoding=encoding, **kwargs)
+
+        cls.__init__, cls.forward = __init__, forward
+        cls.constrain = lambda self, u: constrain(u, min_bounds, max_bounds)
+        return cls
+    return decorate
+
+
 def clamp(u, min_bounds, max_bounds):
     return torch.min(torch.max(u, min_bounds), max_bounds)
+
+
+def _boxqp_torch(x0, Q, c, lower, upper, max_iter=100, min_grad=1e-8,
+                 tol=1e-8, step_dec=0.6, min_step=1e-22, armijo=0.1):
+    """constraint.py:150-266 for ONE problem of any dimension in torch ops on
+    the tensors' device (the device routines stop at four dimensions - the
+    sweep kernels' m <= 4): projected Newton steps with an Armijo
+    back-tracking line search along the clamped path."""
+    obj = lambda x: 0.5 * (x @ Q @ x) + x @ c
+    x = clamp(x0, lower, upper)
+    x = torch.where(torch.isinf(x), torch.zeros_like(x), x)
+    D = x.shape[0]
+    clamped = torch.zeros(D, dtype=torch.bool, device=x.device)
+    free = ~clamped
+    Ufree = torch.zeros(D, D, dtype=x.dtype, device=x.device)
+    f, f_old, result = obj(x), None, 0
+    for it in range(max_iter):
+        if it > 0 and bool((f_old - f) < tol * f_old.abs()):
+            result = 4
+            break
+        f_old = f
+        g = Q @ x + c
+        was = clamped
+        clamped = ((x == lower) & (g > 0)) | ((x == upper) & (g < 0))
+        free = ~clamped
+        if bool(clamped.all()):
+            result = 6
+            break
+        if it == 0 or bool((was != clamped).any()):
+            Ufree, info = torch.linalg.cholesky_ex(Q[free][:, free], upper=True)
+            if int(info) != 0:
+                result = -1
+                break
+        if float(g[free].norm()) < min_grad:
+            result = 5
+            break
+        g_c = Q @ (x * clamped.to(x.dtype)) + c
+        step_dir = torch.zeros_like(x)
+        step_dir[free] = -torch.cholesky_solve(
+            g_c[free].unsqueeze(1), Ufree, upper=True).squeeze(1) - x[free]
+        slope = (step_dir * g).sum()
+        step = 1.0
+        xc = clamp(x + step * step_dir, lower, upper)
+        fc = obj(xc)
+        while bool((fc - f_old) / (step * slope) < armijo):
+            step *= step_dec
+            xc = clamp(x + step * step_dir, lower, upper)
+            fc = obj(xc)
+            if step < min_step:
+                result = 2
+                break
+        x, f = xc, fc
+        if result != 0:
+            break
+    else:
+        result = 1
+    return x, result, Ufree, free.to(torch.uint8)
 
 
 @torch.no_grad()
 def boxqp(x0, Q, c, lower, upper, **kwargs):
     """constraint.py:150-266 on the GPU: min 0.5 x^T Q x + c^T x subject to
-    lower <= x <= upper, warm-started at x0, for D <= 4 dimensions.
+    lower <= x <= upper, warm-started at x0 (D <= 4: the sweep kernels' device
+    routine, batched; larger un-batched problems: the same algorithm in torch
+    ops on the GPU).
 
     Un-batched like the reference - x0, c, lower, upper of shape (D,), Q (D, D)
     - it returns (x, result, Ufree, free) with `result` an int (BOXQP_RESULTS),
@@ -49,8 +156,13 @@ def boxqp(x0, Q, c, lower, upper, **kwargs):
             free.squeeze(-1)
     D = x0.shape[-1]
     if D > 4:
-        raise NotImplementedError(
-            "the device routine solves problems of up to four dimensions")
+        if x0.dim() != 1:
+            raise NotImplementedError(
+                "batches: the device routine solves problems of up to four "
+                "dimensions")
+        opts = dict(dtype=Q.dtype, device=Q.device)
+        b = lambda t: torch.as_tensor(t).to(**opts).expand(D)
+        return _boxqp_torch(x0.to(**opts), Q, c.to(**opts), b(lower), b(upper))
     batch = x0.shape[:-1]
     opts = dict(dtype=Q.dtype, device=Q.device)
     flat = lambda t, *s: t.to(**opts).expand(*batch, *s).reshape(

@@ -3,13 +3,15 @@
 Same public surface as the reference's pddp/utils/encoding.py:25-362
 (StateEncoding, infer_*_size, encode, decode_mean / var / std / covar /
 covar_sqrt) written independently on batched torch ops; works on any device.
-The HIP hot path currently implements IGNORE_UNCERTAINTY natively; the other
-encodings are host-side helpers here.
+The HIP kernels read and write these layouts directly (csrc/problem_kernels.hip,
+default_kernels.hip, bnn_*.hip); the functions here are the host-side helpers of
+the reference's API.
 """
 from enum import IntEnum
 
 import functools
 
+import numpy as np  # noqa: F401  (the reference's module exposes it to `import *`)
 import torch
 
 
@@ -20,6 +22,14 @@ class StateEncoding(IntEnum):
     VARIANCE_ONLY = 2
     STANDARD_DEVIATION_ONLY = 3
     IGNORE_UNCERTAINTY = 4
+
+
+def _constant_of(Z, t):
+    """The moments an encoding does not carry are constants; like the
+    reference (encoding.py:213-214, 255-256, 296-297, 357-358) they are marked
+    as requiring a gradient when Z does, so that `autograd.grad(..., Z,
+    allow_unused=True)` through them returns None instead of raising."""
+    return t.requires_grad_() if Z.requires_grad else t
 
 
 def infer_encoded_state_size(state_size, encoding=StateEncoding.DEFAULT):
@@ -148,7 +158,7 @@ def decode_covar(Z, encoding=StateEncoding.DEFAULT, state_size=None):
         return torch.diag_embed(other ** 2)
     if encoding == StateEncoding.IGNORE_UNCERTAINTY:
         eye = 1e-6 * torch.eye(D, dtype=Z.dtype, device=Z.device)
-        return eye.expand(*Z.shape[:-1], D, D)
+        return _constant_of(Z, eye.expand(*Z.shape[:-1], D, D))
     raise NotImplementedError("Unknown StateEncoding: {}".format(encoding))
 
 
@@ -164,8 +174,8 @@ def decode_var(Z, encoding=StateEncoding.DEFAULT, state_size=None):
     if encoding == StateEncoding.STANDARD_DEVIATION_ONLY:
         return other ** 2
     if encoding == StateEncoding.IGNORE_UNCERTAINTY:
-        return (1e-6 * torch.ones(D, dtype=Z.dtype, device=Z.device)).expand(
-            *Z.shape[:-1], D)
+        return _constant_of(Z, (1e-6 * torch.ones(
+            D, dtype=Z.dtype, device=Z.device)).expand(*Z.shape[:-1], D))
     raise NotImplementedError("Unknown StateEncoding: {}".format(encoding))
 
 
@@ -175,8 +185,8 @@ def decode_std(Z, encoding=StateEncoding.DEFAULT, state_size=None):
         return _split(Z, encoding, state_size)[1]
     if encoding == StateEncoding.IGNORE_UNCERTAINTY:
         D = _split(Z, encoding, state_size)[2]
-        return (1e-3 * torch.ones(D, dtype=Z.dtype, device=Z.device)).expand(
-            *Z.shape[:-1], D)
+        return _constant_of(Z, (1e-3 * torch.ones(
+            D, dtype=Z.dtype, device=Z.device)).expand(*Z.shape[:-1], D))
     return decode_var(Z, encoding, state_size).sqrt()
 
 
@@ -193,5 +203,5 @@ def decode_covar_sqrt(Z, encoding=StateEncoding.DEFAULT, state_size=None):
         return torch.diag_embed(other)
     if encoding == StateEncoding.IGNORE_UNCERTAINTY:
         eye = 1e-3 * torch.eye(D, dtype=Z.dtype, device=Z.device)
-        return eye.expand(*Z.shape[:-1], D, D)
+        return _constant_of(Z, eye.expand(*Z.shape[:-1], D, D))
     raise NotImplementedError("Unknown StateEncoding: {}".format(encoding))

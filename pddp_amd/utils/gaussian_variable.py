@@ -77,9 +77,11 @@ class GaussianVariable(object):
                                 f(self._std))
 
     @classmethod
-    def random(cls, state_size, **tensor_opts):
-        """gaussian_variable.py:258-275 (test helper)."""
-        mean = torch.randn(state_size, **tensor_opts)
-        A = torch.randn(state_size, state_size, **tensor_opts)
-        covar = A.t() @ A + 1e-3 * torch.eye(state_size, **tensor_opts)
-        return cls(mean, covar=covar)
+    def random(cls, n, reg=1e-1, requires_grad=True, **tensor_opts):
+        """A random valid variable of size n: covariance A^T A + reg I from leaf
+        tensors that require a gradient by default (gaussian_variable.py:258-275;
+        the reference's tests differentiate through it)."""
+        mean = torch.randn(n, requires_grad=requires_grad, **tensor_opts)
+        A = torch.randn(n, n, requires_grad=requires_grad, **tensor_opts)
+        eye = torch.eye(n, dtype=mean.dtype, device=mean.device)
+        return cls(mean, covar=A.t().mm(A) + reg * eye)

@@ -971,7 +971,8 @@ def test_reference_shape_contract(problem, enc_name, N):
     env = [getattr(mod, n) for n in dir(mod) if n.endswith("Env")
            and n != "ModelEnv"][0]()
     torch.manual_seed(N)
-    z0 = GaussianVariable.random(model.state_size).encode(enc).cuda()
+    z0 = GaussianVariable.random(model.state_size, reg=1e-3,
+                                 requires_grad=False).encode(enc).cuda()
     U = torch.randn(N, model.action_size, device="cuda")
     n, m = z0.shape[-1], model.action_size
 
@@ -1601,6 +1602,37 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(workload, extra):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2
     assert line["value"] > 0 and line["steps"] == 3
+
+
+def test_boxqp_many_dimensions_on_the_gpu():
+    """boxqp beyond the device routine's four dimensions: the same algorithm in
+    torch ops on the GPU (utils/constraint.py) - the reference's own unit case
+    (tests/utils/test_constraint.py: 100 dimensions) and the KKT conditions."""
+    from pddp_amd.utils.constraint import boxqp
+    torch.manual_seed(3)
+    D = 100
+    A = torch.randn(D, D, dtype=torch.float64, device="cuda")
+    Q, c = A.t() @ A, torch.randn(D, dtype=torch.float64, device="cuda")
+    lo = -torch.rand(D, dtype=torch.float64, device="cuda")
+    hi = torch.rand(D, dtype=torch.float64, device="cuda")
+    x, result, Ufree, free = boxqp(0.5 * (lo + hi), Q, c, lo, hi)
+    assert result >= 1 and x.shape == (D,)
+    assert bool((x >= lo - 1e-9).all()) and bool((x <= hi + 1e-9).all())
+    g = Q @ x + c
+    fr = free.bool()
+    assert float(g[fr].abs().max()) < 1e-6           # stationary where free
+    at_lo, at_hi = (~fr) & (x == lo), (~fr) & (x == hi)
+    assert bool((at_lo | at_hi | fr).all())
+    assert bool((g[at_lo] > 0).all()) and bool((g[at_hi] < 0).all())
+    # and a small problem through both routes agrees
+    from pddp_amd.utils.constraint import _boxqp_torch
+    x4, r4, _, f4 = boxqp(torch.zeros(4, dtype=torch.float64, device="cuda"),
+                          Q[:4, :4], c[:4], lo[:4], hi[:4])
+    xt, rt, _, ft = _boxqp_torch(torch.zeros(4, dtype=torch.float64,
+                                             device="cuda"), Q[:4, :4], c[:4],
+                                 lo[:4], hi[:4])
+    assert r4 == rt and torch.allclose(x4, xt, atol=1e-10)
+    assert torch.equal(f4.cpu(), ft.cpu())
 
 
 def _bnn_real_size_run():
