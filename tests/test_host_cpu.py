@@ -330,6 +330,8 @@ def test_hot_kernels_keep_their_working_set_in_registers():
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(
         os.path.abspath(__file__))), "tools"))
     from kernel_resources import kernel_resources
+    from pddp_amd import _native
+    _native.build()  # (incremental; a no-op when the library is up to date)
     rows = kernel_resources()
     assert len(rows) > 200
     allowed = (
