@@ -20,7 +20,7 @@ namespace m32 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWaves = 2;  // wavefronts (trajectories) per workgroup
-constexpr int kRing = 3;   // record slots in flight per wavefront
+constexpr int kRing = 2;   // record slots in flight per wavefront
 constexpr int kTileLd = 36;  // row stride of the transpose tile (16-B aligned,
                              // spreads the b128 writes over the banks)
 constexpr int kTile = 32 * kTileLd;
@@ -58,11 +58,14 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
   if constexpr (BOUNDED) { umin = a.u_min[0]; umax = a.u_max[0]; }
 
   // ---- word offsets of this lane's operands inside a record.  Entries
-  // outside the matrices read word 0 and are multiplied by a 0 / 1 mask held
-  // in a VGPR: 64 boolean lane masks would not fit the SGPR file (the first
-  // version spilled them: 117 v_readlane + their hazard nops per step).
+  // outside the matrices read a word of the slot's padding, which is zeroed
+  // once and which the record DMA never touches (its lanes past the record
+  // are masked off) - no per-entry masks: 64 boolean lane masks would not fit
+  // the SGPR file (the first version spilled them: 117 v_readlane + their
+  // hazard nops per step; the second multiplied by 0 / 1 floats: 32 more
+  // vector instructions and 32 more registers per step).
   int oF[16], oL[16];
-  T mF[16], mL[16], mK[16];
+  T mK[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int k = row_of(r, h);
@@ -79,13 +82,10 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
       else if (j == n) o = lay.oLuu;
       else if (j == 31) o = lay.oLu;
     }
-    mF[r] = f < 0 ? T(0) : T(1);
-    mL[r] = o < 0 ? T(0) : T(1);
     mK[r] = k < n ? T(1) : T(0);
-    oF[r] = f < 0 ? 0 : f;
-    oL[r] = o < 0 ? 0 : o;
+    oF[r] = f < 0 ? S : f;  // word S: the first word of the zeroed padding
+    oL[r] = o < 0 ? S : o;
   }
-  const T mJ = j < n ? T(1) : T(0);
   // Cholesky branch (ilqr.py:587-625): + reg f^T F~ on row n (mfma16.hpp)
   int oFf[16];
 #pragma unroll
@@ -97,19 +97,34 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
   const char* rec_b = reinterpret_cast<const char*>(
       a.rec + (size_t)b * (size_t)(N + 1) * S);
   const int chunks = S / 4;
+  const int nd_live = (chunks + kWave - 1) / kWave;  // DMA instructions issued
   uint32_t qoff[NDMA];
 #pragma unroll
-  for (int r = 0; r < NDMA; ++r)
-    qoff[r] = (uint32_t)((lane + kWave * r) % chunks) * 16u;
+  for (int r = 0; r < NDMA; ++r) qoff[r] = (uint32_t)(lane + kWave * r) * 16u;
+  // the last instruction carries the record's tail: its lanes past the
+  // record stay out, so that the slot's padding keeps its zeros
+  const uint32_t qoff_last = (uint32_t)(lane + kWave * (nd_live - 1)) * 16u;
+  const bool in_tail = lane + kWave * (nd_live - 1) < chunks;
   auto dma = [&](int slot, int t) {
     const int tt = t < 0 ? 0 : t;
     const uint32_t base = (uint32_t)tt * (uint32_t)(S * sizeof(T));
     const uint32_t lbase =
         __builtin_amdgcn_readfirstlane(n4::lds_addr(ring + slot * kSlotWords));
 #pragma unroll
-    for (int r = 0; r < NDMA; ++r)
-      n4::lds_dma16(rec_b, base + qoff[r], lbase + r * kWave * 16);
+    for (int r = 0; r < NDMA - 1; ++r) {
+      // (wave-uniform: instructions that would carry no chunk are not issued;
+      // the counted waits below know the number)
+      if (r < nd_live - 1)
+        n4::lds_dma16(rec_b, base + qoff[r], lbase + r * kWave * 16);
+    }
+    if (in_tail)
+      n4::lds_dma16(rec_b, base + qoff_last,
+                    lbase + (uint32_t)(nd_live - 1) * kWave * 16);
   };
+  // zero the padding of every slot once (this wavefront's own ring)
+  for (int sl = 0; sl < kRing; ++sl)
+    for (int wd = S + lane; wd < kSlotWords; wd += kWave)
+      ring[sl * kSlotWords + wd] = T(0);
 
   // ---- terminal value function in the accumulator layout (ilqr.py:581-583)
   T V[16], Vz[16];
@@ -135,14 +150,23 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
   for (int t = N - 1; t >= 0; --t) {
     // record t has landed once at most (kRing - 1) younger {DMA x NDMA, store}
     // groups are outstanding
-    n4::wait_vmcnt<(kRing - 1) * (NDMA + 1)>();
+    switch (nd_live) {  // (counted waits take immediates)
+      case 1: n4::wait_vmcnt<(kRing - 1) * 2>(); break;
+      case 2: n4::wait_vmcnt<(kRing - 1) * 3>(); break;
+      case 3: n4::wait_vmcnt<(kRing - 1) * 4>(); break;
+      case 4: n4::wait_vmcnt<(kRing - 1) * 5>(); break;
+      case 5: n4::wait_vmcnt<(kRing - 1) * 6>(); break;
+      case 6: n4::wait_vmcnt<(kRing - 1) * 7>(); break;
+      case 7: n4::wait_vmcnt<(kRing - 1) * 8>(); break;
+      default: n4::wait_vmcnt<(kRing - 1) * 9>(); break;
+    }
     const T* R = ring + slot * kSlotWords;
     T Fa[16];
     f32x16 Q;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      Fa[r] = R[oF[r]] * mF[r];
-      Q[r] = R[oL[r]] * mL[r];
+      Fa[r] = R[oF[r]];
+      Q[r] = R[oL[r]];
     }
     const T Un = BOUNDED ? R[lay.oU] : T(0);
     T ffrow = T(0);  // (f^T F~)[j]: f^T F_z for j < n, f.f at j = n
@@ -249,12 +273,15 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
       if constexpr (CHOL) {
         // V' = sym + K^T Quu K + K^T Quz + Quz^T K,  K = -sE Q_uz_reg
         const T Qg_k = tile[k * kTileLd + 31];
-        const T v = sym + c2 * (Qg_k * Qg_j) - sE * (Qg_k * Quz_j + Quz_k * Qg_j);
-        V[r] = v * (mK[r] * mJ);
-        Vz[r] = (Q[r] + Quz_k * kt - Qg_k * wz) * mK[r];
+        // (no masks on V', V_z': their entries outside the n x n block meet
+        // zero rows / columns of F~ in both products of the next step, and
+        // V_z' is read from lane j = 31 only - they are finite whenever the
+        // step itself is)
+        V[r] = sym + c2 * (Qg_k * Qg_j) - sE * (Qg_k * Quz_j + Quz_k * Qg_j);
+        Vz[r] = Q[r] + Quz_k * kt - Qg_k * wz;
       } else {
-        V[r] = __builtin_fmaf(c * Quz_k, Quz_j, sym) * (mK[r] * mJ);
-        Vz[r] = __builtin_fmaf(Quz_k, w, Q[r]) * mK[r];  // (lanes j = 31)
+        V[r] = __builtin_fmaf(c * Quz_k, Quz_j, sym);
+        Vz[r] = __builtin_fmaf(Quz_k, w, Q[r]);  // (lanes j = 31)
       }
     }
     slot = slot + 1 == kRing ? 0 : slot + 1;
@@ -272,7 +299,9 @@ static int launch_mfma32(const RiccatiArgs<float>& a, hipStream_t st,
   const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
   const RecLayout lay(a.n, 1);
   const int chunks = lay.stride / 4;
-  const int ndma = (chunks + kWave - 1) / kWave <= 4 ? 4 : 8;
+  // (strictly fewer chunks than DMA lanes: the slot keeps zeroed padding)
+  const int ndma = chunks / kWave + 1 <= 4 ? 4 : 8;
+  if (chunks >= ndma * kWave) return PDDP_E_UNSUPPORTED;
   const size_t lds = sizeof(float) * ((size_t)m32::kWaves *
                                           (m32::kRing * ndma * kWave * 4 +
                                            m32::kTile) +
