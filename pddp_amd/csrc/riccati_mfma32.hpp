@@ -13,6 +13,8 @@
 // words a lane gathers serve both products (see riccati_mfma16.hpp).
 #pragma once
 
+#include <type_traits>
+
 #include "riccati_mfma16.hpp"
 
 namespace pddp {
@@ -146,8 +148,13 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
   T* gains_b = a.gains + (size_t)b * (size_t)N * lay.gstride;
   T kprev = T(0);
   int status = PDDP_BWD_OK;
-  int slot = 0;
-  for (int t = N - 1; t >= 0; --t) {
+  static_assert(kRing == 2, "the step is instantiated once per ring slot");
+  // one step of the sweep on the record in ring slot SLOT - a compile-time
+  // constant, so that the 32 operand gathers are ds_read with an immediate
+  // slot offset on per-lane addresses computed once (round 1: an address
+  // computation per gather and step)
+  auto step = [&](auto slot_c, int t) {
+    constexpr int slot = decltype(slot_c)::value;
     // record t has landed once at most (kRing - 1) younger {DMA x NDMA, store}
     // groups are outstanding
     switch (nd_live) {  // (counted waits take immediates)
@@ -284,7 +291,10 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
         Vz[r] = __builtin_fmaf(Quz_k, w, Q[r]);  // (lanes j = 31)
       }
     }
-    slot = slot + 1 == kRing ? 0 : slot + 1;
+  };
+  for (int t = N - 1; t >= 0; t -= 2) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t >= 1) step(std::integral_constant<int, 1>{}, t - 1);
   }
   n4::wait_vmcnt<0>();
   if (lane == 0) a.status[b] = status;
