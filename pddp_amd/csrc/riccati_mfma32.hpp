@@ -3,7 +3,8 @@
 // the DEFAULT (Cholesky) encoding of the double cartpole is n = 27
 // (BASELINE.json configs[3]: 0.96 GB of records per GPU and sweep).
 //
-// One wavefront per trajectory, two 32x32x32 products per step (16 MFMA
+// One sweeping wavefront per trajectory (two per workgroup, plus a producer
+// wavefront that streams their records), two 32x32x32 products per step (16 MFMA
 // instructions each) on the augmented F~ = [F_z | F_u | 0], L~ = [[L_zz, L_uz^T,
 // L_z], [L_uz, L_uu, L_u]] with V_z riding in column 31 of X = V F~.  The
 // accumulator layout (column on the lane, row (r & 3) + 8 (r >> 2) + 4 h in
@@ -21,8 +22,13 @@ namespace pddp {
 namespace m32 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kWaves = 2;  // wavefronts (trajectories) per workgroup
-constexpr int kRing = 2;   // record slots in flight per wavefront
+constexpr int kWaves = 2;  // sweeping wavefronts (trajectories) per workgroup
+constexpr int kRing = 2;   // record slots per sweeping wavefront
+// + one producer wavefront per workgroup: it issues the record DMAs of both
+// trajectories (an LDS-DMA instruction parks its wavefront for ~90 cycles -
+// eight per step were 720 of the sweeping wave's ~7600) and meets them at one
+// barrier per step
+constexpr int kThreads = kWave * (kWaves + 1);
 constexpr int kTileLd = 36;  // row stride of the transpose tile (16-B aligned,
                              // spreads the b128 writes over the banks)
 constexpr int kTile = 32 * kTileLd;
@@ -30,7 +36,7 @@ constexpr int kTile = 32 * kTileLd;
 PDDP_DEV int row_of(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 template <bool BOUNDED, bool FAST, int NDMA, bool CHOL>
-__global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
+__global__ __launch_bounds__(kThreads) void riccati_mfma32_kernel(
     RiccatiArgs<float> a) {
   using T = float;
   constexpr int kSlotWords = NDMA * kWave * 4;
@@ -38,22 +44,79 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   constexpr int per_wave = kRing * kSlotWords + kTile;
-  float* ring = smem + wave * per_wave;
-  float* tile = ring + kRing * kSlotWords;
   float* ls_tail = smem + kWaves * per_wave;
   if constexpr (BOUNDED) {
-    for (int q = threadIdx.x; q < n4::kLsSteps; q += kWave * kWaves)
+    for (int q = threadIdx.x; q < n4::kLsSteps; q += kThreads)
       ls_tail[q] = (T)n4::kLs.v[q];
   }
   const T lstep0 = (T)n4::kLs.v[lane & 15];
-  __syncthreads();
-
-  const int b = blockIdx.x * kWaves + wave;
-  if (b >= a.B) return;
-  if (a.active != nullptr && a.active[b] == 0) return;
   const int n = a.n, N = a.N;
   const RecLayout lay(n, 1);
   const int S = lay.stride;
+  const int chunks = S / 4;
+  const int nd_live = (chunks + kWave - 1) / kWave;  // DMA instructions per record
+  auto live_of = [&](int bb) {
+    return bb < a.B && (a.active == nullptr || a.active[bb] != 0);
+  };
+  auto step_barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+
+  if (wave == kWaves) {
+    // =====================================================================
+    // producer: record t of both trajectories has landed before barrier
+    // N - 1 - t; record t - 1 is requested right after it, into the slot the
+    // sweeping waves have just finished with (they passed the barrier).
+    // =====================================================================
+    uint32_t qoff[NDMA];
+#pragma unroll
+    for (int r = 0; r < NDMA; ++r) qoff[r] = (uint32_t)(lane + kWave * r) * 16u;
+    // the last instruction carries the record's tail: its lanes past the
+    // record stay out, so that the slot's padding keeps its zeros
+    const uint32_t qoff_last = (uint32_t)(lane + kWave * (nd_live - 1)) * 16u;
+    const bool in_tail = lane + kWave * (nd_live - 1) < chunks;
+    auto dma = [&](int w, int slot, int t) {
+      const int bb = blockIdx.x * kWaves + w;
+      if (!live_of(bb) || t < 0) return;  // (wave-uniform)
+      const char* rec_b = reinterpret_cast<const char*>(
+          a.rec + (size_t)bb * (size_t)(N + 1) * S);
+      const uint32_t base = (uint32_t)t * (uint32_t)(S * sizeof(T));
+      const uint32_t lbase = __builtin_amdgcn_readfirstlane(
+          n4::lds_addr(smem + w * per_wave + slot * kSlotWords));
+#pragma unroll
+      for (int r = 0; r < NDMA - 1; ++r) {
+        if (r < nd_live - 1)  // (instructions without a chunk are not issued)
+          n4::lds_dma16(rec_b, base + qoff[r], lbase + r * kWave * 16);
+      }
+      if (in_tail)
+        n4::lds_dma16(rec_b, base + qoff_last,
+                      lbase + (uint32_t)(nd_live - 1) * kWave * 16);
+    };
+    __syncthreads();  // the sweeping waves have zeroed their slots' padding
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) dma(w, 0, N - 1);
+    for (int t = N - 1; t >= 0; --t) {
+      n4::wait_vmcnt<0>();  // record t (the only requests in flight)
+      step_barrier();
+      const int slot_next = (N - t) & 1;  // record t - 1 -> the other slot
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) dma(w, slot_next, t - 1);
+    }
+    return;
+  }
+
+  float* ring = smem + wave * per_wave;
+  float* tile = ring + kRing * kSlotWords;
+  // zero the padding of both slots once: operand entries outside the matrices
+  // read it, and the record DMA never touches it
+  for (int sl = 0; sl < kRing; ++sl)
+    for (int wd = S + lane; wd < kSlotWords; wd += kWave)
+      ring[sl * kSlotWords + wd] = T(0);
+  __syncthreads();
+
+  const int b = blockIdx.x * kWaves + wave;
+  if (!live_of(b)) {  // keep step with the workgroup's barriers
+    for (int t = N - 1; t >= 0; --t) step_barrier();
+    return;
+  }
   const int h = lane >> 5, j = lane & 31;
   const T reg = (T)a.reg[b];
   T umin = T(0), umax = T(0);
@@ -94,40 +157,6 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
   for (int r = 0; r < 16; ++r)
     oFf[r] = lay.oFu + (row_of(r, h) < n ? row_of(r, h) : 0);
 
-  // ---- record DMA: NDMA full-wave 16-byte instructions per record; lanes
-  // past the record re-load an early chunk into the slot's padding
-  const char* rec_b = reinterpret_cast<const char*>(
-      a.rec + (size_t)b * (size_t)(N + 1) * S);
-  const int chunks = S / 4;
-  const int nd_live = (chunks + kWave - 1) / kWave;  // DMA instructions issued
-  uint32_t qoff[NDMA];
-#pragma unroll
-  for (int r = 0; r < NDMA; ++r) qoff[r] = (uint32_t)(lane + kWave * r) * 16u;
-  // the last instruction carries the record's tail: its lanes past the
-  // record stay out, so that the slot's padding keeps its zeros
-  const uint32_t qoff_last = (uint32_t)(lane + kWave * (nd_live - 1)) * 16u;
-  const bool in_tail = lane + kWave * (nd_live - 1) < chunks;
-  auto dma = [&](int slot, int t) {
-    const int tt = t < 0 ? 0 : t;
-    const uint32_t base = (uint32_t)tt * (uint32_t)(S * sizeof(T));
-    const uint32_t lbase =
-        __builtin_amdgcn_readfirstlane(n4::lds_addr(ring + slot * kSlotWords));
-#pragma unroll
-    for (int r = 0; r < NDMA - 1; ++r) {
-      // (wave-uniform: instructions that would carry no chunk are not issued;
-      // the counted waits below know the number)
-      if (r < nd_live - 1)
-        n4::lds_dma16(rec_b, base + qoff[r], lbase + r * kWave * 16);
-    }
-    if (in_tail)
-      n4::lds_dma16(rec_b, base + qoff_last,
-                    lbase + (uint32_t)(nd_live - 1) * kWave * 16);
-  };
-  // zero the padding of every slot once (this wavefront's own ring)
-  for (int sl = 0; sl < kRing; ++sl)
-    for (int wd = S + lane; wd < kSlotWords; wd += kWave)
-      ring[sl * kSlotWords + wd] = T(0);
-
   // ---- terminal value function in the accumulator layout (ilqr.py:581-583)
   T V[16], Vz[16];
   {
@@ -139,8 +168,6 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
       Vz[r] = (k < n) ? term[lay.oLz + k] : T(0);
     }
   }
-  for (int s = 0; s < kRing; ++s) dma(s, N - 1 - s);
-  n4::wait_vmcnt<0>();
 
   // row n of Q~ = (Q_uz | Q_uu | .. | Q_u at column 31): register rn of the
   // lanes of half hn
@@ -155,18 +182,7 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
   // computation per gather and step)
   auto step = [&](auto slot_c, int t) {
     constexpr int slot = decltype(slot_c)::value;
-    // record t has landed once at most (kRing - 1) younger {DMA x NDMA, store}
-    // groups are outstanding
-    switch (nd_live) {  // (counted waits take immediates)
-      case 1: n4::wait_vmcnt<(kRing - 1) * 2>(); break;
-      case 2: n4::wait_vmcnt<(kRing - 1) * 3>(); break;
-      case 3: n4::wait_vmcnt<(kRing - 1) * 4>(); break;
-      case 4: n4::wait_vmcnt<(kRing - 1) * 5>(); break;
-      case 5: n4::wait_vmcnt<(kRing - 1) * 6>(); break;
-      case 6: n4::wait_vmcnt<(kRing - 1) * 7>(); break;
-      case 7: n4::wait_vmcnt<(kRing - 1) * 8>(); break;
-      default: n4::wait_vmcnt<(kRing - 1) * 9>(); break;
-    }
+    step_barrier();  // record t has landed (the producer waited for it)
     const T* R = ring + slot * kSlotWords;
     T Fa[16];
     f32x16 Q;
@@ -266,7 +282,6 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma32_kernel(
       T* dst = gains_b + (size_t)t * lay.gstride + (j < n ? 1 + j : 0);
       if (h == hn && j <= n) *dst = val;
     }
-    dma(slot, t - kRing);  // this slot is consumed: refill it
 
     // ---- V' = sym(Q_zz) + c Q_uz^T Q_uz,  V_z' = Q_z + Q_uz^T w
     const T Quz_j = tile[j * kTileLd + n];  // Q~[n][j]
@@ -317,7 +332,7 @@ static int launch_mfma32(const RiccatiArgs<float>& a, hipStream_t st,
                                            m32::kTile) +
                                       n4::kLsSteps);
   const dim3 grid((a.B + m32::kWaves - 1) / m32::kWaves),
-      block(kWave * m32::kWaves);
+      block(m32::kThreads);
   const bool bounded = a.u_min != nullptr;
 #define PDDP_M32(Bd, F, ND)                                                    \
   do {                                                                         \
