@@ -116,19 +116,69 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     const int p = lane + kBnnGroup * q;
     has[q] = p < P;
     const size_t row = (size_t)c * P + (has[q] ? p : 0);
+    // rows of D (and out_dim = D or 2 D) floats: 8-byte vector accesses when D
+    // is a compile-time even number (rows are then 8-byte aligned)
+    constexpr bool kVec = DT > 0 && DT % 2 == 0;
+    float xin[DX], net[DX], nls[DX];
+    if constexpr (kVec) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2* xr = reinterpret_cast<const f32x2*>(s.Xp + row * D);
+      const f32x2* nr = reinterpret_cast<const f32x2*>(
+          s.net_out + row * s.out_dim);  // (dereferenced for t > 0 only)
+#pragma unroll
+      for (int d2 = 0; d2 < DX / 2; ++d2) {
+        const f32x2 a = xr[d2];
+        xin[2 * d2] = a[0];
+        xin[2 * d2 + 1] = a[1];
+        if (t > 0) {
+          const f32x2 b = nr[d2];
+          net[2 * d2] = b[0];
+          net[2 * d2 + 1] = b[1];
+          if (s.eps_out != nullptr) {
+            const f32x2 e = nr[DX / 2 + d2];
+            nls[2 * d2] = e[0];
+            nls[2 * d2 + 1] = e[1];
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < DX; ++d) {
+        if (d >= D) break;
+        xin[d] = s.Xp[row * D + d];
+        if (t > 0) {
+          net[d] = s.net_out[row * s.out_dim + d];
+          if (s.eps_out != nullptr) nls[d] = s.net_out[row * s.out_dim + D + d];
+        }
+      }
+    }
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
       if (d >= D) break;
-      float v = s.Xp[row * D + d];
+      float v = xin[d];
       if (t > 0) {  // X + dx, dx = out[:D] * dX_std + dX_mean   (modules.py:262)
-        float dx = s.net_out[row * s.out_dim + d] * s.dX_std[d] + s.dX_mean[d];
+        float dx = net[d] * s.dX_std[d] + s.dX_mean[d];
         if (s.eps_out != nullptr)  // + exp(log_std + log dX_std) eps (:242-260)
-          dx = dx + expf(s.net_out[row * s.out_dim + D + d] + logf(s.dX_std[d])) *
+          dx = dx + expf(nls[d] + logf(s.dX_std[d])) *
                         s.eps_out[(has[q] ? p : 0) * D + d];
         v = v + dx;
       }
       x[q][d] = v;
-      if (t > 0 && has[q]) s.Xp[row * D + d] = v;
+    }
+    if (t > 0 && has[q]) {
+      if constexpr (kVec) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2* xw = reinterpret_cast<f32x2*>(s.Xp + row * D);
+#pragma unroll
+        for (int d2 = 0; d2 < DX / 2; ++d2)
+          xw[d2] = f32x2{x[q][2 * d2], x[q][2 * d2 + 1]};
+      } else {
+#pragma unroll
+        for (int d = 0; d < DX; ++d) {
+          if (d >= D) break;
+          s.Xp[row * D + d] = x[q][d];
+        }
+      }
     }
   }
 
