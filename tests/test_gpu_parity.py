@@ -1061,6 +1061,58 @@ def test_backward_large_state_vs_oracle(n, m, dtype):
                              reg=reg, b=b)
 
 
+@pytest.mark.parametrize("n,B", [(27, 37), (20, 9), (15, 2), (30, 5), (14, 7),
+                                 (9, 6)])
+def test_matrix_core_sweeps_with_active_mask_and_ragged_batches(n, B):
+    """The matrix-core sweeps (riccati_mfma16.hpp; riccati_mfma32.hpp with its
+    producer wavefront: two trajectories per workgroup, one barrier per step)
+    on batch sizes that leave a workgroup half empty and under an `active`
+    mask: active trajectories get exactly the un-masked launch's gains,
+    inactive ones are not touched (gains and status), and the result is the
+    generic kernel's to rounding."""
+    from pddp_amd import _native
+    dt = torch.float32
+    N, m = 11, 1
+    lay = _native.record_layout(n, m)
+    g = torch.Generator(device="cuda").manual_seed(n)
+    r = lambda *s: torch.randn(*s, generator=g, device="cuda", dtype=dt)
+    eye = torch.eye(n, device="cuda")
+    F_z, F_u = eye + 0.05 * r(B, N, n, n), 0.3 * r(B, N, n, m)
+    L_z, L_u = r(B, N + 1, n), r(B, N, m)
+    R = 0.2 * r(B, N + 1, n, n)
+    L_zz = eye + R @ R.transpose(-1, -2)
+    L_uz = 0.05 * r(B, N, m, n)
+    L_uu = 1.0 + 0.04 * r(B, N, m, m) ** 2
+    U = 0.5 * r(B, N, m)
+    rec = torch.empty(B, N + 1, lay.stride, dtype=dt, device="cuda")
+    p, st = _native.ptr, _native.stream_handle(rec.device)
+    _native.call("pddp_pack_records", dt, B, N, n, m, p(F_z), p(F_u), p(L_z),
+                 p(L_u), p(L_zz), p(L_uz), p(L_uu), p(U), p(rec), st)
+    u_min, u_max = -torch.ones(m, device="cuda"), torch.ones(m, device="cuda")
+    reg = torch.full((B,), 1e-3, dtype=torch.float64, device="cuda")
+
+    def run(active, variant, branch):
+        gains = torch.full((B, N, lay.gain_stride), 7.0, device="cuda")
+        status = torch.full((B,), -5, dtype=torch.int32, device="cuda")
+        _native.call("pddp_riccati_backward_variant", dt, B, N, n, m, p(rec),
+                     p(u_min), p(u_max), p(reg), branch,
+                     None if active is None else p(active), p(gains),
+                     p(status), st, variant)
+        torch.cuda.synchronize()
+        return gains, status
+
+    act = (torch.arange(B, device="cuda") % 3 != 1).to(torch.uint8)
+    a = act.bool()
+    for branch in (0, 1):
+        full, sf = run(None, 0, branch)
+        ref, sr = run(None, 1, branch)
+        part, sp = run(act, 0, branch)
+        assert int(sf.abs().max()) == 0 and int(sr.abs().max()) == 0
+        assert torch.equal(part[a], full[a])
+        assert bool((part[~a] == 7.0).all()) and bool((sp[~a] == -5).all())
+        assert float((full - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
 def test_graph_replay_equals_eager_rounds():
     """ILQRSolver.capture_round(): a fit driven by hipGraph replays ends in
     exactly the eager result (same kernels, same order, same buffers), also
