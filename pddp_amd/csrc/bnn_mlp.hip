@@ -285,6 +285,15 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       b2r[r] = n < H ? bb : 0.f;
     }
   }
+  // what the layer-2 accumulator starts from: the bias, or zero on a tangent
+  // row (a property of the lane, not of the tile) - the C operand of the
+  // tile's first MFMA, no copy
+  f32x16 binit;
+  {
+    const bool tangent_lane = row_of(0, li).tangent;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) binit[r] = tangent_lane ? 0.f : b2r[r];
+  }
   // layer 1 of tile i for this block: inputs requested by l1_load (early),
   // four MFMAs, mask and ReLU on the accumulators, four ds_write_b128
   float xin[KS1];
@@ -355,15 +364,13 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     masks_of(a.MT2, ro, m2);
     // ---- layer 2 on the matrix cores; the accumulator starts at the bias
     f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-      acc[r] = ro.tangent ? 0.f : b2r[r];  // tangents: no bias
     const f32x4* bsrc =
         reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const f32x4 b4 = bsrc[q * 64];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 0], b4[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 0], b4[0],
+                                                 q == 0 ? binit : acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 1], b4[1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 2], b4[2], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 3], b4[3], acc, 0, 0, 0);
