@@ -51,6 +51,8 @@
 // replaces autograd's replicate-the-input pass; the caller (bnn_jvp.hip) sends
 // 8-row groups: the input and the D + m mean / action directions - the
 // Cholesky directions are per-particle multiples of the mean ones.
+#include <cstdlib>
+
 #include "pddp_common.hpp"
 
 namespace pddp {
@@ -82,10 +84,19 @@ PDDP_DEV int unit_of(int j, int r, int h) {
   return 32 * j + (r & 3) + 8 * (r >> 2) + 4 * h;
 }
 
-template <int H, int W1S>
+// BAL (H = 200): the six blocks that share a SIMD with another block hand the
+// last one or two 8-unit chunks of their layer-2 contraction to the finisher
+// wavefront (whose SIMD holds one block only): 196 MFMAs per SIMD and tile
+// instead of 208.  The finisher leaves partial accumulators in LDS; the owners
+// add them one tile later, before their (deferred) mask / ReLU epilogue - no
+// extra barrier.
+constexpr int kMlpGivers = 6;
+template <int H, int W1S, bool BAL = false>
 constexpr size_t bnn_mlp_lds_floats() {
-  // two h1^T buffers, two buffers of h2 (1024 words per block)
-  return 2 * (H / 2) * 64 + 2 * ((H + 31) / 32) * 1024;
+  // two h1^T buffers, two buffers of h2 (1024 words per block), BAL: two
+  // buffers of six partial accumulator tiles
+  return 2 * (H / 2) * 64 + 2 * ((H + 31) / 32) * 1024 +
+         (BAL ? 2 * kMlpGivers * 1024 : 0);
 }
 
 // kMlpW1Stride: inputs | zeros | bias slot of layer 1 (8: in_dim <= 7, 16: <=
@@ -116,8 +127,10 @@ PDDP_DEV bool group_first_positive(float v) {
 // read nor written.  A tile takes 32 / kJvpLive whole groups - with cartpole's
 // 6 live rows of 8 that is 5 groups per tile instead of 4: a fifth fewer
 // tiles.
-template <int H, int kMlpW1Stride, int kJvpGroup = 0, int kJvpLive = kJvpGroup>
+template <int H, int kMlpW1Stride, int kJvpGroup = 0, int kJvpLive = kJvpGroup,
+          bool BAL = false>
 __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
+  static_assert(!BAL || H == 200, "the balanced roles are laid out for 7 blocks");
   constexpr bool JVP = kJvpGroup != 0;
   constexpr int G = JVP ? kJvpGroup : 1;  // rows per (state, particle)
   constexpr int LIVE = JVP ? kJvpLive : 1;
@@ -138,6 +151,13 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   float* h1t = lds;                       // [2][KS * 64]
   float* h2b = h1t + 2 * KS * 64;         // [2][NB * 1024]
   constexpr int kH1 = KS * 64, kH2 = NB * 1024;
+  float* part = h2b + 2 * kH2;            // BAL: [2][kMlpGivers * 1024]
+  constexpr int kPart = kMlpGivers * 1024;
+  // BAL: the chunks q >= q_own(wave) of a block's contraction are the
+  // finisher's; block 3 shares its SIMD with the finisher and keeps all of its
+  // own, blocks 0 .. 2 give two chunks, blocks 4 .. 6 one
+  auto q_own = [](int w) { return !BAL ? NQ : (w == 3 ? NQ : (w < 3 ? NQ - 2 : NQ - 1)); };
+  auto giver_index = [](int w) { return w < 3 ? w : w - 1; };  // 0 .. 5 (w != 3)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -174,10 +194,14 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
 
+  // barriers of a workgroup: one after the first tile's layer 1, then one per
+  // iteration; BAL runs two more iterations (epilogues and layer 3 trail by
+  // one tile each)
+  const int iters = my + (BAL ? 2 : 0);
   if (wave > NB) {
     // spare wavefronts (H < 200) only keep step
     tile_barrier();
-    for (int i = 0; i < my; ++i) tile_barrier();
+    for (int i = 0; i < iters; ++i) tile_barrier();
     return;
   }
 
@@ -236,6 +260,56 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
         }
       }
     };
+    if constexpr (BAL) {
+      // the givers' last chunks: lane (i = li, h = lh) holds
+      // W2[32 jb + i][8 q + 4 h + e] like the owner itself would
+      constexpr int kGiver[kMlpGivers] = {0, 1, 2, 4, 5, 6};
+      float a2h[kMlpGivers][8];
+#pragma unroll
+      for (int gi = 0; gi < kMlpGivers; ++gi) {
+        const int jb = kGiver[gi];
+        const int u = 32 * jb + li;
+        const bool uok = u < H;
+        const float* w2row = a.W2 + (size_t)(uok ? u : 0) * H + 4 * lh;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = w2row[8 * (NQ - 2 + c) + e];
+            a2h[gi][4 * c + e] = uok ? v : 0.f;
+          }
+      }
+      auto partials = [&](int i) {  // of tile i, for the owners' next iteration
+        const f32x4* bsrc =
+            reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
+        const f32x4 b23 = bsrc[(NQ - 2) * 64], b24 = bsrc[(NQ - 1) * 64];
+        f32x4* pw = reinterpret_cast<f32x4*>(part + (i & 1) * kPart) + lane;
+#pragma unroll
+        for (int gi = 0; gi < kMlpGivers; ++gi) {
+          f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+          if (gi < 3) {  // blocks 0 .. 2 give chunk NQ - 2 as well
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2h[gi][e], b23[e], acc, 0, 0, 0);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2h[gi][4 + e], b24[e], acc, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            pw[(gi * 4 + g) * 64] = f32x4{acc[4 * g], acc[4 * g + 1],
+                                          acc[4 * g + 2], acc[4 * g + 3]};
+        }
+      };
+      tile_barrier();
+      for (int i = 0; i < iters; ++i) {
+        // h2 of tile i - 2 was completed by the owners in iteration i - 1
+        if (i >= 2) layer3(i - 2);
+        if (i < my) partials(i);
+        tile_barrier();
+      }
+      return;
+    }
     tile_barrier();
     for (int i = 0; i < my; ++i) {
       if (i > 0) layer3(i - 1);
@@ -354,30 +428,9 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   layer1(0);
   tile_barrier();  // h1t[0] ready
 
-  for (int i = 0; i < my; ++i) {
-    const RowOf ro = row_of(blockIdx.x + i * gridDim.x, li);
-    const bool nxt = i + 1 < my;
-    if (nxt) l1_load(i + 1);
-    // mask of layer 2, requested before the MFMAs so that its latency is
-    // theirs
-    f32x4 m2[4];
-    masks_of(a.MT2, ro, m2);
-    // ---- layer 2 on the matrix cores; the accumulator starts at the bias
-    f32x16 acc;
-    const f32x4* bsrc =
-        reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const f32x4 b4 = bsrc[q * 64];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 0], b4[0],
-                                                 q == 0 ? binit : acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 1], b4[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 2], b4[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 3], b4[3], acc, 0, 0, 0);
-    }
-    // accumulator register r of this lane: unit unit_of(j, r, lh), data row
-    // li - mask, ReLU in place; to LDS as held (the finisher's reads know the
-    // order)
+  // mask, ReLU of an accumulator tile and its way to LDS as held (the
+  // finisher's reads know the order)
+  auto epilogue = [&](int i, const f32x16& acc, const f32x4 (&m2)[4]) {
     f32x4* hw = reinterpret_cast<f32x4*>(h2b + (i & 1) * kH2) + (j * 4 * 64 + lane);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -393,13 +446,76 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       }
       hw[g * 64] = h2;
     }
+  };
+  // layer 2 on the matrix cores; the accumulator starts at the bias
+  const int qown = q_own(wave);
+  auto layer2 = [&](int i) {
+    f32x16 acc;
+    const f32x4* bsrc =
+        reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      if (BAL && q >= NQ - 2 && q >= qown) continue;  // (wave-uniform)
+      const f32x4 b4 = bsrc[q * 64];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 0], b4[0],
+                                                 q == 0 ? binit : acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 1], b4[1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 2], b4[2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 3], b4[3], acc, 0, 0, 0);
+    }
+    return acc;
+  };
+
+  if constexpr (BAL) {
+    // iteration i: the epilogue of tile i - 1 (with the finisher's partial
+    // sums of its last chunks), layer 2 of tile i, layer 1 of tile i + 1
+    f32x16 acc = binit;
+    f32x4 m2[4];
+    for (int i = 0; i < iters; ++i) {
+      if (i + 1 < my) l1_load(i + 1);
+      if (i >= 1 && i <= my) {
+        if (wave != 3) {
+          const f32x4* pr = reinterpret_cast<const f32x4*>(
+                                part + ((i - 1) & 1) * kPart) +
+                            (giver_index(wave) * 4 * 64 + lane);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 v = pr[g * 64];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * g + e] += v[e];
+          }
+        }
+        epilogue(i - 1, acc, m2);
+      }
+      if (i < my) {
+        // mask of layer 2, requested before the MFMAs so that its latency
+        // is theirs (used by the epilogue, one iteration later)
+        masks_of(a.MT2, row_of(blockIdx.x + i * gridDim.x, li), m2);
+        acc = layer2(i);
+      }
+      if (i + 1 < my) layer1(i + 1);
+      tile_barrier();
+    }
+    return;
+  }
+
+  for (int i = 0; i < my; ++i) {
+    const RowOf ro = row_of(blockIdx.x + i * gridDim.x, li);
+    const bool nxt = i + 1 < my;
+    if (nxt) l1_load(i + 1);
+    // mask of layer 2, requested before the MFMAs so that its latency is
+    // theirs
+    f32x4 m2[4];
+    masks_of(a.MT2, ro, m2);
+    const f32x16 acc = layer2(i);
+    epilogue(i, acc, m2);
     if (nxt) layer1(i + 1);
     tile_barrier();
   }
 }
 
-template <int H, int W1S, int JVP = 0, int LIVE = JVP>
-static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
+template <int H, int W1S, int JVP, int LIVE, bool BAL>
+static int launch_bnn_mlp_b(const BnnMlpArgs& a, hipStream_t st) {
   // per device (a process may drive several GPUs): CU count queried once -
   // hipGetDeviceProperties costs ms - and the > 64 KB dynamic-LDS opt-in,
   // which is a per-device function attribute
@@ -420,17 +536,31 @@ static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   constexpr int trows = JVP == 0 ? kMlpTile : (kMlpTile / LIVE) * JVP;
   const int ntiles = (a.R + trows - 1) / trows;
   const int grid = ntiles < cus ? ntiles : cus;  // persistent: one per CU
-  constexpr size_t lds = sizeof(float) * bnn_mlp_lds_floats<H, W1S>();
+  constexpr size_t lds = sizeof(float) * bnn_mlp_lds_floats<H, W1S, BAL>();
+  static_assert(lds <= 160 * 1024, "a workgroup's LDS");
   if (!attr_set[dev]) {  // more than 64 KB of dynamic LDS needs the opt-in
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)bnn_mlp_kernel<H, W1S, JVP, LIVE>,
+        (const void*)bnn_mlp_kernel<H, W1S, JVP, LIVE, BAL>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set[dev] = true;
   }
-  PDDP_LAUNCH((bnn_mlp_kernel<H, W1S, JVP, LIVE>), dim3(grid),
+  PDDP_LAUNCH((bnn_mlp_kernel<H, W1S, JVP, LIVE, BAL>), dim3(grid),
                      dim3(kMlpThreads), lds, st, a);
   return launch_status();
+}
+
+template <int H, int W1S, int JVP = 0, int LIVE = JVP>
+static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
+  if constexpr (H == 200) {
+    // the balanced role layout (PDDP_MLP_BALANCED=0: its A/B twin without)
+    static const bool balanced = [] {
+      const char* e = getenv("PDDP_MLP_BALANCED");
+      return e == nullptr || e[0] != '0';
+    }();
+    if (balanced) return launch_bnn_mlp_b<H, W1S, JVP, LIVE, true>(a, st);
+  }
+  return launch_bnn_mlp_b<H, W1S, JVP, LIVE, false>(a, st);
 }
 
 template <int H, int JVP = 0, int LIVE = JVP>
