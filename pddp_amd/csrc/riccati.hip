@@ -36,6 +36,16 @@ static int launch_n4_qpipe(const RiccatiArgs<double>& a, hipStream_t st, bool f,
   return launch_n4_qpipe_f64(a, st, f, mirror);
 }
 
+// riccati_defer.hip
+int launch_n4_defer_f32(const RiccatiArgs<float>& a, hipStream_t st, bool fast);
+int launch_n4_defer_f64(const RiccatiArgs<double>& a, hipStream_t st, bool fast);
+static int launch_n4_defer(const RiccatiArgs<float>& a, hipStream_t st, bool f) {
+  return launch_n4_defer_f32(a, st, f);
+}
+static int launch_n4_defer(const RiccatiArgs<double>& a, hipStream_t st, bool f) {
+  return launch_n4_defer_f64(a, st, f);
+}
+
 template <typename T, int NMAX, int M>
 static int launch_generic(const RiccatiArgs<T>& a, hipStream_t st) {
   PDDP_LAUNCH((riccati_generic_kernel<T, NMAX, M>), dim3(a.B), dim3(kWave), 0,
@@ -123,6 +133,11 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
     return launch_n4_qpipe(a, st, variant == 21, true);
   if (variant == 22 || variant == 23)
     return launch_n4_qpipe(a, st, variant == 23, false);
+  //          24 / 25: the rank-one value update deferred by two steps, four
+  //          wavefronts (riccati_n4_defer.hpp; IEEE / approximate division;
+  //          bounded eig-clamp branch only)
+  if (variant == 24 || variant == 25)
+    return launch_n4_defer(a, st, variant == 25);
   if (variant < 0 || variant > 13 || variant == 4 || variant == 5)
     return PDDP_E_BADARG;
 
