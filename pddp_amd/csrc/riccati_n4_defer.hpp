@@ -68,10 +68,18 @@ constexpr int kTraj = 16;
 // cycles each role waits at the phase barrier ([role]) and in total
 // ([4 + role]); tools/defer_wait.py
 __device__ unsigned long long g_defer_stats[8];
-#define PDDP_DW_DECL unsigned long long wait_acc = 0; const long long t_begin = clock64();
-#define PDDP_DW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t0_ = clock64(); asm volatile("s_barrier" ::: "memory"); wait_acc += (unsigned long long)(clock64() - t0_); } while (0)
-#define PDDP_DW_END(ROLE) do { if (lane == 0) { atomicAdd(&g_defer_stats[ROLE], wait_acc); atomicAdd(&g_defer_stats[4 + ROLE], (unsigned long long)(clock64() - t_begin)); } } while (0)
+#define PDDP_DW_DECL unsigned long long wait_acc = 0; const long long t_begin = clock64(); PDDP_DW_SEGDECL
+#define PDDP_DW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t0_ = clock64(); seg_acc[7] += (unsigned long long)(t0_ - seg_last); asm volatile("s_barrier" ::: "memory"); seg_last = clock64(); wait_acc += (unsigned long long)(seg_last - t0_); } while (0)
+#define PDDP_DW_END(ROLE) do { if (lane == 0) { atomicAdd(&g_defer_stats[ROLE], wait_acc); atomicAdd(&g_defer_stats[4 + ROLE], (unsigned long long)(clock64() - t_begin)); for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_defer_seg[ROLE][i_], seg_acc[i_]); } } while (0)
+// segment profile of a phase: cycles from the previous stamp (or the phase
+// barrier) to stamp I; the s_memtime read drains lgkmcnt, so a segment that
+// follows LDS reads shows their full latency
+__device__ unsigned long long g_defer_seg[4][8];
+#define PDDP_DW_SEGDECL unsigned long long seg_acc[8] = {}; long long seg_last = clock64();
+#define PDDP_DW_STAMP(I) do { const long long n_ = clock64(); seg_acc[I] += (unsigned long long)(n_ - seg_last); seg_last = n_; } while (0)
 #else
+#define PDDP_DW_SEGDECL
+#define PDDP_DW_STAMP(I)
 #define PDDP_DW_DECL
 #define PDDP_DW_BARRIER() n4::lds_publish_barrier()
 #define PDDP_DW_END(ROLE)
@@ -110,6 +118,89 @@ PDDP_DEV double bdot4(double a, double v, double f0, double f1, double f2,
   a = fma_(qb<2>(v), f2, a);
   return fma_(qb<3>(v), f3, a);
 }
+
+
+// ---- flags carried in the SIGN BIT of a 32-bit word (role Q's lean BoxQP).
+// A compare that goes through an SGPR pair (v_cmp -> v_cndmask) costs a
+// dependent chain ~40 cycles per trip; a subtraction leaves
+// the same predicate in the sign bit of a VGPR, where v_and / v_or / v_bfi
+// combine it at 4 cycles each.  The two instructions the optimiser would turn
+// back into compare + select are issued by hand.
+PDDP_DEV int sgn(float x) { return __float_as_int(x); }
+PDDP_DEV int splat(int w) {  // 0 / -1 from the sign bit
+  int r;
+  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(w));
+  return r;
+}
+PDDP_DEV float bsel(int mask, float a, float b) {  // mask ? a : b, bitwise
+  float r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+  return r;
+}
+PDDP_DEV int bseli(int mask, int a, int b) {
+  int r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+  return r;
+}
+
+// The closed form of the scalar BoxQP (riccati_n4.hpp QpClosed: the paths the
+// reference's loop, utils/constraint.py:150-266, takes on all but ~0.01 % of
+// the steps) without a single compare on its value chain.  Same case analysis
+// as QpClosed::solve; what differs is rounding only: the objective is
+// evaluated as v (Q/2 v + c) (three instructions less per evaluation; it feeds
+// the convergence and Armijo tests, which are decided far from their
+// thresholds wherever the closed form applies), the tolerance products are
+// fused into the subtraction whose sign is tested, Q is taken as positive
+// definite and finite (the caller routes every other value - and every `slow`
+// case - through QpClosed and the reference's loop), and x0 as finite (it is
+// the previous step's minimiser, inside finite bounds).
+struct QpLean {
+  float x, inv;
+  int free_w, slow_w;  // flags in the sign bit
+  PDDP_DEV void solve(float x0, float Q, float c, float lo, float hi) {
+    const float d_lo = lo - x0, d_hi = x0 - hi;  // sign: x0 > lo, x0 < hi
+    const float xs = __builtin_amdgcn_fmed3f(x0, lo, hi);
+    const float hQ = 0.5f * Q;
+    inv = __builtin_amdgcn_rcpf(Q);
+    // ---- iteration 0                                        (:191-239)
+    const float g0 = fma_(Q, xs, c);
+    // clamped: (x == lo & g > 0) | (x == hi & g < 0), with x == lo <=> x0 <= lo
+    // <=> sign(lo - x0) clear: one three-input bit operation on the sign bits
+    // of (x0 - hi, lo - x0, g).  (g > 0 is read as "sign clear": a gradient
+    // that is exactly zero ON a bound counts as clamped - the reference frees
+    // that coordinate; x is the same either way.)
+    const int ncl0 = (sgn(d_hi) & ~sgn(d_lo) & ~sgn(g0)) | (~sgn(d_hi) & sgn(g0));
+    const int small0 = sgn(__builtin_fabsf(g0) - 1e-8f);
+    const int done0 = ncl0 | small0;
+    const float newton = -(c * inv);
+    const float s0 = newton - xs;
+    const float xa = xs + s0;
+    const float x1 = __builtin_amdgcn_fmed3f(xa, lo, hi);
+    const float d1_lo = lo - xa, d1_hi = xa - hi;  // x1 == lo <=> xa <= lo
+    const float f0 = xs * fma_(hQ, xs, c), f1 = x1 * fma_(hQ, x1, c);
+    const float num = f1 - f0;
+    // ---- iteration 1: exit tests, one more full step
+    const int conv = sgn(fma_(-1e-8f, __builtin_fabsf(f0), -num));
+    const float g1 = fma_(Q, x1, c);
+    const int ncl1 = (sgn(d1_hi) & ~sgn(d1_lo) & ~sgn(g1)) | (~sgn(d1_hi) & sgn(g1));
+    const int small1 = sgn(__builtin_fabsf(g1) - 1e-8f);
+    const int stop1 = conv | ncl1 | small1;
+    const float x2 = __builtin_amdgcn_fmed3f(x1 + (newton - x1), lo, hi);
+    x = bsel(splat(done0), xs, bsel(splat(stop1), x1, x2));
+    // free = (done0 & !ncl0) | (!done0 & (conv | !ncl1)), done0 = ncl0 | small0
+    free_w = ~ncl0 & (small0 | conv | ~ncl1);
+    // ---- does the reference's loop leave these paths?  (QpClosed: pass0,
+    // guard, live1 & on_bound1)
+    const float sdotg = s0 * g0;
+    const int npass = sgn(fma_(0.1f, sdotg, -num));  // !(num <= 0.1 sdotg)
+    const int pass0 = sgn(sdotg) & ~npass;
+    const int onb1 = ~(sgn(d1_lo) & sgn(d1_hi));
+    const float lhs = __builtin_fabsf(x1 - xs) * __builtin_fabsf(sdotg);
+    const float rhs = (3.0f * __builtin_fabsf(num)) * __builtin_fabsf(s0);
+    const int guard = onb1 & sgn(sdotg) & sgn(num) & ~sgn(rhs - lhs);
+    slow_w = ~done0 & (~(pass0 | guard) | (~stop1 & onb1));
+  }
+};
 
 template <typename T, bool FAST, int R>
 __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
@@ -206,60 +297,93 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
     const T umin = a.u_min[0], umax = a.u_max[0];
     // (k, c, w) of step tq + 1; the coefficients of step tq
     T kprev = T(0), c1 = T(0), w1 = T(0);
-    T A0p = T(0), B0p = T(0), g1 = T(0);
-    T Un = T(0);  // U of step tq
+    T A0p = T(0), B0p = T(0), g1 = T(0), g1sq = T(0);
+    T lo_b = T(0), hi_b = T(0);  // bounds of step tq's BoxQP: u_min/max - U
     int status = PDDP_BWD_OK;
     __syncthreads();
     int p = 0;
+    // The exact path of one step: QpClosed, the reference's loop behind it.
+    // Lanes outside `take` keep what they hold.
+    auto exact = [&](bool take, bool alive, T Quu, T Qu, T qp_Q, T& kt, T& sK,
+                     T& c, T& w) {
+      int st = PDDP_BWD_OK;
+      if (!is_finite(Quu)) st = PDDP_BWD_NAN;       // eig raises (ilqr.py:631)
+      n4::QpClosed<T, FAST> qc;
+      qc.solve(kprev, qp_Q, Qu, lo_b, hi_b);
+      T kx = qc.x;
+      bool Kzero = !qc.free_, fail = qc.fail;
+      const bool slow = qc.slow && alive && take;
+      if (__builtin_expect(__any(slow), 0)) {
+        // rare: the reference's loop, one slow trajectory at a time on the
+        // whole wavefront
+        unsigned long long todo = __ballot(slow && q == 0);
+        while (todo != 0) {
+          const int src = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const n4::SlowQpOut<T> o = n4q::boxqp1_wave<T, FAST>(
+              __shfl(kprev, src), __shfl(qp_Q, src), __shfl(Qu, src),
+              __shfl(lo_b, src), __shfl(hi_b, src), ls_tail, lane);
+          const bool mine = (lane >> 2) == (src >> 2);
+          kx = mine ? o.x : kx;
+          Kzero = mine ? ((o.result_free & 1) == 0) : Kzero;
+          fail = mine ? (o.result_free < 2) : fail;
+        }
+      }
+      // K = -s Quz: 1 / Q through v_rcp (FAST) or an IEEE division
+      T sx;
+      if constexpr (FAST) sx = qc.inv;
+      else sx = T(1) / qp_Q;
+      sx = Kzero ? T(0) : sx;
+      const int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
+      T cx, wx;
+      n4q::rank_one_coeffs(kx, sx, Quu, Qu, cx, wx);
+      kt = take ? kx : kt; sK = take ? sx : sK;
+      c = take ? cx : c; w = take ? wx : w;
+      status = (take & alive & (stt != PDDP_BWD_OK)) ? stt : status;
+    };
     auto phase = [&](const int s) {
       const int tq = N + 1 - p;
-      // what M and Y published last phase: the coefficients of step tq - 1
+      // what M and Y published last phase: the coefficients of step tq - 1;
+      // U of step tq - 1 (record N - p: slot (p - 1) % R)
       const T* pi = &xin[(p + 1) & 1][tr][0];
       const T A00 = pi[0], G0 = pi[1], g2 = pi[2], B00 = pi[3];
-      // U of step tq - 1 (record N - p: slot (p - 1) % R), for the next phase
       const T Unext = ring[((s + R - 1) % R) * G::SLOT + rbase + 46];
       T kt = T(0), sK = T(0), c = T(0), w = T(0);
+      T* pq = &xq[p & 1][tr][0];
       if (tq <= N - 1) {
+        PDDP_DW_STAMP(0);
         const bool alive = counted & (status == PDDP_BWD_OK);
-        const T Quu = fma_(c1, mul_nc(g1, g1), A0p);
+        const T Quu = fma_(c1, g1sq, A0p);
         const T Qu = fma_(w1, g1, B0p);
-        int st = PDDP_BWD_OK;
-        if (!is_finite(Quu)) st = PDDP_BWD_NAN;     // eig raises (ilqr.py:631)
-        const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
-        const T qp_Q = e + reg;                     // ilqr.py:634
-        n4::QpClosed<T, FAST> qc;
-        const T lo_b = umin - Un, hi_b = umax - Un;
-        qc.solve(kprev, qp_Q, Qu, lo_b, hi_b);
-        kt = qc.x;
-        bool Kzero = !qc.free_, fail = qc.fail;
-        const bool slow = qc.slow && alive;
-        if (__builtin_expect(__any(slow), 0)) {
-          // rare: the reference's loop, one slow trajectory at a time on the
-          // whole wavefront
-          unsigned long long todo = __ballot(slow && q == 0);
-          while (todo != 0) {
-            const int src = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const n4::SlowQpOut<T> o = n4q::boxqp1_wave<T, FAST>(
-                __shfl(kprev, src), __shfl(qp_Q, src), __shfl(Qu, src),
-                __shfl(lo_b, src), __shfl(hi_b, src), ls_tail, lane);
-            const bool mine = (lane >> 2) == (src >> 2);
-            kt = mine ? o.x : kt;
-            Kzero = mine ? ((o.result_free & 1) == 0) : Kzero;
-            fail = mine ? (o.result_free < 2) : fail;
+        if constexpr (FAST && sizeof(T) == 4) {
+          // e = Quu < 0 ? 1e-12 : Quu (ilqr.py:633), + reg (:634)
+          const T qp_Q = bsel(splat(sgn(Quu)), 1e-12f, Quu) + reg;
+          QpLean ql;
+          ql.solve(kprev, qp_Q, Qu, lo_b, hi_b);
+          kt = ql.x;
+          sK = __int_as_float(splat(ql.free_w) & __float_as_int(ql.inv));
+          n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, w);
+          // every lane of the quad holds the same four words
+          *reinterpret_cast<f32x4*>(pq) = f32x4{kt, sK, c, w};
+          PDDP_DW_STAMP(1);
+          // off the chain (role M and Y read after the barrier): anything
+          // the lean form does not cover goes through the exact path
+          const bool odd = !is_finite(Quu) |
+                           !__builtin_amdgcn_classf(qp_Q, 0x180) |
+                           (ql.slow_w < 0);
+          if (__builtin_expect(__any(odd & alive), 0)) {
+            exact(odd & alive, alive, Quu, Qu, qp_Q, kt, sK, c, w);
+            *reinterpret_cast<f32x4*>(pq) = f32x4{kt, sK, c, w};
           }
+        } else {
+          const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
+          const T qp_Q = e + reg;                     // ilqr.py:634
+          exact(true, alive, Quu, Qu, qp_Q, kt, sK, c, w);
+          if (q == 0) { pq[0] = kt; pq[1] = sK; pq[2] = c; pq[3] = w; }
+          PDDP_DW_STAMP(1);
         }
-        // K = -s Quz: 1 / Q through v_rcp (FAST) or an IEEE division
-        if constexpr (FAST) sK = qc.inv;
-        else sK = T(1) / qp_Q;
-        sK = Kzero ? T(0) : sK;
-        const int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
-        n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, w);
-        status = (alive & (stt != PDDP_BWD_OK)) ? stt : status;
-      }
-      if (q == 0) {
-        T* pq = &xq[p & 1][tr][0];
-        pq[0] = kt; pq[1] = sK; pq[2] = c; pq[3] = w;
+      } else if (q == 0) {
+        pq[0] = T(0); pq[1] = T(0); pq[2] = T(0); pq[3] = T(0);
       }
       // off the chain: the coefficients of step tq - 1 given (c, w) of step
       // tq + 1;  g_{tq,tq-1} = G0 + c_{tq+1} g_{tq+1,tq} g_{tq+1,tq-1}
@@ -267,8 +391,11 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       A0p = fma_(c1, mul_nc(g2, g2), A00);
       B0p = fma_(w1, g2, B00);
       g1 = g1n;
+      g1sq = mul_nc(g1n, g1n);
       kprev = kt; c1 = c; w1 = w;
-      Un = Unext;
+      lo_b = umin - Unext;
+      hi_b = umax - Unext;
+      PDDP_DW_STAMP(2);
       PDDP_DW_BARRIER();
     };
     while (p < P) {
@@ -319,21 +446,12 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       const T* pq = &xq[(p + 1) & 1][tr][0];  // step tq + 1
       const T kq = pq[0], sq = pq[1], cq = pq[2], wq = pq[3];
       const T Quz0 = xz[(p + 1) & 1][tr][q];  // Quz0_{tq-1}[q] (M, last phase)
-      asm volatile("" ::: "memory");  // (the exchange reads first)
+      asm volatile("" ::: "memory");  // (nothing else queues before these)
       const Ops oa = o_prev, ob = o_cur;
-      const Ops on = gather((s + 1) % R);  // record t - 1, for the next phase
-      const T Lz = ob.Lz, Lu = ob.Lu;
       const bool okA = (tq <= N - 1) & (tq >= 1);  // records tq, tq - 1 exist
       const bool okB = (tq <= N - 1) & (t >= 0);   // ... and t
       const bool okT = (t >= 0);
-      // (vi) gains of step tq + 1: its s arrived, its y was finalised last phase
-      if (tq + 1 <= N - 1 && exists) {
-        T* dst = reinterpret_cast<T*>(
-            gains_w + (size_t)(((bc - b0) * N + (tq + 1)) * kGain + 1 + q) *
-                          sizeof(T));
-        *dst = -(sq * y1);
-        if (q == 0) dst[-1] = kq;
-      }
+      PDDP_DW_STAMP(0);
       // (i) y_tq = y'_tq + (c_{tq+1} g_{tq+1,tq}) y_{tq+1} carried to tq
       const T y = fma_(mul_nc(cq, g1a), y1c, yp);
       // (ii) carry it to tq - 1 and tq - 2; dot products with f
@@ -345,25 +463,37 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       T gb = quad_sum(mul_nc(ob.fq, yc));
       ycc = okB ? ycc : T(0);
       gb = okB ? gb : T(0);
+      xy[p & 1][tr][q] = ycc;  // y_tq at time t: taken into S0_t next phase
+      PDDP_DW_STAMP(1);
       // (iii) y'_{tq-1} = Quz0_{tq-1} + (c_{tq+1} g_{tq+1,tq-1}) y_{tq+1} at tq - 1
       const T ypn = fma_(mul_nc(cq, g1b), y1cc, Quz0);
       T G0 = quad_sum(mul_nc(ob.fq, ypn));
       G0 = okT ? G0 : T(0);
       // (iv) r_{tq-1} = r0_{tq-1} + w_{tq+1} y_{tq+1} at tq - 1; step t's part
       const T r = fma_(wq, y1cc, r0n);
-      T B00 = Lu + quad_sum(mul_nc(ob.fq, r));
+      T B00 = ob.Lu + quad_sum(mul_nc(ob.fq, r));
       B00 = okT ? B00 : T(0);
-      const T r0 = bdot4(Lz, r, ob.F0, ob.F1, ob.F2, ob.F3);
-      r0n = okT ? r0 : r0n;
       // (v) publish
       if (q == 0) {
         T* po = &xin[p & 1][tr][0];
         po[1] = G0; po[2] = gb; po[3] = B00;
       }
-      xy[p & 1][tr][q] = ycc;  // y_tq at time t: taken into S0_t next phase
+      asm volatile("" ::: "memory");  // (published; the rest is off the path)
+      PDDP_DW_STAMP(2);
+      const T r0 = bdot4(ob.Lz, r, ob.F0, ob.F1, ob.F2, ob.F3);
+      r0n = okT ? r0 : r0n;
+      // (vi) gains of step tq + 1: its s arrived, its y was finalised last phase
+      if (tq + 1 <= N - 1 && exists) {
+        T* dst = reinterpret_cast<T*>(
+            gains_w + (size_t)(((bc - b0) * N + (tq + 1)) * kGain + 1 + q) *
+                          sizeof(T));
+        *dst = -(sq * y1);
+        if (q == 0) dst[-1] = kq;
+      }
       y1 = y; y1c = yc; y1cc = ycc; g1a = ga; g1b = gb; yp = ypn;
       o_prev = ob;
-      o_cur = on;
+      o_cur = gather((s + 1) % R);  // record t - 1, for the next phase
+      PDDP_DW_STAMP(3);
       PDDP_DW_BARRIER();
     };
     while (p < P) {
@@ -424,10 +554,10 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
     // c of step t + 3 and its vector carried to t + 1
     const T cq = xq[(p + 1) & 1][tr][2];
     const T yv = xy[(p + 1) & 1][tr][q];
-    asm volatile("" ::: "memory");
+    asm volatile("" ::: "memory");  // (nothing else queues before these)
     const Words w = wn;
-    wn = gather((s + 1) % R);  // record t - 1, for the next phase
     if (t >= 0) {
+      PDDP_DW_STAMP(0);
       // W_{t+1} = S0_{t+1} + c y y^T
       Acc4<T> W = S0;
       opa(W, mul_nc(cq, yv), yv);
@@ -437,6 +567,7 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       opa(Tm, W.v1, w.F1);
       opa(Tm, W.v2, w.F2);
       opa(Tm, W.v3, w.F3);
+      PDDP_DW_STAMP(1);
       // A00 = Luu + f^T W f (h = W f through the column: W symmetric to rounding)
       T h = mul_nc(W.v0, w.f0);
       h = fma_(W.v1, w.f1, h);
@@ -448,6 +579,10 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       Quz0 = fma_(w.f1, Tm.v1, Quz0);
       Quz0 = fma_(w.f2, Tm.v2, Quz0);
       Quz0 = fma_(w.f3, Tm.v3, Quz0);
+      xz[p & 1][tr][q] = Quz0;
+      if (q == 0) xin[p & 1][tr][0] = A00;
+      asm volatile("" ::: "memory");  // (published; S0 is this wave's own)
+      PDDP_DW_STAMP(2);
       // S0_t = 0.5 (Lzz + F^T T) + 0.5 (Lzz + F^T T)^T: column part C and its
       // mirror R accumulate the same products in the same order as the partner
       // lane's mirror / column, so that C + R is symmetric to the last bit
@@ -467,9 +602,9 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       opa(Rm, Tm.v3, h3);
       S0.v0 = C.v0 + Rm.v0; S0.v1 = C.v1 + Rm.v1;
       S0.v2 = C.v2 + Rm.v2; S0.v3 = C.v3 + Rm.v3;
-      xz[p & 1][tr][q] = Quz0;
-      if (q == 0) xin[p & 1][tr][0] = A00;
+      PDDP_DW_STAMP(3);
     }
+    wn = gather((s + 1) % R);  // record t - 1, for the next phase
     PDDP_DW_BARRIER();
   };
   while (p < P) {
