@@ -27,4 +27,13 @@ extern "C" int pddp_debug_defer_stats(unsigned long long* out, int reset) {
   }
   return 0;
 }
+extern "C" int pddp_debug_defer_seg(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_seg), 256);
+  if (reset) {
+    unsigned long long z[32] = {};
+    hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4d::g_defer_seg), z, 256);
+  }
+  return 0;
+}
 #endif

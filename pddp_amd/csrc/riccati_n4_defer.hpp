@@ -39,16 +39,8 @@
 //      one block per trajectory, operands and result in the quad layout),
 //   P  streams the records (four LDS-DMA instructions per step).
 //
-// Every role reads what the others published in the PREVIOUS phase.  There is
-// no s_barrier in the loop (a release costs every wave ~100-250 cycles of
-// vector issue, MI355X_MICROARCH.md "start-of-segment VALU penalty", and would
-// put role Q's chain behind the slowest role every step): a role publishes
-// its words, then its phase number in `prog[role]`; LDS executes a wave's
-// operations in order, so whoever reads prog[role] >= p and THEN the words
-// sees the words of phase p.  Exchange buffers are four slots deep (p & 3):
-// no role can be more than two phases ahead of one it depends on.  Role Q
-// never waits in steady state - it checks the progress words it read at the
-// start of a phase when it needs the coefficients at the end.  tools/defer_proto.py is the numpy
+// Every role reads what the others published in the PREVIOUS phase (two
+// parities of each exchange buffer).  tools/defer_proto.py is the numpy
 // restatement of this schedule, checked against the oracle: same results as
 // the plain recursion to rounding (fp64 ~5e-12 on the oracle's gains; the
 // products run on W, which lacks the last two - negative - rank-one terms, so
@@ -73,17 +65,23 @@ constexpr int kThreads = 4 * kWave;
 constexpr int kTraj = 16;
 
 #ifdef PDDP_QP_STATS
-// cycles each role spends polling progress words ([role]) and in total
+// cycles each role waits at the phase barrier ([role]) and in total
 // ([4 + role]); tools/defer_wait.py
 __device__ unsigned long long g_defer_stats[8];
-#define PDDP_DW_DECL unsigned long long wait_acc = 0; const long long t_begin = clock64();
-#define PDDP_DW_T0() const long long tw0_ = clock64()
-#define PDDP_DW_T1() wait_acc += (unsigned long long)(clock64() - tw0_)
-#define PDDP_DW_END(ROLE) do { if (lane == 0) { atomicAdd(&g_defer_stats[ROLE], wait_acc); atomicAdd(&g_defer_stats[4 + ROLE], (unsigned long long)(clock64() - t_begin)); } } while (0)
+#define PDDP_DW_DECL unsigned long long wait_acc = 0; const long long t_begin = clock64(); PDDP_DW_SEGDECL
+#define PDDP_DW_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long t0_ = clock64(); seg_acc[7] += (unsigned long long)(t0_ - seg_last); asm volatile("s_barrier" ::: "memory"); seg_last = clock64(); wait_acc += (unsigned long long)(seg_last - t0_); } while (0)
+#define PDDP_DW_END(ROLE) do { if (lane == 0) { atomicAdd(&g_defer_stats[ROLE], wait_acc); atomicAdd(&g_defer_stats[4 + ROLE], (unsigned long long)(clock64() - t_begin)); for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_defer_seg[ROLE][i_], seg_acc[i_]); } } while (0)
+// segment profile of a phase: cycles from the previous stamp (or the phase
+// barrier) to stamp I; the s_memtime read drains lgkmcnt, so a segment that
+// follows LDS reads shows their full latency
+__device__ unsigned long long g_defer_seg[4][8];
+#define PDDP_DW_SEGDECL unsigned long long seg_acc[8] = {}; long long seg_last = clock64();
+#define PDDP_DW_STAMP(I) do { const long long n_ = clock64(); seg_acc[I] += (unsigned long long)(n_ - seg_last); seg_last = n_; } while (0)
 #else
+#define PDDP_DW_SEGDECL
+#define PDDP_DW_STAMP(I)
 #define PDDP_DW_DECL
-#define PDDP_DW_T0()
-#define PDDP_DW_T1()
+#define PDDP_DW_BARRIER() n4::lds_publish_barrier()
 #define PDDP_DW_END(ROLE)
 #endif
 
@@ -204,27 +202,17 @@ struct QpLean {
   }
 };
 
-// progress words: prog[kM / kQ / kY] = last phase whose words are published;
-// prog[kP] = L: records N - 1 - L and younger are in the ring
-constexpr int kM = 0, kQ = 1, kY = 2, kP = 3;
-constexpr int kSpinCap = 1 << 16;  // polls before a wave stops waiting (a
-                                   // protocol error must end the kernel, not
-                                   // hang the GPU; the sweep then reports NaN)
-
 template <typename T, bool FAST, int R>
 __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
     RiccatiArgs<T> a) {
   using G = n4q::QuadGeom<T>;
   constexpr int NI = G::NI, RPI = G::RPI, CH = G::CH, CB = G::CB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // exchange buffers, four slots each (written in phase p at slot p & 3,
-  // read in phase p + 1)
-  __shared__ __attribute__((aligned(16))) T xq[4][kTraj][4];   // Q: k, s, c, w
-  __shared__ __attribute__((aligned(16))) T xin[4][kTraj][4];  // M: A00 | Y: G0, g2, B00
-  __shared__ __attribute__((aligned(16))) T xz[4][kTraj][4];   // M: Quz0[q]
-  __shared__ __attribute__((aligned(16))) T xy[4][kTraj][4];   // Y: carried y[q]
-  __shared__ __attribute__((aligned(16))) int prog[4];
-  __shared__ int abort_flag;
+  // exchange buffers, two parities each (written in phase p, read in p + 1)
+  __shared__ __attribute__((aligned(16))) T xq[2][kTraj][4];   // Q: k, s, c, w
+  __shared__ __attribute__((aligned(16))) T xin[2][kTraj][4];  // M: A00 | Y: G0, g2, B00
+  __shared__ __attribute__((aligned(16))) T xz[2][kTraj][4];   // M: Quz0[q]
+  __shared__ __attribute__((aligned(16))) T xy[2][kTraj][4];   // Y: carried y[q]
   __shared__ T ls_tail[n4::kLsSteps];
   T* ring = reinterpret_cast<T*>(smem_raw);
 
@@ -232,19 +220,12 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
   const int lane = threadIdx.x & (kWave - 1);
   for (int i = threadIdx.x; i < n4::kLsSteps; i += kThreads)
     ls_tail[i] = (T)n4::kLs.v[i];
-  for (int i = threadIdx.x; i < 4 * kTraj * 4; i += kThreads) {
+  for (int i = threadIdx.x; i < 2 * kTraj * 4; i += kThreads) {
     (&xq[0][0][0])[i] = T(0);
     (&xin[0][0][0])[i] = T(0);
     (&xz[0][0][0])[i] = T(0);
     (&xy[0][0][0])[i] = T(0);
   }
-#ifdef PDDP_DEFER_SOLO
-  // timing experiment (tools/defer_solo.sh): one role alone, every wait passes
-  if (threadIdx.x < 4) prog[threadIdx.x] = 1 << 28;
-#else
-  if (threadIdx.x < 4) prog[threadIdx.x] = threadIdx.x == kP ? R - 1 : -1;
-#endif
-  if (threadIdx.x == 0) abort_flag = 0;
 
   const int q = lane & 3, tr = lane >> 2;
   const int N = a.N;
@@ -259,54 +240,6 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
   const int oq = rbase + q, or4 = rbase + 4 * q;
   const int P = N + 2;  // phases: Q solves step tq = N + 1 - p in phase p
   PDDP_DW_DECL
-  // (LDS-qualified volatile pointers: through a generic pointer these become
-  // flat_load / flat_store ... sc0 sc1 behind s_waitcnt vmcnt(0) - every poll
-  // would drain the record DMAs and the gains stores)
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  typedef __attribute__((address_space(3))) volatile int LdsVInt;
-  typedef __attribute__((address_space(3))) const volatile i32x4 LdsVInt4;
-  LdsVInt* vprog = (LdsVInt*)prog;
-  LdsVInt4* vprog4 = (LdsVInt4*)prog;
-  bool dead = false;  // this wave gave up waiting (protocol error)
-  // wait until prog[kM] >= nm, prog[kQ] >= nq, prog[kY] >= ny, prog[kP] >= np
-  auto wait_for = [&](int nm, int nq, int ny, int np) {
-    if (dead) return;
-    PDDP_DW_T0();
-    for (int spins = 0;; ++spins) {
-      // one lane reads the four words (a full-wave read of one address
-      // costs the LDS 1 KB of bandwidth per poll, and three roles poll)
-      i32x4 v = {0, 0, 0, 0};
-      if (lane == 0) v = *vprog4;
-      const int m = __builtin_amdgcn_readfirstlane(v[kM]);
-      const int qq = __builtin_amdgcn_readfirstlane(v[kQ]);
-      const int y = __builtin_amdgcn_readfirstlane(v[kY]);
-      const int pp = __builtin_amdgcn_readfirstlane(v[kP]);
-      if (m >= nm && qq >= nq && y >= ny && pp >= np) break;
-      if (spins >= kSpinCap) {
-        dead = true;
-        abort_flag = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    PDDP_DW_T1();
-    asm volatile("" ::: "memory");  // (the words are read after the flags)
-  };
-  // this role's words of phase p are written: publish the phase number
-  auto publish = [&](int who, int value) {
-    asm volatile("" ::: "memory");  // (after the words)
-#ifdef PDDP_DEFER_SOLO
-    vprog[who] = (1 << 28) + value;
-#else
-    vprog[who] = value;
-#endif
-  };
-#ifdef PDDP_DEFER_SOLO
-  if (role != PDDP_DEFER_SOLO && role != 3) {
-    __syncthreads();
-    return;
-  }
-#endif
 
   if (role == 3) {
     // =================================================================== P
@@ -336,21 +269,20 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
 #pragma unroll
     for (int s = 0; s < R; ++s) dma(s, N - 1 - s);
     n4::wait_vmcnt<0>();
-    __syncthreads();  // ring filled, exchange buffers and progress words set
-    int p = 2;
+    __syncthreads();  // ring filled, exchange buffers zeroed
+    int p = 0;
     while (p < P) {
 #pragma unroll
       for (int s = 0; s < R; ++s) {
         if (p >= P) break;
-        // the slot of record N + 1 - p ((p - 2) % R) is dead once Q has read
-        // its U (phase p - 1) and M and Y have gathered it (their phase p - 3:
-        // over when they publish phase p - 2)
-        wait_for(p - 2, p - 1, p - 2, 0);
-        dma(s, N + 1 - p - R);  // (s = (p - 2) % R)
-        // the group requested R - 4 phases ago has landed once at most R - 4
-        // younger groups are outstanding: record N - 3 - p is in the ring
+        // phase p reads record N - p (Q: U of the next step) and gathers
+        // record N - 2 - p (M, Y: next phase's operands): the slot of record
+        // N + 1 - p is dead from phase p on
+        if (p >= 2) dma((s + R - 2) % R, N + 1 - p - R);
+        // record N - 3 - p (gathered during phase p + 1) was requested in
+        // phase p + 4 - R: at most R - 4 younger groups may be outstanding
         n4::wait_vmcnt<(R - 4) * NI>();
-        if (p + 2 > R - 1) publish(kP, p + 2);
+        PDDP_DW_BARRIER();
         ++p;
       }
     }
@@ -411,24 +343,15 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
     };
     auto phase = [&](const int s) {
       const int tq = N + 1 - p;
+      // what M and Y published last phase: the coefficients of step tq - 1;
+      // U of step tq - 1 (record N - p: slot (p - 1) % R)
+      const T* pi = &xin[(p + 1) & 1][tr][0];
+      const T A00 = pi[0], G0 = pi[1], g2 = pi[2], B00 = pi[3];
+      const T Unext = ring[((s + R - 1) % R) * G::SLOT + rbase + 46];
       T kt = T(0), sK = T(0), c = T(0), w = T(0);
-      T* pq = &xq[p & 3][tr][0];
-      // The coefficients of step tq - 1 - what M and Y published in the last
-      // phase - are fetched as LATE as the LDS latency allows: M and Y start
-      // that phase's combine when this role publishes, so they have a whole
-      // phase of slack.  Progress words first, then (LDS executes in order)
-      // the words and U of step tq - 1 (record N - p: slot (p - 1) % R).
-      i32x4 seen;
-      const T* pi = &xin[(p + 3) & 3][tr][0];
-      T A00, G0, g2, B00, Unext;
-      auto fetch = [&]() {
-        seen = i32x4{0, 0, 0, 0};
-        if (lane == 0) seen = *vprog4;
-        asm volatile("" ::: "memory");
-        A00 = pi[0]; G0 = pi[1]; g2 = pi[2]; B00 = pi[3];
-        Unext = ring[((s + R - 1) % R) * G::SLOT + rbase + 46];
-      };
+      T* pq = &xq[p & 1][tr][0];
       if (tq <= N - 1) {
+        PDDP_DW_STAMP(0);
         const bool alive = counted & (status == PDDP_BWD_OK);
         const T Quu = fma_(c1, g1sq, A0p);
         const T Qu = fma_(w1, g1, B0p);
@@ -437,43 +360,33 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
           const T qp_Q = bsel(splat(sgn(Quu)), 1e-12f, Quu) + reg;
           QpLean ql;
           ql.solve(kprev, qp_Q, Qu, lo_b, hi_b);
-          fetch();
           kt = ql.x;
           sK = __int_as_float(splat(ql.free_w) & __float_as_int(ql.inv));
           n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, w);
-          // anything the lean form does not cover goes through the exact path
+          // every lane of the quad holds the same four words
+          *reinterpret_cast<f32x4*>(pq) = f32x4{kt, sK, c, w};
+          PDDP_DW_STAMP(1);
+          // off the chain (role M and Y read after the barrier): anything
+          // the lean form does not cover goes through the exact path
           const bool odd = !is_finite(Quu) |
                            !__builtin_amdgcn_classf(qp_Q, 0x180) |
                            (ql.slow_w < 0);
-          if (__builtin_expect(__any(odd & alive), 0))
+          if (__builtin_expect(__any(odd & alive), 0)) {
             exact(odd & alive, alive, Quu, Qu, qp_Q, kt, sK, c, w);
-          // every lane of the quad holds the same four words
-          *reinterpret_cast<f32x4*>(pq) = f32x4{kt, sK, c, w};
+            *reinterpret_cast<f32x4*>(pq) = f32x4{kt, sK, c, w};
+          }
         } else {
           const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
           const T qp_Q = e + reg;                     // ilqr.py:634
           exact(true, alive, Quu, Qu, qp_Q, kt, sK, c, w);
-          fetch();
           if (q == 0) { pq[0] = kt; pq[1] = sK; pq[2] = c; pq[3] = w; }
+          PDDP_DW_STAMP(1);
         }
-      } else {
-        fetch();
-        if (q == 0) { pq[0] = T(0); pq[1] = T(0); pq[2] = T(0); pq[3] = T(0); }
+      } else if (q == 0) {
+        pq[0] = T(0); pq[1] = T(0); pq[2] = T(0); pq[3] = T(0);
       }
-      publish(kQ, p);
-      const int seen_m = __builtin_amdgcn_readfirstlane(seen[kM]);
-      const int seen_y = __builtin_amdgcn_readfirstlane(seen[kY]);
-      const int seen_p = __builtin_amdgcn_readfirstlane(seen[kP]);
-      if (__builtin_expect(
-              !(seen_m >= p - 1 && seen_y >= p - 1 && seen_p >= p - 1), 0)) {
-        wait_for(p - 1, -1, p - 1, p - 1);
-        A00 = pi[0]; G0 = pi[1]; g2 = pi[2]; B00 = pi[3];
-        // (U only when P was behind: otherwise the first read was good, and
-        // its slot may be refilled from now on - phase p is published)
-        if (seen_p < p - 1)
-          Unext = ring[((s + R - 1) % R) * G::SLOT + rbase + 46];
-      }
-      // g_{tq,tq-1} = G0 + c_{tq+1} g_{tq+1,tq} g_{tq+1,tq-1}
+      // off the chain: the coefficients of step tq - 1 given (c, w) of step
+      // tq + 1;  g_{tq,tq-1} = G0 + c_{tq+1} g_{tq+1,tq} g_{tq+1,tq-1}
       const T g1n = fma_(c1, mul_nc(g1, g2), G0);
       A0p = fma_(c1, mul_nc(g2, g2), A00);
       B0p = fma_(w1, g2, B00);
@@ -482,6 +395,8 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       kprev = kt; c1 = c; w1 = w;
       lo_b = umin - Unext;
       hi_b = umax - Unext;
+      PDDP_DW_STAMP(2);
+      PDDP_DW_BARRIER();
     };
     while (p < P) {
 #pragma unroll
@@ -491,7 +406,6 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
         ++p;
       }
     }
-    if (dead || abort_flag != 0) status = PDDP_BWD_NAN;
     if (counted && q == 0) a.status[bc] = status;
     PDDP_DW_END(1);
     return;
@@ -529,53 +443,44 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
     Ops o_cur = gather(0), o_prev = o_cur;
     auto phase = [&](const int s) {
       const int tq = N + 1 - p, t = tq - 2;
+      const T* pq = &xq[(p + 1) & 1][tr][0];  // step tq + 1
+      const T kq = pq[0], sq = pq[1], cq = pq[2], wq = pq[3];
+      const T Quz0 = xz[(p + 1) & 1][tr][q];  // Quz0_{tq-1}[q] (M, last phase)
+      asm volatile("" ::: "memory");  // (nothing else queues before these)
       const Ops oa = o_prev, ob = o_cur;
       const bool okA = (tq <= N - 1) & (tq >= 1);  // records tq, tq - 1 exist
       const bool okB = (tq <= N - 1) & (t >= 0);   // ... and t
       const bool okT = (t >= 0);
-      // ---- before (c, w) of step tq + 1 arrive: everything is affine in
-      // alpha = c g_{tq+1,tq}, beta = c g_{tq+1,tq-1}, w and Quz0 - carry the
-      // parts that are known (y'_tq, y_{tq+1}, r0) and combine afterwards
-      const T a1 = bdot4(T(0), yp, oa.F0, oa.F1, oa.F2, oa.F3);   // y'_tq at tq - 1
-      const T ga0 = quad_sum(mul_nc(oa.fq, yp));
-      const T a2 = bdot4(T(0), a1, ob.F0, ob.F1, ob.F2, ob.F3);   // ... at t
-      const T gb0 = quad_sum(mul_nc(ob.fq, a1));
-      const T y1c3 = bdot4(T(0), y1cc, ob.F0, ob.F1, ob.F2, ob.F3);  // y_{tq+1} at t
-      const T g1c = quad_sum(mul_nc(ob.fq, y1cc));                // f_t . y_{tq+1}
-      const T rr0 = bdot4(ob.Lz, r0n, ob.F0, ob.F1, ob.F2, ob.F3);
-      const T b00 = ob.Lu + quad_sum(mul_nc(ob.fq, r0n));
-      // ---- Q's and M's words of the last phase; record t - 1 in the ring
-      wait_for(p - 1, p - 1, -1, p + 1);
-      const T* pq = &xq[(p + 3) & 3][tr][0];  // step tq + 1
-      const T kq = pq[0], sq = pq[1], cq = pq[2], wq = pq[3];
-      const T Quz0 = xz[(p + 3) & 3][tr][q];  // Quz0_{tq-1}[q] (M, last phase)
-      asm volatile("" ::: "memory");
-      const T al = mul_nc(cq, g1a), be = mul_nc(cq, g1b);
-      // (i) y_tq = y'_tq + alpha y_{tq+1};  (ii) carried to tq - 1 and tq - 2
-      const T y = fma_(al, y1c, yp);
-      T yc = fma_(al, y1cc, a1);
-      T ga = fma_(al, g1b, ga0);
-      T ycc = fma_(al, y1c3, a2);
-      T gb = fma_(al, g1c, gb0);
+      PDDP_DW_STAMP(0);
+      // (i) y_tq = y'_tq + (c_{tq+1} g_{tq+1,tq}) y_{tq+1} carried to tq
+      const T y = fma_(mul_nc(cq, g1a), y1c, yp);
+      // (ii) carry it to tq - 1 and tq - 2; dot products with f
+      T yc = bdot4(T(0), y, oa.F0, oa.F1, oa.F2, oa.F3);
+      T ga = quad_sum(mul_nc(oa.fq, y));
       yc = okA ? yc : T(0);
       ga = okA ? ga : T(0);
+      T ycc = bdot4(T(0), yc, ob.F0, ob.F1, ob.F2, ob.F3);
+      T gb = quad_sum(mul_nc(ob.fq, yc));
       ycc = okB ? ycc : T(0);
       gb = okB ? gb : T(0);
-      xy[p & 3][tr][q] = ycc;  // y_tq at time t: taken into S0_t next phase
-      // (iii) y'_{tq-1} = Quz0_{tq-1} + beta y_{tq+1} at tq - 1;  G0 = f_t . y'
-      const T ypn = fma_(be, y1cc, Quz0);
-      T G0 = fma_(be, g1c, quad_sum(mul_nc(ob.fq, Quz0)));
+      xy[p & 1][tr][q] = ycc;  // y_tq at time t: taken into S0_t next phase
+      PDDP_DW_STAMP(1);
+      // (iii) y'_{tq-1} = Quz0_{tq-1} + (c_{tq+1} g_{tq+1,tq-1}) y_{tq+1} at tq - 1
+      const T ypn = fma_(mul_nc(cq, g1b), y1cc, Quz0);
+      T G0 = quad_sum(mul_nc(ob.fq, ypn));
       G0 = okT ? G0 : T(0);
-      // (iv) r_{tq-1} = r0_{tq-1} + w y_{tq+1} at tq - 1: B00 = L_u + f_t . r
-      T B00 = fma_(wq, g1c, b00);
+      // (iv) r_{tq-1} = r0_{tq-1} + w_{tq+1} y_{tq+1} at tq - 1; step t's part
+      const T r = fma_(wq, y1cc, r0n);
+      T B00 = ob.Lu + quad_sum(mul_nc(ob.fq, r));
       B00 = okT ? B00 : T(0);
       // (v) publish
       if (q == 0) {
-        T* po = &xin[p & 3][tr][0];
+        T* po = &xin[p & 1][tr][0];
         po[1] = G0; po[2] = gb; po[3] = B00;
       }
-      publish(kY, p);
-      const T r0 = fma_(wq, y1c3, rr0);  // r0_t = L_z + F_t^T r_{tq-1}
+      asm volatile("" ::: "memory");  // (published; the rest is off the path)
+      PDDP_DW_STAMP(2);
+      const T r0 = bdot4(ob.Lz, r, ob.F0, ob.F1, ob.F2, ob.F3);
       r0n = okT ? r0 : r0n;
       // (vi) gains of step tq + 1: its s arrived, its y was finalised last phase
       if (tq + 1 <= N - 1 && exists) {
@@ -588,6 +493,8 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       y1 = y; y1c = yc; y1cc = ycc; g1a = ga; g1b = gb; yp = ypn;
       o_prev = ob;
       o_cur = gather((s + 1) % R);  // record t - 1, for the next phase
+      PDDP_DW_STAMP(3);
+      PDDP_DW_BARRIER();
     };
     while (p < P) {
 #pragma unroll
@@ -597,10 +504,9 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
         ++p;
       }
     }
-    // gains of step 0 once its BoxQP result is published
-    wait_for(-1, P - 1, -1, 0);
+    // gains of step 0: its BoxQP result was published by the last barrier
     if (exists) {
-      const T* pq = &xq[(P - 1) & 3][tr][0];
+      const T* pq = &xq[(P + 1) & 1][tr][0];
       T* dst = reinterpret_cast<T*>(
           gains_w + (size_t)(((bc - b0) * N + 0) * kGain + 1 + q) * sizeof(T));
       *dst = -(pq[1] * y1);
@@ -645,29 +551,40 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
   Words wn = gather(0);  // record N - 1
   auto phase = [&](const int s) {
     const int t = N - 1 - p;
+    // c of step t + 3 and its vector carried to t + 1
+    const T cq = xq[(p + 1) & 1][tr][2];
+    const T yv = xy[(p + 1) & 1][tr][q];
+    asm volatile("" ::: "memory");  // (nothing else queues before these)
     const Words w = wn;
-    T A00 = T(0), Quz0 = T(0);
     if (t >= 0) {
-      // ---- before c of step t + 3 and its vector arrive: the products on
-      // S0_{t+1} alone.  T = S0 F:  T_i[q] += S0[i][k] F[k][q], S0[i][k] =
-      // lane i's S0_k
+      PDDP_DW_STAMP(0);
+      // W_{t+1} = S0_{t+1} + c y y^T
+      Acc4<T> W = S0;
+      opa(W, mul_nc(cq, yv), yv);
+      // T = W F:  T_i[q] += W[i][k] F[k][q], W[i][k] = lane i's W_k
       Acc4<T> Tm = {T(0), T(0), T(0), T(0)};
-      opa(Tm, S0.v0, w.F0);
-      opa(Tm, S0.v1, w.F1);
-      opa(Tm, S0.v2, w.F2);
-      opa(Tm, S0.v3, w.F3);
-      // f^T S0 f (h = S0 f through the column), f^T T
-      T h = mul_nc(S0.v0, w.f0);
-      h = fma_(S0.v1, w.f1, h);
-      h = fma_(S0.v2, w.f2, h);
-      h = fma_(S0.v3, w.f3, h);
-      A00 = w.Luu + quad_sum(mul_nc(w.fq, h));
-      Quz0 = fma_(w.f0, Tm.v0, w.Luz);
+      opa(Tm, W.v0, w.F0);
+      opa(Tm, W.v1, w.F1);
+      opa(Tm, W.v2, w.F2);
+      opa(Tm, W.v3, w.F3);
+      PDDP_DW_STAMP(1);
+      // A00 = Luu + f^T W f (h = W f through the column: W symmetric to rounding)
+      T h = mul_nc(W.v0, w.f0);
+      h = fma_(W.v1, w.f1, h);
+      h = fma_(W.v2, w.f2, h);
+      h = fma_(W.v3, w.f3, h);
+      const T A00 = w.Luu + quad_sum(mul_nc(w.fq, h));
+      // Quz0[q] = Luz[q] + sum_k f[k] T[k][q]
+      T Quz0 = fma_(w.f0, Tm.v0, w.Luz);
       Quz0 = fma_(w.f1, Tm.v1, Quz0);
       Quz0 = fma_(w.f2, Tm.v2, Quz0);
       Quz0 = fma_(w.f3, Tm.v3, Quz0);
-      // 0.5 (Lzz + F^T T) + 0.5 (Lzz + F^T T)^T: column part C and its mirror
-      // R accumulate the same products in the same order as the partner
+      xz[p & 1][tr][q] = Quz0;
+      if (q == 0) xin[p & 1][tr][0] = A00;
+      asm volatile("" ::: "memory");  // (published; S0 is this wave's own)
+      PDDP_DW_STAMP(2);
+      // S0_t = 0.5 (Lzz + F^T T) + 0.5 (Lzz + F^T T)^T: column part C and its
+      // mirror R accumulate the same products in the same order as the partner
       // lane's mirror / column, so that C + R is symmetric to the last bit
       const T h0 = T(0.5) * w.F0, h1 = T(0.5) * w.F1, h2 = T(0.5) * w.F2,
               h3 = T(0.5) * w.F3;
@@ -685,28 +602,10 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       opa(Rm, Tm.v3, h3);
       S0.v0 = C.v0 + Rm.v0; S0.v1 = C.v1 + Rm.v1;
       S0.v2 = C.v2 + Rm.v2; S0.v3 = C.v3 + Rm.v3;
-    }
-    // ---- Q's and Y's words of the last phase; record t - 1 in the ring
-    wait_for(-1, p - 1, p - 1, p + 1);
-    const T cq = xq[(p + 3) & 3][tr][2];    // c of step t + 3
-    const T yv = xy[(p + 3) & 3][tr][q];    // its vector carried to t + 1
-    asm volatile("" ::: "memory");
-    if (t >= 0) {
-      // W_{t+1} = S0_{t+1} + c y y^T enters every product above through
-      // yF = F^T y and fy = f . y:  f^T W F = f^T S0 F + c fy yF^T, ...
-      const T yF = bdot4(T(0), yv, w.F0, w.F1, w.F2, w.F3);
-      const T fy = quad_sum(mul_nc(w.fq, yv));
-      const T cf = mul_nc(cq, fy);
-      Quz0 = fma_(cf, yF, Quz0);
-      A00 = fma_(cf, fy, A00);
-      xz[p & 3][tr][q] = Quz0;
-      if (q == 0) xin[p & 3][tr][0] = A00;
-      publish(kM, p);
-      opa(S0, mul_nc(cq, yF), yF);  // S0_t += c yF yF^T
-    } else {
-      publish(kM, p);
+      PDDP_DW_STAMP(3);
     }
     wn = gather((s + 1) % R);  // record t - 1, for the next phase
+    PDDP_DW_BARRIER();
   };
   while (p < P) {
 #pragma unroll

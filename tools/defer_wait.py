@@ -1,4 +1,4 @@
-"""Cycles each role spends waiting on the other roles' progress words of the deferred four-wavefront sweep (variant 25).
+"""Barrier waits per role of the deferred four-wavefront sweep (variant 25).
 Needs the counters:
     make -C pddp_amd/csrc FLAGS_riccati_defer="-fno-slp-vectorize -mllvm -amdgpu-mfma-vgpr-form=1 -DPDDP_QP_STATS"
 (never ship that build)."""
@@ -22,6 +22,8 @@ s.set_nominal(z0, U)
 for r in range(4):
     s.round(5e-6, 1e10, 1 << 30)
 lib.pddp_debug_defer_stats(out, 1)
+seg = (ctypes.c_ulonglong * 32)()
+lib.pddp_debug_defer_seg(seg, 1)
 rounds = 10
 for r in range(rounds):
     s.backward(active=s.active, variant=variant)
@@ -31,6 +33,11 @@ for role, name in enumerate(("M (matrices)", "Q (scalars)", "Y (vectors)",
                              "P (producer)")):
     tot = out[4 + role] / (wg * rounds)
     wait = out[role] / (wg * rounds)
-    print("%-13s %7.0f cycles per sweep, %5.0f per phase, %4.0f of them polling "
-          "progress words (%.0f %%)" % (name, tot, tot / (N + 2), wait / (N + 2),
+    print("%-13s %7.0f cycles per sweep, %5.0f per phase, %4.0f of them at the "
+          "barrier (%.0f %%)" % (name, tot, tot / (N + 2), wait / (N + 2),
                                  100.0 * wait / max(tot, 1)))
+lib.pddp_debug_defer_seg(seg, 1)
+for role, name in enumerate("MQYP"):
+    print(name, "segments (cycles per phase; 7 = last stamp -> barrier):",
+          " ".join("%d:%.0f" % (i, seg[role * 8 + i] / (wg * rounds * (N + 2)))
+                   for i in range(8)))
