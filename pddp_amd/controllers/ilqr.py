@@ -100,27 +100,36 @@ class iLQRController(Controller):
         self._U_nominal = None
         self._K = None
         self._solver = None
+        self._solvers = {}
         self._batched = False
         self._last_rounds = 0  # rounds of the last fit / MPC step
 
     # -- solver plumbing ------------------------------------------------------
     def _get_solver(self, B, N, n, dtype, device, encoding, u_min, u_max,
                     alphas):
-        s = self._solver
         key = (B, N, n, dtype, torch.device(device), int(encoding),
                None if u_min is None else tuple(
                    torch.as_tensor(u_min).flatten().tolist()),
                None if u_max is None else tuple(
                    torch.as_tensor(u_max).flatten().tolist()),
-               tuple(alphas.flatten().tolist()))
-        if s is None or getattr(s, "_key", None) != key:
+               tuple(alphas.flatten().tolist()), self._kernel_variant,
+               self._exact, self._force_plugin)
+        # a small cache: fit() and forward(mpc=True) use different alpha
+        # schedules, i.e. different solvers - both stay (with their captured
+        # graphs; graph freshness against the model is the solver's business,
+        # ILQRSolver._graphs_fresh)
+        s = self._solvers.get(key)
+        if s is None:
             s = _make_solver(self.model, self.cost, encoding, B, N, n, dtype,
                              device, u_min, u_max, alphas, self._model_opts,
                              self._cost_opts, self._force_plugin,
                              self._kernel_variant, self._exact)
             s._key = key
             s.graph_rollout = bool(self._graph)
-            self._solver = s
+            if len(self._solvers) >= 4:  # (oldest out)
+                self._solvers.pop(next(iter(self._solvers)))
+            self._solvers[key] = s
+        self._solver = s
         return s
 
     def _export(self, s):
@@ -184,6 +193,57 @@ class iLQRController(Controller):
         if (s.state == int(iLQRState.MAX_REG)).any():
             warnings.warn("exceeded max regularization term")
         return self._Z_nominal, self._U_nominal, states
+
+    def step(self, z0, U=None, i=0, encoding=StateEncoding.DEFAULT,
+             batch_rollout=True, alphas=None, u_min=None, u_max=None,
+             on_iteration=None, **kwargs):
+        """ilqr.py:183-235: ONE optimisation step from `z0` around `U`
+        (default: the stored nominal controls) - derivative rollout, then
+        backward sweep / line search attempts until one is accepted, has
+        converged or the regularisation is exhausted.  The regularisation
+        state `_mu` / `_delta` carries over between calls exactly as in the
+        reference (`fit` resets it once, `forward(mpc=True)` every control
+        step); the accepted nominals and gains land in `_Z_nominal`,
+        `_U_nominal`, `_K`.  Returns the iLQRState (a tensor of states for a
+        batch).  `alphas` defaults to the signature default of the reference,
+        10 ** linspace(0, -3, 11)."""
+        if U is None:
+            U = self._U_nominal
+        _native.require_gpu(U)
+        U = U.detach()
+        Ub, self._batched = _as_batch(U, 2)
+        B, N, m = Ub.shape
+        z0 = z0.detach().to(dtype=U.dtype, device=U.device)
+        if z0.dim() == 1:
+            z0 = z0.unsqueeze(0).expand(B, -1)
+        al = (mpc_alphas(U.dtype, U.device) if alphas is None
+              else alphas.to(dtype=U.dtype, device=U.device))
+        s = self._get_solver(B, N, z0.shape[-1], U.dtype, U.device, encoding,
+                             u_min, u_max, al)
+        s.set_nominal(z0.contiguous(), Ub.contiguous())
+        s.mu.fill_(float(self._mu))        # (set_nominal reset them)
+        s.delta.fill_(float(self._delta))
+
+        def on_round(r, s):
+            if on_iteration is None:
+                return
+            if self._batched:
+                on_iteration(i, s.state.cpu(), s.Z.clone(), s.U.clone(),
+                             s.J_opt.clone())
+            else:
+                on_iteration(i, iLQRState(int(s.state[0])), s.Z[0].clone(),
+                             s.U[0].clone(), s.J_opt[0].clone())
+        self._last_rounds = s.fit(1, kwargs.get("tol", 5e-6),
+                                  kwargs.get("max_reg", 1e10), on_round,
+                                  graph=self._graph and s.graph_ok())
+        accepted = (s.state == int(iLQRState.ACCEPTED)) | \
+            (s.state == int(iLQRState.CONVERGED))
+        if self._batched or bool(accepted[0]):
+            self._export(s)        # (ilqr.py:167-169: stored on accept only)
+        else:
+            self._mu = float(s.mu[0])
+            self._delta = float(s.delta[0])
+        return self._states(s)
 
     def forward(self, z, i, encoding=StateEncoding.DEFAULT, mpc=False,
                 ignore_uncertainty=True, u_min=None, u_max=None, **kwargs):

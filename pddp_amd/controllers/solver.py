@@ -114,6 +114,7 @@ class ILQRSolver(object):
         self.n_live = torch.zeros(256, **i32)
         self._graph = None  # (key, graph of a round [, round without derivs])
         self._rollout_graph = None
+        self._model_gen = None  # model generation the plugin graphs captured
         self.graph_rollout = False  # nominal rollout of a plugin as a hipGraph
         self._fused = None  # None: untried, True / False: fused kernel applies
         self._derivs_due = True
@@ -181,9 +182,25 @@ class ILQRSolver(object):
         self.active.fill_(1)
         self.fresh.fill_(1)
 
+    def _graphs_fresh(self):
+        """Plugin graphs hold raw pointers to model-owned tensors
+        (normalisation buffers, dropout masks, cached noise); `model.fit()`,
+        `resample()` and loading a state replace those tensors and bump the
+        model's generation (models/bnn.py).  A graph captured under another
+        generation is dropped here and re-captured by its user."""
+        if self.plugin is None:
+            return
+        from ..models.bnn import generation
+        gen = generation(self.plugin.model)
+        if gen != self._model_gen:
+            self._graph = None
+            self._rollout_graph = None
+            self._model_gen = gen
+
     @_on_device
     def nominal_rollout(self, mask=None):
         if self.plugin is not None:
+            self._graphs_fresh()
             if self.graph_rollout and self.plugin.capture_ok(self):
                 # the N + 1 moment-step / network launch pairs of the nominal
                 # rollout as one hipGraph (z0, U, Z are solver-owned buffers)
@@ -256,13 +273,20 @@ class ILQRSolver(object):
                      p(self.active), p(self.fresh), p(self.n_live), self._s())
 
     @_on_device
-    def search_accept(self, tol, max_reg, n_iterations):
+    def search_accept(self, tol, max_reg, n_iterations, events=None):
         """Line search + accept + derivative records of the new nominals in
         one launch (pddp_search_accept_*).  False when the fused kernel does
-        not apply; the caller then makes the separate calls."""
+        not apply; the caller then makes the separate calls.  `events`: a
+        (start, stop) pair attached to THIS launch (bench.py); when the fused
+        kernel does not apply nothing is attached and `last_search_timed` says
+        so."""
+        self.last_search_timed = None
         if self.plugin is not None or self._fused is False:
             return False
         p = _native.ptr
+        if events is not None:
+            _native.lib().pddp_attach_events(*events)
+            self.last_search_timed = "search_accept"
         rc = _native.call_rc(
             "pddp_search_accept", self.dtype, self._pp, self.B, self.N, self.A,
             p(self.Z), p(self.U), p(self.gains), p(self.alphas), p(self.u_min),
@@ -272,6 +296,9 @@ class ILQRSolver(object):
             p(self.delta), p(self.state), p(self.iter), p(self.fresh),
             p(self.n_live), p(self.rec), p(self.L), self._s())
         self._fused = rc == 0
+        if not self._fused and events is not None:
+            _native.lib().pddp_attach_events(None, None)  # nothing launched
+            self.last_search_timed = None
         return self._fused
 
     def round(self, tol=5e-6, max_reg=1e10, n_iterations=50, variant=None,
@@ -288,9 +315,12 @@ class ILQRSolver(object):
             self._derivs_due = False
         self.backward(active=self.active, variant=variant,
                       events=backward_events)
-        if search_events is not None:  # (bench.py: times the fused launch)
-            _native.lib().pddp_attach_events(*search_events)
-        if not self.search_accept(tol, max_reg, n_iterations):
+        if not self.search_accept(tol, max_reg, n_iterations,
+                                  events=search_events):
+            if search_events is not None and self.plugin is None:
+                # the separate line search is what gets timed then
+                _native.lib().pddp_attach_events(*search_events)
+                self.last_search_timed = "line_search"
             self.line_search(active=self.active)
             self.accept(tol, max_reg, n_iterations)
 
@@ -320,6 +350,7 @@ class ILQRSolver(object):
             raise _native.NativeError(
                 "graph capture needs a round without host synchronisation: "
                 "this plugin runs autograd / torch fallbacks inside a round")
+        self._graphs_fresh()
         key = (float(tol), float(max_reg), int(n_iterations),
                self.kernel_variant)
         if self._graph is not None and self._graph[0] == key:

@@ -94,8 +94,9 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          10 / 11 = 6 / 7 in workgroups of four wavefronts,
   //          12 / 13 = 8 / 9 with the BoxQP chain decoupled from the value
   //          update (riccati_n4_pipe.hpp; bounded eig-clamp branch only);
-  //          auto: bounded eig-clamp branch below 16384 (f32) / 8192 (f64)
-  //          trajectories -> 21 / 20; f32 from 12288 trajectories on -> 17;
+  //          auto: bounded eig-clamp branch, f32 below 12288 trajectories ->
+  //          25, up to 16383 -> 21, f64 up to 8192 -> 20; f32 from 16384
+  //          trajectories on -> 17;
   //          bounded Cholesky branch f32 below that -> 9; otherwise 7 (f32) /
   //          6 (f64)
   //          14 / 15: the matrix-core kernels for n <= 30, m = 1, fp32
@@ -143,13 +144,17 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
 
   if (variant == 0 && n == 4 && m == 1 && u_min != nullptr &&
       branch == PDDP_BRANCH_EIG && B < (sizeof(T) == 4 ? 16384 : 8193)) {
-    // the controller's default branch (bounds, eig-clamp): the quad mapping
-    // over three wavefronts (riccati_n4_qpipe.hpp).  Measured inside the fit
-    // loop (bench.py --batch B --kernel-variant v): 39.7 / 41.0 / 49.3 / 74.4
-    // us at B = 1024 / 4096 / 8192 / 12288 against 44.4 / 46.0 / 69.5 / 93.6
-    // for the two-wavefront kernel (variant 13) and 58 / 61 / 66 / 85 for the
-    // one-wave quad kernel (17); from 16384 on the latter is level (98 / 100).
-    // fp64 at B = 4096: 67 against 92 (12) / 95 (6).
+    // the controller's default branch (bounds, eig-clamp).  fp32 below 12288
+    // trajectories: the deferred rank-one form on four wavefronts
+    // (riccati_n4_defer.hpp) - the sweep alone on the bench's records
+    // (tools/sweep_variants_time.py): 35.3 / 36.3 / 37.6 / 43.8 us at B =
+    // 1024 / 2048 / 4096 / 8192 against 37.6 / 38.8 / 39.8 / 46.8 for the
+    // three-wavefront quad kernel (riccati_n4_qpipe.hpp), which stays for
+    // 12288 .. 16383 (50.3 against 52.8 us) and for fp64 (65.4 against 66.6 us
+    // at B = 4096).  Same error distribution against the fp64 kernel on the
+    // same records (tools/sweep_accuracy.py: median 3.1e-5 / p99 1.6e-4 against
+    // 2.9e-5 / 1.3e-4).
+    if (sizeof(T) == 4 && B < 12288) return launch_n4_defer(a, st, true);
     return launch_n4_qpipe(a, st, sizeof(T) == 4, true);
   }
   if (variant == 0 && n == 4 && m == 1 && sizeof(T) == 4 && B >= 12288) {

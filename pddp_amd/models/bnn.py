@@ -47,6 +47,19 @@ def particles_covar(x):
     return d.transpose(-1, -2) @ d / (x.shape[0] - 1)
 
 
+
+def bump_generation(model):
+    """Marks every tensor a captured hipGraph may hold a pointer to
+    (normalisation buffers, dropout masks, cached noise) as replaced: the
+    solver drops its graphs when this number changes
+    (controllers/solver.py `_graphs_fresh`)."""
+    model.__dict__["_pddp_generation"] = generation(model) + 1
+
+
+def generation(model):
+    return getattr(model, "_pddp_generation", 0)
+
+
 class ConcreteDropout(torch.nn.Module):
     """Concrete (continuous-relaxation) dropout with a mask that is sampled
     once per (particle, unit) and then held fixed until `resample()` - the
@@ -304,6 +317,7 @@ def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
         def resample(self):
             self.eps_out = {}
             self.model.resample()
+            bump_generation(self)
 
         def _features(self, X, u):
             if should_constrain:
@@ -391,14 +405,32 @@ def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
                     else:
                         static_idx.copy_(idx)
                         if captured is None:
-                            captured = torch.cuda.CUDAGraph()
-                            with torch.cuda.graph(captured):
-                                step(static_idx)
+                            # a likelihood / layer that synchronises with the
+                            # host (`.item()`, printing, a data-dependent
+                            # branch) cannot be captured: the reference API
+                            # accepts it, so train eagerly instead
+                            try:
+                                captured = torch.cuda.CUDAGraph()
+                                with torch.cuda.graph(captured):
+                                    step(static_idx)
+                            except Exception:  # noqa: BLE001 (any capture error)
+                                captured, use_graph = None, False
+                                torch.cuda.synchronize(X_.device)
+                                step(idx)
+                                it += 1
+                                if it >= n_iter:
+                                    break
+                                continue
                         captured.replay()
                     it += 1
                     if it >= n_iter:
                         break
             self.last_fit_used_graph = captured is not None
+            # graph replays update logit_p in place without touching the
+            # version counters the mask cache is keyed by; new normalisation
+            # buffers / masks: captured solver graphs are stale from here on
+            self.model.__dict__.pop("_mask_cache", None)
+            bump_generation(self)
             return self
 
         def forward(self, X, u, i, resample=False, use_predicted_std=False,
@@ -429,7 +461,7 @@ def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
         def resample(self):
             self.eps_in = {}
             self.output = {}
-            super(BNNDynamicsModel, self).resample()
+            super(BNNDynamicsModel, self).resample()  # (bumps the generation)
 
         def forward(self, z, u, i, encoding=StateEncoding.DEFAULT,
                     identical_inputs=False, resample=False,
@@ -507,3 +539,7 @@ def load_reference_state(model, state):
         model.output = {}
     model.eps_out = {}
     return model
+    if hasattr(model, "model"):
+        model.model.__dict__.pop("_mask_cache", None)
+    bump_generation(model)
+

@@ -38,7 +38,7 @@ TOL = {"f64": 1e-9}
 # error outside the ratio is 5.5e-4 (eig-clamp) / 2.2e-5 (Cholesky).  The
 # sharp statement is test_sweep_variants_vs_oracle_many_trajectories.
 import os  # noqa: E402
-F32_RATIO = float(os.environ.get("PDDP_F32_RATIO", 8.0))  # (override: survey)
+F32_RATIO = 8.0  # (tools/sweep_error_stats.py surveys other ratios itself)
 F32_FLOOR = {0: 1e-3, 1: 3e-5}  # by gain branch (0 eig-clamp, 1 Cholesky)
 STATS = []  # rows recorded by the fp32 comparisons (dumped by conftest)
 
@@ -1854,6 +1854,99 @@ def test_bnn_mpc_graph_replay_equals_eager(use_predicted_std):
     assert torch.isfinite(xe).all() and torch.isfinite(ue).all()
     for a, b in ((0, 255), (7, 100)):
         assert torch.equal(ue[:, a], ue[:, b]) and torch.equal(Ue[a], Ue[b])
+
+
+def test_bnn_graphs_follow_model_resample_and_refit():
+    """A captured round / rollout graph holds raw pointers to the model's
+    normalisation buffers, dropout masks and cached noise; `model.resample()`
+    and `model.fit()` REPLACE those tensors.  With graph=True the sequence
+    MPC step -> resample -> MPC step -> fit -> MPC step must equal the eager
+    run bit for bit (the solver key - B, N, bounds, alphas - does not change,
+    so nothing but the model's generation says the graphs are stale)."""
+    import pddp_amd
+    from pddp_amd.models.bnn import generation
+    B, N = 32, 20
+    enc = pddp_amd.StateEncoding.DEFAULT
+    iu = torch.triu_indices(4, 4)
+    tri = (0.1 * torch.eye(4))[iu[0], iu[1]].cuda()
+    u_min, u_max = torch.tensor([-10.0]), torch.tensor([10.0])
+    runs = {}
+    for graph in (False, True):
+        ctrl, plant, x = _bnn_mpc_controller(B, N, graph, P=32, H=64)
+        model = ctrl.model
+        z = torch.cat([x, tri.expand(B, -1)], -1)
+        us, gens = [], []
+
+        def mpc():
+            us.append(ctrl(z, 0, enc, mpc=True, u_min=u_min,
+                           u_max=u_max).clone())
+            gens.append(generation(model))
+        mpc()
+        torch.manual_seed(11)
+        model.resample()
+        mpc()
+        g = torch.Generator().manual_seed(5)
+        Xd = torch.randn(256, 4, generator=g).cuda()
+        Ud = torch.randn(256, 1, generator=g).cuda()
+        dXd = 0.05 * torch.randn(256, 4, generator=g).cuda()
+        torch.manual_seed(12)
+        model.fit(Xd, Ud, dXd, n_iter=8, batch_size=64, quiet=True,
+                  graph=False)
+        model.eval()
+        mpc()
+        assert gens[0] < gens[1] < gens[2], gens
+        runs[graph] = torch.stack(us)
+        s = ctrl._solver
+        assert (s._graph is not None) == graph
+    assert torch.isfinite(runs[True]).all()
+    assert torch.equal(runs[False], runs[True])
+    # the three plans differ (the model did change under the controller)
+    assert not torch.equal(runs[True][0], runs[True][1])
+    assert not torch.equal(runs[True][1], runs[True][2])
+
+
+def test_controller_step_equals_fit_iterations():
+    """iLQRController.step (ilqr.py:183-235) keeps `_mu` / `_delta` between
+    calls: `fit` (one regularisation reset, then step after step, :277-314) is
+    the same as resetting by hand and calling step() until it converges."""
+    import pddp_amd
+    from pddp_amd.controllers import iLQRController
+    from pddp_amd.controllers.ilqr import iLQRState
+    from pddp_amd.controllers.solver import fit_alphas
+    from pddp_amd.examples import cartpole
+    enc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
+    model, cost = cartpole.CartpoleDynamicsModel(0.1), cartpole.CartpoleCost()
+    N = 30
+    g = torch.Generator().manual_seed(3)
+    z0 = torch.tensor([0.0, 0.0, 3.0, 0.0], dtype=torch.float64).cuda()
+    U = (0.1 * torch.randn(N, 1, generator=g, dtype=torch.float64)).cuda()
+    u_min = torch.tensor([-10.0], dtype=torch.float64)
+    u_max = torch.tensor([10.0], dtype=torch.float64)
+    a = iLQRController(None, model, cost)
+    trace_fit = []
+    Zf, Uf, st_f = a.fit(U.clone(), enc, n_iterations=6, z0=z0, u_min=u_min,
+                         u_max=u_max,
+                         on_iteration=lambda i, st, Z, U_, J: trace_fit.append(
+                             (int(st), float(J))))
+    b = iLQRController(None, model, cost)
+    b._mu, b._delta = 0.0, 2.0                 # _reset_reg (ilqr.py:364-367)
+    trace_step, Ucur, st = [], U.clone(), None
+    for it in range(6):
+        st = b.step(z0, Ucur, it, enc, alphas=fit_alphas(torch.float64, "cuda"),
+                    u_min=u_min, u_max=u_max,
+                    on_iteration=lambda i, s_, Z, U_, J: trace_step.append(
+                        (int(s_), float(J))))
+        if st in (iLQRState.ACCEPTED, iLQRState.CONVERGED):
+            Ucur = b._U_nominal
+        if st in (iLQRState.CONVERGED, iLQRState.MAX_REG):
+            break
+    assert [t[0] for t in trace_fit] == [t[0] for t in trace_step]
+    assert np.allclose([t[1] for t in trace_fit], [t[1] for t in trace_step],
+                       rtol=1e-12)
+    assert st == st_f
+    assert torch.allclose(Uf, b._U_nominal, rtol=1e-12, atol=1e-14)
+    assert torch.allclose(Zf, b._Z_nominal, rtol=1e-12, atol=1e-14)
+    assert abs(a._mu - b._mu) <= 1e-15 and abs(a._delta - b._delta) <= 1e-15
 
 
 def _bnn_problem(problem, B, N, seed=0):
