@@ -251,7 +251,85 @@ def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
 MFMA_F32_PEAK_TFLOPS = 157.0  # MI355X_MICROARCH.md: dense f32 matrix peak
 
 
-def bench_bnn(args):
+
+def bnn_cpu_baseline(model, enc, N, n, m, A, opts):
+    """The torch model of the BNN workloads on the host, ONE thread, same
+    weights: the network work of one trajectory-iteration - the derivative
+    rollout's 1 + n + m rows (the input and its n + m directions,
+    evaluation.py:203-226 replicates the input like this) and the line
+    search's A candidate rows, N moment-matched steps each - timed once.  The
+    sweep, the cost derivatives and autograd's backward pass are NOT included
+    (the figure flatters the CPU); kind "port": pddp_amd's own torch
+    restatement of modules.py:287-386 (the reference does not travel)."""
+    import copy
+    import pddp_amd
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        cpu = copy.deepcopy(model).cpu().eval()
+        cpu.resample()
+        D = cpu.state_size
+        g = torch.Generator().manual_seed(0)
+        z0 = pddp_amd.GaussianVariable(
+            torch.zeros(D), var=1e-2 * torch.ones(D)).encode(enc)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for rows in (1 + n + m, A):
+                z = z0.unsqueeze(0).repeat(rows, 1)
+                for t in range(N):
+                    u = 0.1 * torch.randn(rows, m, generator=g)
+                    z = cpu(z, u, t, enc, **opts)
+        dt = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(threads)
+    return {"value": 1.0 / dt, "unit": "trajectory-iterations/s", "cores": 1,
+            "kind": "port",
+            "sample": "network part of ONE trajectory-iteration (N = %d steps "
+                      "of %d derivative rows + %d candidate rows, 100 "
+                      "particles) in %.2f s on one host thread; sweep, cost "
+                      "derivatives and the backward pass of autograd excluded"
+                      % (N, 1 + n + m, A, dt)}
+
+
+def sweep_roofline_of(s, lib, reps=6):
+    """HBM roofline entry of the backward sweep of a live solver: events on
+    the dispatch, algorithmic bytes of SURVEY 8(d)."""
+    pool = EventPool(lib)
+    for _ in range(2):
+        s.backward(active=s.active, variant=s.kernel_variant)
+    for _ in range(reps):
+        s.backward(active=s.active, variant=s.kernel_variant,
+                   events=pool.pair())
+    torch.cuda.synchronize(s.device)
+    d = np.array(pool.durations())
+    nbytes = s.B * algorithmic_bytes_per_trajectory(
+        s.N, s.n, s.m, s.rec.element_size(), True)
+    ach = nbytes / float(d.mean()) / 1e9
+    return {"bound": "hbm", "kernel": "backward Riccati sweep (n = %d)" % s.n,
+            "avg_launch_us": float(d.mean()) * 1e6,
+            "min_launch_us": float(d.min()) * 1e6,
+            "algorithmic_bytes_per_launch": nbytes, "achieved": ach,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": profile_traffic("n%d_sweep" % s.n)}
+
+
+def profile_traffic(tag):
+    """HBM bytes per launch from the committed PMC summaries (profiles/),
+    newest round first; None when no summary names `tag`."""
+    for rnd in ("r03", "r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, tag))
+        if os.path.exists(path):
+            try:
+                with open(path) as fh:
+                    v = json.load(fh)
+                return {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                        "source": "profiles/%s" % os.path.basename(path)}
+            except (OSError, KeyError, ValueError):
+                pass
+    return None
+
+
+def bench_bnn(args, emit=True):
     """Secondary workloads.  --workload cartpole_bnn = BASELINE.json configs[2]:
     cartpole with the BNN dynamics model ([200, 200] hidden, 100 particles,
     moment-matched rollouts, DEFAULT encoding n = 14), horizon 100, B = 4096
@@ -389,14 +467,23 @@ def bench_bnn(args):
         },
         "cpu_baseline": None,
     }
+    if world == 1:
+        from pddp_amd import _native
+        out["roofline"]["other_kernels"] = [
+            sweep_roofline_of(s, _native.lib())]
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = bnn_cpu_baseline(
+                model, enc, N, n, m, A, {"use_predicted_std": False,
+                                         "infer_noise_variables": True})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
+    if rank == 0 and emit:
         print(json.dumps(out))
+    return out
 
 
-def bench_mpc_bnn(args):
+def bench_mpc_bnn(args, emit=True):
     """--workload mpc_bnn = BASELINE.json configs[4]: the receding-horizon loop
     of examples/mpc_animation.py:29-39 on cartpole with the BNN dynamics model,
     horizon 50, 256 restarts x 200 control steps, 11-alpha schedule
@@ -420,6 +507,8 @@ def bench_mpc_bnn(args):
     ienc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
     iu = torch.triu_indices(4, 4)
     tri = (0.1 * torch.eye(4))[iu[0], iu[1]].to(dev)  # var 1e-2: chol = 0.1 I
+
+    keep = {}
 
     def run(graph):
         torch.manual_seed(0)
@@ -466,6 +555,7 @@ def bench_mpc_bnn(args):
             x = control_step(x)
         torch.cuda.synchronize(dev)
         dt = time.perf_counter() - t0
+        keep["model"], keep["solver"] = model, ctrl._solver
         return dt, rounds[0] / K, getattr(ctrl._solver.plugin,
                                           "last_derivs_path", None), \
             bool(torch.isfinite(x).all()), int(resets)
@@ -499,8 +589,47 @@ def bench_mpc_bnn(args):
             "modes": res, "derivative_path": path, "state_finite": finite},
         "roofline": None, "cpu_baseline": None,
     }
-    if rank == 0:
+    if world == 1 and "model" in keep:
+        # the dominant kernel of a control step: the fused network in forward
+        # mode (derivative rollout of every restart), timed alone
+        from pddp_amd import _native
+        model, sv = keep["model"], keep["solver"]
+        D, m, H, grp = 4, 1, 200, 8
+        live = 1 + D + m
+        in_dim = len(CM.non_angular_indices) + 2 * len(CM.angular_indices) + m
+        F = torch.randn(B * P * grp, in_dim, device=dev)
+        model.model._jvp_native(F, P, D, grp, live=live)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            model.model._jvp_native(F, P, D, grp, live=live)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        dur = e0.elapsed_time(e1) * 1e-3 / 5
+        flop = 2.0 * B * P * live * (in_dim * H + H * H + H * D)
+        out["roofline"] = {
+            "bound": "mfma",
+            "kernel": "fused BNN network, forward mode, %d restarts "
+                      "(launch-bound at this batch: a control step is %.1f "
+                      "rounds of ~%d launches)" % (B, rps, 2 * (N + 1)),
+            "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
+            "avg_launch_us": dur * 1e6, "algorithmic_flop_per_launch": flop,
+            "traffic": None,
+            "other_kernels": [sweep_roofline_of(sv, _native.lib())]}
+        if not args.no_cpu_baseline:
+            cb = bnn_cpu_baseline(model, enc, N, 14, 1, 11,
+                                  {"use_predicted_std": False,
+                                   "infer_noise_variables": True})
+            # a control step is `rps` trajectory-iterations of every restart
+            cb["value"] = cb["value"] / max(rps, 1e-9)
+            cb["unit"] = "restart-control-steps/s"
+            cb["sample"] += "; x %.2f rounds per control step" % rps
+            out["cpu_baseline"] = cb
+    if rank == 0 and emit:
         print(json.dumps(out))
+    return out
 
 
 class EventPool(object):
@@ -630,6 +759,9 @@ def main():
     ap.add_argument("--no-points", action="store_true",
                     help="skip the extra roofline points (B = 16384, fp64, "
                          "cold cache)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short runs of BASELINE configs[2] / [3] / "
+                         "[4] appended to the default line")
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="backward kernel (include/pddp_hip.h): 0 auto")
     args = ap.parse_args()
@@ -668,6 +800,7 @@ def main():
     R_EV = 2
     pool_sweep, pool_search = EventPool(lib), EventPool(lib)
     reps, reps_ev = [], []
+    accepted_acc = torch.zeros((), dtype=torch.int64, device=device)
     for rep in range(R + R_EV):
         with_events = rep >= R
         # every repetition times the same K rounds from the same nominal
@@ -688,6 +821,10 @@ def main():
             # accepted nominals
             s.round(5e-6, 1e10, n_iter, backward_events=ev[i][0],
                     search_events=ev[i][1])
+            if with_events:  # (no host sync: a device-side sum)
+                # attempts of this round that were accepted (state 1 ACCEPTED,
+                # 5 CONVERGED; every trajectory is live throughout the region)
+                accepted_acc += ((s.state == 1) | (s.state == 5)).sum()
         if world > 1:  # the one exchange of the path: best rollout over RCCL
             gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
         torch.cuda.synchronize(device)
@@ -723,15 +860,21 @@ def main():
     # every timed launch swept `attempted_all / launches` trajectories on average
     sweep_bytes = attempted_all / launches * per_traj
     achieved = sweep_bytes / float(d_sweep.mean()) / 1e9
+    # share of the attempts that were accepted (only those read the winner
+    # back, write a new nominal and its records)
+    accepted_share = float(accepted_acc.item()) / max(attempted_all, 1)
     search_bytes = search_accept_bytes(attempted_all / launches, N, n, m,
-                                       int(s.A), s.lay.stride, itemsize)
+                                       int(s.A), s.lay.stride, itemsize,
+                                       accepted_share)
+    search_timed = getattr(s, "last_search_timed", None)
 
     # HBM traffic of the same kernels from rocprofv3 PMC passes (FETCH_SIZE and
     # WRITE_SIZE cannot share a pass, and counters cannot be read from inside
     # this process): taken from the committed summary of the profiled run of
     # this very command, see profiles/.
     traffic, traffic_search = None, None
-    for tname in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json",
+                  "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if not (os.path.exists(tpath) and B == 4096 and N == 100
                 and args.dtype == "f32"):
@@ -803,14 +946,20 @@ def main():
                     "bound": "hbm",
                     "kernel": "fused line search + accept + records "
                               "(line_search_lds_kernel<.., FUSED>)",
+                    "launch_timed": search_timed,
                     "avg_launch_us": float(d_search.mean()) * 1e6,
                     "min_launch_us": float(d_search.min()) * 1e6,
+                    "accepted_share": accepted_share,
                     "algorithmic_bytes_per_launch": search_bytes,
                     "achieved": search_bytes / float(d_search.mean()) / 1e9,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": search_bytes / float(d_search.mean()) / 1e9 /
                             HBM_PEAK_GBS,
                     "traffic": traffic_search,
+                    "traffic_frac": (
+                        traffic_search["hbm_bytes_per_launch"] /
+                        float(d_search.mean()) / 1e9 / HBM_PEAK_GBS
+                        if traffic_search else None),
                 }],
             },
         }
@@ -829,6 +978,26 @@ def main():
             out["cpu_baseline"] = cpu_baseline("cartpole", 0.1, N, bound)
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_secondary and B == 4096 and N == 100 \
+                and args.dtype == "f32":
+            # BASELINE configs[2] / [3] (one GPU's shard) / [4], shortened, in
+            # the driver's line: 2 rounds, 2 rounds, 20 control steps
+            import copy
+            del s
+            torch.cuda.empty_cache()
+            sec = []
+            for wl, k, w in (("cartpole_bnn", 2, 1),
+                             ("double_cartpole_bnn", 2, 1), ("mpc_bnn", 20, 2)):
+                a2 = copy.copy(args)
+                a2.workload, a2.steps, a2.warmup = wl, k, w
+                a2.batch = a2.horizon = None
+                try:
+                    sec.append((bench_mpc_bnn if wl == "mpc_bnn"
+                                else bench_bnn)(a2, emit=False))
+                except Exception as e:  # (reported, not hidden)
+                    sec.append({"workload": wl, "error": repr(e)[:300]})
+                torch.cuda.empty_cache()
+            out["secondary"] = sec
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
