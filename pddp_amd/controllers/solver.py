@@ -39,8 +39,10 @@ def _on_device(fn):
 
 
 def fit_alphas(dtype, device):
-    """ilqr.py:282 (the schedule `fit` actually uses)."""
-    return (1.025 ** (-torch.arange(10.0, dtype=torch.float64) ** 2)).to(
+    """ilqr.py:282 (the schedule `fit` actually uses).  The reference forms it
+    in its default dtype, float32, and casts (`.to(dtype=Z.dtype)`, :189): a
+    float64 run sees the float32-ROUNDED step sizes."""
+    return (1.025 ** (-torch.arange(10.0, dtype=torch.float32) ** 2)).to(
         dtype=dtype, device=device)
 
 

@@ -538,8 +538,7 @@ def load_reference_state(model, state):
                         for k, v in state.items() if k.startswith("eps_in/")}
         model.output = {}
     model.eps_out = {}
-    return model
-    if hasattr(model, "model"):
-        model.model.__dict__.pop("_mask_cache", None)
+    mlp.__dict__.pop("_mask_cache", None)
     bump_generation(model)
+    return model
 

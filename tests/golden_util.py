@@ -32,3 +32,18 @@ def rel_err(a, b):
     b = np.asarray(b, np.float64)
     scale = max(np.abs(b).max(), 1e-300) if b.size else 1.0
     return np.abs(a - b).max() / scale if b.size else 0.0
+
+
+def elementwise_err(a, b, floor=1e-6):
+    """Largest |a - b| / max(|b|, floor * max|b| per last-axis row): every entry
+    against its OWN size (entries below `floor` of the largest entry of their
+    row are measured against that floor - they are sums that cancel to that
+    level).  rel_err measures everything against the global maximum and never
+    looks at a small gain next to a large one."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if not b.size:
+        return 0.0
+    row = np.abs(b).max(axis=-1, keepdims=True)
+    den = np.maximum(np.abs(b), floor * np.maximum(row, 1e-300))
+    return float((np.abs(a - b) / den).max())

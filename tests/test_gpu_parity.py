@@ -8,7 +8,8 @@ import pytest
 import torch
 
 import oracle as orc
-from golden_util import DT, FWD_NAMES, load, np_dtype, rel_err, tags
+from golden_util import (DT, FWD_NAMES, elementwise_err, load, np_dtype,
+                         rel_err, tags)
 
 pytestmark = pytest.mark.gpu
 
@@ -264,6 +265,11 @@ def test_backward_vs_reference_golden(problem, dtype):
                         # numbers; held to 1e-8
                         assert rel_err(kb, g[key + "/k"]) < 1e-8, key
                         assert rel_err(Kb, g[key + "/K"]) < 1e-8, key
+                        # ... and entry by entry (a small gain next to a large
+                        # one is invisible in the max-norm ratio): each K[t, i,
+                        # j] to 1e-6 of its own size (of 1e-6 of its row's
+                        # largest entry at least - sums that cancel that far)
+                        assert elementwise_err(Kb, g[key + "/K"]) < 1e-6, key
                     elif int(g64[key + "/ok"]):
                         # fp32: against the reference's fp64 run, no further
                         # off than F32_RATIO x the reference's own fp32 run
@@ -1854,6 +1860,210 @@ def test_bnn_mpc_graph_replay_equals_eager(use_predicted_std):
     assert torch.isfinite(xe).all() and torch.isfinite(ue).all()
     for a, b in ((0, 255), (7, 100)):
         assert torch.equal(ue[:, a], ue[:, b]) and torch.equal(Ue[a], Ue[b])
+
+
+def _round3():
+    from golden_util import GOLDEN_DIR
+    import os
+    return np.load(os.path.join(GOLDEN_DIR, "round3_extras.npz"))
+
+
+def test_bnn_training_step_vs_reference_golden():
+    """One fixed-noise training step of the BNN dynamics model against the
+    reference's own (tools/make_golden.py --round3, group train/): the
+    normalisation `fit` computes (modules.py:170-176), the likelihood
+    (losses.py:20-38), the concrete-dropout regulariser (modules.py:550-583,
+    753-771), every parameter gradient, and the parameters after three
+    Adam(amsgrad) steps (modules.py:179) - float64 on the GPU, held masks."""
+    import pddp_amd
+    from pddp_amd.examples.cartpole import CartpoleDynamicsModel as CM
+    from pddp_amd.models.bnn import (bnn_dynamics_model_factory,
+                                     gaussian_log_likelihood)
+    from pddp_amd.utils.angular import augment_state
+    g = _round3()
+    dt = torch.float64
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=dt).cuda()
+    X, U, dX = t(g["train/X"]), t(g["train/U"]), t(g["train/dX"])
+    Nd = X.shape[0]
+    model = bnn_dynamics_model_factory(4, 1, [32, 24], CM.angular_indices,
+                                       CM.non_angular_indices)(
+        n_particles=10).to(dt).cuda()
+    # normalisation through OUR fit (no training step: n_iter = 0)
+    model.train()
+    model.fit(X, U, dX, n_iter=0, quiet=True, graph=False)
+    for nm in ("X_mean", "X_std", "X_std_inv", "dX_mean", "dX_std",
+               "dX_std_inv"):
+        assert rel_err(getattr(model, nm).cpu().numpy(),
+                       g["train/state/" + nm]) < 1e-12, nm
+    mlp = model.model
+    ours = {"model.fc_0.weight": mlp.hidden[0].weight,
+            "model.fc_0.bias": mlp.hidden[0].bias,
+            "model.drop_0.logit_p": mlp.drops[0].logit_p,
+            "model.fc_1.weight": mlp.hidden[1].weight,
+            "model.fc_1.bias": mlp.hidden[1].bias,
+            "model.drop_1.logit_p": mlp.drops[1].logit_p,
+            "model.fc_out.weight": mlp.out.weight,
+            "model.fc_out.bias": mlp.out.bias}
+    names = [str(n) for n in g["train/param_names"]]
+    assert sorted(names) == sorted(ours)
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert len(trainable) == len(names)  # the same set is trained
+    with torch.no_grad():
+        for n in names:
+            ours[n].copy_(t(g["train/init/" + n]).reshape(ours[n].shape))
+        for k in (0, 1):
+            mlp.drops[k].noise = t(g["train/state/drop_%d.noise" % k])
+            mlp.drops[k].temperature.copy_(
+                t(g["train/state/drop_%d.temperature" % k]))
+    params = [ours[n] for n in names]
+    opt = torch.optim.Adam(params, float(g["train/lr"]), amsgrad=True)
+    rs = float(g["train/reg_scale"])
+    for step in range(3):
+        opt.zero_grad()
+        Xa = augment_state(X, CM.angular_indices, CM.non_angular_indices)
+        out = mlp((torch.cat([Xa, U], -1) - model.X_mean) * model.X_std_inv,
+                  resample=False)
+        mean, log_std = out.split([4, 4], -1)
+        mean = mean * model.dX_std + model.dX_mean
+        log_std = log_std + model.dX_std.log()
+        nll = -gaussian_log_likelihood(dX, mean, log_std.exp()).mean()
+        reg = mlp.regularization() / Nd
+        loss = nll + rs * reg
+        loss.backward()
+        for nm, v in (("nll", nll), ("reg", reg), ("loss", loss)):
+            want = float(g["train/step%d/%s" % (step, nm)])
+            assert abs(v.item() - want) < 1e-9, (step, nm)
+        if step == 0:
+            for n in names:
+                e = rel_err(ours[n].grad.cpu().numpy().reshape(-1),
+                            g["train/grad0/" + n].reshape(-1))
+                assert e < 1e-9, (n, e)
+        opt.step()
+    for n in names:
+        e = rel_err(ours[n].detach().cpu().numpy().reshape(-1),
+                    g["train/after3/" + n].reshape(-1))
+        assert e < 1e-9, (n, e)
+
+
+def test_pddp_controller_fit_vs_reference_golden():
+    """PDDPController.fit (pddp.py:61-206) against the reference's own run
+    (group pddp/): a deterministic plant (the true cartpole model, no noise),
+    a model that records what it is trained on, the reference's uniform draw
+    replayed.  Held: the exploration trials (trial 0 replays U, trial 1 maps
+    sampling_noise * rand to [u_min, u_max], :127-132), the closed-loop MPC
+    trials of H = 2 N steps (:180), every dataset `model.fit` receives -
+    including the keep-the-LAST-rows rule at max_dataset_size = 20 (:262-265)
+    - the trial numbering, and the final plan."""
+    import pddp_amd
+    from pddp_amd import GaussianVariable
+    from pddp_amd.controllers import PDDPController
+    from pddp_amd.controllers import pddp as pddp_mod
+    from pddp_amd.examples.cartpole import CartpoleCost, CartpoleDynamicsModel
+    g = _round3()
+    dt = torch.float64
+    enc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
+    ienc = enc
+
+    class FlatEnv(object):
+        def __init__(self, model, x0):
+            self.model, self.x0, self.x = model, x0.clone(), x0.clone()
+
+        def reset(self):
+            self.x = self.x0.clone()
+
+        def get_state(self):
+            return GaussianVariable(self.x.clone(),
+                                    var=1e-6 * torch.ones_like(self.x))
+
+        def apply(self, u):
+            with torch.no_grad():
+                self.x = self.model(self.x, u.detach().to(self.x), 0,
+                                    ienc).detach()
+
+    fitted = []
+
+    class RecModel(CartpoleDynamicsModel):
+        def fit(self, X, U, dX, quiet=False, **kw):
+            fitted.append((X.cpu().numpy(), U.cpu().numpy(), dX.cpu().numpy()))
+
+    x0 = torch.as_tensor(g["pddp/x0"], dtype=dt).cuda()
+    env = FlatEnv(CartpoleDynamicsModel(0.1).double().cuda(), x0)
+    ctrl = PDDPController(env, RecModel(0.1).double().cuda(),
+                          CartpoleCost().double().cuda(), training_opts={})
+    U0 = torch.as_tensor(g["pddp/U0"], dtype=dt).cuda()
+    draws = [torch.as_tensor(d, dtype=dt).cuda() for d in g["pddp/rand_draws"]]
+    trials = []
+    real = torch.rand_like
+
+    def replay(t_, *a, **k):
+        return draws.pop(0).reshape(t_.shape).to(t_)
+    pddp_mod.torch.rand_like = replay
+    try:
+        Z, U, st = ctrl.fit(
+            U0, encoding=enc, quiet=True, max_trials=4,
+            n_initial_sample_trajectories=2, sampling_noise=0.8,
+            max_dataset_size=20,
+            u_min=torch.tensor([-3.0], dtype=dt),
+            u_max=torch.tensor([3.0], dtype=dt), n_iterations=4,
+            on_trial=lambda i, X_, U_: trials.append(
+                (i, X_.cpu().numpy(), U_.cpu().numpy())))
+    finally:
+        pddp_mod.torch.rand_like = real
+    assert not draws  # every recorded draw was consumed
+    assert len(trials) == int(g["pddp/n_trials"])
+    assert len(fitted) == int(g["pddp/n_fits"])
+    for k, (i, X_, U_) in enumerate(trials):
+        assert i == int(g["pddp/trial%d/index" % k])
+        assert X_.shape == g["pddp/trial%d/X" % k].shape  # H = N, N, 2N, 2N
+        assert rel_err(X_, g["pddp/trial%d/X" % k]) < 1e-6, k
+        assert rel_err(U_, g["pddp/trial%d/U" % k]) < 1e-6, k
+    for k, (X_, U_, dX_) in enumerate(fitted):
+        assert X_.shape == g["pddp/fit%d/X" % k].shape  # 16, then the last 20
+        assert rel_err(X_, g["pddp/fit%d/X" % k]) < 1e-6, k
+        assert rel_err(U_, g["pddp/fit%d/U" % k]) < 1e-6, k
+        assert rel_err(dX_, g["pddp/fit%d/dX" % k]) < 1e-5, k
+    assert int(st) == int(g["pddp/state"])
+    assert rel_err(U.cpu().numpy(), g["pddp/U"]) < 1e-6
+    assert rel_err(Z.cpu().numpy(), g["pddp/Z"]) < 1e-6
+
+
+@pytest.mark.parametrize("ename", ["ignore", "default"])
+def test_aggregate_cost_vs_reference_golden(ename):
+    """`forward` / `backward` / line search (ilqr.py:393-791) under an
+    AggregateCost built with the operator overloads (costs/base.py:25-181:
+    cost * 0.6 + cost' * 0.25 + 0.5) against the reference's outputs (group
+    agg/), on the GPU: derivative records through the plugin path, HIP sweep,
+    candidates and costs - float64, 1e-9."""
+    import pddp_amd
+    from pddp_amd.controllers import ilqr
+    from pddp_amd.controllers.solver import fit_alphas
+    from pddp_amd.examples.cartpole import CartpoleCost, CartpoleDynamicsModel
+    g = _round3()
+    dt = torch.float64
+    enc = {"ignore": pddp_amd.StateEncoding.IGNORE_UNCERTAINTY,
+           "default": pddp_amd.StateEncoding.DEFAULT}[ename]
+    agg = (CartpoleCost().double() * 0.6 +
+           CartpoleCost(pole_length=0.8).double() * 0.25 + 0.5).cuda()
+    model = CartpoleDynamicsModel(0.1).double().cuda()
+    pre = "agg/%s/" % ename
+    z0 = torch.as_tensor(g[pre + "z0"], dtype=dt).cuda()
+    U = torch.as_tensor(g[pre + "U"], dtype=dt).cuda()
+    um = torch.tensor([-10.0], dtype=dt)
+    uM = torch.tensor([10.0], dtype=dt)
+    out = ilqr.forward(z0, U.clone(), model, agg, enc, True, {}, {},
+                       u_min=um, u_max=uM)
+    names = ("Z", "F_z", "F_u", "L", "L_z", "L_u", "L_zz", "L_uz", "L_uu")
+    for nm, v in zip(names, out):
+        e = rel_err(v.cpu().numpy(), g[pre + nm])
+        assert e < 1e-9, (nm, e)
+    k, K = ilqr.backward(*out, reg=1.0, u_min=um, u_max=uM, U=U)
+    assert rel_err(k.cpu().numpy(), g[pre + "k"]) < 1e-9
+    assert rel_err(K.cpu().numpy(), g[pre + "K"]) < 1e-9
+    Zn, Un = ilqr._control_law(model, out[0], U, k, K,
+                               fit_alphas(dt, "cuda"), enc, {}, u_min=um,
+                               u_max=uM)
+    J = ilqr._trajectory_cost(agg, Zn, Un, enc, {})
+    assert rel_err(J.cpu().numpy(), g[pre + "J"]) < 1e-9
 
 
 def test_bnn_graphs_follow_model_resample_and_refit():

@@ -477,10 +477,199 @@ def capture_bnn_real_size():
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
 
 
+def capture_round3():
+    """Round-3 fixtures (one file, tests/golden/round3_extras.npz):
+      train/  one fixed-noise training step of the BNN dynamics model through
+              the reference's own modules (normalisation by BNN.fit with
+              n_iter = 0, modules.py:170-176; model forward with held dropout
+              masks, :187-188; likelihood losses.py:20-38; regulariser
+              :550-583, 753-771; backward; Adam(amsgrad) :179) - loss terms,
+              every parameter gradient, the parameters after 3 steps;
+      pddp/   PDDPController.fit (pddp.py:61-206) on a deterministic
+              environment with a model that records what it is trained on:
+              exploration actions, the H = 2 N closed-loop trial, the
+              keep-the-last-rows dataset rule;
+      agg/    forward / backward / line search of ilqr.py under an
+              AggregateCost (costs/base.py:125-181) built with the operator
+              overloads."""
+    from pddp.models.bnn import bnn_dynamics_model_factory
+    from pddp.models.bnn.losses import gaussian_log_likelihood
+    from pddp.examples.cartpole import (CartpoleCost, CartpoleDynamicsModel,
+                                        CartpoleEnv)
+    from pddp.controllers import PDDPController
+    from pddp.utils.angular import augment_state
+    store = {}
+    dtype = torch.float64
+    CM = CartpoleDynamicsModel
+
+    # ------------------------------------------------------------- train/
+    torch.manual_seed(21)
+    D, m, Nd = 4, 1, 48
+    cls = bnn_dynamics_model_factory(D, m, [32, 24], CM.angular_indices,
+                                     CM.non_angular_indices)
+    model = cls(n_particles=10).to(dtype)
+    X = torch.randn(Nd, D, dtype=dtype)
+    U = torch.randn(Nd, m, dtype=dtype)
+    dX = 0.1 * torch.randn(Nd, D, dtype=dtype)
+    store["train/X"], store["train/U"], store["train/dX"] = np_(X), np_(U), np_(dX)
+    model.train()
+    # (normalisation only: one step at learning rate 0 - n_iter = 0 never
+    # ends, modules.py:394-411 counts up to `total` exactly)
+    model.fit(X, U, dX, n_iter=1, learning_rate=0.0, quiet=True)
+    for nm in ("X_mean", "X_std", "X_std_inv", "dX_mean", "dX_std",
+               "dX_std_inv"):
+        store["train/state/" + nm] = np_(getattr(model, nm))
+    X_ = torch.cat([augment_state(X, CM.angular_indices,
+                                  CM.non_angular_indices), U], dim=-1)
+    params = [p for p in model.parameters() if p.requires_grad]
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    lr, reg_scale = 1e-3, 1.0
+    # held masks drawn by the first forward below (modules.py:609-614: no
+    # concrete mask yet -> uniform noise of the batch's shape, then kept)
+    for name, mod in model.model.named_children():
+        if name.startswith("drop"):
+            mod.concrete_noise = None
+    opt = torch.optim.Adam(params, lr, amsgrad=True)
+    store["train/lr"], store["train/reg_scale"] = np.array(lr), np.array(reg_scale)
+    first = True
+    for step in range(3):
+        opt.zero_grad()
+        x_ = model._normalize_input(X_)
+        out = model.model(x_, resample=False)
+        mean, log_std = out.split([D, D], dim=-1)
+        mean, log_std = model._scale_output(mean, log_std)
+        nll = -gaussian_log_likelihood(dX, mean, log_std.exp()).mean()
+        reg = model.model.regularization() / Nd
+        loss = nll + reg_scale * reg
+        if first:
+            # initial weights and the masks' noise (drawn by this forward)
+            for name, mod in model.model.named_children():
+                if hasattr(mod, "noise") and name.startswith("drop"):
+                    store["train/state/%s.noise" % name] = np_(mod.noise)
+                    store["train/state/%s.temperature" % name] = np_(mod.temperature)
+            first = False
+        loss.backward()
+        store["train/step%d/nll" % step] = np_(nll)
+        store["train/step%d/reg" % step] = np_(reg)
+        store["train/step%d/loss" % step] = np_(loss)
+        if step == 0:
+            for n_, p_ in zip(names, params):
+                store["train/grad0/" + n_] = np_(p_.grad)
+                store["train/init/" + n_] = np_(p_)  # (before the first step)
+        opt.step()
+    for n_, p_ in zip(names, params):
+        store["train/after3/" + n_] = np_(p_)
+    store["train/param_names"] = np.array(names)
+
+    # -------------------------------------------------------------- pddp/
+    class FlatEnv(object):
+        """Deterministic cartpole plant: the true model, no noise."""
+
+        def __init__(self, model, x0):
+            self.model, self.x0 = model, x0.clone()
+            self.x = x0.clone()
+
+        def reset(self):
+            self.x = self.x0.clone()
+
+        def get_state(self):
+            return GaussianVariable(self.x.clone(),
+                                    var=1e-6 * torch.ones_like(self.x))
+
+        def apply(self, u):
+            z = self.x
+            with torch.no_grad():
+                self.x = self.model(z, u.detach().to(z), 0,
+                                    StateEncoding.IGNORE_UNCERTAINTY).detach()
+
+    class RecModel(CartpoleDynamicsModel):
+        fitted = []
+
+        def fit(self, X, U, dX, quiet=False, **kw):
+            RecModel.fitted.append((np_(X), np_(U), np_(dX)))
+
+    enc = StateEncoding.IGNORE_UNCERTAINTY
+    Np = 8
+    rmodel = RecModel(0.1).to(dtype)
+    x0 = torch.tensor([0.0, 0.0, 0.3, 0.0], dtype=dtype)
+    env = FlatEnv(CartpoleDynamicsModel(0.1).to(dtype), x0)
+    cost = CartpoleCost().to(dtype)
+    ctrl = PDDPController(env, rmodel, cost, training_opts={})
+    torch.manual_seed(31)
+    U0 = 0.2 * torch.randn(Np, 1, dtype=dtype)
+    store["pddp/U0"], store["pddp/x0"] = np_(U0), np_(x0)
+    u_min = torch.tensor([-3.0], dtype=dtype)
+    u_max = torch.tensor([3.0], dtype=dtype)
+    draws, trials = [], []
+    real_rand_like = torch.rand_like
+
+    def rec_rand_like(t, *a, **k):
+        r = real_rand_like(t, *a, **k)
+        draws.append(np_(r))
+        return r
+    torch.rand_like = rec_rand_like
+    try:
+        Zf, Uf, st = ctrl.fit(
+            U0, encoding=enc, quiet=True, max_trials=4,
+            n_initial_sample_trajectories=2, sampling_noise=0.8,
+            max_dataset_size=20, u_min=u_min, u_max=u_max, n_iterations=4,
+            on_trial=lambda t, X_, U_: trials.append((t, np_(X_), np_(U_))))
+    finally:
+        torch.rand_like = real_rand_like
+    store["pddp/rand_draws"] = np.stack(draws)
+    for k, (t, X_, U_) in enumerate(trials):
+        store["pddp/trial%d/index" % k] = np.array(t)
+        store["pddp/trial%d/X" % k], store["pddp/trial%d/U" % k] = X_, U_
+    for k, (X_, U_, dX_) in enumerate(RecModel.fitted):
+        store["pddp/fit%d/X" % k] = X_
+        store["pddp/fit%d/U" % k] = U_
+        store["pddp/fit%d/dX" % k] = dX_
+    store["pddp/n_trials"] = np.array(len(trials))
+    store["pddp/n_fits"] = np.array(len(RecModel.fitted))
+    store["pddp/Z"], store["pddp/U"] = np_(Zf), np_(Uf)
+    store["pddp/state"] = np.array(int(st))
+
+    # --------------------------------------------------------------- agg/
+    Na = 12
+    agg = CartpoleCost().to(dtype) * 0.6 + CartpoleCost(
+        pole_length=0.8).to(dtype) * 0.25 + 0.5
+    amodel = CartpoleDynamicsModel(0.1).to(dtype)
+    for ename in ("ignore", "default"):
+        e = ENCODINGS[ename]
+        z0 = GaussianVariable(
+            torch.tensor([0.01, -0.02, 0.4, 0.0], dtype=dtype),
+            var=1e-2 * torch.ones(4, dtype=dtype)).encode(e).detach()
+        Ua = nominal_controls(Na, 1, dtype, "cos")
+        um = torch.tensor([-10.0], dtype=dtype)
+        uM = torch.tensor([10.0], dtype=dtype)
+        Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu = forward(
+            z0, Ua.clone(), amodel, agg, e, True, {}, {}, u_min=um, u_max=uM)
+        pre = "agg/%s/" % ename
+        store[pre + "z0"], store[pre + "U"] = np_(z0), np_(Ua)
+        for nm, v in (("Z", Z), ("F_z", F_z), ("F_u", F_u), ("L", L),
+                      ("L_z", L_z), ("L_u", L_u), ("L_zz", L_zz),
+                      ("L_uz", L_uz), ("L_uu", L_uu)):
+            store[pre + nm] = np_(v)
+        k, K = backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu, reg=1.0,
+                        u_min=um, u_max=uM, U=Ua)
+        store[pre + "k"], store[pre + "K"] = np_(k), np_(K)
+        al = ALPHAS_FIT().to(dtype)
+        Zn, Un = _control_law(amodel, Z, Ua, k, K, al, e, {}, u_min=um,
+                              u_max=uM)
+        J = _trajectory_cost(agg, Zn, Un, e, {})
+        store[pre + "J"] = np_(J)
+    path = os.path.join(OUT, "round3_extras.npz")
+    np.savez_compressed(path, **store)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     np.random.seed(0)
+    if "--round3" in sys.argv:
+        capture_round3()
+        return
     if "--bnn-only" in sys.argv:
         capture_bnn()
         return
