@@ -483,6 +483,147 @@ def bench_bnn(args, emit=True):
     return out
 
 
+def bench_gp(args, emit=True):
+    """--workload double_cartpole_gp: BASELINE.json configs[3] AS STATED -
+    double cartpole (state 6) with GP dynamics, horizon 150 - on the build's
+    own GP plugin (pddp_amd/models/gp.py: squared-exponential GPs, exact
+    moment matching; the reference has no GP: PARITY UNPINNED, checker
+    oracle/gp_port.py).  The moment-matched step is batched torch (no HIP
+    kernel yet) and costs E^2 M^2 kernel evaluations per row, its Jacobians
+    come from autograd: the batch is what fits a short run (default 16
+    trajectories per GPU, 60 training points), not configs[3]'s 1024 - stated
+    in the line.  A step is one round of the fit loop."""
+    import pddp_amd
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.examples import double_cartpole as ex
+    from pddp_amd.models.gp import gp_dynamics_model_factory
+    world, rank, dev = init_ranks()
+    CM, cost_cls = ex.DoubleCartpoleDynamicsModel, ex.DoubleCartpoleCost
+    B = args.batch or 16
+    N = args.horizon or 150
+    K = args.steps if args.steps != 30 else 2
+    W = args.warmup if args.warmup != 5 else 1
+    M = 60
+    D, m, A = 6, 1, 10
+    n = D + D * (D + 1) // 2
+    g = torch.Generator().manual_seed(0)
+    true = CM(0.05)
+    mean0 = torch.tensor([0.0, 0.0, 3.14159, 0.0, 3.14159, 0.0])
+    X = mean0 + torch.cat([0.5 * torch.randn(M, 2, generator=g),
+                           0.8 * torch.randn(M, 1, generator=g),
+                           torch.randn(M, 1, generator=g),
+                           0.8 * torch.randn(M, 1, generator=g),
+                           torch.randn(M, 1, generator=g)], -1)
+    U = 6.0 * torch.randn(M, 1, generator=g)
+    with torch.no_grad():
+        dX = true(X, U, 0, pddp_amd.StateEncoding.IGNORE_UNCERTAINTY) - X
+    model = gp_dynamics_model_factory(D, m, CM.angular_indices,
+                                      CM.non_angular_indices)().to(dev)
+    model.fit(X.to(dev), U.to(dev), dX.to(dev))
+    model.eval()
+    cost = cost_cls().to(dev)
+    enc = pddp_amd.StateEncoding.DEFAULT
+    plugin = TorchProblem(model, cost, enc, {}, {})
+    s = ILQRSolver(None, B, N, torch.float32, dev, torch.tensor([-20.0]),
+                   torch.tensor([20.0]), fit_alphas(torch.float32, dev),
+                   plugin=plugin, n=n, m=m)
+    g = torch.Generator().manual_seed(rank)
+    z0 = torch.stack([pddp_amd.GaussianVariable(
+        mean0 + 1e-2 * torch.randn(D, generator=g),
+        var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).to(dev)
+    s.set_nominal(z0, (0.1 * torch.randn(B, N, m, generator=g)).to(dev))
+    for _ in range(W):
+        s.round(5e-6, 1e10, 1 << 30)
+    s.n_live.zero_()
+    live0 = int(s.active.sum().item())
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(K):
+        s.round(5e-6, 1e10, 1 << 30)
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    liveK = int(s.active.sum().item())
+    attempted = live0 + int(s.n_live.sum().item()) - liveK
+    # the dominant operation: one moment-matched step of the candidate rows
+    rows = B * A
+    zr = z0.repeat_interleave(A, 0)
+    ur = torch.zeros(rows, m, device=dev)
+    with torch.no_grad():
+        model(zr, ur, 0, enc)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            model(zr, ur, 0, enc)
+        torch.cuda.synchronize(dev)
+        dur = (time.perf_counter() - t1) / 3
+    d_in = 9
+    # kernel evaluations' flops: Q needs ~ (2 d^2 + 4 d) flops per (a, b, i, j)
+    flop = rows * D * D * M * M * (2 * d_in * d_in + 4 * d_in)
+    out = {
+        "metric": "pddp_iterations_per_sec", "value": attempted / elapsed,
+        "unit": "trajectory-iterations/s", "n_gpus": world, "steps": K,
+        "warmup": W, "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "BASELINE.json configs[3] as stated: double cartpole "
+                        "(state 6, DEFAULT encoding n=27 m=1) with GP dynamics "
+                        "(the build's own plugin - the reference has no GP: "
+                        "PARITY UNPINNED, checker oracle/gp_port.py), %d "
+                        "training points, exact moment matching in batched "
+                        "torch ops, autograd Jacobians, horizon=%d, batch=%d "
+                        "trajectories per GPU (REDUCED from configs[3]'s 1024 "
+                        "per GPU: no HIP kernel for the GP step yet), bounds "
+                        "+-20, 10 line-search alphas" % (M, N, B),
+            "batch_per_gpu": B, "horizon": N, "alphas": A,
+            "training_points": M, "parity": "unpinned",
+            "live_trajectories_start_end": [live0, liveK],
+            "derivative_path": getattr(plugin, "last_derivs_path", None)},
+        "roofline": {
+            "bound": "mfma", "kernel": "GP moment-matched step (torch ops: "
+                                       "einsum / solve / exp), %d candidate "
+                                       "rows" % rows,
+            "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
+            "avg_launch_us": dur * 1e6, "algorithmic_flop_per_launch": flop,
+            "traffic": None},
+        "cpu_baseline": None,
+    }
+    if world == 1:
+        from pddp_amd import _native
+        out["roofline"]["other_kernels"] = [sweep_roofline_of(s, _native.lib())]
+        if not args.no_cpu_baseline:
+            import copy
+            cpu = copy.deepcopy(model).cpu()
+            threads = torch.get_num_threads()
+            torch.set_num_threads(1)
+            try:
+                zc, uc = z0[:1].cpu().repeat(1 + n + m, 1), torch.zeros(1 + n + m, m)
+                t2 = time.perf_counter()
+                with torch.no_grad():
+                    for t in range(8):
+                        zc = cpu(zc, uc, t, enc)
+                per_step = (time.perf_counter() - t2) / 8
+            finally:
+                torch.set_num_threads(threads)
+            # one trajectory-iteration: N steps of (1 + n + m) derivative rows
+            # and of A candidate rows
+            sec = per_step * N * (1 + n + m + A) / (1 + n + m)
+            out["cpu_baseline"] = {
+                "value": 1.0 / sec, "unit": "trajectory-iterations/s",
+                "cores": 1, "kind": "port",
+                "sample": "8 moment-matched steps of %d rows of the same torch "
+                          "GP on one host thread (%.3f s per step), scaled to "
+                          "N = %d steps of derivative + candidate rows; sweep "
+                          "and autograd's backward pass excluded"
+                          % (1 + n + m, per_step, N)}
+    if rank == 0 and emit:
+        print(json.dumps(out))
+    return out
+
+
 def bench_mpc_bnn(args, emit=True):
     """--workload mpc_bnn = BASELINE.json configs[4]: the receding-horizon loop
     of examples/mpc_animation.py:29-39 on cartpole with the BNN dynamics model,
@@ -747,7 +888,7 @@ def main():
                          "trajectories in total, sharded over the GPUs")
     ap.add_argument("--workload", default="cartpole",
                     choices=["cartpole", "cartpole_bnn", "double_cartpole_bnn",
-                             "mpc_bnn"],
+                             "double_cartpole_gp", "mpc_bnn"],
                     help="cartpole = BASELINE configs[1] (the headline line); "
                          "cartpole_bnn = configs[2]; double_cartpole_bnn = "
                          "configs[3]'s problem with the reference's BNN model; "
@@ -768,6 +909,8 @@ def main():
     launch_ranks_if_asked(args)
     if args.workload == "mpc_bnn":
         return bench_mpc_bnn(args)
+    if args.workload == "double_cartpole_gp":
+        return bench_gp(args)
     if args.workload != "cartpole":
         return bench_bnn(args)
 
@@ -987,13 +1130,15 @@ def main():
             torch.cuda.empty_cache()
             sec = []
             for wl, k, w in (("cartpole_bnn", 2, 1),
-                             ("double_cartpole_bnn", 2, 1), ("mpc_bnn", 20, 2)):
+                             ("double_cartpole_bnn", 2, 1),
+                             ("double_cartpole_gp", 1, 1), ("mpc_bnn", 20, 2)):
                 a2 = copy.copy(args)
                 a2.workload, a2.steps, a2.warmup = wl, k, w
                 a2.batch = a2.horizon = None
                 try:
-                    sec.append((bench_mpc_bnn if wl == "mpc_bnn"
-                                else bench_bnn)(a2, emit=False))
+                    fn = {"mpc_bnn": bench_mpc_bnn,
+                          "double_cartpole_gp": bench_gp}.get(wl, bench_bnn)
+                    sec.append(fn(a2, emit=False))
                 except Exception as e:  # (reported, not hidden)
                     sec.append({"workload": wl, "error": repr(e)[:300]})
                 torch.cuda.empty_cache()

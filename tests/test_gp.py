@@ -1,0 +1,187 @@
+"""GP dynamics plugin (pddp_amd/models/gp.py; BASELINE.json north_star "GP
+dynamics", configs[3]).  The reference has no GP: PARITY UNPINNED - the torch
+model is held to the independent numpy restatement (oracle/gp_port.py) and to
+sampling."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import pddp_amd  # noqa: E402
+from pddp_amd import GaussianVariable, StateEncoding  # noqa: E402
+from pddp_amd.models.gp import gp_dynamics_model_factory  # noqa: E402
+
+
+def _toy(seed=0, M=14, angular=(2,)):
+    """A small GP on a cartpole-shaped system (D = 4, one angle, m = 1)."""
+    g = torch.Generator().manual_seed(seed)
+    D, m = 4, 1
+    X = torch.randn(M, D, generator=g, dtype=torch.float64)
+    U = torch.randn(M, m, generator=g, dtype=torch.float64)
+    dX = 0.3 * torch.sin(X @ torch.randn(D, D, generator=g, dtype=torch.float64)) \
+        + 0.2 * U
+    cls = gp_dynamics_model_factory(D, m, list(angular))
+    model = cls().double()
+    model.fit(X, U, dX)
+    return model, X, U, dX
+
+
+def _oracle_state(model):
+    import oracle.gp_port as gp
+    ell = model.log_ell.exp().detach().numpy()
+    sf2 = (2 * model.log_sf).exp().detach().numpy()
+    sn2 = (2 * model.log_sn).exp().detach().numpy()
+    return gp, ell, sf2, sn2
+
+
+def test_gp_conditioning_and_moments_vs_numpy_port():
+    model, X, U, dX = _toy()
+    gp, ell, sf2, sn2 = _oracle_state(model)
+    Xt = model.Xt.numpy()
+    Kinv, beta = gp.condition(Xt, dX.numpy(), ell, sf2, sn2)
+    assert np.allclose(model.Kinv.numpy(), Kinv, rtol=1e-8, atol=1e-8)
+    assert np.allclose(model.beta.numpy(), beta, rtol=1e-8, atol=1e-9)
+    g = torch.Generator().manual_seed(1)
+    d = Xt.shape[1]
+    for trial in range(3):
+        m = 0.5 * torch.randn(d, generator=g, dtype=torch.float64)
+        A = 0.3 * torch.randn(d, d, generator=g, dtype=torch.float64)
+        S = A @ A.t()
+        S[-1, :] = 0.0
+        S[:, -1] = 0.0  # the action is known exactly
+        with torch.no_grad():
+            mu, Sig, W = model.moments(m, S)
+        mu_o, Sig_o, V_o = gp.moments(Xt, Kinv, beta, ell, sf2, sn2,
+                                      m.numpy(), S.numpy())
+        assert np.allclose(mu.numpy(), mu_o, rtol=1e-9, atol=1e-11)
+        assert np.allclose(Sig.numpy(), Sig_o, rtol=1e-8, atol=1e-10)
+        assert np.allclose((S @ W).numpy(), V_o, rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("encoding", [StateEncoding.DEFAULT,
+                                      StateEncoding.FULL_COVARIANCE_MATRIX,
+                                      StateEncoding.VARIANCE_ONLY])
+def test_gp_forward_vs_numpy_port(encoding):
+    from pddp_amd.utils.encoding import decode_covar, decode_mean
+    model, X, U, dX = _toy(seed=2)
+    gp, ell, sf2, sn2 = _oracle_state(model)
+    Xt = model.Xt.numpy()
+    Kinv, beta = gp.condition(Xt, dX.numpy(), ell, sf2, sn2)
+    g = torch.Generator().manual_seed(3)
+    rows = []
+    for r in range(3):
+        mean = torch.tensor([0.1, -0.2, 0.7, 0.05], dtype=torch.float64) + \
+            0.1 * torch.randn(4, generator=g, dtype=torch.float64)
+        A = 0.15 * torch.randn(4, 4, generator=g, dtype=torch.float64)
+        covar = A @ A.t() + 1e-3 * torch.eye(4, dtype=torch.float64)
+        rows.append(GaussianVariable(mean, covar=covar).encode(encoding))
+    z = torch.stack(rows)
+    u = 0.3 * torch.randn(3, 1, generator=g, dtype=torch.float64)
+    with torch.no_grad():
+        zn = model(z, u, 0, encoding)
+    assert zn.shape == z.shape
+    for r in range(3):
+        mean = decode_mean(z[r], encoding, state_size=4).numpy()
+        covar = decode_covar(z[r], encoding, state_size=4).numpy()
+        Mn, Cn = gp.step(Xt, Kinv, beta, ell, sf2, sn2, mean, covar,
+                         u[r].numpy(), [2], [0, 1, 3])
+        got_m = decode_mean(zn[r], encoding, state_size=4).numpy()
+        got_C = decode_covar(zn[r], encoding, state_size=4).numpy()
+        assert np.allclose(got_m, Mn, rtol=1e-9, atol=1e-11)
+        if encoding == StateEncoding.VARIANCE_ONLY:
+            assert np.allclose(np.diag(got_C), np.diag(Cn), rtol=1e-8)
+        else:
+            assert np.allclose(got_C, Cn, rtol=1e-7, atol=1e-10)
+    # a single (unbatched) state gives the same row
+    with torch.no_grad():
+        z0 = model(z[0], u[0], 0, encoding)
+    assert torch.allclose(z0, zn[0], rtol=1e-12, atol=1e-14)
+
+
+def test_gp_moments_vs_sampling():
+    """The closed-form moments are those of sample means of the posterior
+    mean function's outputs plus the posterior variance (law of total
+    variance), up to Monte-Carlo error."""
+    model, X, U, dX = _toy(seed=4, M=10)
+    gp, ell, sf2, sn2 = _oracle_state(model)
+    Xt = model.Xt
+    d = Xt.shape[1]
+    g = torch.Generator().manual_seed(5)
+    m = 0.3 * torch.randn(d, generator=g, dtype=torch.float64)
+    A = 0.25 * torch.randn(d, d, generator=g, dtype=torch.float64)
+    S = A @ A.t()
+    with torch.no_grad():
+        mu, Sig, _ = model.moments(m, S)
+    n = 200000
+    xs = m + torch.randn(n, d, generator=g, dtype=torch.float64) @ \
+        torch.linalg.cholesky(S + 1e-12 * torch.eye(d, dtype=torch.float64)).t()
+    with torch.no_grad():
+        K = model._kernel(xs, Xt)                       # [E, n, M]
+        f = torch.einsum("enm,em->ne", K, model.beta)   # posterior means
+        kxx = (2 * model.log_sf).exp()
+        var = kxx - torch.einsum("enm,emk,enk->ne", K, model.Kinv, K) \
+            + (2 * model.log_sn).exp()
+    mu_s = f.mean(0)
+    Sig_s = torch.cov(f.t()) + torch.diag(var.mean(0))
+    assert torch.allclose(mu, mu_s, atol=5e-3)
+    assert torch.allclose(Sig, Sig_s, atol=5e-3)
+
+
+def test_gp_hyperparameter_steps_improve_likelihood():
+    model, X, U, dX = _toy(seed=6, M=24)
+    Xt = model.Xt
+    with torch.no_grad():
+        before = float(model._nlml(Xt, dX))
+    model.fit(X, U, dX, n_iter=25, learning_rate=0.05)
+    with torch.no_grad():
+        after = float(model._nlml(model.Xt, dX))
+    assert after < before
+
+
+@pytest.mark.gpu
+def test_gp_controller_on_gpu_matches_cpu_model():
+    """The GP plugin under iLQRController on the GPU (plugin path: autograd
+    Jacobians of the moment-matched step, HIP sweep / accept): the rollout
+    equals the CPU model's, and a fit lowers the cost."""
+    from pddp_amd.controllers import iLQRController
+    from pddp_amd.examples.cartpole import CartpoleCost, CartpoleDynamicsModel
+    CM = CartpoleDynamicsModel
+    g = torch.Generator().manual_seed(7)
+    true = CM(0.1).double()
+    enc0 = StateEncoding.IGNORE_UNCERTAINTY
+    X = torch.cat([torch.randn(60, 2, generator=g, dtype=torch.float64),
+                   3.0 + 0.8 * torch.randn(60, 1, generator=g, dtype=torch.float64),
+                   torch.randn(60, 1, generator=g, dtype=torch.float64)], -1)
+    U = 3.0 * torch.randn(60, 1, generator=g, dtype=torch.float64)
+    with torch.no_grad():
+        dX = true(X, U, 0, enc0) - X
+    cls = gp_dynamics_model_factory(4, 1, CM.angular_indices,
+                                    CM.non_angular_indices)
+    cpu = cls().double()
+    cpu.fit(X, U, dX)
+    gpu = cls().double().cuda()
+    gpu.fit(X.cuda(), U.cuda(), dX.cuda())
+    enc = StateEncoding.DEFAULT
+    z0 = GaussianVariable(torch.tensor([0.0, 0.0, 3.0, 0.0], dtype=torch.float64),
+                          var=1e-2 * torch.ones(4, dtype=torch.float64)).encode(enc)
+    N = 8
+    Us = 0.5 * torch.randn(N, 1, generator=g, dtype=torch.float64)
+    z_c, z_g = z0, z0.cuda()
+    with torch.no_grad():
+        for t in range(N):
+            z_c = cpu(z_c, Us[t], t, enc)
+            z_g = gpu(z_g, Us[t].cuda(), t, enc)
+    assert torch.allclose(z_g.cpu(), z_c, rtol=1e-7, atol=1e-9)
+    ctrl = iLQRController(None, gpu, CartpoleCost().double().cuda())
+    J = []
+    Z, Uo, st = ctrl.fit(Us.cuda(), enc, n_iterations=4, z0=z0.cuda(),
+                         u_min=torch.tensor([-10.0], dtype=torch.float64),
+                         u_max=torch.tensor([10.0], dtype=torch.float64),
+                         on_iteration=lambda i, s_, Z_, U_, J_: J.append(float(J_)))
+    assert torch.isfinite(Z).all() and torch.isfinite(Uo).all()
+    assert min(J) < J[0] or len(J) == 1
+    assert ctrl._solver.plugin is not None
