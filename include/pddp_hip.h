@@ -90,26 +90,29 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
 
 /* The same sweep through a chosen kernel variant (A/B measurements):
  * 0 auto (what the entry points above use), 1 generic kernel (one wavefront
- * per trajectory, any n <= 32, m <= 4), 2 specialised n=4/m=1 kernel
- * (16 lanes per trajectory), 3 variant 2 with v_rcp/v_sqrt approximations
- * instead of IEEE division / square root (f32 only), 6 / 7 = 2 / 3 with the
- * scalar BoxQP in closed form (the reference's loop as fall-back), 8 / 9 =
- * 6 / 7 with every step split over two wavefronts (bounded problems only),
- * 10 / 11 = 6 / 7 in workgroups of four wavefronts, 12 / 13 = 8 / 9 with the
- * BoxQP chain decoupled from the value update (bounded eig-clamp branch only).
- * 16 / 17: four lanes per trajectory, sixteen trajectories per wavefront
- * (IEEE / approximate division; all four branches; f32 and f64); 18 = 16 with
- * every BoxQP through the reference's loop (bounded branches).
- * 20 / 21: the quad mapping over three wavefronts of a workgroup - record
- * producer, matrices, scalars (IEEE / approximate division; bounded eig-clamp
- * branch only; f32 and f64); 22 / 23 = 20 / 21 without the mirrored Qzz row.
- * Auto for n=4/m=1: bounded eig-clamp branch below 16384 (f32) / 8193 (f64)
- * trajectories -> 21 / 20; f32 from 12288 trajectories on -> 17; bounded
- * Cholesky branch f32 below that -> 9; otherwise 7 (f32) / 6 (f64).
+ * per trajectory, any n <= 32, m <= 4; larger n: four wavefronts), and for
+ * n = 4, m = 1:
+ *   6 / 7   sixteen lanes per trajectory, BoxQP in closed form with the
+ *           reference's loop as fall-back (IEEE division / v_rcp + v_sqrt,
+ *           f32 only for the odd numbers throughout);
+ *   8 / 9   the same step split over two wavefronts (bounded problems only);
+ *   16 / 17 four lanes per trajectory, sixteen trajectories per wavefront
+ *           (all four branches); 18 = 16 with every BoxQP through the
+ *           reference's loop (bounded branches);
+ *   20 / 21 the quad mapping over three wavefronts of a workgroup - record
+ *           producer, matrices, scalars (bounded eig-clamp branch only);
+ *   24 / 25 the rank-one value update deferred by two steps, four wavefronts
+ *           - producer, matrices on the 4x4x1 matrix instruction, carried
+ *           vectors, scalars (bounded eig-clamp branch only);
  * 14 / 15: the matrix-core kernels for n <= 30, m = 1 (IEEE / approximate
  * division; auto for those shapes other than n = 4); f64: n <= 14 on the f64
  * matrix cores, variant 14 only (15 and n > 14: PDDP_E_UNSUPPORTED; auto then
- * takes the generic kernel). */
+ * takes the generic kernel).
+ * Auto for n = 4, m = 1: bounded eig-clamp branch: f32 below 12288
+ * trajectories -> 25, up to 16383 -> 21, f64 up to 8192 -> 20; f32 from 12288
+ * trajectories on -> 17; bounded Cholesky branch f32 below that -> 9; otherwise
+ * 7 (f32) / 6 (f64).  Any other number: PDDP_E_BADARG (rounds 1-2 carried
+ * 2 / 3, 10 - 13, 22 / 23: superseded A/B twins, removed). */
 int pddp_riccati_backward_variant_f32(int B, int N, int n, int m,
                                       const float* rec, const float* u_min,
                                       const float* u_max, const double* reg,

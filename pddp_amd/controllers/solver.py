@@ -151,6 +151,8 @@ class ILQRSolver(object):
         if self.dtype != torch.float32:
             return 0  # the f64 kernels are IEEE throughout
         if self.n == 4 and self.m == 1:
+            if bounded and branch == BRANCH_EIG and self.B < 12288:
+                return 24
             if bounded and branch == BRANCH_EIG and self.B < 16384:
                 return 20
             if self.B >= 12288:

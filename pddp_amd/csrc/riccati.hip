@@ -3,7 +3,6 @@
 #include "riccati_generic.hpp"
 #include "riccati_n4.hpp"
 #include "riccati_n4_split.hpp"
-#include "riccati_n4_pipe.hpp"
 #include "riccati_mfma16.hpp"
 #include "riccati_mfma32.hpp"
 
@@ -23,17 +22,13 @@ static int launch_n4_quad(const RiccatiArgs<double>& a, hipStream_t st, bool f,
   return launch_n4_quad_f64(a, st, f, loop_always);
 }
 
-int launch_n4_qpipe_f32(const RiccatiArgs<float>& a, hipStream_t st, bool fast,
-                        bool mirror);
-int launch_n4_qpipe_f64(const RiccatiArgs<double>& a, hipStream_t st, bool fast,
-                        bool mirror);
-static int launch_n4_qpipe(const RiccatiArgs<float>& a, hipStream_t st, bool f,
-                           bool mirror = true) {
-  return launch_n4_qpipe_f32(a, st, f, mirror);
+int launch_n4_qpipe_f32(const RiccatiArgs<float>& a, hipStream_t st, bool fast);
+int launch_n4_qpipe_f64(const RiccatiArgs<double>& a, hipStream_t st, bool fast);
+static int launch_n4_qpipe(const RiccatiArgs<float>& a, hipStream_t st, bool f) {
+  return launch_n4_qpipe_f32(a, st, f);
 }
-static int launch_n4_qpipe(const RiccatiArgs<double>& a, hipStream_t st, bool f,
-                           bool mirror = true) {
-  return launch_n4_qpipe_f64(a, st, f, mirror);
+static int launch_n4_qpipe(const RiccatiArgs<double>& a, hipStream_t st, bool f) {
+  return launch_n4_qpipe_f64(a, st, f);
 }
 
 // riccati_defer.hip
@@ -86,25 +81,28 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   RiccatiArgs<T> a{B, N, n, rec, u_min, u_max, reg, branch, active, gains,
                    status};
   hipStream_t st = (hipStream_t)stream;
-  // variant: 0 auto, 1 generic, 2 specialised n=4 (IEEE div/sqrt, BoxQP as
-  //          the reference's loop), 3 the same with rcp / sqrt approximations
-  //          (f32 only), 6 / 7 = 2 / 3 with the BoxQP in closed form (loop as
-  //          fall-back), 8 / 9 = 6 / 7 with the step split over two
-  //          wavefronts (riccati_n4_split.hpp; bounded problems only),
-  //          10 / 11 = 6 / 7 in workgroups of four wavefronts,
-  //          12 / 13 = 8 / 9 with the BoxQP chain decoupled from the value
-  //          update (riccati_n4_pipe.hpp; bounded eig-clamp branch only);
-  //          auto: bounded eig-clamp branch, f32 below 12288 trajectories ->
-  //          25, up to 16383 -> 21, f64 up to 8192 -> 20; f32 from 16384
-  //          trajectories on -> 17;
-  //          bounded Cholesky branch f32 below that -> 9; otherwise 7 (f32) /
-  //          6 (f64)
-  //          14 / 15: the matrix-core kernels for n <= 30, m = 1, fp32
-  //          (riccati_mfma16.hpp / riccati_mfma32.hpp; IEEE / approximate
-  //          division) - auto for those shapes other than n = 4
-  //          (n = 15 .. 30: the 32x32-tile form, riccati_mfma32.hpp)
-  //          fp64: the 16x16 form (n <= 14) on the f64 matrix cores, IEEE
-  //          division (variant 14; auto for those shapes)
+  // variant: 0 auto; 1 generic kernel (any n, m <= 4, IEEE throughout);
+  //          6 / 7 the n = 4, m = 1 kernel on sixteen lanes per trajectory
+  //          (riccati_n4.hpp; IEEE division / v_rcp + v_sqrt, f32), BoxQP in
+  //          closed form with the reference's loop as fall-back; 8 / 9 the
+  //          same step split over two wavefronts (riccati_n4_split.hpp;
+  //          bounded branches); 14 / 15 the matrix-core kernels for n <= 30,
+  //          m = 1 (riccati_mfma16.hpp / riccati_mfma32.hpp; fp64: the 16x16
+  //          form for n <= 14, variant 14); 16 / 17 four lanes per trajectory
+  //          (riccati_n4_quad.hpp), 18 = 16 with every BoxQP through the
+  //          reference's loop; 20 / 21 the quad mapping over three wavefronts
+  //          (riccati_n4_qpipe.hpp); 24 / 25 the deferred rank-one form on four
+  //          wavefronts (riccati_n4_defer.hpp).  (Rounds 1-2 also carried 2 / 3
+  //          - BoxQP always through the loop -, 10 / 11 - four-wave workgroups
+  //          -, 12 / 13 - the two-wavefront pipelined form - and 22 / 23 - the
+  //          three-wavefront form without Qzz's mirror: superseded A/B
+  //          history, removed in round 3.)
+  //          auto: n = 4, m = 1, bounded eig-clamp branch: f32 below 12288
+  //          trajectories -> 25, up to 16383 -> 21, f64 up to 8192 -> 20;
+  //          f32 from 12288 trajectories on (other branches; all from 16384)
+  //          -> 17; bounded Cholesky branch f32 below that -> 9; otherwise 7
+  //          (f32) / 6 (f64); other shapes with m = 1, n <= 30 (f64: n <= 14)
+  //          -> 15 / 14; everything else -> 1
   if (variant == 14 || variant == 15 ||
       (variant == 0 && m == 1 && n != 4 && n <= (sizeof(T) == 4 ? 30 : 14))) {
     if (m != 1) return PDDP_E_UNSUPPORTED;
@@ -128,18 +126,14 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          20 / 21: the quad mapping over three wavefronts - producer,
   //          matrices, scalars (riccati_n4_qpipe.hpp; IEEE / approximate
   //          division; bounded eig-clamp branch only)
-  //          22 / 23 = 20 / 21 without Qzz's mirror (V symmetric to rounding
-  //          only; A/B twin)
   if (variant == 20 || variant == 21)
-    return launch_n4_qpipe(a, st, variant == 21, true);
-  if (variant == 22 || variant == 23)
-    return launch_n4_qpipe(a, st, variant == 23, false);
+    return launch_n4_qpipe(a, st, variant == 21);
   //          24 / 25: the rank-one value update deferred by two steps, four
   //          wavefronts (riccati_n4_defer.hpp; IEEE / approximate division;
   //          bounded eig-clamp branch only)
   if (variant == 24 || variant == 25)
     return launch_n4_defer(a, st, variant == 25);
-  if (variant < 0 || variant > 13 || variant == 4 || variant == 5)
+  if (variant != 0 && variant != 1 && (variant < 6 || variant > 9))
     return PDDP_E_BADARG;
 
   if (variant == 0 && n == 4 && m == 1 && u_min != nullptr &&
@@ -155,7 +149,7 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
     // same records (tools/sweep_accuracy.py: median 3.1e-5 / p99 1.6e-4 against
     // 2.9e-5 / 1.3e-4).
     if (sizeof(T) == 4 && B < 12288) return launch_n4_defer(a, st, true);
-    return launch_n4_qpipe(a, st, sizeof(T) == 4, true);
+    return launch_n4_qpipe(a, st, sizeof(T) == 4);
   }
   if (variant == 0 && n == 4 && m == 1 && sizeof(T) == 4 && B >= 12288) {
     // large batches: four lanes per trajectory (riccati_n4_quad.hpp) - a
@@ -166,30 +160,21 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
     // 69 / 90 / 131)
     return launch_n4_quad(a, st, true);
   }
-  if (variant == 0 && n == 4 && m == 1 && u_min != nullptr && B <= 16384) {
-    // latency-bound batches: the two-wavefront kernels
-    // (f32 only: with f64 the one-wave line search that follows is placed
-    // badly after a kernel of two-wave workgroups - DESIGN.md 3.1b - and its
-    // LDS slice does not leave room for four-wave workgroups)
-    if (sizeof(T) == 4) variant = branch == PDDP_BRANCH_EIG ? 13 : 9;
-  }
-  if (variant == 12 || variant == 13) {
-    // BoxQP chain decoupled from the value update (riccati_n4_pipe.hpp):
-    // bounded eig-clamp branch only
-    if (u_min == nullptr || branch != PDDP_BRANCH_EIG)
-      return PDDP_E_UNSUPPORTED;
-    return launch_n4_pipe<T>(a, st, variant == 13 && sizeof(T) == 4);
+  if (variant == 0 && n == 4 && m == 1 && u_min != nullptr && B <= 16384 &&
+      branch == PDDP_BRANCH_CHOLESKY && sizeof(T) == 4) {
+    // latency-bound batches of the bounded Cholesky branch: the two-wavefront
+    // kernel.  (f32 only: with f64 the one-wave line search
+    // that follows is placed badly after a kernel of two-wave workgroups, and
+    // its LDS slice does not leave room for four-wave workgroups)
+    variant = 9;
   }
   if (variant == 8 || variant == 9) {
     if (u_min == nullptr) return PDDP_E_UNSUPPORTED;
     return launch_n4_split<T>(a, st, variant == 9 && sizeof(T) == 4);
   }
   if (variant != 1 && n == 4 && m == 1) {
-    const bool fast = (variant == 0 || variant == 3 || variant == 7 ||
-                       variant == 11) && sizeof(T) == 4;
-    const bool cf = (variant == 0 || variant == 6 || variant == 7 ||
-                     variant == 10 || variant == 11);
-    return launch_n4<T>(a, st, fast, variant >= 10 ? 4 : 1, cf);
+    const bool fast = (variant == 0 || variant == 7) && sizeof(T) == 4;
+    return launch_n4<T>(a, st, fast);
   }
   switch (m) {
     case 1: return dispatch_nmax<T, 1>(a, st);
@@ -272,18 +257,6 @@ int pddp_boxqp_f64(int count, int m, const double* x0, const double* Q,
   return pddp::boxqp_impl<double>(count, m, x0, Q, c, lower, upper, x, result,
                                   Ufree, free_mask, stream);
 }
-
-#ifdef PDDP_PIPE_TIMING
-int pddp_debug_pipe_wait(unsigned long long* out, int reset) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4::g_pipe_wait), 32);
-  if (reset) {
-    unsigned long long z[4] = {0, 0, 0, 0};
-    hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4::g_pipe_wait), z, 32);
-  }
-  return 0;
-}
-#endif
 
 #ifdef PDDP_QP_STATS
 int pddp_debug_qp_stats(unsigned long long* out, int reset) {

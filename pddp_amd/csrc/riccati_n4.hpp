@@ -884,30 +884,16 @@ __global__ __launch_bounds__(kWave) void boxqp1_kernel(
 }  // namespace n4
 
 template <typename T>
-static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st, bool fast_math,
-                     int waves_per_group, bool qp_closed_form) {
+static int launch_n4(const RiccatiArgs<T>& a, hipStream_t st, bool fast_math) {
+  // four trajectories per one-wave workgroup; bounded problems solve the
+  // BoxQP in closed form (QpClosed), the reference's loop as fall-back
   const bool bounded = a.u_min != nullptr;
   const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
   constexpr int G = 4;
   const dim3 grid((a.B + G - 1) / G), block(kWave);
-  if (bounded && qp_closed_form) {
-    const dim3 grid4((a.B + 15) / 16), block4(kWave * 4);
-#define PDDP_N4_CF(C, F)                                                     \
-  do {                                                                       \
-    if (waves_per_group == 4)                                                \
-      PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, true, F, 4, true, 4>), grid4, \
-                  block4, 0, st, a);                                         \
-    else                                                                     \
-      PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, true, F, 4, true, 1>), grid,  \
-                  block, 0, st, a);                                          \
-  } while (0)
-    if (fast_math) { if (chol) PDDP_N4_CF(true, true); else PDDP_N4_CF(false, true); }
-    else { if (chol) PDDP_N4_CF(true, false); else PDDP_N4_CF(false, false); }
-#undef PDDP_N4_CF
-    return launch_status();
-  }
 #define PDDP_N4_LAUNCH(C, Bd, F)                                             \
-  PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, Bd, F, 4>), grid, block, 0, st, a)
+  PDDP_LAUNCH((n4::riccati_n4_kernel<T, C, Bd, F, 4, Bd, 1>), grid, block, 0, \
+              st, a)
   if (fast_math) {
     if (chol) { if (bounded) PDDP_N4_LAUNCH(true, true, true); else PDDP_N4_LAUNCH(true, false, true); }
     else { if (bounded) PDDP_N4_LAUNCH(false, true, true); else PDDP_N4_LAUNCH(false, false, true); }

@@ -57,16 +57,12 @@ PDDP_DEV void rank_one_coeffs(T k, T s, T Quu, T Qu, T& c, T& w) {
   w = fma_(-s, fma_(Quu, k, Qu), k);
 }
 
-// MIRROR (the default): Qzz[q, :] is computed next to Qzz[:, q] (the same
-// products in the same order as the partner lane), so that 0.5 (Q + Q^T) - and
-// with it V - is symmetric to the last bit.  Without it the column is formed
-// from 0.5 (Lzz + Lzz^T)[:, q] + (F^T V F)[:, q] alone (V symmetric up to the
-// rounding of F^T V F; the lanes of a quad never have to agree on a replicated
-// scalar here - those are role Q's).  Measured: 20 instructions less on role M
-// buy nothing (40.2 against 41.3 us in the bench, within run-to-run noise) -
-// a step is as long as the dependent chain through role Q's BoxQP, not role
-// M's instruction stream; the A/B twin stays as variants 22 / 23.
-template <typename T, bool FAST, int R, bool MIRROR = true>
+// Qzz[q, :] is computed next to Qzz[:, q] (the same products in the same order
+// as the partner lane), so that 0.5 (Q + Q^T) - and with it V - is symmetric
+// to the last bit.  (A twin without the mirror products - 20 instructions less
+// on role M - measured the same, 40.2 against 41.3 us: a step is as long as
+// the dependent chain through role Q's BoxQP; removed in round 3.)
+template <typename T, bool FAST, int R>
 __global__ __launch_bounds__(kQpThreads) void riccati_n4_qpipe_kernel(
     RiccatiArgs<T> a) {
   using G = QuadGeom<T>;
@@ -357,45 +353,20 @@ __global__ __launch_bounds__(kQpThreads) void riccati_n4_qpipe_kernel(
     Quz_n = fma_(w.f1, T1, Quz_n);
     Quz_n = fma_(w.f2, T2, Quz_n);
     Quz_n = fma_(w.f3, T3, Quz_n);
-    // Qzz[:, q] and (MIRROR) its mirror Qzz[q, :]
+    // Qzz[:, q] and its mirror Qzz[q, :]
     T C0 = w.Lc0, C1 = w.Lc1, C2 = w.Lc2, C3 = w.Lc3;
     T R0 = w.Lr0, R1 = w.Lr1, R2 = w.Lr2, R3 = w.Lr3;
-    if constexpr (!MIRROR) {  // the column of Lzz + Lzz^T
-      C0 += R0; C1 += R1; C2 += R2; C3 += R3;
-    }
     T Qz_n = w.Lz;
     if constexpr (sizeof(T) == 4) {
-      if constexpr (MIRROR) {
-        dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F0, T0);
-        dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F1, T1);
-        dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F2, T2);
-        dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F3, T3);
-        dpp_fmac4_lanes<true>(R0, R1, R2, R3, T0, w.F0);
-        dpp_fmac4_lanes<true>(R0, R1, R2, R3, T1, w.F1);
-        dpp_fmac4_lanes<true>(R0, R1, R2, R3, T2, w.F2);
-        dpp_fmac4_lanes<true>(R0, R1, R2, R3, T3, w.F3);
-      } else {  // S = (Lzz + Lzz^T)[:, q] + 2 (F^T T)[:, q]
-        const T D0 = T0 + T0, D1 = T1 + T1, D2 = T2 + T2, D3 = T3 + T3;
-        dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F0, D0);
-        dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F1, D1);
-        dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F2, D2);
-        dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F3, D3);
-      }
+      dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F0, T0);
+      dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F1, T1);
+      dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F2, T2);
+      dpp_fmac4_lanes<false>(C0, C1, C2, C3, w.F3, T3);
+      dpp_fmac4_lanes<true>(R0, R1, R2, R3, T0, w.F0);
+      dpp_fmac4_lanes<true>(R0, R1, R2, R3, T1, w.F1);
+      dpp_fmac4_lanes<true>(R0, R1, R2, R3, T2, w.F2);
+      dpp_fmac4_lanes<true>(R0, R1, R2, R3, T3, w.F3);
       dpp_dot4(Qz_n, vz, w.F0, w.F1, w.F2, w.F3);
-    } else if constexpr (!MIRROR) {
-      const T D0 = T0 + T0, D1 = T1 + T1, D2 = T2 + T2, D3 = T3 + T3;
-      C0 = fma_(qb<0>(w.F0), D0, C0); C1 = fma_(qb<1>(w.F0), D0, C1);
-      C2 = fma_(qb<2>(w.F0), D0, C2); C3 = fma_(qb<3>(w.F0), D0, C3);
-      C0 = fma_(qb<0>(w.F1), D1, C0); C1 = fma_(qb<1>(w.F1), D1, C1);
-      C2 = fma_(qb<2>(w.F1), D1, C2); C3 = fma_(qb<3>(w.F1), D1, C3);
-      C0 = fma_(qb<0>(w.F2), D2, C0); C1 = fma_(qb<1>(w.F2), D2, C1);
-      C2 = fma_(qb<2>(w.F2), D2, C2); C3 = fma_(qb<3>(w.F2), D2, C3);
-      C0 = fma_(qb<0>(w.F3), D3, C0); C1 = fma_(qb<1>(w.F3), D3, C1);
-      C2 = fma_(qb<2>(w.F3), D3, C2); C3 = fma_(qb<3>(w.F3), D3, C3);
-      Qz_n = fma_(w.F0, qb<0>(vz), Qz_n);
-      Qz_n = fma_(w.F1, qb<1>(vz), Qz_n);
-      Qz_n = fma_(w.F2, qb<2>(vz), Qz_n);
-      Qz_n = fma_(w.F3, qb<3>(vz), Qz_n);
     } else {
       C0 = fma_(qb<0>(w.F0), T0, C0); C1 = fma_(qb<1>(w.F0), T0, C1);
       C2 = fma_(qb<2>(w.F0), T0, C2); C3 = fma_(qb<3>(w.F0), T0, C3);
@@ -418,11 +389,7 @@ __global__ __launch_bounds__(kQpThreads) void riccati_n4_qpipe_kernel(
       Qz_n = fma_(w.F2, qb<2>(vz), Qz_n);
       Qz_n = fma_(w.F3, qb<3>(vz), Qz_n);
     }
-    if constexpr (MIRROR) {
-      S0 = C0 + R0; S1 = C1 + R1; S2 = C2 + R2; S3 = C3 + R3;
-    } else {
-      S0 = C0; S1 = C1; S2 = C2; S3 = C3;
-    }
+    S0 = C0 + R0; S1 = C1 + R1; S2 = C2 + R2; S3 = C3 + R3;
     Quz = Quz_n;
     Qz = Qz_n;
     // ---- what role Q needs for step t - 1
@@ -456,7 +423,7 @@ __global__ __launch_bounds__(kQpThreads) void riccati_n4_qpipe_kernel(
 // bounded eig-clamp branch only; 16 trajectories per workgroup of three waves
 template <typename T>
 static int launch_n4_qpipe(const RiccatiArgs<T>& a, hipStream_t st,
-                           bool fast_math, bool mirror = true) {
+                           bool fast_math) {
   constexpr int R = 8;
   using G = n4q::QuadGeom<T>;
   if (a.u_min == nullptr || a.branch != PDDP_BRANCH_EIG)
@@ -465,8 +432,7 @@ static int launch_n4_qpipe(const RiccatiArgs<T>& a, hipStream_t st,
   const dim3 grid((a.B + 15) / 16), block(n4q::kQpThreads);
 #define PDDP_QP_GO(F)                                                         \
   do {                                                                        \
-    auto kern = mirror ? n4q::riccati_n4_qpipe_kernel<T, F, R, true>          \
-                       : n4q::riccati_n4_qpipe_kernel<T, F, R, false>;        \
+    auto kern = n4q::riccati_n4_qpipe_kernel<T, F, R>;                        \
     const hipError_t e = hipFuncSetAttribute(                                 \
         (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
         (int)lds);                                                            \

@@ -21,12 +21,12 @@ int launch_n4_quad_f64(const RiccatiArgs<double>& a, hipStream_t st,
 
 namespace pddp {
 int launch_n4_qpipe_f32(const RiccatiArgs<float>& a, hipStream_t st,
-                        bool fast_math, bool mirror) {
-  return launch_n4_qpipe<float>(a, st, fast_math, mirror);
+                        bool fast_math) {
+  return launch_n4_qpipe<float>(a, st, fast_math);
 }
 int launch_n4_qpipe_f64(const RiccatiArgs<double>& a, hipStream_t st,
-                        bool fast_math, bool mirror) {
-  return launch_n4_qpipe<double>(a, st, fast_math, mirror);
+                        bool fast_math) {
+  return launch_n4_qpipe<double>(a, st, fast_math);
 }
 }  // namespace pddp
 

@@ -41,9 +41,9 @@ def main():
         variants = tuple(int(v) for v in a.variants.split(","))
     for variant in variants:
         for branch, bounded in ((0, False), (0, True), (1, False), (1, True)):
-            if variant in (8, 9, 12, 13, 20, 21, 22, 23) and not bounded:
+            if variant in (8, 9, 20, 21, 24, 25) and not bounded:
                 continue
-            if variant in (12, 13, 20, 21, 22, 23) and branch != 0:
+            if variant in (20, 21, 24, 25) and branch != 0:
                 continue
             for _ in range(3):
                 s.backward(reg=reg, branch=branch, bounded=bounded, variant=variant)
