@@ -19,8 +19,9 @@ the script starts N ranks itself (a fresh `python -m torch.distributed.run`
 child, before this process has touched the GPU) and relays its line; under the
 driver's own torchrun launch it simply is one of the ranks.  Ranks own disjoint
 shards (--scaling weak: --batch trajectories per GPU; strong: --batch in total;
-no data-path collective) and exchange their best rollout once per timed region
-through RCCL.
+no data-path collective) and exchange their best rollout through RCCL after
+every round (--exchange-every E: every E rounds; 0: once per timed region) -
+one `all_gather_into_tensor` of a fixed-size record, no host synchronisation.
 
 The timed region (W warm-up rounds, then exactly K rounds between barrier +
 synchronize pairs) is repeated --repeats times from the same nominal; the line
@@ -401,10 +402,13 @@ def bench_bnn(args, emit=True):
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(K):
+    for i in range(K):
         s.round(5e-6, 1e10, n_iter)
-    if world > 1:  # the one exchange of the path: best rollout over RCCL
-        gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
+        if world > 1 and args.exchange_every > 0 and \
+                (i + 1) % args.exchange_every == 0:
+            gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo, sync=False)
+    if world > 1 and args.exchange_every <= 0:
+        gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo, sync=False)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -900,6 +904,10 @@ def main():
     ap.add_argument("--no-points", action="store_true",
                     help="skip the extra roofline points (B = 16384, fp64, "
                          "cold cache)")
+    ap.add_argument("--exchange-every", type=int, default=1,
+                    help="multi-GPU: all-gather the best rollout every E "
+                         "rounds inside the timed region (SURVEY 8(e): one "
+                         "exchange per iteration; 0: once, after the rounds)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short runs of BASELINE configs[2] / [3] / "
                          "[4] appended to the default line")
@@ -964,12 +972,17 @@ def main():
             # accepted nominals
             s.round(5e-6, 1e10, n_iter, backward_events=ev[i][0],
                     search_events=ev[i][1])
+            if world > 1 and args.exchange_every > 0 and \
+                    (i + 1) % args.exchange_every == 0:
+                # the exchange of the path: best rollout over RCCL, no host
+                # synchronisation (launches keep queueing behind it)
+                gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo, sync=False)
             if with_events:  # (no host sync: a device-side sum)
                 # attempts of this round that were accepted (state 1 ACCEPTED,
                 # 5 CONVERGED; every trajectory is live throughout the region)
                 accepted_acc += ((s.state == 1) | (s.state == 5)).sum()
-        if world > 1:  # the one exchange of the path: best rollout over RCCL
-            gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
+        if world > 1 and args.exchange_every <= 0:  # one exchange per region
+            gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo, sync=False)
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()

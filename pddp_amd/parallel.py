@@ -23,19 +23,23 @@ def shard_bounds(total, rank, world_size):
 
 def pack_best(J, Z, U, offset=0):
     """Fused buffer [J, index, Z.flatten(), U.flatten()] of this rank's best
-    (lowest finite cost) trajectory.  J [B], Z [B, N+1, n], U [B, N, m]."""
+    (lowest finite cost) trajectory, in the run's own dtype (the index is
+    exact in float32 up to 2^24 trajectories).  J [B], Z [B, N+1, n],
+    U [B, N, m].  Device ops only - no host synchronisation."""
     Jc = torch.where(torch.isfinite(J), J, torch.full_like(J, float("inf")))
     idx = torch.argmin(Jc)
-    head = torch.stack([Jc[idx].to(torch.float64),
-                        (idx + offset).to(torch.float64)])
-    return torch.cat([head, Z[idx].reshape(-1).to(torch.float64),
-                      U[idx].reshape(-1).to(torch.float64)])
+    head = torch.stack([Jc[idx], (idx + offset).to(J.dtype)])
+    return torch.cat([head, Z[idx].reshape(-1).to(J.dtype),
+                      U[idx].reshape(-1).to(J.dtype)])
 
 
-def gather_best_rollout(J, Z, U, offset=0, group=None):
+def gather_best_rollout(J, Z, U, offset=0, group=None, sync=True):
     """All-gathers every rank's best rollout and returns the global best as
     (J_best, global_index, Z_best [N+1, n], U_best [N, m]); identical on every
-    rank.  Works without an initialised process group (world size 1)."""
+    rank.  Works without an initialised process group (world size 1).
+    `sync=False`: the index comes back as a 0-dim device tensor and nothing
+    waits for the host - the form for one exchange PER ITERATION (SURVEY
+    8(e)) inside a loop of asynchronous launches."""
     mine = pack_best(J, Z, U, offset)
     if dist.is_available() and dist.is_initialized():
         world = dist.get_world_size(group)
@@ -50,4 +54,5 @@ def gather_best_rollout(J, Z, U, offset=0, group=None):
     nz = Z[0].numel()
     Zb = row[2:2 + nz].reshape(Z.shape[1:]).to(Z.dtype)
     Ub = row[2 + nz:].reshape(U.shape[1:]).to(U.dtype)
-    return row[0].to(J.dtype), int(row[1].item()), Zb, Ub
+    index = row[1].round().to(torch.int64)
+    return row[0].to(J.dtype), (int(index.item()) if sync else index), Zb, Ub

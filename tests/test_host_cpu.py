@@ -251,6 +251,10 @@ def test_best_rollout_single_process():
     Jb, idx, Zb, Ub = gather_best_rollout(J, Z, U, offset=100)
     assert idx == 102 and float(Jb) == 1.5
     assert torch.allclose(Zb, Z[2]) and torch.allclose(Ub, U[2])
+    # the sync-free form (one exchange per iteration): the index stays a tensor
+    Jb2, idx2, Zb2, Ub2 = gather_best_rollout(J, Z, U, offset=100, sync=False)
+    assert isinstance(idx2, torch.Tensor) and int(idx2) == 102
+    assert torch.equal(Zb2, Zb) and float(Jb2) == 1.5
 
 
 @pytest.mark.parametrize("problem", ["cartpole", "pendulum"])

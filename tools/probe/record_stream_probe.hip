@@ -84,6 +84,25 @@ __global__ __launch_bounds__(256) void plain_read(const float4* src, float* out,
   }
   if (acc == 123.456f) out[0] = acc;
 }
+// the ceiling proper (round 3): EIGHT independent 16-byte loads in flight per
+// lane, non-temporal, block-contiguous tiles (MI355X_MICROARCH.md, HBM: a
+// swept read wants >= 8 loads per lane outstanding; one grid-stride load per
+// iteration - plain_read above - measures latency, not bandwidth)
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int K>
+__global__ __launch_bounds__(256) void deep_read(const f4v* src, float* out, size_t n4) {
+  float acc = 0.f;
+  const size_t tile = (size_t)256 * K;
+  for (size_t base = (size_t)blockIdx.x * tile; base + tile <= n4; base += (size_t)gridDim.x * tile) {
+    f4v v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      v[k] = __builtin_nontemporal_load(src + base + (size_t)k * 256 + threadIdx.x);
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc += v[k].x + v[k].y + v[k].z + v[k].w;
+  }
+  if (acc == 123.456f) out[0] = acc;
+}
 int main() {
   const int B = 4096, N = 100, S = 452;
   const size_t words = (size_t)B * (N + 1) * S;
@@ -142,6 +161,20 @@ int main() {
     }
     printf("%-44s avg %7.1f us  min %7.1f us  -> %.2f TB/s\n", "plain coalesced float4 read (reference)",
            sum / 5 * 1e3, best * 1e3, (double)n4 * 16 / (sum / 5 * 1e-3) * 1e-12);
+  }
+  for (int grid : {256 * 4, 256 * 8, 256 * 16}) {
+    float best = 1e9f, sum = 0;
+    const size_t n4 = (size_t)B * N * S / 4;
+    for (int i = 0; i < 6; ++i) {
+      hipMemsetAsync(flush, i, 512u << 20);
+      hipEventRecord(e0);
+      hipLaunchKernelGGL((deep_read<8>), dim3(grid), dim3(256), 0, 0, (const f4v*)rec, out, n4);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (i) { sum += ms; best = ms < best ? ms : best; }
+    }
+    printf("8 x 16 B loads in flight per lane, nt, %5d blocks  avg %7.1f us  min %7.1f us  -> %.2f TB/s\n",
+           grid, sum / 5 * 1e3, best * 1e3, (double)n4 * 16 / (sum / 5 * 1e-3) * 1e-12);
   }
   return 0;
 }
