@@ -185,13 +185,38 @@ class TorchProblem(object):
                                           s.state))
 
     # -- fused BNN rollout: csrc/bnn_rollout.hip + csrc/bnn_mlp.hip -------------
-    def _qr_cost_native_ok(self, s):
+    def _qr_cost_native_ok(self, s, co=None):
         """QR cost on the angle-augmented state, DEFAULT encoding, f32: value,
         gradient and Hessian of every (trajectory, step) in one launch
-        (include/pddp_hip.h pddp_qr_cost_derivs_f32)."""
+        (include/pddp_hip.h pddp_qr_cost_derivs_f32).  An AggregateCost
+        (costs/base.py: op(first, second) built by the arithmetic overloads)
+        qualifies when every leaf does and every op is one of + - * / ** (the
+        last with a constant exponent): its derivatives follow from the
+        leaves' by the product / quotient / power rules
+        (`_cost_derivs_tree`), no autograd pass per time step."""
+        from ..costs.base import AggregateCost
         from ..costs.quadratic import QRCost
         from ..utils.encoding import StateEncoding
-        co = self.cost
+        top = co is None
+        co = self.cost if co is None else co
+        if isinstance(co, AggregateCost):
+            if not getattr(self, "use_native_cost", True) or self.cost_opts:
+                return False
+            if co.op not in (torch.add, torch.sub, torch.mul, torch.div,
+                             torch.pow):
+                return False
+            kids = [c for c in (co.first, co.second)
+                    if isinstance(c, torch.nn.Module)]
+            if not kids or (co.op is torch.pow and
+                            isinstance(co.second, torch.nn.Module)):
+                return False
+            consts = [c for c in (co.first, co.second)
+                      if not isinstance(c, torch.nn.Module)]
+            if any(isinstance(c, torch.Tensor) and c.numel() != 1
+                   for c in consts):
+                return False
+            return all(self._qr_cost_native_ok(s, c) for c in kids)
+        del top
         mc = getattr(co, "model_class", None)
         if not getattr(self, "use_native_cost", True) or self.cost_opts:
             return False
@@ -206,9 +231,94 @@ class TorchProblem(object):
                 and isinstance(co, QRCost))
 
     @torch.no_grad()
-    def _cost_derivs_qr(self, s, L, L_z, L_u, L_zz, L_uz, L_uu):
+    def _cost_derivs_tree(self, s, co):
+        """(L [B,N+1], L_z, L_u, L_zz, L_uz, L_uu) of a cost expression tree:
+        QR leaves through the HIP kernel, inner nodes by calculus on the
+        batched tensors.  With x = (z, u), c = a op b:
+            +, -:  linear
+            *:     c' = a' b + a b',  c'' = a'' b + a b'' + a' b'^T + b' a'^T
+            /:     c = a r, r = 1 / b: r' = -b' / b^2,
+                   r'' = -b'' / b^2 + 2 b' b'^T / b^3
+            ** e:  c' = e a^(e-1) a',  c'' = e a^(e-1) a'' + e (e-1) a^(e-2) a' a'^T
+        (blocks zz, uz, uu; the terminal step has the z blocks only)."""
+        from ..costs.base import AggregateCost
+        B, N, n, m = s.B, s.N, s.n, s.m
+        opts = dict(dtype=s.dtype, device=s.device)
+
+        def zeros():
+            return (torch.zeros(B, N + 1, **opts),
+                    torch.zeros(B, N + 1, n, **opts),
+                    torch.zeros(B, N, m, **opts),
+                    torch.zeros(B, N + 1, n, n, **opts),
+                    torch.zeros(B, N, m, n, **opts),
+                    torch.zeros(B, N, m, m, **opts))
+        if not isinstance(co, torch.nn.Module):  # a constant
+            out = zeros()
+            out[0].fill_(float(co))
+            return out
+        if not isinstance(co, AggregateCost):
+            out = zeros()
+            self._cost_derivs_qr(s, *out, co=co)
+            return out
+        a = self._cost_derivs_tree(s, co.first)
+        op = co.op
+
+        def scale(t, f):
+            """t * f with f [B, N+1] (or its first N steps) broadcast."""
+            ff = f[:, :t.shape[1]]
+            return t * ff.reshape(B, t.shape[1], *([1] * (t.dim() - 2)))
+
+        def outer(p_, q_):
+            """Blocks of p q^T + q p^T for gradients p = (pz, pu), q."""
+            (pz, pu), (qz, qu) = p_, q_
+            zz = pz.unsqueeze(-1) * qz.unsqueeze(-2)
+            zz = zz + zz.transpose(-1, -2)
+            uz = pu.unsqueeze(-1) * qz[:, :N].unsqueeze(-2) + \
+                qu.unsqueeze(-1) * pz[:, :N].unsqueeze(-2)
+            uu = pu.unsqueeze(-1) * qu.unsqueeze(-2)
+            uu = uu + uu.transpose(-1, -2)
+            return zz, uz, uu
+
+        def mul(a, b):
+            (la, az, au, azz, auz, auu), (lb, bz, bu, bzz, buz, buu) = a, b
+            zz, uz, uu = outer((az, au), (bz, bu))
+            return (la * lb, scale(az, lb) + scale(bz, la),
+                    scale(au, lb) + scale(bu, la),
+                    scale(azz, lb) + scale(bzz, la) + zz,
+                    scale(auz, lb) + scale(buz, la) + uz,
+                    scale(auu, lb) + scale(buu, la) + uu)
+
+        def power(a, e):
+            la, az, au, azz, auz, auu = a
+            f1 = e * la ** (e - 1.0)
+            f2 = 0.5 * e * (e - 1.0) * la ** (e - 2.0)  # (outer() doubles)
+            zz, uz, uu = outer((az, au), (az, au))
+            return (la ** e, scale(az, f1), scale(au, f1),
+                    scale(azz, f1) + scale(zz, f2),
+                    scale(auz, f1) + scale(uz, f2),
+                    scale(auu, f1) + scale(uu, f2))
+        if op is torch.pow:
+            return power(a, float(co.second))
+        b = self._cost_derivs_tree(s, co.second)
+        if op is torch.add:
+            return tuple(x + y for x, y in zip(a, b))
+        if op is torch.sub:
+            return tuple(x - y for x, y in zip(a, b))
+        if op is torch.mul:
+            return mul(a, b)
+        return mul(a, power(b, -1.0))  # torch.div
+
+    @torch.no_grad()
+    def _cost_derivs_qr(self, s, L, L_z, L_u, L_zz, L_uz, L_uu, co=None):
         import ctypes
-        co, mc = self.cost, self.cost.model_class
+        from ..costs.base import AggregateCost
+        co = self.cost if co is None else co
+        if isinstance(co, AggregateCost):
+            for dst, src in zip((L, L_z, L_u, L_zz, L_uz, L_uu),
+                                self._cost_derivs_tree(s, co)):
+                dst.copy_(src)
+            return
+        mc = co.model_class
         ang = [int(i) for i in mc.angular_indices]
         non = [int(i) for i in mc.non_angular_indices]
         na, m = len(non) + 2 * len(ang), s.m

@@ -1503,6 +1503,63 @@ def test_qr_cost_native_derivatives_vs_autograd_path(problem):
                        rb[..., lay.o_Fz:lay.o_Fz + n * n])
 
 
+def test_aggregate_cost_tree_on_native_leaves_vs_autograd_path():
+    """An AggregateCost (costs/base.py:125-181) on the native path: the QR
+    leaves through pddp_qr_cost_derivs_f32, the ops (* / + - **) by the
+    product / quotient / power rules on the batched tensors
+    (controllers/plugin.py:_cost_derivs_tree) - against autograd's double
+    backward through the composed forward (the path the reference's golden
+    holds in float64: test_aggregate_cost_vs_reference_golden)."""
+    import pddp_amd
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.examples.cartpole import CartpoleCost, CartpoleDynamicsModel
+    model = CartpoleDynamicsModel(0.1).cuda()
+    a_, b_ = CartpoleCost().cuda(), CartpoleCost(pole_length=0.8).cuda()
+    cost = ((a_ * 0.6 + b_ * 0.25 + 0.5) ** 1.5 - a_ / (b_ + 2.0)) * \
+        (b_ * 0.01 + 1.0)
+    D, m, B, N = 4, 1, 3, 6
+    n = D + D * (D + 1) // 2
+    enc = pddp_amd.StateEncoding.DEFAULT
+    out = []
+    for native in (True, False):
+        plugin = TorchProblem(model, cost, enc, {}, {})
+        plugin.use_native_cost = native
+        s = ILQRSolver(None, B, N, torch.float32, "cuda", torch.full((m,), -10.0),
+                       torch.full((m,), 10.0),
+                       fit_alphas(torch.float32, "cuda"), plugin=plugin, n=n,
+                       m=m)
+        assert plugin._qr_cost_native_ok(s) == native
+        g = torch.Generator().manual_seed(3)
+        mean = torch.tensor(MEAN0["cartpole"], dtype=torch.float32)
+        z0 = torch.stack([pddp_amd.GaussianVariable(
+            mean + 0.3 * torch.randn(D, generator=g),
+            var=(0.02 + 0.05 * torch.rand(D, generator=g))).encode(enc)
+            for _ in range(B)]).cuda()
+        U = (0.5 * torch.randn(B, N, m, generator=g)).cuda()
+        U[:, 1] = -20.0  # clamped
+        s.set_nominal(z0, U)
+        s.derivs()
+        torch.cuda.synchronize()
+        assert plugin.last_derivs_path["cost"] == \
+            ("hip" if native else "autograd")
+        out.append((s.rec.clone(), s.L.clone(), s.J_opt.clone()))
+    (ra, La, Ja), (rb, Lb, Jb) = out
+    assert torch.isfinite(ra).all()
+    lay = s.lay
+    assert float((La - Lb).abs().max()) / float(Lb.abs().max()) < 1e-5
+    assert float((Ja - Jb).abs().max()) / float(Jb.abs().max()) < 1e-5
+    for name, o, cnt, upto in (("L_z", lay.o_Lz, n, N + 1),
+                               ("L_u", lay.o_Lu, m, N),
+                               ("L_zz", lay.o_Lzz, n * n, N + 1),
+                               ("L_uz", lay.o_Luz, m * n, N),
+                               ("L_uu", lay.o_Luu, m * m, N)):
+        a, b = ra[:, :upto, o:o + cnt], rb[:, :upto, o:o + cnt]
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-6)
+        assert err < 5e-4, (name, err)
+
+
 def _dist(x):
     x = np.asarray(x, np.float64)
     return (float(np.median(x)), float(np.percentile(x, 99)), float(x.max()))

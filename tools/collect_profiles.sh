@@ -4,41 +4,41 @@
 # Writes raw output under gpurun_out/<tag>_* ; tools/summarise_profiles.py then
 # condenses it into profiles/ (tracked).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 if [ "${2:-}" != "bnn" ]; then
 cd /tmp
 # per-kernel time (kernel trace + stats only)
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats -- \
-    python3 $R/bench.py --steps 30 --warmup 5 --repeats 1 --no-points > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/${TAG}_stats.err
+    python3 $R/bench.py --steps 30 --warmup 5 --repeats 1 --no-points --no-secondary > $R/gpurun_out/${TAG}_bench_under_rocprof.json 2> $R/gpurun_out/${TAG}_stats.err
 # HBM traffic: FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots)
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch -- \
-    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-cpu-baseline > /dev/null 2>&1
+    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-secondary --no-cpu-baseline > /dev/null 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write -- \
-    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-cpu-baseline > /dev/null 2>&1
+    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-secondary --no-cpu-baseline > /dev/null 2>&1
 # instruction mix / stall counters of the sweep
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY \
     --output-format csv -d $R/gpurun_out/${TAG}_pmc_sq -- \
-    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-cpu-baseline > /dev/null 2>&1
+    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-secondary --no-cpu-baseline > /dev/null 2>&1
 cd $R
 # un-profiled runs: the headline line and the scaling points
 python3 bench.py --steps 30 --warmup 5 > gpurun_out/${TAG}_bench.json 2>/dev/null
 for B in 1024 8192 12288 16384 65536; do
-  python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-points --batch $B 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_B$B.json
+  python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-points --no-secondary --batch $B 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_B$B.json
 done
-python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-points --dtype f64 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_f64.json
-for v in 1 2 7 9 12 13 16 17; do
-  python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-points --kernel-variant $v 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_variant$v.json
+python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-points --no-secondary --dtype f64 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_f64.json
+for v in 1 7 9 16 17 20 21 24 25; do
+  python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-points --no-secondary --kernel-variant $v 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_variant$v.json
 done
 # the B = 16384 sweep (quad kernel) under the counters
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_B16384 -- \
-    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-cpu-baseline --batch 16384 > /dev/null 2>&1
+    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-secondary --no-cpu-baseline --batch 16384 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch_B16384 -- \
-    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-cpu-baseline --batch 16384 > /dev/null 2>&1
+    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-secondary --no-cpu-baseline --batch 16384 > /dev/null 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_B16384 -- \
-    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-cpu-baseline --batch 16384 > /dev/null 2>&1
+    python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-secondary --no-cpu-baseline --batch 16384 > /dev/null 2>&1
 cd $R
 tail -c 600 gpurun_out/${TAG}_bench.json
 fi
