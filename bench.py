@@ -292,7 +292,7 @@ def bnn_cpu_baseline(model, enc, N, n, m, A, opts):
                       % (N, 1 + n + m, A, dt)}
 
 
-def sweep_roofline_of(s, lib, reps=6):
+def sweep_roofline_of(s, lib, reps=6, traffic_tag=None):
     """HBM roofline entry of the backward sweep of a live solver: events on
     the dispatch, algorithmic bytes of SURVEY 8(d)."""
     pool = EventPool(lib)
@@ -311,22 +311,36 @@ def sweep_roofline_of(s, lib, reps=6):
             "min_launch_us": float(d.min()) * 1e6,
             "algorithmic_bytes_per_launch": nbytes, "achieved": ach,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": profile_traffic("n%d_sweep" % s.n)}
+            "traffic": profile_traffic(
+                {4: "riccati_n4", 14: "riccati_mfma16",
+                 27: "riccati_mfma32"}.get(s.n, "riccati_generic"),
+                traffic_tag)}
 
 
-def profile_traffic(tag):
-    """HBM bytes per launch from the committed PMC summaries (profiles/),
-    newest round first; None when no summary names `tag`."""
+def profile_traffic(kernel_substr, workload_tag=None):
+    """HBM bytes per launch of a kernel from the committed PMC summaries
+    (profiles/<round>[_<workload>]_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE
+    / WRITE_SIZE in separate passes, 2*FETCH+WRITE), newest round first; None
+    when no summary has a kernel whose name contains `kernel_substr`.  Counters
+    cannot be read from inside this process: the summaries are of profiled
+    runs of the same bench command (tools/collect_profiles.sh)."""
+    import glob
     for rnd in ("r03", "r02", "r01"):
-        path = os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (rnd, tag))
-        if os.path.exists(path):
+        pat = os.path.join(ROOT, "profiles", "%s_%spmc_traffic.json" % (
+            rnd, (workload_tag + "_") if workload_tag else "*"))
+        for path in sorted(glob.glob(pat)):
             try:
                 with open(path) as fh:
-                    v = json.load(fh)
-                return {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
-                        "source": "profiles/%s" % os.path.basename(path)}
+                    kernels = json.load(fh)["kernels"]
             except (OSError, KeyError, ValueError):
-                pass
+                continue
+            for name, v in kernels.items():
+                if kernel_substr in name:
+                    return {"hbm_bytes_per_launch": v["hbm_bytes_per_launch"],
+                            "kernel": name[:100],
+                            "source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE"
+                                      " / WRITE_SIZE, 2*FETCH+WRITE)"
+                                      % os.path.basename(path)}
     return None
 
 
@@ -467,14 +481,23 @@ def bench_bnn(args, emit=True):
             "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
             "avg_launch_us": dur * 1e6,
-            "algorithmic_flop_per_launch": flop, "traffic": None,
+            "algorithmic_flop_per_launch": flop,
+            # (the network kernel is matrix-bound; its HBM traffic is reported
+            # for completeness where a profiled run of this workload exists)
+            "traffic": profile_traffic(
+                "bnn_mlp_kernel<%d, %d, %d, %d" % (
+                    H, 8 if in_dim < 8 else 16, grp,
+                    4 if live <= 4 else (6 if live <= 6 else 8)),
+                "dcbnn" if args.workload == "double_cartpole_bnn" else "cpbnn"),
         },
         "cpu_baseline": None,
     }
     if world == 1:
         from pddp_amd import _native
         out["roofline"]["other_kernels"] = [
-            sweep_roofline_of(s, _native.lib())]
+            sweep_roofline_of(s, _native.lib(), traffic_tag=(
+                "dcbnn" if args.workload == "double_cartpole_bnn"
+                else "cpbnn"))]
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = bnn_cpu_baseline(
                 model, enc, N, n, m, A, {"use_predicted_std": False,

@@ -58,5 +58,12 @@ if [ "${2:-}" = "bnn" ]; then
       python3 $R/bench.py --workload double_cartpole_bnn --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_dcbnn -- \
       python3 $R/bench.py --workload double_cartpole_bnn --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  # configs[2] under the counters: the n = 14 sweep and the network kernel
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_cpbnn -- \
+      python3 $R/bench.py --workload cartpole_bnn --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch_cpbnn -- \
+      python3 $R/bench.py --workload cartpole_bnn --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_cpbnn -- \
+      python3 $R/bench.py --workload cartpole_bnn --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
   cd $R
 fi
