@@ -296,10 +296,12 @@ def sweep_roofline_of(s, lib, reps=6, traffic_tag=None):
     """HBM roofline entry of the backward sweep of a live solver: events on
     the dispatch, algorithmic bytes of SURVEY 8(d)."""
     pool = EventPool(lib)
+    # every trajectory swept (active=None): the bytes below are those of all B;
+    # the gains of converged trajectories are rewritten with the same values
     for _ in range(2):
-        s.backward(active=s.active, variant=s.kernel_variant)
+        s.backward(active=None, variant=s.kernel_variant)
     for _ in range(reps):
-        s.backward(active=s.active, variant=s.kernel_variant,
+        s.backward(active=None, variant=s.kernel_variant,
                    events=pool.pair())
     torch.cuda.synchronize(s.device)
     d = np.array(pool.durations())
@@ -311,7 +313,9 @@ def sweep_roofline_of(s, lib, reps=6, traffic_tag=None):
             "min_launch_us": float(d.min()) * 1e6,
             "algorithmic_bytes_per_launch": nbytes, "achieved": ach,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-            "traffic": profile_traffic(
+            # counters exist only for the profiled shapes (traffic_tag names
+            # the committed summary of THIS workload); None elsewhere
+            "traffic": None if traffic_tag is None else profile_traffic(
                 {4: "riccati_n4", 14: "riccati_mfma16",
                  27: "riccati_mfma32"}.get(s.n, "riccati_generic"),
                 traffic_tag)}

@@ -12,6 +12,7 @@
 //   augment_state    pddp/utils/angular.py:251-286
 #pragma once
 
+#include <type_traits>
 #include "pddp_common.hpp"
 
 namespace pddp {
@@ -116,15 +117,17 @@ PDDP_DEV void sincos_core(float x, float& s, float& c) {
   const double kd = __builtin_rint(xd * 0.63661977236758138243);  // 2 / pi
   double rd = __builtin_fma(kd, -1.57079632679489655800e+00, xd);
   rd = __builtin_fma(kd, -6.12323399573676603587e-17, rd);
+  // x = +-inf: kd = +-inf and rd = inf - inf = NaN; x = NaN: rd = NaN.  The
+  // polynomials, the swap and the sign flips keep a NaN a NaN - no test needed
   sincos_poly((float)rd, (int)kd, s, c);
-  const bool nonfinite = !(fabsf(x) < __builtin_inff());
-  s = nonfinite ? __builtin_nanf("") : s;
-  c = nonfinite ? __builtin_nanf("") : c;
 }
+constexpr float kTrigCoreLimit = 1073741824.0f;  // 2^30
 PDDP_DEV void sincos_(float x, float& s, float& c) {
   sincos_core(x, s, c);
-  const float ax = fabsf(x);
-  const bool big = (ax >= 1073741824.0f) & (ax < __builtin_inff());
+  // one compare on the rollouts' chain: an infinite argument takes the
+  // library's path as well (NaN from both); a state stays infinite for one
+  // step only - its sine is NaN and so is everything after it
+  const bool big = fabsf(x) >= kTrigCoreLimit;
   if (__builtin_expect(__any(big), 0)) {
     float sl, cl;
     sincosf(x, &sl, &cl);
@@ -403,8 +406,30 @@ PDDP_DEV void augment(const T* z, const Trig<T, MODEL>& tr, T* a, T* d) {
   }
 }
 
+// Which augmented-state rows / columns of a cost matrix hold a non-zero entry
+// (bit i: row i or column i does).  CartpoleCost's stage Q (reference
+// examples/cartpole/cost.py:46-51) lives on {x, sin, cos} = 0b11001: of the 25
+// products of dx^T Q dx, 16 are against structural zeros.
+inline unsigned live_mask(const double* Q, int na) {
+  unsigned mask = 0;
+  for (int i = 0; i < na; ++i)
+    for (int j = 0; j < na; ++j)
+      if (Q[i * PDDP_MAX_AUG + j] != 0.0) mask |= (1u << i) | (1u << j);
+  return mask;
+}
+template <int MODEL>
+constexpr unsigned kFullMask = (1u << ModelDims<MODEL>::na) - 1u;
+
 // Cost value only (line search, ilqr.py:764-791). u == nullptr <=> terminal.
-template <typename T, int MODEL>
+// QM: the live rows / columns of the matrix (live_mask); the terms dropped are
+// products with an exact zero, which leave every finite partial sum unchanged
+// (x + 0 * y == x), so the value is bitwise that of the full double loop.  A
+// non-finite entry of a dropped row would have turned the sum into NaN through
+// 0 * inf: the rollouts keep that - such a state is non-finite in a live row
+// one step later at the latest (positions integrate the velocities, sin / cos
+// of a non-finite angle are NaN) and the terminal cost is always evaluated in
+// full, so J is NaN in both forms.
+template <typename T, int MODEL, unsigned QM = kFullMask<MODEL>>
 PDDP_DEV T cost_value(const ProblemT<T>& P, const T* z, const T* u,
                       const Trig<T, MODEL>& tr, bool terminal) {
   using D = ModelDims<MODEL>;
@@ -417,9 +442,11 @@ PDDP_DEV T cost_value(const ProblemT<T>& P, const T* z, const T* u,
   T cost = T(0);
 #pragma unroll
   for (int j = 0; j < na; ++j) {
+    if (!((QM >> j) & 1u)) continue;
     T dq = T(0);
 #pragma unroll
-    for (int i = 0; i < na; ++i) dq += dx[i] * Q[i * PDDP_MAX_AUG + j];
+    for (int i = 0; i < na; ++i)
+      if ((QM >> i) & 1u) dq += dx[i] * Q[i * PDDP_MAX_AUG + j];
     cost += dq * dx[j];
   }
   if (!terminal) {

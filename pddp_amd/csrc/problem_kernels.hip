@@ -5,6 +5,7 @@
 //   derivative records ilqr.py:464-473 via analytic Jacobians / Hessians
 //                      (parallel over trajectory AND time step)
 //   line search       ilqr.py:677-723 _control_law + :764-791 _trajectory_cost
+#include <type_traits>
 #include "models.hpp"
 #include "problem_args.hpp"
 #include "accept.hpp"
@@ -317,7 +318,9 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
 // itself issues at half the SIMD's rate.  The helper (same four trajectories,
 // same LDS slice) helps with the staging, sleeps at a barrier through the
 // rollouts, and takes every other row of the tail.
-template <typename T, int MODEL, bool FUSED, int WPB, int H = 1>
+// QM: live rows / columns of the stage cost matrix (models.hpp live_mask).
+template <typename T, int MODEL, bool FUSED, int WPB, int H = 1,
+          unsigned QM = kFullMask<MODEL>>
 __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
     ProblemT<T> P, LineSearchArgs<T> a, AcceptArgs<T> c, T* rec, T* Lout) {
   using D = ModelDims<MODEL>;
@@ -367,8 +370,8 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
   T umin[m], umax[m];  // hoisted: a load in the loop sits on the chain
 #pragma unroll
   for (int r = 0; r < m; ++r) {
-    umin[r] = bounded ? a.u_min[r] : T(0);
-    umax[r] = bounded ? a.u_max[r] : T(0);
+    umin[r] = bounded ? a.u_min[r] : -(T)__builtin_inff();
+    umax[r] = bounded ? a.u_max[r] : (T)__builtin_inff();
   }
   const T* Zs = smem + (size_t)grp * per;
   const T* Us = Zs + (N + 1) * n;
@@ -392,8 +395,18 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
     for (int j = 0; j < n; ++j) z[j] = Zs[j];  // Z_new[0] = Z[0]  (ilqr.py:690)
     T J = T(0);
     for (int t = 0; t < N; ++t) {
-      const T* zr = Zs + t * n;
-      const T* gr = Gs + t * GS;
+      // the step's nominal row, requested from LDS first; the sines and
+      // cosines of the state need none of it and run while it arrives (the
+      // compiler, left alone, starts with the control law and stalls on it)
+      T zr[n], gr[GS], us[m];
+#pragma unroll
+      for (int j = 0; j < n; ++j) zr[j] = Zs[t * n + j];
+#pragma unroll
+      for (int j = 0; j < GS; ++j) gr[j] = Gs[t * GS + j];
+#pragma unroll
+      for (int j = 0; j < m; ++j) us[j] = Us[t * m + j];
+      const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < m; ++r) {
         T du = alpha * gr[r];  // alpha * k[i]                    (ilqr.py:708)
@@ -401,15 +414,15 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
 #pragma unroll
         for (int c = 0; c < n; ++c) s += (z[c] - zr[c]) * gr[m + r * n + c];
         du = du + s;  // + dz K^T                                 (ilqr.py:710)
-        const T v = Us[t * m + r] + du;
-        un[r] = bounded ? clamp_nan(v, umin[r], umax[r]) : v;
+        const T v = us[r] + du;
+        // unbounded: umin / umax are -inf / +inf
+        un[r] = clamp_nan(v, umin[r], umax[r]);
       }
 #pragma unroll
       for (int j = 0; j < n; ++j) Zci[(size_t)t * zstep + j] = z[j];
 #pragma unroll
       for (int j = 0; j < m; ++j) Uci[(size_t)t * ustep + j] = un[j];
-      const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
-      J += cost_value<T, MODEL>(P, z, un, tr, false);
+      J += cost_value<T, MODEL, QM>(P, z, un, tr, false);
       dynamics<T, MODEL, false>(P, z, un, tr, zn, nullptr, nullptr);
 #pragma unroll
       for (int j = 0; j < n; ++j) z[j] = zn[j];
@@ -568,6 +581,18 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
 // --------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------
+// The one sparse stage-cost pattern instantiated per model: the shipped
+// example cost's (cartpole: {x, sin, cos}); a cost matrix with entries outside
+// it runs the full form.  Models without a sparse instantiation: the full mask
+// (the dispatch below then folds to one launch).
+template <int MODEL>
+constexpr unsigned kSparseMask =
+    MODEL == PDDP_MODEL_CARTPOLE ? 0b11001u : kFullMask<MODEL>;
+template <int MODEL, unsigned QM>
+static bool stage_cost_on(const pddp_problem& p) {
+  if (QM == kFullMask<MODEL>) return false;
+  return (live_mask(p.Q, ModelDims<MODEL>::na) & ~QM) == 0;
+}
 template <typename T, int MODEL>
 static int launch_rollout(const pddp_problem& p, RolloutArgs<T> a,
                           hipStream_t st) {
@@ -593,11 +618,17 @@ static int launch_line_search(const pddp_problem& p, LineSearchArgs<T> a,
                      (size_t)a.N * (D::m + D::m * D::n);
   const size_t lds = 4 * per * sizeof(T);
   if (a.A <= 16 && lds <= 64 * 1024) {  // nominal data staged in LDS
-    if (4 * lds <= 64 * 1024)
-      PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, false, 4>),
-                         dim3((a.B + 15) / 16), dim3(kWave * 4), 4 * lds, st, P,
-                         a, AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
-    else
+    if (4 * lds <= 64 * 1024) {
+      if (stage_cost_on<MODEL, kSparseMask<MODEL>>(p))
+        PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, false, 4, 1,
+                                            kSparseMask<MODEL>>),
+                           dim3((a.B + 15) / 16), dim3(kWave * 4), 4 * lds, st,
+                           P, a, AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
+      else
+        PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, false, 4>),
+                           dim3((a.B + 15) / 16), dim3(kWave * 4), 4 * lds, st,
+                           P, a, AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
+    } else
       PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, false, 1>),
                          dim3((a.B + 3) / 4), dim3(kWave), lds, st, P, a,
                          AcceptArgs<T>{}, (T*)nullptr, (T*)nullptr);
@@ -630,12 +661,18 @@ static int launch_search_accept(const pddp_problem& p, SearchAcceptArgs<T> a,
   if (a.ls.A > 16 || lds > 64 * 1024) return PDDP_E_UNSUPPORTED;
   a.ac.n = D::n;
   a.ac.m = D::m;
-  if (4 * lds <= 64 * 1024)
+  if (4 * lds <= 64 * 1024) {
     // four rollout waves (one per SIMD of a CU) + their four helpers
-    PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 4, 2>),
-                       dim3((a.ls.B + 15) / 16), dim3(kWave * 8), 4 * lds, st, P,
-                       a.ls, a.ac, a.rec, a.L);
-  else
+    if (stage_cost_on<MODEL, kSparseMask<MODEL>>(p))
+      PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 4, 2,
+                                          kSparseMask<MODEL>>),
+                         dim3((a.ls.B + 15) / 16), dim3(kWave * 8), 4 * lds, st,
+                         P, a.ls, a.ac, a.rec, a.L);
+    else
+      PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 4, 2>),
+                         dim3((a.ls.B + 15) / 16), dim3(kWave * 8), 4 * lds, st,
+                         P, a.ls, a.ac, a.rec, a.L);
+  } else
     PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 1>),
                        dim3((a.ls.B + 3) / 4), dim3(kWave), lds, st, P, a.ls,
                        a.ac, a.rec, a.L);
