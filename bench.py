@@ -893,16 +893,18 @@ def sweep_point(lib, B, N, dtype, device, variant, rounds=12, cold=False,
             "frac": nbytes / float(d.mean()) / 1e9 / HBM_PEAK_GBS}
 
 
-def search_accept_bytes(B, N, n, m, A, S, itemsize, accepted_share=1.0):
-    """Algorithmic bytes of the fused line search + accept + records launch:
+def search_accept_bytes(B, N, n, m, A, S, itemsize, accepted_share=1.0,
+                        records=True):
+    """Algorithmic bytes of the fused line search + accept (+ records) launch:
     reads the nominal (Z, U) and the gains; writes the A candidate rollouts and
     their costs; for an accepted trajectory reads the winning rollout back,
-    writes it as the new nominal, copies the gains (self._K) and writes the
-    derivative records + stage costs of the new nominal."""
+    writes it as the new nominal, copies the gains (self._K) and - `records`:
+    when the next sweep reads them from HBM - writes the derivative records +
+    stage costs of the new nominal."""
     zu = (N + 1) * n + N * m
     gains = N * (m + m * n)
     per = zu + gains + A * zu + A
-    per_acc = 2 * zu + 2 * gains + (N + 1) * (S + 1)
+    per_acc = 2 * zu + 2 * gains + ((N + 1) * (S + 1) if records else 0)
     return itemsize * B * (per + accepted_share * per_acc)
 
 
@@ -1046,9 +1048,12 @@ def main():
     # share of the attempts that were accepted (only those read the winner
     # back, write a new nominal and its records)
     accepted_share = float(accepted_acc.item()) / max(attempted_all, 1)
+    # the sweep from the nominal evaluates its records itself: none written
+    from_nominal = getattr(s, "_nominal_sweep", False) is True
     search_bytes = search_accept_bytes(attempted_all / launches, N, n, m,
                                        int(s.A), s.lay.stride, itemsize,
-                                       accepted_share)
+                                       accepted_share,
+                                       records=not from_nominal)
     search_timed = getattr(s, "last_search_timed", None)
 
     # HBM traffic of the same kernels from rocprofv3 PMC passes (FETCH_SIZE and
@@ -1116,7 +1121,14 @@ def main():
                 "backward_kernel_variant": args.kernel_variant,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "backward Riccati sweep",
+                "bound": "hbm",
+                "kernel": ("backward Riccati sweep from the nominal "
+                           "(riccati_n4_gen_kernel: the derivative records "
+                           "are evaluated inside the workgroups, in LDS - "
+                           "`algorithmic_bytes_per_launch` is SURVEY 8(d)'s "
+                           "figure for the sweep that reads them, `traffic` "
+                           "what this launch moves)") if from_nominal
+                          else "backward Riccati sweep",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "avg_launch_us": float(d_sweep.mean()) * 1e6,
@@ -1127,7 +1139,11 @@ def main():
                 "traffic": traffic,
                 "other_kernels": [{
                     "bound": "hbm",
-                    "kernel": "fused line search + accept + records "
+                    "kernel": ("fused line search + accept "
+                               "(line_search_lds_kernel<.., FUSED>; no "
+                               "records: the sweep evaluates them)")
+                              if from_nominal else
+                              "fused line search + accept + records "
                               "(line_search_lds_kernel<.., FUSED>)",
                     "launch_timed": search_timed,
                     "avg_launch_us": float(d_search.mean()) * 1e6,

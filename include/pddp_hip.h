@@ -265,12 +265,34 @@ int pddp_accept_f64(int B, int N, int n, int m, int A, const double* Zc,
                     int32_t* iter, uint8_t* active, uint8_t* fresh,
                     int32_t* n_live, void* stream);
 
+/* ---- the backward sweep of a sample problem FROM ITS NOMINAL TRAJECTORY: the
+ * derivative records (ilqr.py:464-473: F_z, F_u, L_z ... of every step) are
+ * evaluated inside the sweep's workgroups, in LDS, and never written - the
+ * 79 MB per launch that pddp_derivs_* / pddp_search_accept_* write and
+ * pddp_riccati_backward_* reads at B = 4096, N = 100 stay on the chip.
+ * Results as pddp_derivs_* followed by pddp_riccati_backward_* (auto kernel):
+ * gains [B][N][5], status [B]; L [B][N+1] the stage / terminal costs of the
+ * nominal; for trajectories with fresh[b] != 0 (all, when fresh is NULL)
+ * J_opt[b] = sum_t L[b][t] in t order (ilqr.py:289 L.sum()) and fresh[b] is
+ * cleared.  Z [B][N+1][4], U [B][N] un-clamped nominal actions.  Cartpole
+ * under IGNORE_UNCERTAINTY, f32, bounded (u_min, u_max non-NULL), branch
+ * PDDP_BRANCH_EIG, N >= 8: PDDP_E_UNSUPPORTED otherwise (make the two calls
+ * then).  `rec` of pddp_search_accept_* may be NULL with this sweep. */
+int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
+                           const float* Z, const float* U, const float* u_min,
+                           const float* u_max, const double* reg, int branch,
+                           const uint8_t* active, uint8_t* fresh, float* gains,
+                           int32_t* status, float* L, float* J_opt,
+                           void* stream);
+
 /* ---- one launch for the rest of a round: the line search, the accept step
  * and the derivative records of the trajectories whose nominal changed and
  * whose fit goes on.  Same arguments and semantics as the three calls; Z, U, active are
  * in/out; `fresh` is cleared for the trajectories whose records were written
  * here.  Sample problems with at most 16 step sizes; returns
- * PDDP_E_UNSUPPORTED otherwise (make the three calls then). */
+ * PDDP_E_UNSUPPORTED otherwise (make the three calls then).  rec == NULL (and
+ * L == NULL): no records are written and `fresh` stays set - the caller's
+ * next sweep is pddp_sweep_nominal_*, which needs none. */
 int pddp_search_accept_f32(const pddp_problem* problem, int B, int N, int A,
                            float* Z, float* U, const float* gains,
                            const float* alphas, const float* u_min,

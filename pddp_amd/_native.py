@@ -74,6 +74,8 @@ _SIGS = {
                           [_P] * 11,
     "pddp_accept": [c_int] * 5 + [_P] * 5 + [c_double, c_double, c_int] +
                    [_P] * 12,
+    "pddp_sweep_nominal_f32": [_P, c_int, c_int] + [_P] * 5 + [c_int] +
+                              [_P] * 7,
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
     "pddp_bnn_moment_step_f32": [_P, _P],
     "pddp_bnn_mlp_jvp_f32": [c_int] * 6 + [_P] * 11,

@@ -91,7 +91,7 @@ class ILQRSolver(object):
         self.z0 = torch.zeros(B, n, **opts)
         self.Z = torch.zeros(B, N + 1, n, **opts)
         self.U = torch.zeros(B, N, m, **opts)
-        self.rec = torch.zeros(B, N + 1, S, **opts)
+        self._rec = torch.zeros(B, N + 1, S, **opts)
         self.L = torch.zeros(B, N + 1, **opts)
         self.J_opt = torch.zeros(B, **opts)
         self.gains = torch.zeros(B, N, gs, **opts)
@@ -120,7 +120,48 @@ class ILQRSolver(object):
         self.graph_rollout = False  # nominal rollout of a plugin as a hipGraph
         self._fused = None  # None: untried, True / False: fused kernel applies
         self._derivs_due = True
+        # The sweep that evaluates the derivative records itself, from the
+        # nominal (pddp_sweep_nominal_f32): None untried, then True / False.
+        # With it `rec` is not kept up to date by round(); `sync_records()`
+        # brings it up to date for whoever reads it.
+        self._nominal_sweep = None if self._nominal_sweep_possible() else False
+        self._rec_stale = False
         self._pp = None if problem is None else ctypes.addressof(problem)
+
+    def _nominal_sweep_possible(self):
+        """pddp_sweep_nominal_f32's domain (include/pddp_hip.h), at the
+        batches where `auto` picks the deferred sweep anyway."""
+        # include/pddp_problem.h: PDDP_MODEL_CARTPOLE = 1,
+        # PDDP_ENC_IGNORE_UNCERTAINTY = 4
+        return (self.plugin is None and self.problem is not None and
+                self.dtype == torch.float32 and self.n == 4 and self.m == 1 and
+                self.problem.model == 1 and self.problem.encoding == 4 and
+                self.u_min is not None and self.u_max is not None and
+                self.branch == BRANCH_EIG and self.kernel_variant == 0 and
+                self.N >= 8 and self.B < 12288)
+
+    @property
+    def rec(self):
+        """The derivative records [B][N+1][S] of the nominal, up to date."""
+        self.sync_records()
+        return self._rec
+
+    @_on_device
+    def sync_records(self):
+        """Brings `rec` / `L` up to date with the nominal when round() left
+        them behind (the sweep from the nominal writes no records)."""
+        if self._rec_stale:
+            p = _native.ptr
+            _native.call("pddp_derivs", self.dtype, self._pp, self.B, self.N,
+                         p(self.Z), p(self.U), p(self.u_min), p(self.u_max),
+                         None, p(self._rec), p(self.L), p(self._J_scratch()),
+                         None, self._s())
+            self._rec_stale = False
+
+    def _J_scratch(self):
+        if getattr(self, "_jscr", None) is None:
+            self._jscr = torch.zeros_like(self.J_opt)
+        return self._jscr
 
     # -- views in the reference's tensor layout -----------------------------
     def record_views(self):
@@ -227,10 +268,13 @@ class ILQRSolver(object):
     def derivs(self, mask=None, set_state=True, in_graph=False):
         if self.plugin is not None:
             return self.plugin.derivs(self, mask, set_state, in_graph)
+        if mask is not None:
+            self.sync_records()  # (the rows outside the mask)
+        self._rec_stale = False
         p = _native.ptr
         _native.call("pddp_derivs", self.dtype, self._pp, self.B, self.N,
                      p(self.Z), p(self.U), p(self.u_min), p(self.u_max),
-                     p(mask), p(self.rec), p(self.L), p(self.J_opt),
+                     p(mask), p(self._rec), p(self.L), p(self.J_opt),
                      p(self.state) if set_state else None, self._s())
 
     @_on_device
@@ -240,12 +284,13 @@ class ILQRSolver(object):
         (IEEE / approximate division), 6 / 7 closed-form BoxQP, 8 / 9 split
         over two wavefronts, see include/pddp_hip.h.  `events`: a
         (start, stop) pair of pddp_event handles to attach to the dispatch."""
+        self.sync_records()
         p = _native.ptr
         reg = self.mu if reg is None else reg
         branch = self.branch if branch is None else branch
         umin = self.u_min if bounded else None
         umax = self.u_max if bounded else None
-        args = (self.B, self.N, self.n, self.m, p(self.rec), p(umin), p(umax),
+        args = (self.B, self.N, self.n, self.m, p(self._rec), p(umin), p(umax),
                 p(reg), int(branch), p(active), p(self.gains),
                 p(self.bwd_status), self._s(), int(variant))
         if events is None:
@@ -253,6 +298,29 @@ class ILQRSolver(object):
         else:
             _native.call("pddp_riccati_backward_timed", self.dtype, *args,
                          events[0], events[1])
+
+    @_on_device
+    def sweep_nominal(self, events=None):
+        """Backward sweep straight from the nominal (pddp_sweep_nominal_f32):
+        derivative records evaluated in the workgroups, stage costs to `L`,
+        J_opt of the fresh nominals.  False when it does not apply."""
+        p = _native.ptr
+        if events is not None:
+            _native.lib().pddp_attach_events(*events)
+        fn = _native.lib().pddp_sweep_nominal_f32
+        rc = fn(self._pp, self.B, self.N, p(self.Z), p(self.U), p(self.u_min),
+                p(self.u_max), p(self.mu), int(self.branch), p(self.active),
+                p(self.fresh), p(self.gains), p(self.bwd_status), p(self.L),
+                p(self.J_opt), self._s())
+        if rc == _native.E_UNSUPPORTED:
+            if events is not None:
+                _native.lib().pddp_attach_events(None, None)
+            self._nominal_sweep = False
+            return False
+        _native.check(rc, "pddp_sweep_nominal")
+        self._nominal_sweep = True
+        self._rec_stale = True
+        return True
 
     @_on_device
     def line_search(self, active=None, use_status=True):
@@ -277,7 +345,8 @@ class ILQRSolver(object):
                      p(self.active), p(self.fresh), p(self.n_live), self._s())
 
     @_on_device
-    def search_accept(self, tol, max_reg, n_iterations, events=None):
+    def search_accept(self, tol, max_reg, n_iterations, events=None,
+                      records=True):
         """Line search + accept + derivative records of the new nominals in
         one launch (pddp_search_accept_*).  False when the fused kernel does
         not apply; the caller then makes the separate calls.  `events`: a
@@ -298,7 +367,8 @@ class ILQRSolver(object):
             p(self.Uc), p(self.Jc), float(tol), float(max_reg),
             int(n_iterations), p(self.gains_acc), p(self.J_opt), p(self.mu),
             p(self.delta), p(self.state), p(self.iter), p(self.fresh),
-            p(self.n_live), p(self.rec), p(self.L), self._s())
+            p(self.n_live), p(self._rec) if records else None,
+            p(self.L) if records else None, self._s())
         self._fused = rc == 0
         if not self._fused and events is not None:
             _native.lib().pddp_attach_events(None, None)  # nothing launched
@@ -314,6 +384,25 @@ class ILQRSolver(object):
         nominals (so the first call is a no-op from the second round on)."""
         if variant is None:
             variant = self.kernel_variant
+        if self._nominal_sweep is not False and variant == 0 and \
+                self._fused is not False and \
+                self.sweep_nominal(events=backward_events):
+            # records evaluated inside the sweep; the fused launch then writes
+            # none (`fresh` stays set until the next sweep has summed the
+            # stage costs of the new nominal into J_opt)
+            self._derivs_due = False
+            if self.search_accept(tol, max_reg, n_iterations,
+                                  events=search_events, records=False):
+                return
+            # (the fused launch does not apply: > 16 step sizes) the separate
+            # calls; records by the masked derivs launch from now on
+            self._nominal_sweep = False
+            self.line_search(active=self.active)
+            self.accept(tol, max_reg, n_iterations)
+            self._derivs_due = True
+            return
+        if self._rec_stale:
+            self.sync_records()
         if self._derivs_due or not self._fused or always_derivs:
             self.derivs(mask=self.fresh)
             self._derivs_due = False
@@ -333,7 +422,7 @@ class ILQRSolver(object):
         round is all HIP launches and sync-free torch ops (the BNN path)."""
         return self.plugin is None or self.plugin.capture_ok(self)
 
-    _STATE = ("Z", "U", "rec", "L", "J_opt", "gains", "gains_acc", "Jc",
+    _STATE = ("Z", "U", "_rec", "L", "J_opt", "gains", "gains_acc", "Jc",
               "bwd_status", "state", "iter", "mu", "delta", "active", "fresh",
               "n_live")
 
@@ -368,6 +457,7 @@ class ILQRSolver(object):
                 # set_nominal() must not sweep the previous nominal's records
                 self.round(tol, max_reg, n_iterations, always_derivs=True)
             self._graph = (key, graph, None)
+            self._graph_nominal = self._nominal_sweep is True
             return graph
         # warm-up outside the capture (noise caches, masks, per-kernel
         # attributes, allocator) on a snapshot of the solver's state
@@ -396,6 +486,8 @@ class ILQRSolver(object):
     def replay_round(self, with_derivs=True):
         g = self._graph[1] if (with_derivs or self._graph[2] is None) \
             else self._graph[2]
+        if getattr(self, "_graph_nominal", False):
+            self._rec_stale = True  # the captured sweep writes no records
         g.replay()
 
     def fit(self, n_iterations=50, tol=5e-6, max_reg=1e10, on_round=None,

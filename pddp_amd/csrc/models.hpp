@@ -213,10 +213,32 @@ PDDP_DEV void solve3(const T (&A)[3][3], T (&B)[3][NR]) {
     }
 }
 
+// A caller may pass a callable that is invoked at a few points of the longer
+// evaluations below - about every hundred instructions - and do nothing by
+// default.  The sweep that evaluates its records itself (riccati_n4_defer.hpp,
+// generator wavefronts) puts its phase barrier there: a record evaluation is
+// several phases long and every wavefront of the workgroup has to arrive at
+// the barrier of every phase.
+// A sync point is numbered (an integral_constant: the callee may act on a
+// subset) and names the values the segment before it produced - the callee
+// can pin them (pin_value) so that the compiler keeps that segment's
+// arithmetic on its side of the barrier.
+struct NoSync {
+  template <class K, class... A>
+  PDDP_DEV void operator()(K, A&...) const {}
+};
+template <int K>
+using SyncPoint = std::integral_constant<int, K>;
+template <class T>
+PDDP_DEV void pin_value(T& x) {
+  asm volatile("" : "+v"(x));
+}
+
 // z_next = model(z, u); if JAC also F_z [n][n] and F_u [n][m] (row-major).
-template <typename T, int MODEL, bool JAC>
+template <typename T, int MODEL, bool JAC, class Sync = NoSync>
 PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
-                       const Trig<T, MODEL>& tr, T* zn, T* Fz, T* Fu) {
+                       const Trig<T, MODEL>& tr, T* zn, T* Fz, T* Fu,
+                       Sync&& sync = Sync()) {
   using D = ModelDims<MODEL>;
   constexpr int n = D::n, m = D::m;
   const T dt = P.dt;
@@ -231,16 +253,16 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
     const T mc = P.p[0], mp = P.p[1], l = P.p[2], mu = P.p[3], g = P.p[4];
     const T x = z[0], xd = z[1], th = z[2], thd = z[3], F = u[0];
     const T s = tr.s[0], c = tr.c[0];
-    const T a0 = mp * l * thd * thd * s;
-    const T a1 = g * s;
-    const T a2 = F - mu * xd;
-    const T a3 = T(4) * (mc + mp) - T(3) * mp * c * c;
-    const T num_t = a0 * c + T(2) * ((mc + mp) * a1 + a2 * c);
+    T a0 = mp * l * thd * thd * s;
+    T a1 = g * s;
+    T a2 = F - mu * xd;
+    T a3 = T(4) * (mc + mp) - T(3) * mp * c * c;
+    T num_t = a0 * c + T(2) * ((mc + mp) * a1 + a2 * c);
     // one reciprocal of a3 serves both accelerations (and the Jacobians)
-    const T ia3 = inv_(a3);
+    T ia3 = inv_(a3);
     const T il = T(1) / l;  // loop-invariant: hoisted out of the rollouts
     const T thdd = (T(-3) * num_t) * (ia3 * il);
-    const T num_x = T(2) * a0 + T(3) * mp * a1 * c + T(4) * a2;
+    T num_x = T(2) * a0 + T(3) * mp * a1 * c + T(4) * a2;
     const T xdd = num_x * ia3;
     const T nxd = xd + xdd * dt;
     const T nthd = thd + thdd * dt;
@@ -249,19 +271,21 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
     zn[2] = th + nthd * dt;
     zn[3] = nthd;
     if constexpr (JAC) {
-      const T da0_th = mp * l * thd * thd * c;
-      const T da0_thd = T(2) * mp * l * thd * s;
+      sync(SyncPoint<1>{}, a0, a1, a2, a3, num_t, num_x, ia3);
+      T da0_th = mp * l * thd * thd * c;
+      T da0_thd = T(2) * mp * l * thd * s;
       const T da1_th = g * c;
-      const T da3_th = T(6) * mp * c * s;
-      const T dnt_th = da0_th * c - a0 * s + T(2) * ((mc + mp) * da1_th - a2 * s);
-      const T dnt_thd = da0_thd * c;
+      T da3_th = T(6) * mp * c * s;
+      T dnt_th = da0_th * c - a0 * s + T(2) * ((mc + mp) * da1_th - a2 * s);
+      T dnt_thd = da0_thd * c;
       const T dnt_xd = T(-2) * mu * c;
       const T dnt_F = T(2) * c;
-      const T dnx_th = T(2) * da0_th + T(3) * mp * (da1_th * c - a1 * s);
+      T dnx_th = T(2) * da0_th + T(3) * mp * (da1_th * c - a1 * s);
       const T dnx_thd = T(2) * da0_thd;
       const T dnx_xd = T(-4) * mu;
       const T dnx_F = T(4);
       const T kt = T(-3) * il;
+      sync(SyncPoint<2>{}, da0_thd, da3_th, dnt_th, dnt_thd, dnx_th);
       const T dthdd_xd = kt * dnt_xd * ia3;
       const T dthdd_th = kt * (dnt_th * a3 - num_t * da3_th) * ia3 * ia3;
       const T dthdd_thd = kt * dnt_thd * ia3;
@@ -465,11 +489,13 @@ PDDP_DEV T cost_value(const ProblemT<T>& P, const T* z, const T* u,
 }
 
 // Cost with gradient and Hessian w.r.t. (z, u) (ilqr.py:464-465,471-473).
-// l_uz is identically zero for QRCost and is not returned.
-template <typename T, int MODEL>
+// l_uz is identically zero for QRCost and is not returned.  QM as in
+// cost_value: rows / columns outside it only ever contribute exact zeros.
+template <typename T, int MODEL, unsigned QM = kFullMask<MODEL>,
+          class Sync = NoSync>
 PDDP_DEV T cost_derivs(const ProblemT<T>& P, const T* z, const T* u,
                        const Trig<T, MODEL>& tr, bool terminal, T* l_z,
-                       T* l_zz, T* l_u, T* l_uu) {
+                       T* l_zz, T* l_u, T* l_uu, Sync&& sync = Sync()) {
   using D = ModelDims<MODEL>;
   constexpr int na = D::na, n = D::n, m = D::m;
   const T* Q = terminal ? P.Qt : P.Q;
@@ -480,35 +506,49 @@ PDDP_DEV T cost_derivs(const ProblemT<T>& P, const T* z, const T* u,
   T cost = T(0);
 #pragma unroll
   for (int j = 0; j < na; ++j) {
+    if (!((QM >> j) & 1u)) continue;
     T dq = T(0);
 #pragma unroll
-    for (int i = 0; i < na; ++i) dq += dx[i] * Q[i * PDDP_MAX_AUG + j];
+    for (int i = 0; i < na; ++i)
+      if ((QM >> i) & 1u) dq += dx[i] * Q[i * PDDP_MAX_AUG + j];
     cost += dq * dx[j];
   }
 #pragma unroll
   for (int i = 0; i < na; ++i) {
     T s = T(0);
+    if ((QM >> i) & 1u) {
 #pragma unroll
-    for (int j = 0; j < na; ++j)
-      s += (Q[i * PDDP_MAX_AUG + j] + Q[j * PDDP_MAX_AUG + i]) * dx[j];
+      for (int j = 0; j < na; ++j)
+        if ((QM >> j) & 1u)
+          s += (Q[i * PDDP_MAX_AUG + j] + Q[j * PDDP_MAX_AUG + i]) * dx[j];
+    }
     g[i] = s;
   }
 #pragma unroll
   for (int c = 0; c < n; ++c) l_z[c] = T(0);
 #pragma unroll
-  for (int i = 0; i < na; ++i) l_z[D::col[i]] += d[i] * g[i];
+  for (int i = 0; i < na; ++i)
+    if ((QM >> i) & 1u) l_z[D::col[i]] += d[i] * g[i];
+  if constexpr (n == 4 && na == 5)
+    sync(SyncPoint<4>{}, cost, g[0], g[1], g[2], g[3], g[4], l_z[0], l_z[1],
+         l_z[2], l_z[3]);
 #pragma unroll
   for (int i = 0; i < n * n; ++i) l_zz[i] = T(0);
 #pragma unroll
-  for (int i = 0; i < na; ++i)
+  for (int i = 0; i < na; ++i) {
+    if (!((QM >> i) & 1u)) continue;
 #pragma unroll
     for (int k = 0; k < na; ++k)
-      l_zz[D::col[i] * n + D::col[k]] +=
-          d[i] * ((Q[i * PDDP_MAX_AUG + k] + Q[k * PDDP_MAX_AUG + i]) * d[k]);
+      if ((QM >> k) & 1u)
+        l_zz[D::col[i] * n + D::col[k]] +=
+            d[i] *
+            ((Q[i * PDDP_MAX_AUG + k] + Q[k * PDDP_MAX_AUG + i]) * d[k]);
+  }
   // second derivative of the augmentation: d2 sin = -sin, d2 cos = -cos
 #pragma unroll
   for (int i = 0; i < na; ++i)
-    if (D::kind[i] != 0) l_zz[D::col[i] * n + D::col[i]] += g[i] * (-a[i]);
+    if (D::kind[i] != 0 && ((QM >> i) & 1u))
+      l_zz[D::col[i] * n + D::col[i]] += g[i] * (-a[i]);
   if (!terminal) {
     T du[m];
 #pragma unroll
@@ -533,6 +573,66 @@ PDDP_DEV T cost_derivs(const ProblemT<T>& P, const T* z, const T* u,
     }
   }
   return cost;
+}
+
+// One derivative record (layout: pddp_hip.h) of state z under the un-clamped
+// nominal action un; returns the stage / terminal cost.  The dynamics see the
+// clamped action; the record keeps the un-clamped nominal u for the BoxQP
+// bounds (ilqr.py:457-473, 602-603).  QM: live rows of the STAGE cost matrix
+// (a terminal row is evaluated in full whatever QM says when `terminal` is a
+// run-time flag shared by both; pass the full mask then).
+template <typename T, int MODEL, unsigned QM = kFullMask<MODEL>,
+          class Sync = NoSync>
+PDDP_DEV T record_of(const ProblemT<T>& P, const T* z, const T* un,
+                     bool terminal, bool bounded, const T* u_min,
+                     const T* u_max, T* w, Sync&& sync = Sync()) {
+  using D = ModelDims<MODEL>;
+  constexpr int n = D::n, m = D::m;
+  constexpr RecLayout lay(n, m);
+  constexpr int S = lay.stride;
+  T u[m], zn[n];
+  T Fz[n * n], Fu[n * m], lz[n], lzz[n * n], lu[m], luu[m * m];
+#pragma unroll
+  for (int j = 0; j < m; ++j) {
+    u[j] = bounded ? clamp1(un[j], u_min[j], u_max[j]) : un[j];
+    lu[j] = T(0);
+  }
+#pragma unroll
+  for (int j = 0; j < m * m; ++j) luu[j] = T(0);
+  Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
+  sync(SyncPoint<0>{}, tr.s[0], tr.c[0]);
+  if (!terminal) {
+    dynamics<T, MODEL, true>(P, z, u, tr, zn, Fz, Fu, sync);
+  } else {
+#pragma unroll
+    for (int j = 0; j < n * n; ++j) Fz[j] = T(0);
+#pragma unroll
+    for (int j = 0; j < n * m; ++j) Fu[j] = T(0);
+  }
+  if constexpr (n == 4 && m == 1)
+    sync(SyncPoint<3>{}, Fz[5], Fz[6], Fz[7], Fz[13], Fz[14], Fz[15], Fu[1],
+         Fu[3]);
+  const T l =
+      cost_derivs<T, MODEL, QM>(P, z, u, tr, terminal, lz, lzz, lu, luu, sync);
+#pragma unroll
+  for (int j = 0; j < n * n; ++j) w[lay.oFz + j] = Fz[j];
+#pragma unroll
+  for (int j = 0; j < n * n; ++j) w[lay.oLzz + j] = lzz[j];
+#pragma unroll
+  for (int j = 0; j < n * m; ++j) w[lay.oFu + j] = Fu[j];
+#pragma unroll
+  for (int j = 0; j < m * n; ++j) w[lay.oLuz + j] = T(0);
+#pragma unroll
+  for (int j = 0; j < n; ++j) w[lay.oLz + j] = lz[j];
+#pragma unroll
+  for (int j = 0; j < m * m; ++j) w[lay.oLuu + j] = luu[j];
+#pragma unroll
+  for (int j = 0; j < m; ++j) w[lay.oLu + j] = lu[j];
+#pragma unroll
+  for (int j = 0; j < m; ++j) w[lay.oU + j] = un[j];
+#pragma unroll
+  for (int j = lay.oU + m; j < S; ++j) w[j] = T(0);
+  return l;
 }
 
 }  // namespace pddp

@@ -89,58 +89,7 @@ PDDP_DEV void store4(double* p, double a, double b, double c, double d) {
   *reinterpret_cast<double2*>(p + 2) = make_double2(c, d);
 }
 
-// One derivative record (include/pddp_hip.h layout) of the nominal point
-// (z, u_nominal) in `w`; returns the cost l.  Derivatives are taken AT the
-// clamped action; the record keeps the un-clamped nominal u for the BoxQP
-// bounds (ilqr.py:457-473, 602-603).
-template <typename T, int MODEL>
-PDDP_DEV T record_of(const ProblemT<T>& P, const T* z, const T* un,
-                     bool terminal, bool bounded, const T* u_min,
-                     const T* u_max, T* w) {
-  using D = ModelDims<MODEL>;
-  constexpr int n = D::n, m = D::m;
-  constexpr RecLayout lay(n, m);
-  constexpr int S = lay.stride;
-  T u[m], zn[n];
-  T Fz[n * n], Fu[n * m], lz[n], lzz[n * n], lu[m], luu[m * m];
-#pragma unroll
-  for (int j = 0; j < m; ++j) {
-    u[j] = bounded ? clamp1(un[j], u_min[j], u_max[j]) : un[j];
-    lu[j] = T(0);
-  }
-#pragma unroll
-  for (int j = 0; j < m * m; ++j) luu[j] = T(0);
-  const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
-  const T l = cost_derivs<T, MODEL>(P, z, u, tr, terminal, lz, lzz, lu, luu);
-  if (!terminal) {
-    dynamics<T, MODEL, true>(P, z, u, tr, zn, Fz, Fu);
-  } else {
-#pragma unroll
-    for (int j = 0; j < n * n; ++j) Fz[j] = T(0);
-#pragma unroll
-    for (int j = 0; j < n * m; ++j) Fu[j] = T(0);
-  }
-#pragma unroll
-  for (int j = 0; j < n * n; ++j) w[lay.oFz + j] = Fz[j];
-#pragma unroll
-  for (int j = 0; j < n * n; ++j) w[lay.oLzz + j] = lzz[j];
-#pragma unroll
-  for (int j = 0; j < n * m; ++j) w[lay.oFu + j] = Fu[j];
-#pragma unroll
-  for (int j = 0; j < m * n; ++j) w[lay.oLuz + j] = T(0);
-#pragma unroll
-  for (int j = 0; j < n; ++j) w[lay.oLz + j] = lz[j];
-#pragma unroll
-  for (int j = 0; j < m * m; ++j) w[lay.oLuu + j] = luu[j];
-#pragma unroll
-  for (int j = 0; j < m; ++j) w[lay.oLu + j] = lu[j];
-#pragma unroll
-  for (int j = 0; j < m; ++j) w[lay.oU + j] = un[j];
-#pragma unroll
-  for (int j = lay.oU + m; j < S; ++j) w[j] = T(0);
-  return l;
-}
-
+// (record_of: models.hpp)
 
 constexpr int kDerivThreads = 64;
 
@@ -527,8 +476,9 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
 #pragma unroll
           for (int j = 0; j < m; ++j) Ub[t * m + j] = un[j];
         }
-        if (fresh_i) {
-          // derivative record of the new nominal (the next round's sweep)
+        if (fresh_i && rec != nullptr) {
+          // derivative record of the new nominal (the next round's sweep;
+          // rec == nullptr: that sweep evaluates them itself)
           T w[S];
           const T l = record_of<T, MODEL>(P, zc, un, terminal, bounded, a.u_min,
                                          a.u_max, w);
@@ -553,7 +503,7 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
         group_copy(Ga + off, G + off, cnt, ai);
       }
       if constexpr (H == 1) {
-        if (fresh_i) {
+        if (fresh_i && rec != nullptr) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           if (ai == 0) {
@@ -567,7 +517,7 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
     }
     if constexpr (H == 2) {
       __syncthreads();  // both waves' stage costs Ls[t] are in LDS
-      if (amin_out >= 0 && fresh_i && hid == 0 && ai == 0) {
+      if (amin_out >= 0 && fresh_i && rec != nullptr && hid == 0 && ai == 0) {
         const T* Ls = smem + (size_t)grp * per;
         T Jacc = T(0);
         for (int t = 0; t <= N; ++t) Jacc += Ls[t];  // L.sum(), in t order
@@ -776,7 +726,7 @@ static int search_accept_impl(const pddp_problem* p, int B, int N, int A, T* Z,
   if (int rc = check_problem(p)) return rc;
   if (B <= 0 || N <= 0 || A <= 0 || !Z || !U || !gains || !alphas || !active ||
       !bwd_status || !Zc || !Uc || !Jc || !gains_acc || !J_opt || !mu ||
-      !delta || !state || !iter || !fresh || !rec || !L)
+      !delta || !state || !iter || !fresh || (rec != nullptr && !L))
     return PDDP_E_BADARG;
   SearchAcceptArgs<T> a;
   a.ls = LineSearchArgs<T>{B, N, A, Z, U, gains, alphas, u_min, u_max, active,

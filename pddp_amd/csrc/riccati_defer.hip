@@ -17,6 +17,30 @@ int launch_n4_defer_f64(const RiccatiArgs<double>& a, hipStream_t st,
 
 }  // namespace pddp
 
+extern "C" int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
+                                      const float* Z, const float* U,
+                                      const float* u_min, const float* u_max,
+                                      const double* reg, int branch,
+                                      const uint8_t* active, uint8_t* fresh,
+                                      float* gains, int32_t* status, float* L,
+                                      float* J_opt, void* stream) {
+  if (problem == nullptr || B <= 0 || N <= 0 || Z == nullptr || U == nullptr ||
+      reg == nullptr || gains == nullptr || status == nullptr ||
+      L == nullptr || J_opt == nullptr)
+    return PDDP_E_BADARG;
+  pddp::RiccatiArgs<float> a;
+  a.B = B; a.N = N; a.n = 4;
+  a.rec = nullptr;
+  a.u_min = u_min; a.u_max = u_max;
+  a.reg = reg;
+  a.branch = branch;
+  a.active = active;
+  a.gains = gains;
+  a.status = status;
+  const pddp::n4d::GenArgs<float> gen = {Z, U, L, J_opt, fresh};
+  return pddp::launch_n4_gen(*problem, a, gen, (hipStream_t)stream);
+}
+
 #ifdef PDDP_QP_STATS
 extern "C" int pddp_debug_defer_stats(unsigned long long* out, int reset) {
   hipDeviceSynchronize();
@@ -25,6 +49,11 @@ extern "C" int pddp_debug_defer_stats(unsigned long long* out, int reset) {
     unsigned long long z[8] = {};
     hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4d::g_defer_stats), z, 64);
   }
+  return 0;
+}
+extern "C" int pddp_debug_defer_marks(long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_marks), 64);
   return 0;
 }
 extern "C" int pddp_debug_defer_seg(unsigned long long* out, int reset) {

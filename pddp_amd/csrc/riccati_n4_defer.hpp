@@ -48,6 +48,7 @@
 // plain form's).
 #pragma once
 
+#include "models.hpp"
 #include "riccati_n4_qpipe.hpp"
 
 namespace pddp {
@@ -75,10 +76,15 @@ __device__ unsigned long long g_defer_stats[8];
 // barrier) to stamp I; the s_memtime read drains lgkmcnt, so a segment that
 // follows LDS reads shows their full latency
 __device__ unsigned long long g_defer_seg[4][8];
+// time marks of workgroup 0: [wave M / generator][begin, first phase, last
+// phase done, end]
+__device__ long long g_defer_marks[2][4];
+#define PDDP_DW_MARK(W, I) do { if (blockIdx.x == 0 && lane == 0) g_defer_marks[W][I] = clock64(); } while (0)
 #define PDDP_DW_SEGDECL unsigned long long seg_acc[8] = {}; long long seg_last = clock64();
 #define PDDP_DW_STAMP(I) do { const long long n_ = clock64(); seg_acc[I] += (unsigned long long)(n_ - seg_last); seg_last = n_; } while (0)
 #else
 #define PDDP_DW_SEGDECL
+#define PDDP_DW_MARK(W, I)
 #define PDDP_DW_STAMP(I)
 #define PDDP_DW_DECL
 #define PDDP_DW_BARRIER() n4::lds_publish_barrier()
@@ -202,12 +208,46 @@ struct QpLean {
   }
 };
 
-template <typename T, bool FAST, int R>
-__global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
-    RiccatiArgs<T> a) {
+// What the sweep needs to evaluate its records itself (generator wavefronts,
+// NP > 0 below): the nominal trajectory instead of `a.rec`, and where the
+// stage costs and their sum go.
+template <typename T>
+struct GenArgs {
+  const T* Z;      // [B][N + 1][4]
+  const T* U;      // [B][N]  (un-clamped nominal actions)
+  T* L;            // [B][N + 1] stage / terminal cost of the nominal
+  T* J_opt;        // [B]: sum of L in t order, where `fresh` is set
+  uint8_t* fresh;  // [B] nullable: "the nominal changed"; cleared
+};
+
+// NP = 0: role P streams the records from `a.rec` by LDS-DMA (above).
+// NP > 0: nothing is read from `a.rec`.  NP GENERATOR wavefronts evaluate the
+// records of the nominal (gen.Z, gen.U) with the sample problem's closed
+// forms (models.hpp record_of - the code of derivs_kernel and of the fused
+// line search's tail) straight into the ring: one lane per (trajectory, step),
+// a wavefront = a BLOCK of four consecutive steps of the sixteen trajectories.
+// A block takes a generator 4 NP phases (its evaluation is cut into segments
+// by the phase barrier: the sync points of models.hpp, which also pin the
+// segment's results so that the compiler keeps the arithmetic between the
+// barriers it was written between); block j = records N-1-4j .. N-4-4j is
+// first read in phase 4j - 1, written in phase 4j - 2, and its slots are dead
+// from phase 4j + 5 - R on: R >= 4 NP + 6 ring slots.  Built: one generator,
+// twelve slots (two generators and sixteen slots were measured too: the fifth
+// wavefront costs every phase barrier more than the shorter segments save).
+// Role Q evaluates the terminal record before the first phase; generator 0
+// sums the stage costs (J_opt) in the phases after its last block.  The 79 MB
+// of records per launch at B = 4096 are then neither written by the line
+// search's tail nor read here.
+template <typename T, bool FAST, int R, int NP, unsigned QM>
+PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
+                         const ProblemT<T>& prob) {
   using G = n4q::QuadGeom<T>;
+  constexpr bool GEN = NP > 0;
+  constexpr int kThreads = (3 + (GEN ? NP : 1)) * kWave;
   constexpr int NI = G::NI, RPI = G::RPI, CH = G::CH, CB = G::CB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // GEN: terminal L_zz (16) and L_z (4) of every trajectory
+  __shared__ __attribute__((aligned(16))) T term_sh[GEN ? kTraj : 1][20];
   // exchange buffers, two parities each (written in phase p, read in p + 1)
   __shared__ __attribute__((aligned(16))) T xq[2][kTraj][4];   // Q: k, s, c, w
   __shared__ __attribute__((aligned(16))) T xin[2][kTraj][4];  // M: A00 | Y: G0, g2, B00
@@ -240,8 +280,124 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
   const int oq = rbase + q, or4 = rbase + 4 * q;
   const int P = N + 2;  // phases: Q solves step tq = N + 1 - p in phase p
   PDDP_DW_DECL
+  if (role == 0) PDDP_DW_MARK(0, 0);
 
-  if (role == 3) {
+  // GEN: stage costs of the sixteen trajectories, [kTraj][N + 1], behind the ring
+  T* Lsh = ring + R * G::SLOT;
+  if constexpr (GEN) {
+    if (role >= 3) {
+      // =========================================================== generator
+      constexpr int MODEL = PDDP_MODEL_CARTPOLE;
+      const int g = role - 3;
+      const int gt = lane & 15, sb = lane >> 4;
+      const bool gex = b0 + gt < a.B;
+      const int gb = gex ? b0 + gt : a.B - 1;
+      const int grbase = (gt / RPI) * G::GS + (gt % RPI) * kRec;
+      const T* Zg = gen.Z + (size_t)gb * (size_t)(N + 1) * 4;
+      const T* Ug = gen.U + (size_t)gb * (size_t)N;
+      T* Lg = gen.L + (size_t)gb * (size_t)(N + 1);
+      const int nblk = (N + 3) / 4;
+      // (asked now: needed after the last block only)
+      const bool sums = gex && (a.active == nullptr || a.active[gb] != 0) &&
+                        (gen.fresh == nullptr || gen.fresh[gb] != 0);
+      // A pass = one block = SP phases: block j is evaluated in the phases
+      // 4j - 1 - SP .. 4j - 2 and first read in phase 4j - 1.  The passes of
+      // the blocks 0 .. NP reach back before phase 0: those of their sync
+      // points are no-ops (`noop_left`), the one that ends "phase -1" is the
+      // workgroup's start barrier, the rest are phase barriers - of which
+      // every wavefront of the workgroup executes exactly P.
+      constexpr int SP = 4 * NP;
+      // the sync points of record_of (models.hpp) this generator stops at:
+      // SP - 1 at most (the pass ends with one more, after the LDS writes)
+      constexpr unsigned kStops = NP == 1 ? 0b11010u : 0b11111u;
+      int p = 0, nsync = 0, noop_left = 0;
+      bool started = false;
+      auto barrier = [&]() {
+        ++nsync;
+        if (noop_left > 0) {
+          --noop_left;
+        } else if (!started) {
+          __syncthreads();
+          started = true;
+        } else if (p < P) {
+          PDDP_DW_BARRIER();
+          ++p;
+        }
+      };
+      auto sync = [&](auto point, auto&... vals) {
+        if constexpr ((kStops >> decltype(point)::value) & 1u) {
+          (pin_value(vals), ...);
+          barrier();
+        }
+      };
+      // operands of the block evaluated next, requested one pass ahead
+      T zq[4], uq;
+      auto request = [&](int j) {
+        int tau = N - 1 - 4 * j - sb;
+        tau = tau < 0 ? 0 : tau;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Zg + 4 * tau);
+        zq[0] = v[0]; zq[1] = v[1]; zq[2] = v[2]; zq[3] = v[3];
+        uq = Ug[tau];
+      };
+      auto pass = [&](int j) {
+        nsync = 0;
+        const T z[4] = {zq[0], zq[1], zq[2], zq[3]};
+        const T u = uq;
+        if (j + NP < nblk) request(j + NP);
+        const int tau = N - 1 - 4 * j - sb;
+        T w[kRec];
+        const T l = record_of<T, MODEL, QM>(prob, z, &u, false, true, a.u_min,
+                                            a.u_max, w, sync);
+        while (nsync < SP - 1) barrier();
+        // the block's slots: record tau lives in slot (N - 1 - tau) % R
+        T* dst = ring + ((4 * j + sb) % R) * G::SLOT + grbase;
+#pragma unroll
+        for (int k = 0; k < kRec; k += 4)
+          *reinterpret_cast<f32x4*>(dst + k) =
+              f32x4{w[k], w[k + 1], w[k + 2], w[k + 3]};
+        if (tau >= 0) {
+          Lsh[gt * (N + 1) + tau] = l;
+          if (gex) Lg[tau] = l;
+        }
+        barrier();  // SP-th: the block is visible from the next phase on
+      };
+      PDDP_DW_MARK(1, 0);
+      request(g);
+      noop_left = SP - 4 * g;  // (block g <= NP - 1 starts in phase 4g - 1 - SP)
+#pragma unroll 1
+      for (int j = g; j < nblk; j += NP) {
+        pass(j);
+        if (j == g) PDDP_DW_MARK(1, 1);
+      }
+      noop_left = 0;
+      if (!started) barrier();
+      // every stage cost is in LDS now (the last block's barrier is behind
+      // us): J_opt = L.sum() in t order, in the phases this wavefront would
+      // otherwise idle through.  The LDS reads sixteen at a time - one read
+      // per add would expose the LDS latency a hundred times.
+      if (g == 0 && lane < kTraj && sums) {
+        T Jacc = T(0);
+        const T* Lt = Lsh + gt * (N + 1);
+        int t = 0;
+        for (; t + 16 <= N + 1; t += 16) {
+          T v[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = Lt[t + i];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) Jacc += v[i];
+        }
+        for (; t <= N; ++t) Jacc += Lt[t];
+        gen.J_opt[gb] = Jacc;
+        if (gen.fresh != nullptr) gen.fresh[gb] = 0;
+      }
+      while (p < P) barrier();
+      PDDP_DW_MARK(1, 2);
+      PDDP_DW_MARK(1, 3);
+      PDDP_DW_END(3);
+      return;
+    }
+  }
+  if (!GEN && role == 3) {
     // =================================================================== P
     const char* rec_w = reinterpret_cast<const char*>(
         a.rec + (size_t)b0 * (size_t)(N + 1) * kRec);
@@ -300,6 +456,28 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
     T A0p = T(0), B0p = T(0), g1 = T(0), g1sq = T(0);
     T lo_b = T(0), hi_b = T(0);  // bounds of step tq's BoxQP: u_min/max - U
     int status = PDDP_BWD_OK;
+    if constexpr (GEN) {
+      // the terminal record (L_zz, L_z of z_N: what roles M and Y start
+      // from), while the generators evaluate the first blocks
+      if (lane < kTraj) {
+        constexpr int MODEL = PDDP_MODEL_CARTPOLE;
+        const bool gex = b0 + lane < a.B;
+        const int gb = gex ? b0 + lane : a.B - 1;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(
+            gen.Z + ((size_t)gb * (size_t)(N + 1) + N) * 4);
+        const T zN[4] = {v[0], v[1], v[2], v[3]};
+        T lz[4], lzz[16], lu[1], luu[1];
+        const T l = cost_derivs<T, MODEL>(prob, zN, nullptr,
+                                          trig_of<T, MODEL>(zN), true, lz, lzz,
+                                          lu, luu);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) term_sh[lane][i] = lzz[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) term_sh[lane][16 + i] = lz[i];
+        Lsh[lane * (N + 1) + N] = l;
+        if (gex) gen.L[(size_t)gb * (size_t)(N + 1) + N] = l;
+      }
+    }
     __syncthreads();
     int p = 0;
     // The exact path of one step: QpClosed, the reference's loop behind it.
@@ -417,8 +595,8 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
     // tq - 1 (y1cc), its dot products g1a = f_tq . y1, g1b = f_{tq-1} . y1c;
     // yp = y'_tq (everything of y_tq but the c_{tq+1} term); r0n = r0_{tq-1}
     T y1 = T(0), y1c = T(0), y1cc = T(0), g1a = T(0), g1b = T(0), yp = T(0);
-    T r0n;
-    {
+    T r0n = T(0);
+    if constexpr (!GEN) {
       const T* term = a.rec + ((size_t)bc * (size_t)(N + 1) + N) * kRec;
       r0n = term[40 + q];  // r0_N = L_z[N]
     }
@@ -437,6 +615,7 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       return o;
     };
     __syncthreads();
+    if constexpr (GEN) r0n = term_sh[tr][16 + q];
     int p = 0;
     // on entry to phase p: o_cur = record t = N - 1 - p (the package step),
     // o_prev = record tq - 1 = N - p (in phase 0 it does not exist: okA false)
@@ -540,14 +719,19 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
     return w;
   };
   // S0_{t+1}, column q ("S0_N": the terminal value function, ilqr.py:581-583)
-  Acc4<T> S0;
-  {
+  Acc4<T> S0 = {T(0), T(0), T(0), T(0)};
+  if constexpr (!GEN) {
     const T* term = a.rec + ((size_t)bc * (size_t)(N + 1) + N) * kRec;
     S0.v0 = term[16 + 0 + q]; S0.v1 = term[16 + 4 + q];
     S0.v2 = term[16 + 8 + q]; S0.v3 = term[16 + 12 + q];
   }
   __syncthreads();
+  if constexpr (GEN) {
+    S0.v0 = term_sh[tr][0 + q]; S0.v1 = term_sh[tr][4 + q];
+    S0.v2 = term_sh[tr][8 + q]; S0.v3 = term_sh[tr][12 + q];
+  }
   int p = 0;
+  PDDP_DW_MARK(0, 1);
   Words wn = gather(0);  // record N - 1
   auto phase = [&](const int s) {
     const int t = N - 1 - p;
@@ -615,7 +799,22 @@ __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
       ++p;
     }
   }
+  PDDP_DW_MARK(0, 2);
   PDDP_DW_END(0);
+}
+
+template <typename T, bool FAST, int R>
+__global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
+    RiccatiArgs<T> a) {
+  defer_body<T, FAST, R, 0, 0u>(a, GenArgs<T>{}, ProblemT<T>{});
+}
+
+constexpr int kGenWaves = 1;   // generator wavefronts
+constexpr int kGenRing = 12;   // ring slots = three blocks (>= 4 NP + 6)
+template <unsigned QM>
+__global__ __launch_bounds__((3 + kGenWaves) * kWave) void riccati_n4_gen_kernel(
+    RiccatiArgs<float> a, GenArgs<float> gen, ProblemT<float> P) {
+  defer_body<float, true, kGenRing, kGenWaves, QM>(a, gen, P);
 }
 
 }  // namespace n4d
@@ -642,6 +841,38 @@ static int launch_n4_defer(const RiccatiArgs<T>& a, hipStream_t st,
   if (fast_math && sizeof(T) == 4) PDDP_DF_GO(true);
   else PDDP_DF_GO(false);
 #undef PDDP_DF_GO
+  return launch_status();
+}
+
+// The same sweep from the nominal trajectory of a cartpole problem (f32,
+// bounded, eig-clamp branch): records evaluated in the workgroup, none read.
+static int launch_n4_gen(const pddp_problem& p, const RiccatiArgs<float>& a,
+                         const n4d::GenArgs<float>& gen, hipStream_t st) {
+  using G = n4q::QuadGeom<float>;
+  if (p.model != PDDP_MODEL_CARTPOLE ||
+      p.encoding != PDDP_ENC_IGNORE_UNCERTAINTY || a.u_min == nullptr ||
+      a.u_max == nullptr || a.branch != PDDP_BRANCH_EIG || a.N < 8)
+    return PDDP_E_UNSUPPORTED;
+  const ProblemT<float> P = convert_problem<float>(p);
+  const size_t lds = ((size_t)n4d::kGenRing * G::SLOT +
+                      (size_t)n4d::kTraj * (a.N + 1)) * sizeof(float);
+  if (lds > 150 * 1024) return PDDP_E_UNSUPPORTED;
+  const dim3 grid((a.B + 15) / 16), block((3 + n4d::kGenWaves) * kWave);
+  constexpr unsigned kSparse = 0b11001u;  // CartpoleCost: {x, sin, cos}
+  const bool sparse =
+      (live_mask(p.Q, ModelDims<PDDP_MODEL_CARTPOLE>::na) & ~kSparse) == 0;
+#define PDDP_GEN_GO(QMV)                                                      \
+  do {                                                                        \
+    auto kern = n4d::riccati_n4_gen_kernel<QMV>;                              \
+    const hipError_t e = hipFuncSetAttribute(                                 \
+        (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+        (int)lds);                                                            \
+    if (e != hipSuccess) return (int)e;                                       \
+    PDDP_LAUNCH(kern, grid, block, lds, st, a, gen, P);                       \
+  } while (0)
+  if (sparse) PDDP_GEN_GO(kSparse);
+  else PDDP_GEN_GO(kFullMask<PDDP_MODEL_CARTPOLE>);
+#undef PDDP_GEN_GO
   return launch_status();
 }
 

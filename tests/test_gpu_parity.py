@@ -1166,6 +1166,7 @@ def test_fused_round_equals_separate_kernels(problem, dtype):
     inlined into two kernels is contracted into FMAs differently)."""
     B, N = 37, 33
     s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N, seed=3)
+    s._nominal_sweep = False  # (the launch that WRITES records is the subject)
     s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
     names = ("Z", "U", "rec", "L", "J_opt", "mu", "delta", "state", "iter",
              "active", "fresh", "gains", "gains_acc", "Jc", "Zc", "Uc",
@@ -1205,6 +1206,84 @@ def test_fused_round_equals_separate_kernels(problem, dtype):
             getattr(s, k).copy_(fused[k])
         s._derivs_due = False
     assert accepted > 0
+
+
+@pytest.mark.parametrize("B,N", [(37, 33), (16, 100), (5, 10), (130, 47)])
+def test_sweep_from_nominal_equals_records_then_sweep(B, N):
+    """pddp_sweep_nominal_f32 (derivative records evaluated inside the sweep's
+    workgroups, never written) against pddp_derivs_f32 followed by the
+    deferred sweep on those records: gains, status, stage costs and J_opt =
+    L.sum() - ragged batches, horizons that are not a multiple of the
+    generators' four-step blocks, masked trajectories."""
+    s, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=11)
+    assert s._nominal_sweep is None  # in its domain, untried
+    s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    s.mu.fill_(1.0)
+    s.active[::5] = 0
+    s.derivs()
+    s.backward(active=s.active, variant=25)
+    ref = {k: getattr(s, k).clone() for k in ("gains", "bwd_status", "L",
+                                              "J_opt")}
+    s.gains.zero_()
+    s.bwd_status.fill_(-7)
+    s.L.zero_()
+    s.J_opt.fill_(123.0)
+    s.fresh.fill_(1)
+    s.fresh[1::7] = 0
+    assert s.sweep_nominal()
+    torch.cuda.synchronize()
+    live = s.active.bool().cpu()
+    g, gr = s.gains.cpu()[live].double(), ref["gains"].cpu()[live].double()
+    assert torch.isfinite(g).all()
+    # (the records of the two paths agree to rounding - the same code inlined
+    # into two kernels - and a hundred steps of an f32 sweep carry that on)
+    err = float((g - gr).abs().max() / gr.abs().max())
+    assert err < 3e-4, err
+    assert torch.equal(s.bwd_status.cpu()[live], ref["bwd_status"].cpu()[live])
+    assert (s.bwd_status.cpu()[~live] == -7).all()
+    assert float((s.L - ref["L"]).abs().max()) <= 1e-6 * float(
+        ref["L"].abs().max())
+    fr = torch.ones(B, dtype=torch.bool)
+    fr[1::7] = False
+    take = (live & fr)
+    J, Jr = s.J_opt.cpu(), ref["J_opt"].cpu()
+    assert float((J[take] - Jr[take]).abs().max()) <= 1e-6 * float(Jr.abs().max())
+    assert (J[~take] == 123.0).all()
+    assert int(s.fresh.cpu()[take].sum()) == 0
+    # the records themselves, on demand
+    s._rec_stale = True
+    rec = s.rec
+    s.derivs()
+    assert torch.equal(rec, s.rec)
+
+
+def test_round_from_nominal_equals_round_with_records():
+    """ILQRSolver.round() through the sweep from the nominal (no records in
+    HBM) against the same rounds through the fused launch that writes them:
+    the same decisions, nominals and regularisation, round by round."""
+    B, N = 64, 40
+    a, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=5)
+    b, *_ = _setup("cartpole", "f32", B, N, seed=5)
+    b._nominal_sweep = False
+    for s in (a, b):
+        s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    accepted = 0
+    for r in range(14):
+        a.round(n_iterations=10)
+        b.round(n_iterations=10)
+        assert a._nominal_sweep is True and a._rec_stale
+        for k in ("state", "iter", "active", "mu", "delta", "bwd_status"):
+            assert torch.equal(getattr(a, k), getattr(b, k)), (r, k)
+        for k in ("Z", "U", "gains_acc"):
+            x, y = getattr(a, k).double(), getattr(b, k).double()
+            assert float((x - y).abs().max()) <= 1e-3 * float(
+                y.abs().max().clamp_min(1.0)), (r, k)
+        accepted += int(((a.state == 1) | (a.state == 5)).sum())
+    assert accepted > B
+    x, y = a.rec.double(), b.rec.double()  # brought up to date on access
+    live = a.active.bool()
+    assert float((x[live] - y[live]).abs().max()) <= 1e-3 * float(
+        y.abs().max())
 
 
 @pytest.mark.parametrize("H", [64, 128, 200])
@@ -2211,7 +2290,10 @@ def test_controller_step_equals_fit_iterations():
     assert np.allclose([t[1] for t in trace_fit], [t[1] for t in trace_step],
                        rtol=1e-12)
     assert st == st_f
-    assert torch.allclose(Uf, b._U_nominal, rtol=1e-12, atol=1e-14)
+    # (fit runs the fused launch, step the separate ones: their derivative
+    # records agree to rounding - the same code inlined into two kernels - and
+    # six iterations carry that on)
+    assert torch.allclose(Uf, b._U_nominal, rtol=1e-9, atol=1e-11)
     assert torch.allclose(Zf, b._Z_nominal, rtol=1e-12, atol=1e-14)
     assert abs(a._mu - b._mu) <= 1e-15 and abs(a._delta - b._delta) <= 1e-15
 

@@ -16,6 +16,9 @@ lib = ctypes.CDLL(_native.LIB_PATH)
 out = (ctypes.c_ulonglong * 8)()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 25
+# variant 0: the sweep from the nominal (generator wavefronts; their two waves
+# are summed under "P")
+nominal = variant == 0
 N = 100
 s, z0, U, _ = bench.make_cartpole_solver(B, N, torch.float32, "cuda", 0, variant)
 s.set_nominal(z0, U)
@@ -26,7 +29,10 @@ seg = (ctypes.c_ulonglong * 32)()
 lib.pddp_debug_defer_seg(seg, 1)
 rounds = 10
 for r in range(rounds):
-    s.backward(active=s.active, variant=variant)
+    if nominal:
+        assert s.sweep_nominal()
+    else:
+        s.backward(active=s.active, variant=variant)
 lib.pddp_debug_defer_stats(out, 1)
 wg = (B + 15) // 16
 for role, name in enumerate(("M (matrices)", "Q (scalars)", "Y (vectors)",
@@ -41,3 +47,11 @@ for role, name in enumerate("MQYP"):
     print(name, "segments (cycles per phase; 7 = last stamp -> barrier):",
           " ".join("%d:%.0f" % (i, seg[role * 8 + i] / (wg * rounds * (N + 2)))
                    for i in range(8)))
+if hasattr(lib, "pddp_debug_defer_marks"):
+    mk = (ctypes.c_longlong * 8)()
+    lib.pddp_debug_defer_marks(mk)
+    for w, name in enumerate(("M", "generator")):
+        t = [mk[4 * w + i] for i in range(4)]
+        print(name, "workgroup 0, cycles from its begin: first phase %d, "
+              "phases done %d, end %d" % (t[1] - t[0], t[2] - t[0],
+                                          t[3] - t[0]))
