@@ -277,7 +277,7 @@ int pddp_accept_f64(int B, int N, int n, int m, int A, const double* Zc,
  * cleared.  Z [B][N+1][4], U [B][N] un-clamped nominal actions.  Cartpole
  * under IGNORE_UNCERTAINTY, f32, bounded (u_min, u_max non-NULL), branch
  * PDDP_BRANCH_EIG, N >= 8: PDDP_E_UNSUPPORTED otherwise (make the two calls
- * then).  `rec` of pddp_search_accept_* may be NULL with this sweep. */
+ * then).  `L` of pddp_search_accept_* may be NULL with this sweep. */
 int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
                            const float* Z, const float* U, const float* u_min,
                            const float* u_max, const double* reg, int branch,
@@ -290,9 +290,9 @@ int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
  * whose fit goes on.  Same arguments and semantics as the three calls; Z, U, active are
  * in/out; `fresh` is cleared for the trajectories whose records were written
  * here.  Sample problems with at most 16 step sizes; returns
- * PDDP_E_UNSUPPORTED otherwise (make the three calls then).  rec == NULL (and
- * L == NULL): no records are written and `fresh` stays set - the caller's
- * next sweep is pddp_sweep_nominal_*, which needs none. */
+ * PDDP_E_UNSUPPORTED otherwise (make the three calls then).  L == NULL: no
+ * records are written and `fresh` stays set - the caller's next sweep is
+ * pddp_sweep_nominal_*, which needs none (`rec` is not touched then). */
 int pddp_search_accept_f32(const pddp_problem* problem, int B, int N, int A,
                            float* Z, float* U, const float* gains,
                            const float* alphas, const float* u_min,

@@ -367,8 +367,8 @@ class ILQRSolver(object):
             p(self.Uc), p(self.Jc), float(tol), float(max_reg),
             int(n_iterations), p(self.gains_acc), p(self.J_opt), p(self.mu),
             p(self.delta), p(self.state), p(self.iter), p(self.fresh),
-            p(self.n_live), p(self._rec) if records else None,
-            p(self.L) if records else None, self._s())
+            p(self.n_live), p(self._rec), p(self.L) if records else None,
+            self._s())
         self._fused = rc == 0
         if not self._fused and events is not None:
             _native.lib().pddp_attach_events(None, None)  # nothing launched

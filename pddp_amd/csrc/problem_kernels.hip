@@ -325,7 +325,7 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
   const T* Zs = smem + (size_t)grp * per;
   const T* Us = Zs + (N + 1) * n;
   const T* Gs = Us + N * m;
-  const size_t zstep = (size_t)a.A * n, ustep = (size_t)a.A * m;
+  const size_t zstep_c = (size_t)a.A * n, ustep_c = (size_t)a.A * m;
   // the state machine's inputs, requested now: their latency hides behind
   // the rollout
   AcceptIn<T> acc_in = {};
@@ -338,12 +338,13 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
     const int idx = b * a.A + ai;
     T* Zci = a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
     T* Uci = a.Uc + ((size_t)b * N * a.A + ai) * m;
+    const size_t zstep = zstep_c, ustep = ustep_c;
 
     T z[n], zn[n], un[m];
 #pragma unroll
     for (int j = 0; j < n; ++j) z[j] = Zs[j];  // Z_new[0] = Z[0]  (ilqr.py:690)
     T J = T(0);
-    for (int t = 0; t < N; ++t) {
+    auto step = [&](const int t) {
       // the step's nominal row, requested from LDS first; the sines and
       // cosines of the state need none of it and run while it arrives (the
       // compiler, left alone, starts with the control law and stalls on it)
@@ -375,7 +376,20 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
       dynamics<T, MODEL, false>(P, z, un, tr, zn, nullptr, nullptr);
 #pragma unroll
       for (int j = 0; j < n; ++j) z[j] = zn[j];
+    };
+    // four steps per trip, by hand (the wave-uniform test inside sincos_ is a
+    // convergent operation: the compiler does not unroll such a loop with a
+    // run-time trip count): a quarter of the loop branches and address
+    // updates - 42.3 -> 37.5 us for the rollouts at B = 4096
+    int t = 0;
+    for (; t + 3 < N; t += 4) {
+      step(t);
+      step(t + 1);
+      step(t + 2);
+      step(t + 3);
     }
+#pragma unroll 1
+    for (; t < N; ++t) step(t);
 #pragma unroll
     for (int j = 0; j < n; ++j) Zci[(size_t)N * zstep + j] = z[j];
     const T lf =
@@ -447,13 +461,55 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
       T* Ga = c.gains_acc + (size_t)b * N * GS;
       T zc[n], uc[m];
       const int t_first = ai + 16 * hid;  // rows t_first, t_first + 16 H, ...
+      constexpr int KR = 4;  // rows per lane the short form below covers
+      if (Lout == nullptr && N + 1 <= 16 * H * KR) {
+        // No records to write (the next sweep evaluates them): the tail is
+        // the winner's rows - all of this lane's requested at once, one
+        // memory latency instead of one per row - and the gains, which are
+        // still in the LDS copy staged for the rollouts.  What is left of the
+        // tail (~9 us of a launch that accepts everything) is this gather:
+        // 16- and 4-byte rows out of the 160- / 40-byte steps of Zc / Uc, long
+        // evicted from L2 - a 64-byte sector from memory for each.  (Measured
+        // and not kept: the full step - the winner 19 times in 20 - rolled out
+        // once more by the helper wavefront into adjacent rows: the second
+        // rollout on the SIMD slows the first by a quarter; the full step's
+        // lane writing its rows over the nominal's in LDS: +3 us per launch,
+        // as much as it saves.)
+        const T* cz = srcz;
+        const T* cu = srcu;
+        const size_t czs = zstep_c, cus = ustep_c;
+        T zz[KR][n], uu[KR][m];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+          const int t = t_first + 16 * H * k;
+          const int tz = t <= N ? t : N, tu = t < N ? t : 0;
+#pragma unroll
+          for (int j = 0; j < n; ++j) zz[k][j] = cz[(size_t)tz * czs + j];
+#pragma unroll
+          for (int j = 0; j < m; ++j) uu[k][j] = cu[(size_t)tu * cus + j];
+        }
+        const T* Gl = smem + (size_t)grp * per + (N + 1) * n + N * m;
+        for (int o = ai + 16 * hid; o < N * GS; o += 16 * H) Ga[o] = Gl[o];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+          const int t = t_first + 16 * H * k;
+          if (t <= N) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) Zb[t * n + j] = zz[k][j];
+          }
+          if (t < N) {
+#pragma unroll
+            for (int j = 0; j < m; ++j) Ub[t * m + j] = uu[k][j];
+          }
+        }
+      } else {
       {
         const int tz = t_first <= N ? t_first : N;
         const int tu = t_first < N ? t_first : 0;
 #pragma unroll
-        for (int j = 0; j < n; ++j) zc[j] = srcz[(size_t)tz * zstep + j];
+        for (int j = 0; j < n; ++j) zc[j] = srcz[(size_t)tz * zstep_c + j];
 #pragma unroll
-        for (int j = 0; j < m; ++j) uc[j] = srcu[(size_t)tu * ustep + j];
+        for (int j = 0; j < m; ++j) uc[j] = srcu[(size_t)tu * ustep_c + j];
       }
 #pragma unroll 1
       for (int t = t_first; t <= N; t += 16 * H) {
@@ -462,9 +518,9 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
           const int t2 = t + 16 * H;
           const int tz = t2 <= N ? t2 : N, tu = t2 < N ? t2 : 0;
 #pragma unroll
-          for (int j = 0; j < n; ++j) zn_[j] = srcz[(size_t)tz * zstep + j];
+          for (int j = 0; j < n; ++j) zn_[j] = srcz[(size_t)tz * zstep_c + j];
 #pragma unroll
-          for (int j = 0; j < m; ++j) un_[j] = srcu[(size_t)tu * ustep + j];
+          for (int j = 0; j < m; ++j) un_[j] = srcu[(size_t)tu * ustep_c + j];
         }
         const bool terminal = (t == N);
         T un[m];
@@ -476,9 +532,9 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
 #pragma unroll
           for (int j = 0; j < m; ++j) Ub[t * m + j] = un[j];
         }
-        if (fresh_i && rec != nullptr) {
+        if (fresh_i && Lout != nullptr) {
           // derivative record of the new nominal (the next round's sweep;
-          // rec == nullptr: that sweep evaluates them itself)
+          // Lout == nullptr: that sweep evaluates them itself)
           T w[S];
           const T l = record_of<T, MODEL>(P, zc, un, terminal, bounded, a.u_min,
                                          a.u_max, w);
@@ -502,8 +558,9 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
         const int cnt = hid == 0 ? half : N * GS - half;
         group_copy(Ga + off, G + off, cnt, ai);
       }
+      }  // (the form that may write records)
       if constexpr (H == 1) {
-        if (fresh_i && rec != nullptr) {
+        if (fresh_i && Lout != nullptr) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
           if (ai == 0) {
@@ -517,7 +574,7 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
     }
     if constexpr (H == 2) {
       __syncthreads();  // both waves' stage costs Ls[t] are in LDS
-      if (amin_out >= 0 && fresh_i && rec != nullptr && hid == 0 && ai == 0) {
+      if (amin_out >= 0 && fresh_i && Lout != nullptr && hid == 0 && ai == 0) {
         const T* Ls = smem + (size_t)grp * per;
         T Jacc = T(0);
         for (int t = 0; t <= N; ++t) Jacc += Ls[t];  // L.sum(), in t order
@@ -726,7 +783,7 @@ static int search_accept_impl(const pddp_problem* p, int B, int N, int A, T* Z,
   if (int rc = check_problem(p)) return rc;
   if (B <= 0 || N <= 0 || A <= 0 || !Z || !U || !gains || !alphas || !active ||
       !bwd_status || !Zc || !Uc || !Jc || !gains_acc || !J_opt || !mu ||
-      !delta || !state || !iter || !fresh || (rec != nullptr && !L))
+      !delta || !state || !iter || !fresh || (L != nullptr && !rec))
     return PDDP_E_BADARG;
   SearchAcceptArgs<T> a;
   a.ls = LineSearchArgs<T>{B, N, A, Z, U, gains, alphas, u_min, u_max, active,

@@ -1161,9 +1161,12 @@ def test_graph_replay_equals_eager_rounds():
 def test_fused_round_equals_separate_kernels(problem, dtype):
     """pddp_search_accept_* (line search + accept + derivative records of the
     accepted nominals in one launch) against the three separate launches, round
-    by round from the same state: decisions, masks, nominals and gains are
-    bit-identical; the derivative records agree to rounding (the same code
-    inlined into two kernels is contracted into FMAs differently)."""
+    by round from the same state: decisions, masks and gains are identical;
+    the candidates, their costs, the accepted nominals and the derivative
+    records agree to rounding (the same closed forms inlined into two kernels -
+    and into the two copies of the rollout loop's hand-unrolled step - are
+    contracted into FMAs differently; bit for bit only with -ffp-contract=off,
+    csrc/Makefile)."""
     B, N = 37, 33
     s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N, seed=3)
     s._nominal_sweep = False  # (the launch that WRITES records is the subject)
@@ -1171,9 +1174,10 @@ def test_fused_round_equals_separate_kernels(problem, dtype):
     names = ("Z", "U", "rec", "L", "J_opt", "mu", "delta", "state", "iter",
              "active", "fresh", "gains", "gains_acc", "Jc", "Zc", "Uc",
              "bwd_status", "n_live")
-    exact = ("Z", "U", "mu", "delta", "state", "iter", "active", "gains_acc",
-             "Jc", "bwd_status", "n_live")
+    exact = ("mu", "delta", "state", "iter", "active", "gains_acc",
+             "bwd_status", "n_live")
     tol = 1e-5 if dtype == "f32" else 1e-12
+    tol_roll = 2e-3 if dtype == "f32" else 1e-8  # (diverging candidates)
     accepted = 0
     for r in range(12):
         pre = {k: getattr(s, k).clone() for k in names}
@@ -1191,6 +1195,21 @@ def test_fused_round_equals_separate_kernels(problem, dtype):
             x, y = fused[k], getattr(s, k)
             assert torch.equal(torch.nan_to_num(x.double(), nan=1.5),
                                torch.nan_to_num(y.double(), nan=1.5)), (r, k)
+        for k in ("Z", "U"):
+            x, y = fused[k].double(), getattr(s, k).double()
+            assert float((x - y).abs().max()) <= tol_roll * float(
+                y.abs().max().clamp_min(1.0)), (r, k)
+        x, y = fused["Jc"].double(), s.Jc.double()
+        fin = torch.isfinite(y) & (y.abs() < 1e6)
+        assert torch.equal(torch.isfinite(x), torch.isfinite(y)), (r, "Jc")
+        # (a candidate that diverges amplifies the rounding difference without
+        # bound: nine in ten agree, and so does every trajectory's best)
+        rel = ((x - y).abs() / y.abs().clamp_min(1.0))[fin]
+        assert float(rel.quantile(0.9)) <= tol_roll, (r, "Jc")
+        bx = torch.nan_to_num(x, nan=1e30).amin(1)
+        by = torch.nan_to_num(y, nan=1e30).amin(1)
+        assert float(((bx - by).abs() / by.abs().clamp_min(1.0)).max()) \
+            <= tol_roll, (r, "Jc min")
         # records and J_opt = L.sum(): the fused launch wrote them for the
         # accepted nominals, the separate path does at its next round start
         s.derivs(mask=s.fresh)

@@ -26,16 +26,29 @@ def main():
     s.set_nominal(z0, U)
     ps, pl = bench.EventPool(lib), bench.EventPool(lib)
     acc = []
+    hist = torch.zeros(16, dtype=torch.int64, device=device)
+    pr = bench.EventPool(lib)  # the rollouts alone (the separate line search)
     for _ in range(args.rounds):
-        s.round(5e-6, 1e10, 1 << 30, backward_events=ps.pair(),
-                search_events=pl.pair())
-        acc.append(((s.state == 1) | (s.state == 5)).sum())
+        if s._nominal_sweep is not False and s.sweep_nominal(events=ps.pair()):
+            lib.pddp_attach_events(*pr.pair())
+            s.line_search(active=s.active)
+            s.search_accept(5e-6, 1e10, 1 << 30, events=pl.pair(),
+                            records=False)
+        else:
+            s.round(5e-6, 1e10, 1 << 30, backward_events=ps.pair(),
+                    search_events=pl.pair())
+        ok = (s.state == 1) | (s.state == 5)
+        acc.append(ok.sum())
+        hist += torch.bincount(s.Jc.argmin(1)[ok], minlength=16)[:16]
     torch.cuda.synchronize(device)
+    print("winning step size of the accepted attempts (index: count):",
+          {i: int(c) for i, c in enumerate(hist.tolist()) if c})
     ds, dl = np.array(ps.durations()) * 1e6, np.array(pl.durations()) * 1e6
+    dr = np.array(pr.durations()) * 1e6 if pr.pairs else np.zeros(len(dl))
     acc = [int(a.item()) / args.batch for a in acc]
-    for i, (a, x, y) in enumerate(zip(acc, ds, dl)):
-        print("round %2d  accepted %.3f  sweep %6.1f us  search %6.1f us"
-              % (i, a, x, y))
+    for i, (a, x, y, r) in enumerate(zip(acc, ds, dl, dr)):
+        print("round %2d  accepted %.3f  sweep %6.1f us  search %6.1f us  "
+              "(rollouts alone %6.1f us)" % (i, a, x, y, r))
     # least squares: search = c0 + c1 * share
     A = np.stack([np.ones(len(acc) - 5), np.array(acc[5:])], 1)
     c = np.linalg.lstsq(A, dl[5:], rcond=None)[0]
