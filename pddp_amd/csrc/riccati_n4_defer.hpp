@@ -273,6 +273,28 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
   const int b = b0 + tr;
   const bool exists = b < a.B;
   const int bc = exists ? b : a.B - 1;
+  // GEN: the first operands of this wavefront's role - the generator's first
+  // block, role Q's terminal state - requested before anything waits on
+  // memory (`active` below): one memory latency at the start, not two (in
+  // the fit loop the nominal was written by the launch before: not in L2)
+  T pre_z[4] = {T(0), T(0), T(0), T(0)}, pre_u = T(0);
+  if constexpr (GEN) {
+    const int gt = lane & 15;
+    const int gb = b0 + gt < a.B ? b0 + gt : a.B - 1;
+    int row = -1;
+    if (role >= 3) {
+      row = N - 1 - 4 * (role - 3) - (lane >> 4);
+      row = row < 0 ? 0 : row;
+    } else if (role == 1 && lane < kTraj) {
+      row = N;
+    }
+    if (row >= 0) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(
+          gen.Z + ((size_t)gb * (size_t)(N + 1) + row) * 4);
+      pre_z[0] = v[0]; pre_z[1] = v[1]; pre_z[2] = v[2]; pre_z[3] = v[3];
+      if (row < N) pre_u = gen.U[(size_t)gb * (size_t)N + row];
+    }
+  }
   // (identical in the four waves: they own the same sixteen trajectories)
   const bool counted = exists && (a.active == nullptr || a.active[bc] != 0);
   if (!__any(counted)) return;
@@ -362,7 +384,8 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
         barrier();  // SP-th: the block is visible from the next phase on
       };
       PDDP_DW_MARK(1, 0);
-      request(g);
+      zq[0] = pre_z[0]; zq[1] = pre_z[1]; zq[2] = pre_z[2]; zq[3] = pre_z[3];
+      uq = pre_u;  // (block g: requested at the top of the kernel)
       noop_left = SP - 4 * g;  // (block g <= NP - 1 starts in phase 4g - 1 - SP)
 #pragma unroll 1
       for (int j = g; j < nblk; j += NP) {
@@ -463,9 +486,7 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
         constexpr int MODEL = PDDP_MODEL_CARTPOLE;
         const bool gex = b0 + lane < a.B;
         const int gb = gex ? b0 + lane : a.B - 1;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(
-            gen.Z + ((size_t)gb * (size_t)(N + 1) + N) * 4);
-        const T zN[4] = {v[0], v[1], v[2], v[3]};
+        const T zN[4] = {pre_z[0], pre_z[1], pre_z[2], pre_z[3]};
         T lz[4], lzz[16], lu[1], luu[1];
         const T l = cost_derivs<T, MODEL>(prob, zN, nullptr,
                                           trig_of<T, MODEL>(zN), true, lz, lzz,
