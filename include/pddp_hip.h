@@ -292,7 +292,11 @@ int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
  * here.  Sample problems with at most 16 step sizes; returns
  * PDDP_E_UNSUPPORTED otherwise (make the three calls then).  L == NULL: no
  * records are written and `fresh` stays set - the caller's next sweep is
- * pddp_sweep_nominal_*, which needs none (`rec` is not touched then). */
+ * pddp_sweep_nominal_*, which needs none; `rec`, when not NULL, is then
+ * scratch of at least B (N+1) n scalars: the states of every trajectory's
+ * full-step candidate go there, rows next to one another, INSTEAD of
+ * Zc[b][.][0][.] (the usual winner: its copy into the nominal reads whole
+ * sectors there, 16 bytes out of every A n 4-byte step in Zc). */
 int pddp_search_accept_f32(const pddp_problem* problem, int B, int N, int A,
                            float* Z, float* U, const float* gains,
                            const float* alphas, const float* u_min,

@@ -241,6 +241,27 @@ __global__ __launch_bounds__(kWave) void line_search_kernel(
   a.Jc[idx] = J + lf;  // L.sum(0) + l_f                           (ilqr.py:789)
 }
 
+// u = clamp(U + alpha k + K (z - Z))  (ilqr.py:708-712, utils/constraint.py
+// clamp) with the multiply-adds written out: the rollout and the tail of the
+// fused launch (which re-evaluates the winner's actions instead of gathering
+// them from Uc) must round alike, and the compiler contracts a plain
+// expression differently from one inlined copy to the next.
+template <typename T, int n, int m>
+PDDP_DEV void control_law(const T* z, const T* zr, const T* gr, const T* us,
+                          T alpha, const T* umin, const T* umax, T* un) {
+#pragma unroll
+  for (int r = 0; r < m; ++r) {
+    T s = T(0);
+#pragma unroll
+    for (int c = 0; c < n; ++c)
+      s = n4::fma_(z[c] - zr[c], gr[m + r * n + c], s);  // dz K^T  (ilqr.py:710)
+    const T du = n4::fma_(alpha, gr[r], s);  // alpha * k[i] +       (ilqr.py:708)
+    const T v = us[r] + du;
+    // unbounded: umin / umax are -inf / +inf
+    un[r] = clamp_nan(v, umin[r], umax[r]);
+  }
+}
+
 // Same line search with the trajectory's nominal data staged in LDS: 16 lanes
 // per trajectory (one per alpha, A <= 16), four trajectories per wavefront.
 // Z, U and the gains of a trajectory (4 KB for cartpole at N = 100) are copied
@@ -336,9 +357,17 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
   if (run && hid == 0) {
     const T alpha = a.alphas[ai];
     const int idx = b * a.A + ai;
-    T* Zci = a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
+    // FUSED without records, `rec` given as scratch: the FULL STEP (candidate
+    // 0, the winner of 19 accepted attempts in 20 - tools/ls_tail_profile.py)
+    // writes its states to rec[b][N + 1][n], rows next to one another, instead
+    // of Zc[b][.][0][.]: the tail's copy of the winner into the nominal then
+    // reads whole sectors instead of 16 bytes out of every 160-byte step of Zc
+    // (a per-lane stride in the address update: no instruction more)
+    const bool compact0 = FUSED && Lout == nullptr && rec != nullptr && ai == 0;
+    T* Zci = compact0 ? rec + (size_t)b * (N + 1) * n
+                      : a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
     T* Uci = a.Uc + ((size_t)b * N * a.A + ai) * m;
-    const size_t zstep = zstep_c, ustep = ustep_c;
+    const size_t zstep = compact0 ? (size_t)n : zstep_c, ustep = ustep_c;
 
     T z[n], zn[n], un[m];
 #pragma unroll
@@ -357,17 +386,7 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
       for (int j = 0; j < m; ++j) us[j] = Us[t * m + j];
       const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 0; r < m; ++r) {
-        T du = alpha * gr[r];  // alpha * k[i]                    (ilqr.py:708)
-        T s = T(0);
-#pragma unroll
-        for (int c = 0; c < n; ++c) s += (z[c] - zr[c]) * gr[m + r * n + c];
-        du = du + s;  // + dz K^T                                 (ilqr.py:710)
-        const T v = us[r] + du;
-        // unbounded: umin / umax are -inf / +inf
-        un[r] = clamp_nan(v, umin[r], umax[r]);
-      }
+      control_law<T, n, m>(z, zr, gr, us, alpha, umin, umax, un);
 #pragma unroll
       for (int j = 0; j < n; ++j) Zci[(size_t)t * zstep + j] = z[j];
 #pragma unroll
@@ -475,21 +494,37 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
         // rollout on the SIMD slows the first by a quarter; the full step's
         // lane writing its rows over the nominal's in LDS: +3 us per launch,
         // as much as it saves.)
-        const T* cz = srcz;
-        const T* cu = srcu;
-        const size_t czs = zstep_c, cus = ustep_c;
+        // The winner's ACTIONS are not gathered (a 64-byte sector for four
+        // bytes): they are its control law at the gathered states, evaluated
+        // again from the nominal row in LDS - the same operations in the
+        // same order as in the rollout (control_law), bit for bit.
         T zz[KR][n], uu[KR][m];
+        const bool from_rec = rec != nullptr && amin_out == 0;  // (compact0)
+        const T* cz = from_rec ? rec + (size_t)b * (N + 1) * n : srcz;
+        const size_t czs = from_rec ? (size_t)n : zstep_c;
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
           const int t = t_first + 16 * H * k;
-          const int tz = t <= N ? t : N, tu = t < N ? t : 0;
+          const int tz = t <= N ? t : N;
 #pragma unroll
           for (int j = 0; j < n; ++j) zz[k][j] = cz[(size_t)tz * czs + j];
-#pragma unroll
-          for (int j = 0; j < m; ++j) uu[k][j] = cu[(size_t)tu * cus + j];
         }
         const T* Gl = smem + (size_t)grp * per + (N + 1) * n + N * m;
         for (int o = ai + 16 * hid; o < N * GS; o += 16 * H) Ga[o] = Gl[o];
+        const T alpha_w = a.alphas[amin_out];
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+          const int t = t_first + 16 * H * k;
+          const int tu = t < N ? t : 0;
+          T zr[n], gr[GS], us[m];
+#pragma unroll
+          for (int j = 0; j < n; ++j) zr[j] = Zs[tu * n + j];
+#pragma unroll
+          for (int j = 0; j < GS; ++j) gr[j] = Gs[tu * GS + j];
+#pragma unroll
+          for (int j = 0; j < m; ++j) us[j] = Us[tu * m + j];
+          control_law<T, n, m>(zz[k], zr, gr, us, alpha_w, umin, umax, uu[k]);
+        }
 #pragma unroll
         for (int k = 0; k < KR; ++k) {
           const int t = t_first + 16 * H * k;
