@@ -257,6 +257,7 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
     T a1 = g * s;
     T a2 = F - mu * xd;
     T a3 = T(4) * (mc + mp) - T(3) * mp * c * c;
+    if constexpr (JAC) sync(SyncPoint<5>{}, a0, a1, a2, a3);
     T num_t = a0 * c + T(2) * ((mc + mp) * a1 + a2 * c);
     // one reciprocal of a3 serves both accelerations (and the Jacobians)
     T ia3 = inv_(a3);
@@ -290,6 +291,8 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
       const T dthdd_th = kt * (dnt_th * a3 - num_t * da3_th) * ia3 * ia3;
       const T dthdd_thd = kt * dnt_thd * ia3;
       const T dthdd_F = kt * dnt_F * ia3;
+      T dthdd_thp = dthdd_th, dthdd_xdp = dthdd_xd, dthdd_thdp = dthdd_thd;
+      sync(SyncPoint<6>{}, dthdd_thp, dthdd_xdp, dthdd_thdp);
       const T dxdd_xd = dnx_xd * ia3;
       const T dxdd_th = (dnx_th * a3 - num_x * da3_th) * ia3 * ia3;
       const T dxdd_thd = dnx_thd * ia3;
@@ -297,9 +300,9 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
       Fz[1 * n + 1] = T(1) + dxdd_xd * dt;
       Fz[1 * n + 2] = dxdd_th * dt;
       Fz[1 * n + 3] = dxdd_thd * dt;
-      Fz[3 * n + 1] = dthdd_xd * dt;
-      Fz[3 * n + 2] = dthdd_th * dt;
-      Fz[3 * n + 3] = T(1) + dthdd_thd * dt;
+      Fz[3 * n + 1] = dthdd_xdp * dt;
+      Fz[3 * n + 2] = dthdd_thp * dt;
+      Fz[3 * n + 3] = T(1) + dthdd_thdp * dt;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         Fz[0 * n + j] = Fz[1 * n + j] * dt;
@@ -544,6 +547,9 @@ PDDP_DEV T cost_derivs(const ProblemT<T>& P, const T* z, const T* u,
             d[i] *
             ((Q[i * PDDP_MAX_AUG + k] + Q[k * PDDP_MAX_AUG + i]) * d[k]);
   }
+  if constexpr (n == 4 && na == 5)
+    sync(SyncPoint<7>{}, l_zz[0], l_zz[2], l_zz[8], l_zz[10], l_zz[3],
+         l_zz[12], l_zz[15]);
   // second derivative of the augmentation: d2 sin = -sin, d2 cos = -cos
 #pragma unroll
   for (int i = 0; i < na; ++i)
@@ -609,9 +615,11 @@ PDDP_DEV T record_of(const ProblemT<T>& P, const T* z, const T* un,
 #pragma unroll
     for (int j = 0; j < n * m; ++j) Fu[j] = T(0);
   }
+  // (all of F: a callee that stores them here takes their evaluation along)
   if constexpr (n == 4 && m == 1)
-    sync(SyncPoint<3>{}, Fz[5], Fz[6], Fz[7], Fz[13], Fz[14], Fz[15], Fu[1],
-         Fu[3]);
+    sync(SyncPoint<3>{}, Fz[0], Fz[1], Fz[2], Fz[3], Fz[4], Fz[5], Fz[6],
+         Fz[7], Fz[8], Fz[9], Fz[10], Fz[11], Fz[12], Fz[13], Fz[14], Fz[15],
+         Fu[0], Fu[1], Fu[2], Fu[3]);
   const T l =
       cost_derivs<T, MODEL, QM>(P, z, u, tr, terminal, lz, lzz, lu, luu, sync);
 #pragma unroll

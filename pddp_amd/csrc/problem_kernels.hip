@@ -401,11 +401,13 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
     // run-time trip count): a quarter of the loop branches and address
     // updates - 42.3 -> 37.5 us for the rollouts at B = 4096
     int t = 0;
-    for (; t + 3 < N; t += 4) {
-      step(t);
-      step(t + 1);
-      step(t + 2);
-      step(t + 3);
+    if constexpr (n <= 4) {  // (the larger models' steps spill when copied)
+      for (; t + 3 < N; t += 4) {
+        step(t);
+        step(t + 1);
+        step(t + 2);
+        step(t + 3);
+      }
     }
 #pragma unroll 1
     for (; t < N; ++t) step(t);
@@ -481,7 +483,7 @@ __global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
       T zc[n], uc[m];
       const int t_first = ai + 16 * hid;  // rows t_first, t_first + 16 H, ...
       constexpr int KR = 4;  // rows per lane the short form below covers
-      if (Lout == nullptr && N + 1 <= 16 * H * KR) {
+      if (n <= 6 && Lout == nullptr && N + 1 <= 16 * H * KR) {
         // No records to write (the next sweep evaluates them): the tail is
         // the winner's rows - all of this lane's requested at once, one
         // memory latency instead of one per row - and the gains, which are

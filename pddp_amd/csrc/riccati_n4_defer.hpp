@@ -322,36 +322,25 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
       // (asked now: needed after the last block only)
       const bool sums = gex && (a.active == nullptr || a.active[gb] != 0) &&
                         (gen.fresh == nullptr || gen.fresh[gb] != 0);
-      // A pass = one block = SP phases: block j is evaluated in the phases
-      // 4j - 1 - SP .. 4j - 2 and first read in phase 4j - 1.  The passes of
-      // the blocks 0 .. NP reach back before phase 0: those of their sync
-      // points are no-ops (`noop_left`), the one that ends "phase -1" is the
-      // workgroup's start barrier, the rest are phase barriers - of which
-      // every wavefront of the workgroup executes exactly P.
-      constexpr int SP = 4 * NP;
+      // A pass = one block = four phases: block j is evaluated in the phases
+      // 4j - 5 .. 4j - 2 and first read in phase 4j - 1.  Block 0 is
+      // evaluated before the first phase (its sync points do nothing), block
+      // 1 starts before it too: the first sync point of its pass is the
+      // workgroup's start barrier, the others are phase barriers - of which
+      // every wavefront of the workgroup executes exactly P.  The three
+      // kinds of pass are three instantiations (MODE): a state machine in
+      // the barrier cost the pass a hundred scalar instructions.
+      static_assert(NP == 1, "one generator (see above for two)");
+      constexpr int SP = 4;
       // the sync points of record_of (models.hpp) this generator stops at:
-      // SP - 1 at most (the pass ends with one more, after the LDS writes)
-      constexpr unsigned kStops = NP == 1 ? 0b11010u : 0b11111u;
-      int p = 0, nsync = 0, noop_left = 0;
-      bool started = false;
-      auto barrier = [&]() {
-        ++nsync;
-        if (noop_left > 0) {
-          --noop_left;
-        } else if (!started) {
-          __syncthreads();
-          started = true;
-        } else if (p < P) {
-          PDDP_DW_BARRIER();
-          ++p;
-        }
-      };
-      auto sync = [&](auto point, auto&... vals) {
-        if constexpr ((kStops >> decltype(point)::value) & 1u) {
-          (pin_value(vals), ...);
-          barrier();
-        }
-      };
+      // SP - 1 (the pass ends with one more, after the LDS writes)
+#ifndef PDDP_GEN_STOPS
+#define PDDP_GEN_STOPS 0b00011010u
+#endif
+      constexpr unsigned kStops = PDDP_GEN_STOPS;
+      static_assert(__builtin_popcount(kStops) == SP - 1, "");
+      int p = 0;
+      T* dst = ring;  // this pass's slot, this lane's record (set by pass)
       // operands of the block evaluated next, requested one pass ahead
       T zq[4], uq;
       auto request = [&](int j) {
@@ -361,22 +350,68 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
         zq[0] = v[0]; zq[1] = v[1]; zq[2] = v[2]; zq[3] = v[3];
         uq = Ug[tau];
       };
-      auto pass = [&](int j) {
-        nsync = 0;
+      // MODE 0: before the first phase; 1: the pass that crosses the start
+      // barrier; 2: steady state
+      auto pass = [&](auto mode, int j) {
+        constexpr int MODE = decltype(mode)::value;
+        int nsync = 0;
+        auto barrier = [&]() {
+          if constexpr (MODE == 2) {
+            if (p < P) {  // (always: block j's pass ends with phase 4j - 2)
+              PDDP_DW_STAMP(nsync & 3);  // (stats build: segment lengths)
+              PDDP_DW_BARRIER();
+              ++p;
+            }
+          } else if constexpr (MODE == 1) {
+            if (nsync == 0) {
+              __syncthreads();
+            } else if (p < P) {
+              PDDP_DW_BARRIER();
+              ++p;
+            }
+          }
+          ++nsync;
+        };
+        auto sync = [&](auto point, auto&... vals) {
+          constexpr int K = decltype(point)::value;
+          if constexpr (K == 3) {
+            // F_z, F_u: into the ring as soon as they exist - left to itself
+            // the compiler sinks the whole evaluation to the stores at the
+            // end of the pass, into one segment as long as two phases
+            const T f[] = {vals...};
+            static_assert(sizeof...(vals) == 20, "");
+#pragma unroll
+            for (int k = 0; k < 16; k += 4)
+              *reinterpret_cast<f32x4*>(dst + k) =
+                  f32x4{f[k], f[k + 1], f[k + 2], f[k + 3]};
+            *reinterpret_cast<f32x4*>(dst + 32) =
+                f32x4{f[16], f[17], f[18], f[19]};
+            asm volatile("" ::: "memory");
+          }
+          if constexpr ((kStops >> K) & 1u) {
+            if constexpr (K != 3) (pin_value(vals), ...);
+            barrier();
+          }
+        };
         const T z[4] = {zq[0], zq[1], zq[2], zq[3]};
         const T u = uq;
-        if (j + NP < nblk) request(j + NP);
+        if (j + 1 < nblk) request(j + 1);
         const int tau = N - 1 - 4 * j - sb;
         T w[kRec];
+        // the block's slots: record tau lives in slot (N - 1 - tau) % R
+        dst = ring + ((4 * j + sb) % R) * G::SLOT + grbase;
         const T l = record_of<T, MODEL, QM>(prob, z, &u, false, true, a.u_min,
                                             a.u_max, w, sync);
-        while (nsync < SP - 1) barrier();
-        // the block's slots: record tau lives in slot (N - 1 - tau) % R
-        T* dst = ring + ((4 * j + sb) % R) * G::SLOT + grbase;
+        // (words 0..15 and 32..35, F_z and F_u, went out at sync point 3;
+        // 36..39, L_uz, are zero in every record: written the first time a
+        // slot is used only)
 #pragma unroll
-        for (int k = 0; k < kRec; k += 4)
-          *reinterpret_cast<f32x4*>(dst + k) =
-              f32x4{w[k], w[k + 1], w[k + 2], w[k + 3]};
+        for (int k = 16; k < kRec; k += 4)
+          if (k != 32 && k != 36)
+            *reinterpret_cast<f32x4*>(dst + k) =
+                f32x4{w[k], w[k + 1], w[k + 2], w[k + 3]};
+        if (MODE != 2 || j < R / 4)
+          *reinterpret_cast<f32x4*>(dst + 36) = f32x4{T(0), T(0), T(0), T(0)};
         if (tau >= 0) {
           Lsh[gt * (N + 1) + tau] = l;
           if (gex) Lg[tau] = l;
@@ -385,15 +420,13 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
       };
       PDDP_DW_MARK(1, 0);
       zq[0] = pre_z[0]; zq[1] = pre_z[1]; zq[2] = pre_z[2]; zq[3] = pre_z[3];
-      uq = pre_u;  // (block g: requested at the top of the kernel)
-      noop_left = SP - 4 * g;  // (block g <= NP - 1 starts in phase 4g - 1 - SP)
+      uq = pre_u;  // (block 0: requested at the top of the kernel)
+      pass(std::integral_constant<int, 0>{}, 0);
+      PDDP_DW_MARK(1, 1);
+      if (nblk > 1) pass(std::integral_constant<int, 1>{}, 1);
+      else __syncthreads();
 #pragma unroll 1
-      for (int j = g; j < nblk; j += NP) {
-        pass(j);
-        if (j == g) PDDP_DW_MARK(1, 1);
-      }
-      noop_left = 0;
-      if (!started) barrier();
+      for (int j = 2; j < nblk; ++j) pass(std::integral_constant<int, 2>{}, j);
       // every stage cost is in LDS now (the last block's barrier is behind
       // us): J_opt = L.sum() in t order, in the phases this wavefront would
       // otherwise idle through.  The LDS reads sixteen at a time - one read
@@ -413,7 +446,10 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
         gen.J_opt[gb] = Jacc;
         if (gen.fresh != nullptr) gen.fresh[gb] = 0;
       }
-      while (p < P) barrier();
+      while (p < P) {
+        PDDP_DW_BARRIER();
+        ++p;
+      }
       PDDP_DW_MARK(1, 2);
       PDDP_DW_MARK(1, 3);
       PDDP_DW_END(3);
