@@ -291,7 +291,14 @@ PDDP_DEV void control_law(const T* z, const T* zr, const T* gr, const T* us,
 // QM: live rows / columns of the stage cost matrix (models.hpp live_mask).
 template <typename T, int MODEL, bool FUSED, int WPB, int H = 1,
           unsigned QM = kFullMask<MODEL>>
-__global__ __launch_bounds__(kWave * WPB * H) void line_search_lds_kernel(
+// (f32, n <= 4: at most 128 VGPRs, so that two workgroups of eight waves share
+// a CU at the batches that have more than 256 workgroups)
+__global__ __launch_bounds__(kWave * WPB * H) __attribute__((
+    amdgpu_waves_per_eu(WPB * H >= 8 && sizeof(T) == 4 &&
+                                ModelDims<MODEL>::n <= 4
+                            ? 4
+                            : 1))) void
+line_search_lds_kernel(
     ProblemT<T> P, LineSearchArgs<T> a, AcceptArgs<T> c, T* rec, T* Lout) {
   using D = ModelDims<MODEL>;
   constexpr int n = D::n, m = D::m;

@@ -51,11 +51,6 @@ extern "C" int pddp_debug_defer_stats(unsigned long long* out, int reset) {
   }
   return 0;
 }
-extern "C" int pddp_debug_defer_marks(long long* out) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_marks), 64);
-  return 0;
-}
 extern "C" int pddp_debug_defer_seg(unsigned long long* out, int reset) {
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_seg), 256);
@@ -63,6 +58,13 @@ extern "C" int pddp_debug_defer_seg(unsigned long long* out, int reset) {
     unsigned long long z[32] = {};
     hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4d::g_defer_seg), z, 256);
   }
+  return 0;
+}
+#endif
+#if defined(PDDP_QP_STATS) || defined(PDDP_QP_MARKS)
+extern "C" int pddp_debug_defer_marks(long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_marks), 64);
   return 0;
 }
 #endif

@@ -84,7 +84,12 @@ __device__ long long g_defer_marks[2][4];
 #define PDDP_DW_STAMP(I) do { const long long n_ = clock64(); seg_acc[I] += (unsigned long long)(n_ - seg_last); seg_last = n_; } while (0)
 #else
 #define PDDP_DW_SEGDECL
+#ifdef PDDP_QP_MARKS  // the time marks alone: nothing inside the phases
+__device__ long long g_defer_marks[2][4];
+#define PDDP_DW_MARK(W, I) do { if (blockIdx.x == 0 && lane == 0) g_defer_marks[W][I] = clock64(); } while (0)
+#else
 #define PDDP_DW_MARK(W, I)
+#endif
 #define PDDP_DW_STAMP(I)
 #define PDDP_DW_DECL
 #define PDDP_DW_BARRIER() n4::lds_publish_barrier()
@@ -317,7 +322,6 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
       const int grbase = (gt / RPI) * G::GS + (gt % RPI) * kRec;
       const T* Zg = gen.Z + (size_t)gb * (size_t)(N + 1) * 4;
       const T* Ug = gen.U + (size_t)gb * (size_t)N;
-      T* Lg = gen.L + (size_t)gb * (size_t)(N + 1);
       const int nblk = (N + 3) / 4;
       // (asked now: needed after the last block only)
       const bool sums = gex && (a.active == nullptr || a.active[gb] != 0) &&
@@ -412,10 +416,7 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
                 f32x4{w[k], w[k + 1], w[k + 2], w[k + 3]};
         if (MODE != 2 || j < R / 4)
           *reinterpret_cast<f32x4*>(dst + 36) = f32x4{T(0), T(0), T(0), T(0)};
-        if (tau >= 0) {
-          Lsh[gt * (N + 1) + tau] = l;
-          if (gex) Lg[tau] = l;
-        }
+        if (tau >= 0) Lsh[gt * (N + 1) + tau] = l;  // (to `L` at the end)
         barrier();  // SP-th: the block is visible from the next phase on
       };
       PDDP_DW_MARK(1, 0);
@@ -445,6 +446,27 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
         for (; t <= N; ++t) Jacc += Lt[t];
         gen.J_opt[gb] = Jacc;
         if (gen.fresh != nullptr) gen.fresh[gb] = 0;
+      }
+      // the stage costs to `L`, whole rows (one word at a time from the
+      // passes they were 4-byte writes into 400 000 different sectors, still
+      // draining when the kernel was over: 2 us)
+      {
+        // (L is [B][N + 1]: the sixteen trajectories' rows are one run)
+        const int cnt = ((a.B - b0 < kTraj) ? a.B - b0 : kTraj) * (N + 1);
+        T* Lw = gen.L + (size_t)b0 * (size_t)(N + 1);
+        for (int i0 = lane; i0 < cnt; i0 += 8 * kWave) {
+          T v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * kWave;
+            v[k] = Lsh[i < cnt ? i : 0];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int i = i0 + k * kWave;
+            if (i < cnt) Lw[i] = v[k];
+          }
+        }
       }
       while (p < P) {
         PDDP_DW_BARRIER();
@@ -520,8 +542,6 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
       // from), while the generators evaluate the first blocks
       if (lane < kTraj) {
         constexpr int MODEL = PDDP_MODEL_CARTPOLE;
-        const bool gex = b0 + lane < a.B;
-        const int gb = gex ? b0 + lane : a.B - 1;
         const T zN[4] = {pre_z[0], pre_z[1], pre_z[2], pre_z[3]};
         T lz[4], lzz[16], lu[1], luu[1];
         const T l = cost_derivs<T, MODEL>(prob, zN, nullptr,
@@ -532,7 +552,6 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
 #pragma unroll
         for (int i = 0; i < 4; ++i) term_sh[lane][16 + i] = lz[i];
         Lsh[lane * (N + 1) + N] = l;
-        if (gex) gen.L[(size_t)gb * (size_t)(N + 1) + N] = l;
       }
     }
     __syncthreads();

@@ -31,3 +31,12 @@ for name in ("nominal", "recorded"):
     d = np.array(pool.durations()) * 1e6
     print("%-9s mean %.1f us  min %.1f us  (status != 0: %d)" % (
         name, d.mean(), d.min(), int((s.bwd_status != 0).sum())))
+    import ctypes
+    raw = ctypes.CDLL(_native.LIB_PATH)
+    if hasattr(raw, "pddp_debug_defer_marks"):  # (-DPDDP_QP_MARKS build)
+        mk = (ctypes.c_longlong * 8)()
+        raw.pddp_debug_defer_marks(mk)
+        t = [mk[i] for i in range(4)]
+        print("  wave M of workgroup 0: first phase after %d cycles, phases "
+              "%d cycles (%.0f each)" % (t[1] - t[0], t[2] - t[1],
+                                         (t[2] - t[1]) / 102.0))
