@@ -366,7 +366,8 @@ def bench_bnn(args, emit=True):
     from pddp_amd.controllers.plugin import TorchProblem
     from pddp_amd.controllers.solver import ILQRSolver
     from pddp_amd.models.bnn import bnn_dynamics_model_factory
-    from pddp_amd.parallel import gather_best_rollout, shard_bounds
+    from pddp_amd.parallel import (gather_best_rollout, post_best_rollout,
+                                   shard_bounds)
     world, rank, dev = init_ranks()
     seen = ranks_seen(world, dev)
     torch.manual_seed(0)  # the same network on every rank
@@ -424,9 +425,11 @@ def bench_bnn(args, emit=True):
         s.round(5e-6, 1e10, n_iter)
         if world > 1 and args.exchange_every > 0 and \
                 (i + 1) % args.exchange_every == 0:
-            gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo, sync=False)
+            last_exchange = post_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
     if world > 1 and args.exchange_every <= 0:
-        gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo, sync=False)
+        last_exchange = post_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
+    if world > 1:
+        last_exchange.result()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -954,7 +957,8 @@ def main():
     import torch.distributed as dist
     world, rank, device = init_ranks()
     from pddp_amd import _native
-    from pddp_amd.parallel import gather_best_rollout, shard_bounds
+    from pddp_amd.parallel import (gather_best_rollout, post_best_rollout,
+                                   shard_bounds)
 
     dtype = torch.float32 if args.dtype == "f32" else torch.float64
     N = args.horizon or 100
@@ -1003,15 +1007,18 @@ def main():
                     search_events=ev[i][1])
             if world > 1 and args.exchange_every > 0 and \
                     (i + 1) % args.exchange_every == 0:
-                # the exchange of the path: best rollout over RCCL, no host
-                # synchronisation (launches keep queueing behind it)
-                gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo, sync=False)
+                # the exchange of the path: best rollout over RCCL - one pack
+                # launch on this stream, the all-gather on a side stream
+                # behind an event, no host synchronisation
+                last_exchange = post_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
             if with_events:  # (no host sync: a device-side sum)
                 # attempts of this round that were accepted (state 1 ACCEPTED,
                 # 5 CONVERGED; every trajectory is live throughout the region)
                 accepted_acc += ((s.state == 1) | (s.state == 5)).sum()
         if world > 1 and args.exchange_every <= 0:  # one exchange per region
-            gather_best_rollout(s.J_opt, s.Z, s.U, offset=lo, sync=False)
+            last_exchange = post_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
+        if world > 1:
+            last_exchange.result()  # (this stream waits for the last gather)
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()

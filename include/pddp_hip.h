@@ -265,6 +265,18 @@ int pddp_accept_f64(int B, int N, int n, int m, int A, const double* Zc,
                     int32_t* iter, uint8_t* active, uint8_t* fresh,
                     int32_t* n_live, void* stream);
 
+/* ---- multi-GPU exchange: the record a rank contributes to the
+ * all-gather of the best rollout, out[2 + nz + nu] = {J_best, offset + index,
+ * Z[index][nz], U[index][nu]}, index = the first trajectory of least finite
+ * J (non-finite costs count as +inf; all non-finite: index 0, J_best = inf).
+ * J [B], Z [B][nz], U [B][nu]; one launch, no host synchronisation. */
+int pddp_pack_best_f32(int B, int nz, int nu, const float* J, const float* Z,
+                       const float* U, long long offset, float* out,
+                       void* stream);
+int pddp_pack_best_f64(int B, int nz, int nu, const double* J, const double* Z,
+                       const double* U, long long offset, double* out,
+                       void* stream);
+
 /* ---- the backward sweep of a sample problem FROM ITS NOMINAL TRAJECTORY: the
  * derivative records (ilqr.py:464-473: F_z, F_u, L_z ... of every step) are
  * evaluated inside the sweep's workgroups, in LDS, and never written - the

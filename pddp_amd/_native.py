@@ -74,6 +74,8 @@ _SIGS = {
                           [_P] * 11,
     "pddp_accept": [c_int] * 5 + [_P] * 5 + [c_double, c_double, c_int] +
                    [_P] * 12,
+    "pddp_pack_best": [c_int, c_int, c_int, _P, _P, _P, ctypes.c_longlong, _P,
+                       _P],
     "pddp_sweep_nominal_f32": [_P, c_int, c_int] + [_P] * 5 + [c_int] +
                               [_P] * 7,
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
@@ -95,7 +97,8 @@ _TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
           "pddp_boxqp_m1", "pddp_boxqp", "pddp_pack_records", "pddp_sum_stage_costs",
           "pddp_nominal_rollout",
           "pddp_derivs",
-          "pddp_line_search", "pddp_search_accept", "pddp_accept")
+          "pddp_line_search", "pddp_search_accept", "pddp_accept",
+          "pddp_pack_best")
 
 _lib = None
 

@@ -166,6 +166,66 @@ static int row_sum_impl(int B, int count, const T* L, T* J, void* stream) {
   return launch_status();
 }
 
+
+// The record a rank contributes to the exchange of the best rollout
+// (pddp_amd/parallel.py): out = {J_best, offset + index,
+// Z[index][nz], U[index][nu]} with index = the first trajectory of least
+// finite cost (torch.argmin over J with non-finite entries read as +inf).
+// One launch instead of the eight small torch kernels of the same selection:
+// with a round at 83 us the exchange has to cost a few microseconds.
+constexpr int kPackBestThreads = 1024;
+template <typename T>
+__global__ __launch_bounds__(kPackBestThreads) void pack_best_kernel(
+    int B, int nz, int nu, const T* J, const T* Z, const T* U, long long offset,
+    T* out) {
+  __shared__ T sv[kPackBestThreads];
+  __shared__ int si[kPackBestThreads];
+  const int tid = threadIdx.x;
+  const T kInf = (T)__builtin_inff();
+  T best = kInf;
+  int bi = 0x7fffffff;
+  for (int b = tid; b < B; b += kPackBestThreads) {
+    const T v = J[b];
+    const T key = is_finite(v) ? v : kInf;
+    if (key < best || (key == best && b < bi)) {
+      best = key;
+      bi = b;
+    }
+  }
+  sv[tid] = best;
+  si[tid] = bi;
+  __syncthreads();
+  for (int w = kPackBestThreads / 2; w > 0; w >>= 1) {
+    if (tid < w) {
+      const T v = sv[tid + w];
+      const int i = si[tid + w];
+      if (v < sv[tid] || (v == sv[tid] && i < si[tid])) {
+        sv[tid] = v;
+        si[tid] = i;
+      }
+    }
+    __syncthreads();
+  }
+  const int idx = si[0] < B ? si[0] : 0;
+  if (tid == 0) {
+    out[0] = sv[0];
+    out[1] = (T)(offset + (long long)idx);
+  }
+  const T* zs = Z + (size_t)idx * nz;
+  const T* us = U + (size_t)idx * nu;
+  for (int o = tid; o < nz; o += kPackBestThreads) out[2 + o] = zs[o];
+  for (int o = tid; o < nu; o += kPackBestThreads) out[2 + nz + o] = us[o];
+}
+template <typename T>
+static int pack_best_impl(int B, int nz, int nu, const T* J, const T* Z,
+                          const T* U, long long offset, T* out, void* stream) {
+  if (B <= 0 || nz <= 0 || nu < 0 || !J || !Z || (nu > 0 && !U) || !out)
+    return PDDP_E_BADARG;
+  PDDP_LAUNCH((pack_best_kernel<T>), dim3(1), dim3(kPackBestThreads), 0,
+              (hipStream_t)stream, B, nz, nu, J, Z, U, offset, out);
+  return launch_status();
+}
+
 }  // namespace pddp
 
 extern "C" {
@@ -247,6 +307,17 @@ int pddp_sum_stage_costs_f32(int B, int count, const float* L, float* J,
 int pddp_sum_stage_costs_f64(int B, int count, const double* L, double* J,
                              void* stream) {
   return pddp::row_sum_impl<double>(B, count, L, J, stream);
+}
+
+int pddp_pack_best_f32(int B, int nz, int nu, const float* J, const float* Z,
+                       const float* U, long long offset, float* out,
+                       void* stream) {
+  return pddp::pack_best_impl<float>(B, nz, nu, J, Z, U, offset, out, stream);
+}
+int pddp_pack_best_f64(int B, int nz, int nu, const double* J, const double* Z,
+                       const double* U, long long offset, double* out,
+                       void* stream) {
+  return pddp::pack_best_impl<double>(B, nz, nu, J, Z, U, offset, out, stream);
 }
 
 int pddp_event_create(void** ev) {

@@ -1,5 +1,5 @@
 """Multi-GPU: one process per GPU, trajectories sharded contiguously, ONE
-collective per solve - an all-gather of each rank's best rollout.
+collective per iteration - an all-gather of each rank's best rollout.
 
 The reference has no distributed code; the trajectory batch is a
 new axis and its trajectories are independent, so the data path needs no
@@ -33,6 +33,91 @@ def pack_best(J, Z, U, offset=0):
                       U[idx].reshape(-1).to(J.dtype)])
 
 
+class BestRolloutExchange(object):
+    """The exchange of the best rollout, once PER ITERATION inside a loop of
+    asynchronous launches - built so that a round of 83 us pays
+    a few microseconds for it:
+
+    * `post()` packs this rank's record with ONE launch (`pddp_pack_best_*`;
+      the torch form of the same selection is eight small kernels, half a
+      round) on the caller's stream, and issues the all-gather on a SIDE
+      stream behind an event: the collective (latency-bound: ~2 KB per rank)
+      overlaps with the next round's kernels, nothing waits for the host.
+    * the send / receive buffers rotate (`depth` of them); a buffer is packed
+      again only after the gather that read it has finished (stream waits on
+      events - again no host wait).
+    * `result()` makes the caller's stream wait for the latest gather and
+      returns (J_best, global index [0-dim tensor], Z_best, U_best),
+      identical on every rank."""
+
+    def __init__(self, J, Z, U, group=None, depth=4):
+        self.group = group
+        self.world = (dist.get_world_size(group)
+                      if dist.is_available() and dist.is_initialized() else 1)
+        self.zshape, self.ushape = tuple(Z.shape[1:]), tuple(U.shape[1:])
+        self.nz = int(Z[0].numel())
+        self.nu = int(U[0].numel())
+        self.dtype, self.device = J.dtype, J.device
+        rec = 2 + self.nz + self.nu
+        opts = dict(dtype=J.dtype, device=J.device)
+        self.recv = [torch.zeros(self.world, rec, **opts) for _ in range(depth)]
+        # (a world of one: the record is packed straight into the result)
+        self.send = [torch.zeros(rec, **opts) if self.world > 1 else r[0]
+                     for r in self.recv]
+        # events, made once: slot k packed / its gather finished
+        self.packed = [torch.cuda.Event() for _ in range(depth)]
+        self.done = [torch.cuda.Event() for _ in range(depth)]
+        self.used = [False] * depth
+        self.side = torch.cuda.Stream(device=J.device)
+        self.k = -1
+
+    def post(self, J, Z, U, offset=0):
+        from . import _native
+        k = self.k = (self.k + 1) % len(self.send)
+        main = torch.cuda.current_stream(self.device)
+        if self.used[k] and self.world > 1:
+            main.wait_event(self.done[k])  # slot k: its last gather has read it
+        self.used[k] = True
+        p = _native.ptr
+        _native.call("pddp_pack_best", self.dtype, int(J.numel()), self.nz,
+                     self.nu, p(J), p(Z), p(U), int(offset), p(self.send[k]),
+                     _native.stream_handle(self.device))
+        if self.world > 1:
+            self.packed[k].record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.packed[k])
+                dist.all_gather_into_tensor(self.recv[k].view(-1),
+                                            self.send[k], group=self.group)
+                self.done[k].record(self.side)
+        return self
+
+    def result(self):
+        k = self.k
+        if self.world > 1:
+            torch.cuda.current_stream(self.device).wait_event(self.done[k])
+        out = self.recv[k]
+        row = out[torch.argmin(out[:, 0])]
+        Zb = row[2:2 + self.nz].reshape(self.zshape)
+        Ub = row[2 + self.nz:].reshape(self.ushape)
+        return row[0], row[1].round().to(torch.int64), Zb, Ub
+
+
+_exchanges = {}
+
+
+def post_best_rollout(J, Z, U, offset=0, group=None):
+    """`BestRolloutExchange.post` on an exchange cached per (device, dtype,
+    shapes, group): what a fit loop calls after every round; `.result()` of the
+    returned object when somebody wants the global best."""
+    key = (J.device, J.dtype, tuple(Z.shape), tuple(U.shape), id(group))
+    ex = _exchanges.get(key)
+    if ex is None:
+        if len(_exchanges) >= 4:
+            _exchanges.clear()
+        ex = _exchanges[key] = BestRolloutExchange(J, Z, U, group)
+    return ex.post(J, Z, U, offset)
+
+
 def gather_best_rollout(J, Z, U, offset=0, group=None, sync=True):
     """All-gathers every rank's best rollout and returns the global best as
     (J_best, global_index, Z_best [N+1, n], U_best [N, m]); identical on every
@@ -40,6 +125,10 @@ def gather_best_rollout(J, Z, U, offset=0, group=None, sync=True):
     `sync=False`: the index comes back as a 0-dim device tensor and nothing
     waits for the host - the form for one exchange PER ITERATION (SURVEY
     8(e)) inside a loop of asynchronous launches."""
+    if J.is_cuda and Z.is_contiguous() and U.is_contiguous() and \
+            J.is_contiguous() and Z.dtype == J.dtype and U.dtype == J.dtype:
+        Jb, index, Zb, Ub = post_best_rollout(J, Z, U, offset, group).result()
+        return Jb, (int(index.item()) if sync else index), Zb, Ub
     mine = pack_best(J, Z, U, offset)
     if dist.is_available() and dist.is_initialized():
         world = dist.get_world_size(group)

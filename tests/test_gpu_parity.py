@@ -1227,6 +1227,48 @@ def test_fused_round_equals_separate_kernels(problem, dtype):
     assert accepted > 0
 
 
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_best_rollout_exchange_on_the_device(dtype):
+    """pddp_pack_best_* + BestRolloutExchange (one pack launch per iteration,
+    the all-gather on a side stream; here a world of one) against the torch
+    form of the same selection (parallel.pack_best): first trajectory of least
+    finite cost, non-finite costs skipped, ties to the lower index, all
+    non-finite -> index 0; the rotating buffers over more posts than slots."""
+    from pddp_amd.parallel import (BestRolloutExchange, gather_best_rollout,
+                                   pack_best)
+    td = TDT[dtype]
+    g = torch.Generator().manual_seed(5)
+    B, N, n, m = 3001, 20, 4, 1
+    Z = torch.randn(B, N + 1, n, generator=g, dtype=torch.float64).to(td).cuda()
+    U = torch.randn(B, N, m, generator=g, dtype=torch.float64).to(td).cuda()
+    ex = BestRolloutExchange(torch.zeros(B, dtype=td).cuda(), Z, U, depth=3)
+    for trial in range(7):
+        J = torch.randn(B, generator=g, dtype=torch.float64).to(td)
+        J[torch.randint(0, B, (40,), generator=g)] = float("nan")
+        J[torch.randint(0, B, (40,), generator=g)] = float("inf")
+        J[torch.randint(0, B, (5,), generator=g)] = -float("inf")
+        if trial == 3:  # a tie: the lower index wins
+            J[1700] = J[200] = -50.0
+        if trial == 4:
+            J[:] = float("nan")
+        J = J.cuda()
+        ref = pack_best(J, Z, U, offset=7000)
+        Jb, idx, Zb, Ub = ex.post(J, Z, U, offset=7000).result()
+        assert int(idx) == int(ref[1].round()), trial
+        assert torch.equal(torch.nan_to_num(Jb, posinf=1e30).cpu(),
+                           torch.nan_to_num(ref[0], posinf=1e30).cpu())
+        i = int(idx) - 7000
+        assert torch.equal(Zb, Z[i]) and torch.equal(Ub, U[i])
+        if trial == 3:
+            assert i == 200
+        if trial == 4:
+            assert i == 0
+    # the function form goes through the same exchange on CUDA tensors
+    Jb2, idx2, Zb2, Ub2 = gather_best_rollout(J, Z, U, offset=7000, sync=False)
+    assert isinstance(idx2, torch.Tensor) and int(idx2) == int(idx)
+    assert torch.equal(Zb2, Zb)
+
+
 @pytest.mark.parametrize("B,N", [(37, 33), (16, 100), (5, 10), (130, 47)])
 def test_sweep_from_nominal_equals_records_then_sweep(B, N):
     """pddp_sweep_nominal_f32 (derivative records evaluated inside the sweep's
