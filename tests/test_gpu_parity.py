@@ -2413,6 +2413,55 @@ def _float64_twin(model, cost):
     return m64, copy.deepcopy(cost).double()
 
 
+def _smallest_preactivation(m64, s3, i, t):
+    """min |pre-activation| / rms over the hidden units and particles of the
+    float64 network at step `t` of trajectory `i` of solver `s3` (the rollout
+    is replayed from step 0: with `infer_noise_variables` the model carries
+    the previous call's particles)."""
+    pre = []
+    hooks = [lin.register_forward_hook(lambda mod, inp, out: pre.append(out))
+             for lin in m64.model.hidden]
+    try:
+        with torch.no_grad():
+            z = s3.z0[i:i + 1].clone()
+            for k in range(t + 1):
+                del pre[:]
+                u = s3.U[i:i + 1, k]
+                if s3.u_min is not None:
+                    u = torch.max(torch.min(u, s3.u_max), s3.u_min)
+                z = m64(z, u, k, s3.plugin.encoding, **s3.plugin.model_opts)
+    finally:
+        for h in hooks:
+            h.remove()
+    return min(float(p.abs().min() / p.pow(2).mean().sqrt()) for p in pre)
+
+
+def test_smallest_preactivation_helper():
+    """The replay behind the ReLU-flip signature check of
+    test_full_size_bnn_round, on a small problem: it reproduces the solver's
+    own float64 rollout (so the pre-activations it inspects are the ones of
+    that step), and a typical step is far from a flip."""
+    model, cost, z0, U, solver = _bnn_problem("cartpole", 4, 12)
+    m64, c64 = _float64_twin(model, cost)
+    s3 = solver(m64, c64, 4, torch.float64)
+    s3.set_nominal(z0[:4].double(), U[:4].double())
+    near = _smallest_preactivation(m64, s3, 2, 7)
+    assert 0.0 < near < 1e-2  # (40 000 values of O(1): the smallest is ~1e-5)
+    # the replay is the solver's rollout: same state after step 7
+    pre = []
+    h = m64.model.hidden[0].register_forward_hook(
+        lambda mod, inp, out: pre.append(inp[0]))
+    try:
+        with torch.no_grad():
+            z = s3.z0[2:3].clone()
+            for k in range(8):
+                z = m64(z, s3.U[2:3, k], k, s3.plugin.encoding,
+                        **s3.plugin.model_opts)
+    finally:
+        h.remove()
+    assert rel_err(z.cpu().numpy(), s3.Z[2:3, 8].cpu().numpy()) < 1e-9
+
+
 @pytest.mark.parametrize("problem,B,N", [("cartpole", 4096, 100),
                                          ("double_cartpole", 1024, 150)])
 def test_full_size_bnn_round(problem, B, N):
@@ -2504,6 +2553,15 @@ def test_full_size_bnn_round(problem, B, N):
         per_step = np.abs(a - b).reshape(a.shape[0], a.shape[1], -1).max(-1) / scale
         assert int((per_step > 2e-4).sum()) <= 2, (name, np.sort(per_step.ravel())[-5:])
         assert float(per_step.max()) < 5e-3, (name, float(per_step.max()))
+        # ... and an outlier has to carry the SIGNATURE of such a flip: in the
+        # float64 replay of that trajectory up to that step, some hidden
+        # pre-activation of the primal rows lies within float32 rounding of
+        # zero (a 200-term dot product of O(1) terms: a few 1e-6 of the
+        # layer's rms) - a kernel bug of the same size would not
+        for i_s, t_s in zip(*np.nonzero(per_step > 2e-4)):
+            near = _smallest_preactivation(m64, s3, int(i_s), int(t_s))
+            assert near < 5e-6, (name, int(i_s), int(t_s),
+                                 float(per_step[i_s, t_s]), near)
     s3.gains.copy_(s2.gains.double())
     s3.bwd_status.zero_()
     s3.line_search(active=s3.active)
