@@ -61,6 +61,17 @@ extern "C" int pddp_debug_defer_seg(unsigned long long* out, int reset) {
   return 0;
 }
 #endif
+#ifdef PDDP_QP_MARKS
+extern "C" int pddp_debug_defer_odd(unsigned long long* out, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_odd), 16);
+  if (reset) {
+    unsigned long long z[2] = {};
+    hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4d::g_defer_odd), z, 16);
+  }
+  return 0;
+}
+#endif
 #if defined(PDDP_QP_STATS) || defined(PDDP_QP_MARKS)
 extern "C" int pddp_debug_defer_marks(long long* out) {
   hipDeviceSynchronize();

@@ -80,17 +80,24 @@ __device__ unsigned long long g_defer_seg[4][8];
 // phase done, end]
 __device__ long long g_defer_marks[2][4];
 #define PDDP_DW_MARK(W, I) do { if (blockIdx.x == 0 && lane == 0) g_defer_marks[W][I] = clock64(); } while (0)
+#define PDDP_DW_COUNT(I)
 #define PDDP_DW_SEGDECL unsigned long long seg_acc[8] = {}; long long seg_last = clock64();
 #define PDDP_DW_STAMP(I) do { const long long n_ = clock64(); seg_acc[I] += (unsigned long long)(n_ - seg_last); seg_last = n_; } while (0)
 #else
 #define PDDP_DW_SEGDECL
 #ifdef PDDP_QP_MARKS  // the time marks alone: nothing inside the phases
 __device__ long long g_defer_marks[2][4];
+// [phases of role Q that left the lean BoxQP, those that ran the loop]
+__device__ unsigned long long g_defer_odd[2];
+#define PDDP_DW_COUNT(I) do { if (lane == 0) atomicAdd(&g_defer_odd[I], 1ull); } while (0)
 #define PDDP_DW_MARK(W, I) do { if (blockIdx.x == 0 && lane == 0) g_defer_marks[W][I] = clock64(); } while (0)
 #else
 #define PDDP_DW_MARK(W, I)
 #endif
 #define PDDP_DW_STAMP(I)
+#ifndef PDDP_DW_COUNT
+#define PDDP_DW_COUNT(I)
+#endif
 #define PDDP_DW_DECL
 #define PDDP_DW_BARRIER() n4::lds_publish_barrier()
 #define PDDP_DW_END(ROLE)
@@ -568,6 +575,7 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
       bool Kzero = !qc.free_, fail = qc.fail;
       const bool slow = qc.slow && alive && take;
       if (__builtin_expect(__any(slow), 0)) {
+        PDDP_DW_COUNT(1);
         // rare: the reference's loop, one slow trajectory at a time on the
         // whole wavefront
         unsigned long long todo = __ballot(slow && q == 0);
@@ -626,6 +634,7 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
                            !__builtin_amdgcn_classf(qp_Q, 0x180) |
                            (ql.slow_w < 0);
           if (__builtin_expect(__any(odd & alive), 0)) {
+            PDDP_DW_COUNT(0);
             exact(odd & alive, alive, Quu, Qu, qp_Q, kt, sK, c, w);
             *reinterpret_cast<f32x4*>(pq) = f32x4{kt, sK, c, w};
           }
