@@ -32,8 +32,8 @@
 // float and double; the cost is written once over a number type (plain T for
 // values, HDual<T> for derivatives).
 //
-// FULL_COVARIANCE_MATRIX (z = mean | C row-major, n = D + D^2; cartpole and
-// pendulum): C is taken as given - no symmetrisation, so that the partial
+// FULL_COVARIANCE_MATRIX (z = mean | C row-major, n = D + D^2; round 3: the
+// double cartpole too, n = 42): C is taken as given - no symmetrisation, so that the partial
 // derivatives land on the entries the reference's formulas read - the dynamics
 // return diag(diag(C)), and the cost's trace needs no factorisation.
 // The same kernels, templated on the encoding, serve VARIANCE_ONLY
@@ -577,10 +577,9 @@ static int check_default(const pddp_problem& p) {
   if (p.encoding != kChol && p.encoding != kVar && p.encoding != kStd &&
       p.encoding != kFull)
     return PDDP_E_UNSUPPORTED;
-  // full covariance: n = D + D^2 = 20 / 6 (cartpole, pendulum); the double
-  // cartpole's 42 stays on the plugin path
-  if (p.encoding == kFull && p.model == PDDP_MODEL_DOUBLE_CARTPOLE)
-    return PDDP_E_UNSUPPORTED;
+  // (full covariance: n = D + D^2 = 20 / 6 / 42 - cartpole, pendulum, double
+  // cartpole; its sweep is the large generic kernel)
+
   switch (p.model) {
     case PDDP_MODEL_CARTPOLE:
     case PDDP_MODEL_DOUBLE_CARTPOLE:
@@ -593,9 +592,7 @@ static int check_default(const pddp_problem& p) {
 #define PDDP_DEFAULT_ENC(...)                                                \
   switch (p.encoding) {                                                      \
     case kFull: {                                                            \
-      if constexpr (MODEL != PDDP_MODEL_DOUBLE_CARTPOLE) {                   \
-        constexpr int ENC = kFull; __VA_ARGS__;                              \
-      }                                                                      \
+      constexpr int ENC = kFull; __VA_ARGS__;                                \
     } break;                                                                 \
     case kChol: { constexpr int ENC = kChol; __VA_ARGS__; } break;             \
     case kVar: { constexpr int ENC = kVar; __VA_ARGS__; } break;               \

@@ -32,17 +32,16 @@ def build_problem(name, model, cost, encoding, param_names):
     problems the HIP kernels evaluate in closed form - every sample problem
     under IGNORE_UNCERTAINTY (csrc/problem_kernels.hip) and cartpole, pendulum,
     double cartpole under DEFAULT = UPPER_TRIANGULAR_CHOLESKY, VARIANCE_ONLY and
-    STANDARD_DEVIATION_ONLY, cartpole and pendulum also under
-    FULL_COVARIANCE_MATRIX (csrc/default_kernels.hip; rendezvous carries a full
-    covariance through its dynamics and stays on the plugin path, as does the
-    double cartpole's 42-dimensional full-covariance state).  None otherwise."""
+    STANDARD_DEVIATION_ONLY and FULL_COVARIANCE_MATRIX (csrc/default_kernels.hip;
+    rendezvous carries a full covariance through its dynamics and stays on the
+    plugin path).  None otherwise."""
     if encoding in (StateEncoding.UPPER_TRIANGULAR_CHOLESKY,
                     StateEncoding.VARIANCE_ONLY,
                     StateEncoding.STANDARD_DEVIATION_ONLY):
         if name == "rendezvous":
             return None
     elif encoding == StateEncoding.FULL_COVARIANCE_MATRIX:
-        if name not in ("cartpole", "pendulum"):
+        if name == "rendezvous":
             return None
     elif encoding != StateEncoding.IGNORE_UNCERTAINTY:
         return None

@@ -646,11 +646,12 @@ def test_plugin_path_equals_native_path():
     ("cartpole", "default"), ("pendulum", "default"),
     ("cartpole", "variance"), ("pendulum", "variance"),
     ("cartpole", "std"), ("pendulum", "std"), ("cartpole", "fullcov"),
-    ("pendulum", "fullcov")])
+    ("pendulum", "fullcov"), ("double_cartpole", "fullcov")])
 def test_default_encoding_vs_reference_golden(problem, enc_key):
     """The Gaussian state encodings - DEFAULT (upper-triangular Cholesky, n =
     14 / 5), VARIANCE_ONLY, STANDARD_DEVIATION_ONLY (n = 8 / 4) and
-    FULL_COVARIANCE_MATRIX (n = 20) - through the reference-signature API:
+    FULL_COVARIANCE_MATRIX (n = 20 / 6, and 42 for the double cartpole) -
+    through the reference-signature API:
     forward, backward (zero-copy records, HIP sweep), _control_law + costs, and
     a full fit, against the reference's own outputs (fp64 goldens,
     tools/make_golden.py [--other-encodings]).  All of it on the native path
@@ -674,7 +675,12 @@ def test_default_encoding_vs_reference_golden(problem, enc_key):
     assert int(g["encoding"]) == int(enc)
     cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     u_min, u_max = cu(g["u_min"]), cu(g["u_max"])
-    for tag in ("N5_cos", "N25_cos"):
+    # (horizons 5 and 25; 5 and 12 for the double cartpole's n = 42, round 3:
+    # tools/make_golden.py --dc-fullcov)
+    tags = sorted({k.split("/")[0] for k in g.files if k.endswith("_cos/U")},
+                  key=lambda t: int(t[1:].split("_")[0]))
+    assert len(tags) == 2
+    for tag in tags:
         U = cu(g[tag + "/U"])
         out = forward(cu(g["z0"]), U, model, cost, enc, u_min=u_min,
                       u_max=u_max)
@@ -725,6 +731,53 @@ def test_default_encoding_vs_reference_golden(problem, enc_key):
     assert ctrl._solver.problem.encoding == int(enc)
 
 
+def test_double_cartpole_full_covariance_fit_native_vs_plugin():
+    """The double cartpole under FULL_COVARIANCE_MATRIX (n = 6 + 36 = 42: the
+    largest encoded state of the sample problems) on the native path - rollout,
+    hyper-dual cost records and closed-form dynamics Jacobian of
+    csrc/default_kernels.hip, the large generic sweep, the HIP line search -
+    against the plugin path (autograd through the torch model and cost, torch
+    line search) through a whole bounded fit in float64: the same sequence of
+    accepts and rejections, costs and controls.  (No golden of the reference
+    for this combination; the plugin path is pinned to its goldens for the
+    other problems under this encoding.)"""
+    import pddp_amd
+    from pddp_amd.controllers import iLQRController
+    from pddp_amd.examples import double_cartpole as ex
+    enc = pddp_amd.StateEncoding.FULL_COVARIANCE_MATRIX
+    N = 14
+    g = torch.Generator().manual_seed(11)
+    U0 = (0.2 * torch.randn(N, 1, generator=g, dtype=torch.float64)).cuda()
+    mean = torch.tensor([0.0, 0.0, 3.0, 0.0, 3.1, 0.0], dtype=torch.float64)
+    A = 0.05 * torch.randn(6, 6, generator=g, dtype=torch.float64)
+    z0 = pddp_amd.GaussianVariable(
+        mean, covar=A.t() @ A + 1e-2 * torch.eye(6, dtype=torch.float64)
+    ).encode(enc).cuda()
+    u_min = torch.tensor([-20.0], dtype=torch.float64)
+    u_max = torch.tensor([20.0], dtype=torch.float64)
+    runs = []
+    for force in (False, True):
+        model = ex.DoubleCartpoleDynamicsModel(0.05).double().cuda()
+        cost = ex.DoubleCartpoleCost().double().cuda()
+        ctrl = iLQRController(None, model, cost, force_plugin=force)
+        trace = []
+        Z, U, state = ctrl.fit(
+            U0.clone(), enc, n_iterations=6, z0=z0, u_min=u_min, u_max=u_max,
+            on_iteration=lambda i, st, Z_, U_, J: trace.append((i, int(st),
+                                                                float(J))))
+        assert (ctrl._solver.plugin is not None) == force
+        if not force:
+            assert ctrl._solver.problem.encoded_size == 42
+        runs.append((np.array(trace), U.cpu().numpy(), Z.cpu().numpy(),
+                     int(state)))
+    (ta, Ua, Za, sa), (tb, Ub, Zb, sb) = runs
+    assert ta.shape == tb.shape and np.array_equal(ta[:, :2], tb[:, :2])
+    assert np.allclose(ta[:, 2], tb[:, 2], rtol=1e-8)
+    assert sa == sb
+    assert rel_err(Ua, Ub) < 1e-6 and rel_err(Za, Zb) < 1e-6
+    assert (ta[:, 1] == 1).sum() >= 2  # (accepted steps: the fit moved)
+
+
 @pytest.mark.parametrize("enc_name", ["UPPER_TRIANGULAR_CHOLESKY",
                                       "VARIANCE_ONLY",
                                       "STANDARD_DEVIATION_ONLY",
@@ -743,8 +796,6 @@ def test_default_encoding_native_vs_plugin_path(problem, dtype, enc_name):
     double cartpole (n = 27, no golden captured) and float32."""
     import pddp_amd
     from pddp_amd.controllers.ilqr import _make_solver
-    if enc_name == "FULL_COVARIANCE_MATRIX" and problem == "double_cartpole":
-        pytest.skip("n = 42: plugin path only")
     mod = getattr(pddp_amd.examples, problem)
     td = TDT[dtype]
     model = [getattr(mod, n) for n in dir(mod) if n.endswith("DynamicsModel")

@@ -688,6 +688,13 @@ def main():
         capture_problem("pendulum", "fullcov", torch.float64, [5, 25],
                         with_fit=12)
         return
+    if "--dc-fullcov" in sys.argv:
+        # round 3: the double cartpole under the full covariance (n = 42), the
+        # last (problem, encoding) pair to go native; short horizons - the
+        # reference differentiates 43 replicated inputs per step
+        capture_problem("double_cartpole", "fullcov", torch.float64, [5, 12],
+                        with_fit=6)
+        return
     if "--default-only" in sys.argv:
         capture_problem("cartpole", "default", torch.float64, [5, 25],
                         with_fit=12)
