@@ -40,7 +40,7 @@ namespace m16 {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 constexpr int kWaves = 4;  // independent trajectories (wavefronts) per workgroup
-constexpr int kRing = 4;   // record slots in flight per wavefront
+constexpr int kRing = 3;   // record slots in flight per wavefront
 constexpr int kMaxDma = 4; // LDS-DMA instructions per record (64 x 16 B each)
 
 // the 16x16x4 instruction of each type: accumulator vector, the matrix row
@@ -74,9 +74,20 @@ template <> struct Tile<double> {
   }
 };
 
-template <typename T, bool BOUNDED, bool FAST, bool CHOL>
+// NDMA: LDS-DMA instructions per record, chosen so that a slot (NDMA * 64
+// chunks of 16 bytes) has strictly more chunks than the record: the slot's
+// padding is zeroed once, the last DMA instruction's lanes past the record
+// stay out, and operand entries outside the matrices read the first padding
+// word - no per-entry zero selects; the slot stride is a compile-time
+// constant, so that a step instantiated per ring slot gathers its operands
+// with immediate offsets on addresses computed once (round 3: 141 -> 109
+// vector instructions per step; at B = 4096 this kernel's four wavefronts per
+// SIMD are bound by instruction issue, not by HBM).
+template <typename T, bool BOUNDED, bool FAST, bool CHOL, int NDMA>
 __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
-    RiccatiArgs<T> a, int slot_words, int ndma) {
+    RiccatiArgs<T> a) {
+  constexpr int slot_words = NDMA * kWave * (16 / (int)sizeof(T));
+  constexpr int ndma = NDMA;
   using TL = Tile<T>;
   using Acc = typename TL::Acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -102,6 +113,10 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
   const RecLayout lay(n, 1);
   const int S = lay.stride;
   const int g = lane >> 4, j = lane & 15;
+  // this wavefront's slots: zero the padding behind the record, once
+  for (int sl = 0; sl < kRing; ++sl)
+    for (int wd = S + lane; wd < slot_words; wd += kWave)
+      ring[sl * slot_words + wd] = T(0);
   const T reg = (T)a.reg[b];
   T umin = T(0), umax = T(0);
   if constexpr (BOUNDED) { umin = a.u_min[0]; umax = a.u_max[0]; }
@@ -112,9 +127,9 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
   for (int r = 0; r < 4; ++r) {
     const int k = TL::row(g, r);  // F~ row / L~ row
     oF[r] = (k < n) ? (j < n ? lay.oFz + k * n + j
-                             : (j == n ? lay.oFu + k : -1))
-                    : -1;
-    int o = -1;
+                             : (j == n ? lay.oFu + k : S))
+                    : S;  // (word S: the first word of the zeroed padding)
+    int o = S;
     if (k < n) {
       if (j < n) o = lay.oLzz + k * n + j;
       else if (j == n) o = lay.oLuz + k;  // L_uz^T
@@ -131,25 +146,30 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
   int oFf[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    oFf[r] = (TL::row(g, r) < n) ? lay.oFu + TL::row(g, r) : -1;
+    oFf[r] = (TL::row(g, r) < n) ? lay.oFu + TL::row(g, r) : S;
 
   // ---- record DMA: chunk q of 16 bytes -> lane q % 64 of instruction q / 64
   const char* rec_b = reinterpret_cast<const char*>(
       a.rec + (size_t)b * (size_t)(N + 1) * S);
   const int chunks = S * (int)sizeof(T) / 16;  // S is a multiple of 4 words
   // (padding lanes past the record re-load an early chunk into the slot's pad)
-  uint32_t qoff[kMaxDma];
+  // (the launcher picked NDMA with (NDMA - 1) * 64 < chunks < NDMA * 64: the
+  // last instruction's lanes past the record stay out of it)
+  uint32_t qoff[NDMA];
 #pragma unroll
-  for (int i = 0; i < kMaxDma; ++i)
-    qoff[i] = (uint32_t)((lane + i * kWave) % chunks) * 16u;
+  for (int i = 0; i < NDMA; ++i) qoff[i] = (uint32_t)(lane + i * kWave) * 16u;
+  const bool in_tail = lane + (NDMA - 1) * kWave < chunks;
   auto dma = [&](int slot, int t) {
     const int tt = t < 0 ? 0 : t;
     const uint32_t base = (uint32_t)tt * (uint32_t)(S * sizeof(T));
     const uint32_t lbase =
         __builtin_amdgcn_readfirstlane(n4::lds_addr(ring + slot * slot_words));
 #pragma unroll
-    for (int i = 0; i < kMaxDma; ++i)
-      if (i < ndma) n4::lds_dma16(rec_b, base + qoff[i], lbase + i * kWave * 16);
+    for (int i = 0; i < NDMA - 1; ++i)
+      n4::lds_dma16(rec_b, base + qoff[i], lbase + i * kWave * 16);
+    if (in_tail)
+      n4::lds_dma16(rec_b, base + qoff[NDMA - 1],
+                    lbase + (NDMA - 1) * kWave * 16);
   };
 
   // ---- terminal value function in the accumulator layout (ilqr.py:581-583)
@@ -169,43 +189,46 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
   T* gains_b = a.gains + (size_t)b * (size_t)N * lay.gstride;
   T kprev = T(0);
   int status = PDDP_BWD_OK;
-  int slot = 0;
-  for (int t = N - 1; t >= 0; --t) {
-    // record t has landed once at most (kRing - 1) younger {DMA x ndma, store}
-    // groups are outstanding; counted waits need immediates: ndma is 1 or 2
-    switch (ndma) {
-      case 1: n4::wait_vmcnt<(kRing - 1) * 2>(); break;
-      case 2: n4::wait_vmcnt<(kRing - 1) * 3>(); break;
-      case 3: n4::wait_vmcnt<(kRing - 1) * 4>(); break;
-      default: n4::wait_vmcnt<(kRing - 1) * 5>(); break;
-    }
-    const T* R = ring + slot * slot_words;
+  // gather addresses of slot 0, computed once: the step is instantiated per
+  // ring slot and reaches the others through the read's immediate offset
+  const T* pF[4];
+  const T* pL[4];
+  const T* pFf[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    pF[r] = ring + oF[r];
+    pL[r] = ring + oL[r];
+    pFf[r] = ring + oFf[r];
+  }
+  const T* pU = ring + lay.oU;
+  // (V_z travels as column 15 of X's initial value: zero in the other lanes)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) Vz[r] = (j == 15) ? Vz[r] : T(0);
+  auto step = [&](const int t, auto slot_c) {
+    constexpr int slot = decltype(slot_c)::value;
+    constexpr int so = slot * slot_words;
+    // record t has landed once at most (kRing - 1) younger {DMA x NDMA, store}
+    // groups are outstanding
+    n4::wait_vmcnt<(kRing - 1) * (NDMA + 1)>();
     T Fa[4], La[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const T f = R[oF[r] < 0 ? 0 : oF[r]];
-      const T l = R[oL[r] < 0 ? 0 : oL[r]];
-      Fa[r] = oF[r] < 0 ? T(0) : f;
-      La[r] = oL[r] < 0 ? T(0) : l;
+      Fa[r] = pF[r][so];
+      La[r] = pL[r][so];
     }
-    const T Un = BOUNDED ? R[lay.oU] : T(0);
+    const T Un = BOUNDED ? pU[so] : T(0);
     T ffrow = T(0);  // (f^T F~)[j]: f^T F_z for j < n, f.f at j = n
     if constexpr (CHOL) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const T fk = R[oFf[r] < 0 ? 0 : oFf[r]];
-        ffrow += (oFf[r] < 0 ? T(0) : fk) * Fa[r];
-      }
+      for (int r = 0; r < 4; ++r) ffrow += pFf[r][so] * Fa[r];
       ffrow += __shfl_xor(ffrow, 16);
       ffrow += __shfl_xor(ffrow, 32);
     }
 
-    // ---- X = V F~ ; X[:, 15] = V_z
-    Acc X = {T(0), T(0), T(0), T(0)};
+    // ---- X = V F~ ; X[:, 15] = V_z (column 15 of F~ is zero)
+    Acc X = {Vz[0], Vz[1], Vz[2], Vz[3]};
 #pragma unroll
     for (int r = 0; r < 4; ++r) X = TL::mma(V[r], Fa[r], X);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) X[r] = (j == 15) ? Vz[r] : X[r];
     // ---- Q~ = L~ + F~^T X
     Acc Q = {La[0], La[1], La[2], La[3]};
     Q = TL::mma(Fa[0], X[0], Q);
@@ -301,14 +324,29 @@ __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
         // V' = sym + K^T Quu K + K^T Quz + Quz^T K,  K = -sE Q_uz_reg
         const T Qg_k = tile[k * 16 + 15];
         const T v = sym + c2 * (Qg_k * Qg_j) - sE * (Qg_k * Quz_j + Quz_k * Qg_j);
-        V[r] = (k < n && j < n) ? v : T(0);
-        Vz[r] = (k < n) ? Q[r] + Quz_k * kt - Qg_k * wz : T(0);
+        // (no masks on V', V_z': their entries outside the n x n block only
+        // ever meet zero rows / columns of F~ in the next step's products)
+        V[r] = v;
+        Vz[r] = (j == 15) ? Q[r] + Quz_k * kt - Qg_k * wz : T(0);
       } else {
-        V[r] = (k < n && j < n) ? n4::fma_(c * Quz_k, Quz_j, sym) : T(0);
-        Vz[r] = (k < n) ? n4::fma_(Quz_k, w, Q[r]) : T(0);  // (lanes j = 15)
+        V[r] = n4::fma_(c * Quz_k, Quz_j, sym);
+        Vz[r] = (j == 15) ? n4::fma_(Quz_k, w, Q[r]) : T(0);
       }
     }
-    slot = slot + 1 == kRing ? 0 : slot + 1;
+  };
+  // record tau lives in slot (N - 1 - tau) % kRing
+  int t = N - 1;
+  static_assert(kRing == 3 || kRing == 4, "");
+  for (; t >= kRing - 1; t -= kRing) {
+    step(t, std::integral_constant<int, 0>{});
+    step(t - 1, std::integral_constant<int, 1>{});
+    step(t - 2, std::integral_constant<int, 2>{});
+    if constexpr (kRing == 4) step(t - 3, std::integral_constant<int, 3>{});
+  }
+  if (t >= 0) step(t, std::integral_constant<int, 0>{});
+  if (t >= 1) step(t - 1, std::integral_constant<int, 1>{});
+  if constexpr (kRing == 4) {
+    if (t >= 2) step(t - 2, std::integral_constant<int, 2>{});
   }
   n4::wait_vmcnt<0>();
   if (j == 0 && g == 0) a.status[b] = status;
@@ -324,7 +362,8 @@ static int launch_mfma16(const RiccatiArgs<T>& a, hipStream_t st,
   const bool chol = a.branch == PDDP_BRANCH_CHOLESKY;
   const RecLayout lay(a.n, 1);
   const int chunks = lay.stride * (int)sizeof(T) / 16;
-  const int ndma = (chunks + kWave - 1) / kWave;
+  // strictly more DMA lanes than chunks: the slot keeps a zeroed padding
+  const int ndma = chunks / kWave + 1;
   if (ndma > m16::kMaxDma) return PDDP_E_UNSUPPORTED;
   const int slot_words = ndma * kWave * (16 / (int)sizeof(T));
   const size_t lds = sizeof(T) * ((size_t)m16::kWaves *
@@ -333,14 +372,22 @@ static int launch_mfma16(const RiccatiArgs<T>& a, hipStream_t st,
   const dim3 grid((a.B + m16::kWaves - 1) / m16::kWaves),
       block(kWave * m16::kWaves);
   const bool bounded = a.u_min != nullptr;
+#define PDDP_M16N(Bd, F, C, ND)                                                \
+  PDDP_LAUNCH((m16::riccati_mfma16_kernel<T, Bd, F, C, ND>), grid, block, lds, \
+              st, a)
+#define PDDP_M16C(Bd, F, C)                                                    \
+  do {                                                                         \
+    switch (ndma) {                                                            \
+      case 1: PDDP_M16N(Bd, F, C, 1); break;                                   \
+      case 2: PDDP_M16N(Bd, F, C, 2); break;                                   \
+      case 3: PDDP_M16N(Bd, F, C, 3); break;                                   \
+      default: PDDP_M16N(Bd, F, C, 4); break;                                  \
+    }                                                                          \
+  } while (0)
 #define PDDP_M16(Bd, F)                                                        \
   do {                                                                         \
-    if (chol)                                                                  \
-      PDDP_LAUNCH((m16::riccati_mfma16_kernel<T, Bd, F, true>), grid, block,   \
-                  lds, st, a, slot_words, ndma);                               \
-    else                                                                       \
-      PDDP_LAUNCH((m16::riccati_mfma16_kernel<T, Bd, F, false>), grid, block,  \
-                  lds, st, a, slot_words, ndma);                               \
+    if (chol) PDDP_M16C(Bd, F, true);                                          \
+    else PDDP_M16C(Bd, F, false);                                              \
   } while (0)
   if constexpr (sizeof(T) == 4) {
     if (bounded) { if (fast_math) PDDP_M16(true, true); else PDDP_M16(true, false); }
@@ -348,6 +395,8 @@ static int launch_mfma16(const RiccatiArgs<T>& a, hipStream_t st,
   } else {
     if (bounded) PDDP_M16(true, false); else PDDP_M16(false, false);
   }
+#undef PDDP_M16C
+#undef PDDP_M16N
 #undef PDDP_M16
   return launch_status();
 }
