@@ -348,6 +348,15 @@ int pddp_riccati_backward_timed_f64(int B, int N, int n, int m,
                                     void* stream, int variant, void* start,
                                     void* stop);
 
+/* Arithmetic of the hidden-to-hidden contraction (layer 2) of pddp_bnn_mlp_* /
+ * pddp_bnn_mlp_jvp_*: 0 = exact f32 on v_mfma_f32_32x32x2_f32 (default; bitwise
+ * an fmaf chain), 3 = the bf16-split twin - weights and activations as three
+ * bf16 parts, six v_mfma_f32_32x32x16_bf16 per product: f32 accuracy to
+ * rounding (not bit-exact), 2.5 times fewer matrix cycles; H = 200 only, other
+ * widths stay exact.  Process-wide; -1 only queries.  Returns the previous
+ * mode (PDDP_MLP_BF16X3=1 in the environment makes 3 the initial one). */
+int pddp_bnn_mlp_precision(int mode);
+
 /* ---- pddp/models/bnn/modules.py:774-864: the Bayesian network of the learned
  * dynamics model, fused (fc -> dropout mask -> ReLU, twice, fc_out), float:
  *   Y[r] = W3 relu(M2[p] * (W2 relu(M1[p] * (W1 X[r] + b1)) + b2)) + b3,

@@ -78,6 +78,7 @@ _SIGS = {
                        _P],
     "pddp_sweep_nominal_f32": [_P, c_int, c_int] + [_P] * 5 + [c_int] +
                               [_P] * 7,
+    "pddp_bnn_mlp_precision": [c_int],
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
     "pddp_bnn_moment_step_f32": [_P, _P],
     "pddp_bnn_mlp_jvp_f32": [c_int] * 6 + [_P] * 11,

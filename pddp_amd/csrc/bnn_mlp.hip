@@ -59,6 +59,18 @@ namespace pddp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// x = hi + mid + lo, three bf16 (24 significant bits): the parts of the
+// bf16-split twin of layer 2 (PREC = 3 below).  Both subtractions are exact.
+PDDP_DEV void split3(float x, __bf16& hi, __bf16& mid, __bf16& lo) {
+  hi = (__bf16)x;
+  const float r1 = x - (float)hi;
+  mid = (__bf16)r1;
+  const float r2 = r1 - (float)mid;
+  lo = (__bf16)r2;
+}
 
 struct BnnMlpArgs {
   int R, P, in_dim, H, out_dim;
@@ -91,12 +103,14 @@ PDDP_DEV int unit_of(int j, int r, int h) {
 // add them one tile later, before their (deferred) mask / ReLU epilogue - no
 // extra barrier.
 constexpr int kMlpGivers = 6;
-template <int H, int W1S, bool BAL = false>
+template <int H, int W1S, bool BAL = false, int PREC = 0>
 constexpr size_t bnn_mlp_lds_floats() {
   // two h1^T buffers, two buffers of h2 (1024 words per block), BAL: two
-  // buffers of six partial accumulator tiles
-  return 2 * (H / 2) * 64 + 2 * ((H + 31) / 32) * 1024 +
-         (BAL ? 2 * kMlpGivers * 1024 : 0);
+  // buffers of six partial accumulator tiles.  PREC = 3: h1 as three bf16
+  // planes [part][k-step of 16 units][row 32][half 2][8] = 256 words per
+  // k-step and part
+  return (PREC == 3 ? 2 * 3 * ((H + 15) / 16) * 256 : 2 * (H / 2) * 64) +
+         2 * ((H + 31) / 32) * 1024 + (BAL ? 2 * kMlpGivers * 1024 : 0);
 }
 
 // kMlpW1Stride: inputs | zeros | bias slot of layer 1 (8: in_dim <= 7, 16: <=
@@ -127,10 +141,21 @@ PDDP_DEV bool group_first_positive(float v) {
 // read nor written.  A tile takes 32 / kJvpLive whole groups - with cartpole's
 // 6 live rows of 8 that is 5 groups per tile instead of 4: a fifth fewer
 // tiles.
+// PREC = 3: the BF16-SPLIT TWIN of layer 2 (opt-in, pddp_bnn_mlp_precision):
+// W2 and the layer-1 activations as three bf16 parts each, a product to f32
+// accuracy from six v_mfma_f32_32x32x16_bf16 (hi.hi, hi.mid, mid.hi, mid.mid,
+// hi.lo, lo.hi; 32 cycles for 16 k against 64 cycles for 2 k of the exact-f32
+// instruction): 78 matrix instructions of 32 cycles per tile and block instead
+// of 100 of 64.  The accumulator layout of the two instructions is the same,
+// so mask, ReLU, the h2 buffers and layer 3 (exact f32, as layer 1) are
+// untouched.  Not bit-exact f32: products are exact, the sums are rounded in
+// another order (and the lowest product terms, 2^-24 and below, are dropped).
 template <int H, int kMlpW1Stride, int kJvpGroup = 0, int kJvpLive = kJvpGroup,
-          bool BAL = false>
+          bool BAL = false, int PREC = 0>
 __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   static_assert(!BAL || H == 200, "the balanced roles are laid out for 7 blocks");
+  static_assert(PREC == 0 || (PREC == 3 && !BAL), "");
+  constexpr int KS16 = (H + 15) / 16;  // PREC = 3: k-steps of layer 2
   constexpr bool JVP = kJvpGroup != 0;
   constexpr int G = JVP ? kJvpGroup : 1;  // rows per (state, particle)
   constexpr int LIVE = JVP ? kJvpLive : 1;
@@ -149,8 +174,9 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   // LDS (dynamic): two h1^T buffers, two h2 buffers
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* h1t = lds;                       // [2][KS * 64]
-  float* h2b = h1t + 2 * KS * 64;         // [2][NB * 1024]
-  constexpr int kH1 = KS * 64, kH2 = NB * 1024;
+  constexpr int kH1 = PREC == 3 ? 3 * KS16 * 256 : KS * 64;  // words per buffer
+  float* h2b = h1t + 2 * kH1;             // [2][NB * 1024]
+  constexpr int kH2 = NB * 1024;
   float* part = h2b + 2 * kH2;            // BAL: [2][kMlpGivers * 1024]
   constexpr int kPart = kMlpGivers * 1024;
   // BAL: the chunks q >= q_own(wave) of a block's contraction are the
@@ -328,13 +354,29 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   // =======================================================================
   const int j = wave;
   constexpr int KS1 = kMlpW1Stride / 2;  // MFMA steps of layer 1
-  float a2[KS];
+  float a2[PREC == 3 ? 1 : KS];
+  // PREC = 3: lane (i = li, h = lh) holds W2[32 j + i][16 s + 8 h + e], e < 8,
+  // of k-step s as three bf16 parts: the A operand of the 32x32x16 instruction
+  bf16x8 a2h[PREC == 3 ? KS16 : 1], a2m[PREC == 3 ? KS16 : 1],
+      a2l[PREC == 3 ? KS16 : 1];
   float a1[KS1];
   float b2r[16];
   {
     const int u = 32 * j + li;  // A operand: row i = li is unit u
     const bool uok = u < H;
     const float* w2row = a.W2 + (size_t)(uok ? u : 0) * H + 4 * lh;
+    if constexpr (PREC == 3) {
+#pragma unroll
+      for (int s2 = 0; s2 < KS16; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 16 * s2 + 8 * lh + e;
+          const float v = a.W2[(size_t)(uok ? u : 0) * H + (k < H ? k : 0)];
+          __bf16 hi, mid, lo;
+          split3((uok && k < H) ? v : 0.f, hi, mid, lo);
+          a2h[s2][e] = hi; a2m[s2][e] = mid; a2l[s2][e] = lo;
+        }
+    } else {
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -342,6 +384,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
         const float v = w2row[8 * q + e];  // (clamped address + select: no
         a2[4 * q + e] = uok ? v : 0.f;     // branch per element)
       }
+    }
     // layer 1: W1 | 0 | b1; MFMA step s, k-slot lh takes input slot
     // c = W1S - 1 - (2 s + lh): the bias first, then the inputs from the last
     // to the first (the order of round 1's FMA chain)
@@ -421,7 +464,27 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
           v[e] = fmaxf(pre * mm, 0.f);
         }
       }
-      if (4 * j + g < NQ) dst[g * 64] = v;  // (wave-uniform)
+      if constexpr (PREC == 3) {
+        // unit 32 j + 8 g + 4 lh + e = element 4 lh + e of half g & 1 of
+        // k-step 2 j + (g >> 1): 8 bytes per part
+        const int s2 = 2 * j + (g >> 1);
+        if (s2 < KS16) {  // (wave-uniform)
+          bf16x4 ph, pm, pl;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            __bf16 hi, mid, lo;
+            split3(v[e], hi, mid, lo);
+            ph[e] = hi; pm[e] = mid; pl[e] = lo;
+          }
+          char* base = reinterpret_cast<char*>(h1t + (i & 1) * kH1) +
+                       s2 * 1024 + li * 32 + (g & 1) * 16 + lh * 8;
+          *reinterpret_cast<bf16x4*>(base) = ph;
+          *reinterpret_cast<bf16x4*>(base + KS16 * 1024) = pm;
+          *reinterpret_cast<bf16x4*>(base + 2 * KS16 * 1024) = pl;
+        }
+      } else {
+        if (4 * j + g < NQ) dst[g * 64] = v;  // (wave-uniform)
+      }
     }
   };
   l1_load(0);
@@ -451,17 +514,39 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   const int qown = q_own(wave);
   auto layer2 = [&](int i) {
     f32x16 acc;
-    const f32x4* bsrc =
-        reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
+    if constexpr (PREC == 3) {
+      // B operand: lane (row li, half lh) holds h1[row][16 s + 8 lh + e]
+      const char* bp = reinterpret_cast<const char*>(h1t + (i & 1) * kH1) +
+                       li * 32 + lh * 16;
+      acc = binit;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      if (BAL && q >= NQ - 2 && q >= qown) continue;  // (wave-uniform)
-      const f32x4 b4 = bsrc[q * 64];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 0], b4[0],
-                                                 q == 0 ? binit : acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 1], b4[1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 2], b4[2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 3], b4[3], acc, 0, 0, 0);
+      for (int s2 = 0; s2 < KS16; ++s2) {
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp + s2 * 1024);
+        const bf16x8 bm =
+            *reinterpret_cast<const bf16x8*>(bp + (KS16 + s2) * 1024);
+        const bf16x8 bl =
+            *reinterpret_cast<const bf16x8*>(bp + (2 * KS16 + s2) * 1024);
+        // the small terms first
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2l[s2], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[s2], bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2m[s2], bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2m[s2], bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[s2], bm, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2h[s2], bh, acc, 0, 0, 0);
+      }
+    } else {
+      const f32x4* bsrc =
+          reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        if (BAL && q >= NQ - 2 && q >= qown) continue;  // (wave-uniform)
+        const f32x4 b4 = bsrc[q * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(
+            a2[4 * q + 0], b4[0], q == 0 ? binit : acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 1], b4[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 2], b4[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[4 * q + 3], b4[3], acc, 0, 0, 0);
+      }
     }
     return acc;
   };
@@ -514,7 +599,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   }
 }
 
-template <int H, int W1S, int JVP, int LIVE, bool BAL>
+template <int H, int W1S, int JVP, int LIVE, bool BAL, int PREC = 0>
 static int launch_bnn_mlp_b(const BnnMlpArgs& a, hipStream_t st) {
   // per device (a process may drive several GPUs): CU count queried once -
   // hipGetDeviceProperties costs ms - and the > 64 KB dynamic-LDS opt-in,
@@ -536,23 +621,36 @@ static int launch_bnn_mlp_b(const BnnMlpArgs& a, hipStream_t st) {
   constexpr int trows = JVP == 0 ? kMlpTile : (kMlpTile / LIVE) * JVP;
   const int ntiles = (a.R + trows - 1) / trows;
   const int grid = ntiles < cus ? ntiles : cus;  // persistent: one per CU
-  constexpr size_t lds = sizeof(float) * bnn_mlp_lds_floats<H, W1S, BAL>();
+  constexpr size_t lds =
+      sizeof(float) * bnn_mlp_lds_floats<H, W1S, BAL, PREC>();
   static_assert(lds <= 160 * 1024, "a workgroup's LDS");
   if (!attr_set[dev]) {  // more than 64 KB of dynamic LDS needs the opt-in
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)bnn_mlp_kernel<H, W1S, JVP, LIVE, BAL>,
+        (const void*)bnn_mlp_kernel<H, W1S, JVP, LIVE, BAL, PREC>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set[dev] = true;
   }
-  PDDP_LAUNCH((bnn_mlp_kernel<H, W1S, JVP, LIVE, BAL>), dim3(grid),
+  PDDP_LAUNCH((bnn_mlp_kernel<H, W1S, JVP, LIVE, BAL, PREC>), dim3(grid),
                      dim3(kMlpThreads), lds, st, a);
   return launch_status();
+}
+
+// 0: exact f32 (default); 3: the bf16-split twin of layer 2 (H = 200 only).
+// Process-wide; PDDP_MLP_BF16X3=1 in the environment makes 3 the default.
+static int& mlp_precision() {
+  static int prec = [] {
+    const char* e = getenv("PDDP_MLP_BF16X3");
+    return (e != nullptr && e[0] == '1') ? 3 : 0;
+  }();
+  return prec;
 }
 
 template <int H, int W1S, int JVP = 0, int LIVE = JVP>
 static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   if constexpr (H == 200) {
+    if (mlp_precision() == 3)
+      return launch_bnn_mlp_b<H, W1S, JVP, LIVE, false, 3>(a, st);
     // the balanced role layout (PDDP_MLP_BALANCED=0: its A/B twin without)
     static const bool balanced = [] {
       const char* e = getenv("PDDP_MLP_BALANCED");
@@ -572,6 +670,13 @@ static int launch_bnn_mlp(const BnnMlpArgs& a, hipStream_t st) {
 }  // namespace pddp
 
 extern "C" {
+
+int pddp_bnn_mlp_precision(int mode) {
+  if (mode != 0 && mode != 3 && mode != -1) return PDDP_E_BADARG;
+  const int prev = pddp::mlp_precision();
+  if (mode >= 0) pddp::mlp_precision() = mode;
+  return prev;
+}
 
 int pddp_bnn_mlp_f32(int R, int P, int in_dim, int H, int out_dim,
                      const float* X, const float* W1, const float* b1,

@@ -1428,6 +1428,46 @@ def test_bnn_mlp_kernel_vs_torch(rows, P, in_dim, out_dim, H):
     assert e_native < 4 * e_torch + 1e-7, (e_native, e_torch)
 
 
+@pytest.mark.parametrize("rows,P,in_dim,out_dim", [(37, 100, 6, 8), (301, 100, 6, 8),
+                                                   (64, 33, 15, 16), (1, 100, 9, 12)])
+def test_bnn_mlp_bf16_split_twin_vs_torch(rows, P, in_dim, out_dim):
+    """The bf16-split twin of the network kernel's layer 2
+    (pddp_bnn_mlp_precision(3): W2 and the layer-1 activations as three bf16
+    parts, six v_mfma_f32_32x32x16_bf16 per product) against float64: f32
+    accuracy to rounding - within a small factor of what the library's f32
+    GEMMs lose, and of the exact-f32 kernel."""
+    from pddp_amd import _native
+    from pddp_amd.models.bnn import BayesianMLP
+    H = 200
+    torch.manual_seed(H + rows)
+    net = BayesianMLP(in_dim, out_dim, [H, H]).cuda().eval()
+    x = torch.randn(rows, P, in_dim, device="cuda")
+    lib = _native.lib()
+    prev = lib.pddp_bnn_mlp_precision(3)
+    try:
+        with torch.no_grad():
+            assert net._native_ok(x, False)
+            y3 = net(x)                      # native, bf16-split layer 2
+            assert lib.pddp_bnn_mlp_precision(0) == 3
+            y0 = net(x)                      # native, exact f32 (same masks)
+            net.use_native = False
+            y32 = net(x)                     # library GEMMs, same masks
+            net64 = BayesianMLP(in_dim, out_dim, [H, H]).cuda().double().eval()
+            net64.load_state_dict({k: v.double()
+                                   for k, v in net.state_dict().items()})
+            for d64, d in zip(net64.drops, net.drops):
+                d64.noise = d.noise.double()
+            y64 = net64(x.double())
+    finally:
+        lib.pddp_bnn_mlp_precision(prev)
+    scale = float(y64.abs().max())
+    e3 = float((y3.double() - y64).abs().max()) / scale
+    e0 = float((y0.double() - y64).abs().max()) / scale
+    e_torch = float((y32.double() - y64).abs().max()) / scale
+    assert e3 < 3e-6, (e3, e0, e_torch)
+    assert e3 < 6 * max(e_torch, e0) + 2e-7, (e3, e0, e_torch)
+
+
 @pytest.mark.parametrize("model_opts", [{"use_predicted_std": False},
                                         {"use_predicted_std": True}],
                          ids=["mean_only", "predicted_std"])
@@ -2007,6 +2047,35 @@ def _bnn_real_size_run():
         add("J", r, Jc[r], "ls/J")
     rows.append(dict(what="path", path=path))
     return rows
+
+
+def test_bnn_bf16_split_twin_vs_reference_real_size():
+    """The same check with the network kernel's layer 2 on its bf16-split twin
+    (pddp_bnn_mlp_precision(3)): everything the rollouts and the line search
+    produce stays within the exact kernel's bars - the twin is f32 to rounding;
+    the forward-mode Jacobians go through ReLUs linearised at the primal row,
+    and where a pre-activation is within rounding of zero another summation
+    order gives it the other sign (test_full_size_bnn_round): at most two of
+    the six Jacobian blocks may show such a flip (F_u is ~1e-3 of F_z in
+    magnitude here, so one flipped unit is ~1e-3 of its scale), none wild."""
+    from pddp_amd import _native
+    lib = _native.lib()
+    prev = lib.pddp_bnn_mlp_precision(3)
+    try:
+        rows = _bnn_real_size_run()
+    finally:
+        lib.pddp_bnn_mlp_precision(prev)
+    assert rows[-1]["path"] == {"dynamics": "hip", "cost": "hip"}
+    flips = 0
+    for r in rows[:-1]:
+        if r["what"] in ("F_z", "F_u"):
+            if r["hip_vs_f64"] > 1e-5:
+                flips += 1
+                assert r["hip_vs_f64"] < 5e-3, r
+        else:
+            assert r["hip_vs_f64"] <= 2e-6, r
+            assert r["hip_vs_f32"] <= 2e-6, r
+    assert flips <= 2, [r for r in rows[:-1] if r["what"] in ("F_z", "F_u")]
 
 
 def test_bnn_hip_kernels_vs_reference_real_size():
