@@ -411,7 +411,8 @@ def bench_bnn(args, emit=True):
     z0 = torch.stack([pddp_amd.GaussianVariable(
         mean + 1e-2 * torch.randn(D, generator=g),
         var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).to(dev)
-    s.set_nominal(z0, (0.1 * torch.randn(B, N, m, generator=g)).to(dev))
+    U0 = (0.1 * torch.randn(B, N, m, generator=g)).to(dev)
+    s.set_nominal(z0, U0)
     n_iter = 1 << 30
     for _ in range(W):
         s.round(5e-6, 1e10, n_iter)
@@ -505,6 +506,43 @@ def bench_bnn(args, emit=True):
             sweep_roofline_of(s, _native.lib(), traffic_tag=(
                 "dcbnn" if args.workload == "double_cartpole_bnn"
                 else "cpbnn"))]
+        # the same rounds with layer 2 of the network kernel on its bf16-split
+        # twin (opt-in: pddp_bnn_mlp_precision(3) - f32 to rounding, not
+        # bit-exact; the line above is the exact-f32 kernel)
+        lib = _native.lib()
+        prev = lib.pddp_bnn_mlp_precision(3)
+        try:
+            s.set_nominal(z0, U0)
+            for _ in range(W):
+                s.round(5e-6, 1e10, n_iter)
+            s.n_live.zero_()
+            l0 = int(s.active.sum().item())
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for i in range(K):
+                s.round(5e-6, 1e10, n_iter)
+            torch.cuda.synchronize(dev)
+            el3 = time.perf_counter() - t1
+            att3 = l0 + int(s.n_live.sum().item()) - int(s.active.sum().item())
+            model.model._jvp_native(F, P, D, grp, live=live)
+            e0.record()
+            for _ in range(reps):
+                model.model._jvp_native(F, P, D, grp, live=live)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            dur3 = e0.elapsed_time(e1) * 1e-3 / reps
+        finally:
+            lib.pddp_bnn_mlp_precision(prev)
+        out["bf16_split_twin"] = {
+            "what": "layer 2 of the network kernel as three bf16 parts per "
+                    "operand, six v_mfma_f32_32x32x16_bf16 per product "
+                    "(pddp_bnn_mlp_precision(3)); f32 to rounding, opt-in",
+            "ms_per_step": el3 / K * 1e3, "value": att3 / el3,
+            "network_kernel_avg_launch_us": dur3 * 1e6,
+            "network_kernel_tflops_equivalent": flop / dur3 * 1e-12,
+            "frac_of_exact_f32_matrix_peak": flop / dur3 * 1e-12 /
+                                             MFMA_F32_PEAK_TFLOPS,
+        }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = bnn_cpu_baseline(
                 model, enc, N, n, m, A, {"use_predicted_std": False,

@@ -48,6 +48,15 @@ def particles_covar(x):
 
 
 
+def set_network_precision(mode):
+    """Arithmetic of the fused network kernel's hidden-to-hidden contraction
+    (pddp_bnn_mlp_precision, include/pddp_hip.h): 0 exact f32 (default), 3 the
+    bf16-split twin (f32 to rounding, ~1.5x faster at [200, 200]).  Process-wide;
+    returns the previous mode."""
+    from .. import _native
+    return int(_native.lib().pddp_bnn_mlp_precision(int(mode)))
+
+
 def bump_generation(model):
     """Marks every tensor a captured hipGraph may hold a pointer to
     (normalisation buffers, dropout masks, cached noise) as replaced: the
