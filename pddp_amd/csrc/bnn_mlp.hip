@@ -584,17 +584,22 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     return;
   }
 
+  // the mask of layer 2 of tile i is requested right after the epilogue of
+  // tile i - 1 has used the registers: a whole iteration ahead of its use (the
+  // bf16-split layer 2 is too short to cover the latency of a request made
+  // just before it - 10 % of that kernel)
+  // (likewise the inputs and the layer-1 mask of tile i + 2, as soon as layer
+  // 1 of tile i + 1 has consumed the registers)
+  f32x4 m2[4];
+  masks_of(a.MT2, row_of(blockIdx.x, li), m2);
+  if (my > 1) l1_load(1);
   for (int i = 0; i < my; ++i) {
-    const RowOf ro = row_of(blockIdx.x + i * gridDim.x, li);
     const bool nxt = i + 1 < my;
-    if (nxt) l1_load(i + 1);
-    // mask of layer 2, requested before the MFMAs so that its latency is
-    // theirs
-    f32x4 m2[4];
-    masks_of(a.MT2, ro, m2);
     const f32x16 acc = layer2(i);
     epilogue(i, acc, m2);
+    if (nxt) masks_of(a.MT2, row_of(blockIdx.x + (i + 1) * gridDim.x, li), m2);
     if (nxt) layer1(i + 1);
+    if (i + 2 < my) l1_load(i + 2);
     tile_barrier();
   }
 }
