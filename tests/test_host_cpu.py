@@ -353,6 +353,11 @@ def test_hot_kernels_keep_their_working_set_in_registers():
         # four times into 64 KB of LDS (N > 400 for these two problems)
         "line_search_lds_kernel<double, 4, true, 1, 1,",
         "line_search_lds_kernel<float, 2, true, 1, 1,",
+        # the bf16-split twin of the network kernel (opt-in): 156 registers of
+        # W2 parts at the 256-register limit of an eight-wave workgroup; 5 ..
+        # 25 registers spill around (not inside) the matrix-instruction loop
+        # (with the requests made a tile ahead: 2.35 -> 2.26 ms all the same)
+        ", false, 3>",
     )
     bad = [(r["kernel"], r.get("private_segment_fixed_size", 0),
             r.get("vgpr_spill_count", 0)) for r in rows
