@@ -1320,7 +1320,8 @@ def test_best_rollout_exchange_on_the_device(dtype):
     assert torch.equal(Zb2, Zb)
 
 
-@pytest.mark.parametrize("B,N", [(37, 33), (16, 100), (5, 10), (130, 47)])
+@pytest.mark.parametrize("B,N", [(37, 33), (16, 100), (5, 10), (130, 47),
+                                 (3, 8), (21, 9), (17, 12), (300, 201)])
 def test_sweep_from_nominal_equals_records_then_sweep(B, N):
     """pddp_sweep_nominal_f32 (derivative records evaluated inside the sweep's
     workgroups, never written) against pddp_derivs_f32 followed by the
