@@ -107,7 +107,7 @@ template <int H, int W1S, bool BAL = false, int PREC = 0>
 constexpr size_t bnn_mlp_lds_floats() {
   // two h1^T buffers, two buffers of h2 (1024 words per block), BAL: two
   // buffers of six partial accumulator tiles.  PREC = 3: h1 as three bf16
-  // planes [part][k-step of 16 units][row 32][half 2][8] = 256 words per
+  // planes [part][k-step of 16 units][half 2][row 32][8] = 256 words per
   // k-step and part
   return (PREC == 3 ? 2 * 3 * ((H + 15) / 16) * 256 : 2 * (H / 2) * 64) +
          2 * ((H + 31) / 32) * 1024 + (BAL ? 2 * kMlpGivers * 1024 : 0);
@@ -476,8 +476,11 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
             split3(v[e], hi, mid, lo);
             ph[e] = hi; pm[e] = mid; pl[e] = lo;
           }
+          // (plane layout [k-step][half][row][8]: the 8-byte writes of 64
+          // lanes are two-way on the banks, [row][half] was four-way; the
+          // reads stay one contiguous kilobyte per wavefront)
           char* base = reinterpret_cast<char*>(h1t + (i & 1) * kH1) +
-                       s2 * 1024 + li * 32 + (g & 1) * 16 + lh * 8;
+                       s2 * 1024 + (g & 1) * 512 + li * 16 + lh * 8;
           *reinterpret_cast<bf16x4*>(base) = ph;
           *reinterpret_cast<bf16x4*>(base + KS16 * 1024) = pm;
           *reinterpret_cast<bf16x4*>(base + 2 * KS16 * 1024) = pl;
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     if constexpr (PREC == 3) {
       // B operand: lane (row li, half lh) holds h1[row][16 s + 8 lh + e]
       const char* bp = reinterpret_cast<const char*>(h1t + (i & 1) * kH1) +
-                       li * 32 + lh * 16;
+                       lh * 512 + li * 16;
       acc = binit;
 #pragma unroll
       for (int s2 = 0; s2 < KS16; ++s2) {
