@@ -129,8 +129,11 @@ class ILQRSolver(object):
         self._pp = None if problem is None else ctypes.addressof(problem)
 
     def _nominal_sweep_possible(self):
-        """pddp_sweep_nominal_f32's domain (include/pddp_hip.h), at the
-        batches where `auto` picks the deferred sweep anyway."""
+        """pddp_sweep_nominal_f32's domain (include/pddp_hip.h).  At every
+        batch: from 12288 trajectories on the quad sweep on records is the
+        faster SWEEP (363 against 422 us at B = 65536), but the round without
+        records is still shorter (1.05 against 1.11 ms; 0.186 against 0.220
+        at 12288)."""
         # include/pddp_problem.h: PDDP_MODEL_CARTPOLE = 1,
         # PDDP_ENC_IGNORE_UNCERTAINTY = 4
         return (self.plugin is None and self.problem is not None and
@@ -138,7 +141,7 @@ class ILQRSolver(object):
                 self.problem.model == 1 and self.problem.encoding == 4 and
                 self.u_min is not None and self.u_max is not None and
                 self.branch == BRANCH_EIG and self.kernel_variant == 0 and
-                self.N >= 8 and self.B < 12288)
+                self.N >= 8)
 
     @property
     def rec(self):
