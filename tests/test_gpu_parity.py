@@ -1548,13 +1548,33 @@ def test_bnn_mlp_jvp_kernel_vs_float64(groups, P, in_dim, out_dim, H, G, live):
     linearised at it) against the same forward-mode pass written out layer by
     layer in float64 (what autograd's replicate-the-input pass of
     utils/evaluation.py:203-235 differentiates, modules.py:774-864)."""
+    _jvp_kernel_vs_float64(groups, P, in_dim, out_dim, H, G, live, 0)
+
+
+@pytest.mark.parametrize("G,live", [(8, None), (16, None), (8, 6), (8, 4)])
+@pytest.mark.parametrize("groups,P,in_dim,out_dim", [(37, 100, 6, 4),
+                                                     (64, 33, 15, 16)])
+def test_bnn_mlp_jvp_bf16_split_twin_vs_float64(groups, P, in_dim, out_dim, G,
+                                                live):
+    """The same with layer 2 on its bf16-split twin (H = 200)."""
+    _jvp_kernel_vs_float64(groups, P, in_dim, out_dim, 200, G, live, 3)
+
+
+def _jvp_kernel_vs_float64(groups, P, in_dim, out_dim, H, G, live, precision):
+    from pddp_amd import _native
     from pddp_amd.models.bnn import BayesianMLP
     torch.manual_seed(H + groups)
     net = BayesianMLP(in_dim, out_dim, [H, H]).cuda().eval()
     F = torch.randn(groups, G, in_dim, device="cuda")
+    prev = _native.lib().pddp_bnn_mlp_precision(precision)
+    try:
+        with torch.no_grad():
+            Y = net._jvp_native(F.reshape(groups * G, in_dim).contiguous(), P,
+                                out_dim, G, live=live).reshape(groups, G,
+                                                               out_dim)
+    finally:
+        _native.lib().pddp_bnn_mlp_precision(prev)
     with torch.no_grad():
-        Y = net._jvp_native(F.reshape(groups * G, in_dim).contiguous(), P,
-                            out_dim, G, live=live).reshape(groups, G, out_dim)
         if live is not None:
             # rows past `live` are neither read nor written: compare the rest
             # (live = 5, 3 run the 6- / 4-row packings with a dead row each)
