@@ -526,6 +526,39 @@ typedef struct pddp_qr_cost {
 } pddp_qr_cost;
 int pddp_qr_cost_derivs_f32(const pddp_qr_cost* cost, void* stream);
 
+/* ---- pddp_amd/models/gp.py (the build's own plugin behind models/base.py:24-83
+ * `DynamicsModel.forward(z, u, i, encoding)`; the reference has no GP - PARITY
+ * UNPINNED): one moment-matched step of squared-exponential ARD GPs, one per
+ * state increment, on the features [x_non-angular, sin a, cos a, u]:
+ *   z [R][n] encoded state distributions, u [R][m] (already clamped) actions ->
+ *   z_next [R][n]; with Fz [R][n][n] and Fu [R][n][m] non-NULL (both or
+ *   neither) also d z_next / d z and d z_next / d u (the dynamics half of the
+ *   derivative records, ilqr.py:443-470).
+ * encoding: StateEncoding 1 (upper-triangular Cholesky, n = E + E(E+1)/2), 2
+ * (variance), 3 (standard deviation), 4 (mean only); 0 (full covariance):
+ * PDDP_E_UNSUPPORTED.  Built for (state_size, features + actions) = (2, 4),
+ * (4, 6), (6, 9) - pendulum, cartpole, double cartpole; n + m <= 64; the
+ * training set must fit the workgroup's LDS (M <= ~300 in f32 without the
+ * Jacobian, ~120 with; PDDP_E_UNSUPPORTED beyond).  All arrays on the device. */
+typedef struct pddp_gp_model {
+  int state_size;        /* E: one GP per state increment */
+  int action_size;       /* m */
+  int M;                 /* training points */
+  int encoding;
+  int n_ang, n_non;
+  int ang[4], non[8];    /* angular / non-angular state indices */
+  const void* Xt;        /* [M][d] training inputs, d = n_non + 2 n_ang + m */
+  const void* beta;      /* [E][M]  (K_a + sn2_a I)^-1 y_a */
+  const void* Kinv;      /* [E][M][M] (K_a + sn2_a I)^-1, symmetric */
+  const void* inv_ell2;  /* [E][d]  1 / lengthscale^2 */
+  const void* sf2;       /* [E] signal variances */
+  const void* sn2;       /* [E] noise variances */
+} pddp_gp_model;
+int pddp_gp_step_f32(const pddp_gp_model* gp, int R, const float* z, const float* u,
+                     float* z_next, float* Fz, float* Fu, void* stream);
+int pddp_gp_step_f64(const pddp_gp_model* gp, int R, const double* z, const double* u,
+                     double* z_next, double* Fz, double* Fu, void* stream);
+
 /* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only
  * sees torch's current stream). Host functions. */
 int pddp_event_create(void** ev);

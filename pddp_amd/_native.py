@@ -87,6 +87,7 @@ _SIGS = {
     "pddp_bnn_jvp_features_f32": [_P, _P],
     "pddp_bnn_jvp_moments_f32": [_P, _P],
     "pddp_qr_cost_derivs_f32": [_P, _P],
+    "pddp_gp_step": [_P, c_int, _P, _P, _P, _P, _P, _P],
     "pddp_event_create": [_P],
     "pddp_event_record": [_P, _P],
     "pddp_event_elapsed_ms": [_P, _P, _P],
@@ -99,7 +100,7 @@ _TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
           "pddp_nominal_rollout",
           "pddp_derivs",
           "pddp_line_search", "pddp_search_accept", "pddp_accept",
-          "pddp_pack_best")
+          "pddp_pack_best", "pddp_gp_step")
 
 _lib = None
 
@@ -195,6 +196,16 @@ class BnnJvp(ctypes.Structure):
             "dX_std", "net_out", "Xp", "Xp_next", "eps", "F", "Z_next", "F_z",
             "F_u", "eps_out")] +
         [("independent_noise", ctypes.c_int32)])
+
+
+class GpModel(ctypes.Structure):
+    """pddp_gp_model of include/pddp_hip.h."""
+    _fields_ = (
+        [(k, ctypes.c_int32) for k in ("state_size", "action_size", "M",
+                                       "encoding", "n_ang", "n_non")] +
+        [("ang", ctypes.c_int32 * 4), ("non", ctypes.c_int32 * 8)] +
+        [(k, ctypes.c_void_p) for k in ("Xt", "beta", "Kinv", "inv_ell2",
+                                        "sf2", "sn2")])
 
 
 class QrCost(ctypes.Structure):

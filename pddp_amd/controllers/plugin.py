@@ -136,12 +136,18 @@ class TorchProblem(object):
             # could be asked to differentiate through it)
             native_dyn = self._bnn_native_ok(s, need_cost=False) and \
                 self._bnn_jvp_ok(s)
+            gp_dyn = not native_dyn and self._gp_native_ok(s)
         native_cost = self._qr_cost_native_ok(s)
         # which code produced the records (tests assert on it)
-        self.last_derivs_path = {"dynamics": "hip" if native_dyn else "autograd",
-                                 "cost": "hip" if native_cost else "autograd"}
         if native_dyn:
             self._dyn_derivs_bnn(s, F_z, F_u)
+        elif gp_dyn:
+            # GP plugin: every (trajectory, step) row of the nominal in ONE
+            # launch of the moment-matched step with its Jacobian
+            self._dyn_derivs_gp(s, F_z, F_u)
+            native_dyn = True
+        self.last_derivs_path = {"dynamics": "hip" if native_dyn else "autograd",
+                                 "cost": "hip" if native_cost else "autograd"}
         if native_cost:
             self._cost_derivs_qr(s, L, L_z, L_u, L_zz, L_uz, L_uu)
         with torch.enable_grad():
@@ -183,6 +189,27 @@ class TorchProblem(object):
             if set_state:
                 s.state.copy_(torch.where(sel, torch.zeros_like(s.state),
                                           s.state))
+
+    # -- GP plugin: csrc/gp_step.hip ----------------------------------------------
+    def _gp_native_ok(self, s):
+        mo = self.model
+        if not (hasattr(mo, "native_step") and hasattr(mo, "native_ok")):
+            return False
+        if not getattr(self, "use_native_gp", True) or self.model_opts:
+            return False
+        return bool(mo.native_ok(s.Z[:, 0], self.encoding, jacobian=True))
+
+    @torch.no_grad()
+    def _dyn_derivs_gp(self, s, F_z, F_u):
+        """F_z [B N n n], F_u [B N n m] of the nominal: d z' / d (z, u) at the
+        clamped actions (ilqr.py:443-470), by `pddp_gp_step_*`."""
+        B, N, n, m = s.B, s.N, s.n, s.m
+        z = s.Z[:, :N].reshape(B * N, n)
+        u = s.U
+        if s.u_min is not None:
+            u = clamp(u, s.u_min, s.u_max)
+        self.model.native_step(z, u.reshape(B * N, m), self.encoding,
+                               jacobian=True, Fz=F_z, Fu=F_u)
 
     # -- fused BNN rollout: csrc/bnn_rollout.hip + csrc/bnn_mlp.hip -------------
     def _qr_cost_native_ok(self, s, co=None):

@@ -1,0 +1,777 @@
+// gp_step.hip - one moment-matched step of the GP dynamics plugin
+// (pddp_amd/models/gp.py: squared-exponential ARD GPs per state increment,
+// exact first and second moment of the posterior at a Gaussian input;
+// Deisenroth & Rasmussen 2011 eqs. 14-23) and, optionally, its Jacobian with
+// respect to the encoded state and the action - the records of the GP
+// workload's derivative rollout (BASELINE configs[3]).  PARITY UNPINNED: the
+// reference has no GP (pddp/models/__init__.py:17-20); the checker is the
+// torch module itself (autograd for the Jacobian) and oracle/gp_port.py.
+//
+// One workgroup (four wavefronts) per row (= one trajectory at one time step):
+//   A0  wave 0: decode the encoded state, moment-matched trigonometric
+//       features, m [d], S [d d], cov[x, features] - written to LDS element by
+//       element; with JAC lane k carries the tangent of input k (dual numbers)
+//   A1  lanes 0 .. E + E(E+1)/2: G_s = (S + diag delta_s)^-1 and log det, one
+//       9 x 9 Cholesky per lane, in registers.  Every inverse the moments need
+//       is of this form: (S + L_a)^-1, and R^-1 S = lam - lam G lam with
+//       lam = (L_a^-1 + L_b^-1)^-1, G = (S + lam)^-1 (Woodbury), det R = det(S +
+//       lam) / prod lam.  Meanwhile waves 1-3: nu_i = x_i - m, log k_a(x_i, m)
+//   A2  per output a (a wavefront each, lane = training point): q_a, mu_a,
+//       W_a = (S + L_a)^-1 sum beta q nu
+//   B   per pair a <= b (a wavefront each, lane = i, loop over j):
+//       F_ab = sum_ij (beta_ai beta_bj - [a=b] Kinv_a,ij) exp(n2_ij) - M^2
+//       exponentials per pair, the bulk of the work.  With JAC the same loop
+//       accumulates Y1 = sum c_ij y_ij and Y2 = sum c_ij y_ij y_ij^T (y = L_a^-1
+//       nu_i + L_b^-1 nu_j) through row sums, column sums and v_i = sum_j c_ij
+//       z_bj: ALL derivatives of F_ab with respect to m and S are contractions
+//       of Y1, Y2 (d n2 / dT = y y^T / 2, d n2 / dm = y - lam^-1 (T y)), so the
+//       Jacobian costs no second M^2 loop
+//   C   (JAC) gradients of mu_a, Sigma_ab with respect to (m, S) in LDS
+//       (reverse mode over the small algebra: dG = -G dS G); tangents of W per
+//       (input k, output a) by a loop over the training points
+//   A3  lane k: next mean, covariance, encoding (upper Cholesky) in dual
+//       numbers -> column k of the Jacobian
+// Deterministic: fixed-order wave reductions, no atomics.
+#include "pddp_common.hpp"
+
+namespace pddp {
+namespace gp {
+
+constexpr int kThreads = 256;
+constexpr int kMaxAng = 4, kMaxNon = 8;
+
+template <typename T>
+struct Args {
+  int R, M, m_act, n_ang, n_non, encoding, n;
+  int ang[kMaxAng], non[kMaxNon];
+  const T* Xt;    // [M d]
+  const T* beta;  // [E M]
+  const T* Kinv;  // [E M M]
+  const T* iL;    // [E d]  1 / lengthscale^2
+  const T* sf2;   // [E]
+  const T* sn2;   // [E]
+  const T* z;     // [R n]
+  const T* u;     // [R m]
+  T* z_next;      // [R n]
+  T* Fz;          // [R n n] or null
+  T* Fu;          // [R n m] or null
+};
+
+// ---- dual numbers (one tangent) ----------------------------------------------
+template <typename T>
+struct Dual {
+  T p, t;
+};
+template <typename T> PDDP_DEV Dual<T> operator+(Dual<T> a, Dual<T> b) { return {a.p + b.p, a.t + b.t}; }
+template <typename T> PDDP_DEV Dual<T> operator-(Dual<T> a, Dual<T> b) { return {a.p - b.p, a.t - b.t}; }
+template <typename T> PDDP_DEV Dual<T> operator-(Dual<T> a) { return {-a.p, -a.t}; }
+template <typename T> PDDP_DEV Dual<T> operator*(Dual<T> a, Dual<T> b) { return {a.p * b.p, a.p * b.t + a.t * b.p}; }
+template <typename T> PDDP_DEV Dual<T> operator*(T a, Dual<T> b) { return {a * b.p, a * b.t}; }
+template <typename T> PDDP_DEV Dual<T> operator/(Dual<T> a, Dual<T> b) {
+  const T r = (T)1 / b.p, q = a.p * r;
+  return {q, (a.t - q * b.t) * r};
+}
+using pddp::cos_;
+using pddp::sin_;
+using pddp::sqrt_;
+PDDP_DEV float exp_(float x) { return expf(x); }
+PDDP_DEV double exp_(double x) { return exp(x); }
+PDDP_DEV float log_(float x) { return logf(x); }
+PDDP_DEV double log_(double x) { return log(x); }
+template <typename T> PDDP_DEV Dual<T> exp_(Dual<T> a) { const T e = exp_(a.p); return {e, e * a.t}; }
+template <typename T> PDDP_DEV Dual<T> sin_(Dual<T> a) { return {sin_(a.p), cos_(a.p) * a.t}; }
+template <typename T> PDDP_DEV Dual<T> cos_(Dual<T> a) { return {cos_(a.p), -sin_(a.p) * a.t}; }
+template <typename T> PDDP_DEV Dual<T> sqrt_(Dual<T> a) { const T s = sqrt_(a.p); return {s, a.t / ((T)2 * s)}; }
+template <typename T> PDDP_DEV T prim(T a) { return a; }
+template <typename T> PDDP_DEV T prim(Dual<T> a) { return a.p; }
+template <typename T> PDDP_DEV T tang(T) { return (T)0; }
+template <typename T> PDDP_DEV T tang(Dual<T> a) { return a.t; }
+template <typename X, typename T> PDDP_DEV X lift(T p, T t);
+template <> PDDP_DEV float lift<float, float>(float p, float) { return p; }
+template <> PDDP_DEV double lift<double, double>(double p, double) { return p; }
+template <> PDDP_DEV Dual<float> lift<Dual<float>, float>(float p, float t) { return {p, t}; }
+template <> PDDP_DEV Dual<double> lift<Dual<double>, double>(double p, double t) { return {p, t}; }
+
+template <typename T>
+PDDP_DEV T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---- LDS layout (in T) ---------------------------------------------------------
+template <int E, int D>
+struct Lds {
+  static constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D;
+  int m, S, mx, Sx, G, ld, nu, lk, be, mu, W, h, c, F, Sig, ub, sj;  // always
+  int g, Y1, Y2, dm, dS, gmu, GSmu, gmS, GSS, dW;                // JAC
+  int total;
+  PDDP_HD Lds(int M, int K, bool jac) {
+    int o = 0;
+    auto take = [&](int k) { const int r = o; o += k; return r; };
+    m = take(D); S = take(DD); mx = take(E); Sx = take(E * E);
+    G = take(NS * DD); ld = take(NS); nu = take(M * D); lk = take(E * M);
+    be = take(E * M); mu = take(E); W = take(E * D); h = take(E * D); c = take(E);
+    F = take(NP); Sig = take(NP); ub = take(4 * M); sj = take(4 * M);
+    g = Y1 = Y2 = dm = dS = gmu = GSmu = gmS = GSS = dW = 0;
+    if (jac) {
+      g = take(E * M * D); Y1 = take(NP * D); Y2 = take(NP * DD);
+      dm = take(K * D); dS = take(K * DD);
+      gmu = take(E * D); GSmu = take(E * DD); gmS = take(NP * D); GSS = take(NP * DD);
+      dW = take(K * E * D);
+    }
+    total = o;
+  }
+};
+
+PDDP_DEV void pair_of(int item, int E, int& a, int& b) {
+  a = 0;
+  while (item >= E - a) item -= E - a, ++a;
+  b = a + item;
+}
+
+// Encoded input `idx` of this row as the scalar type X: lane k's tangent seed
+template <typename X, typename T>
+PDDP_DEV X seed(T v, int idx, int k) {
+  return lift<X, T>(v, idx == k ? (T)1 : (T)0);
+}
+
+// The decoded state covariance, element (i, j), on demand (utils/encoding.py
+// decode_covar): nothing of the front end is held in arrays
+template <typename X, typename T, int E>
+PDDP_DEV X sx_of(const T* z, int enc, int i, int j, int k) {
+  if (enc == 1) {  // UPPER_TRIANGULAR_CHOLESKY: Sx = U^T U, U row-major triu
+    X s = lift<X, T>((T)0, (T)0);
+    const int lim = i < j ? i : j;
+    for (int r = 0; r <= lim; ++r) {
+      const int base = E + r * E - r * (r - 1) / 2;  // offset of U[r][r]
+      s = s + seed<X, T>(z[base + (i - r)], base + (i - r), k) *
+                  seed<X, T>(z[base + (j - r)], base + (j - r), k);
+    }
+    return s;
+  }
+  if (i != j) return lift<X, T>((T)0, (T)0);
+  if (enc == 2) return seed<X, T>(z[E + i], E + i, k);  // VARIANCE_ONLY
+  if (enc == 3) {                                      // STANDARD_DEVIATION_ONLY
+    const X s = seed<X, T>(z[E + i], E + i, k);
+    return s * s;
+  }
+  return lift<X, T>((T)1e-6, (T)0);  // IGNORE_UNCERTAINTY (encoding.py:209-212)
+}
+
+// In-register inverse and log-determinant of S + diag(delta) (SPD, D x D)
+template <typename T, int D>
+PDDP_DEV void spd_inverse(const T* S, const T (&delta)[D], T* G, T& logdet) {
+  T a[D * (D + 1) / 2];  // lower triangle, row-major: (i, j <= i) at i(i+1)/2 + j
+#pragma unroll
+  for (int i = 0; i < D; ++i)
+#pragma unroll
+    for (int j = 0; j <= i; ++j) a[i * (i + 1) / 2 + j] = S[i * D + j] + (i == j ? delta[i] : (T)0);
+  T ld = 0;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {  // Cholesky, column by column
+    T d = a[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int r = 0; r < j; ++r) d -= a[j * (j + 1) / 2 + r] * a[j * (j + 1) / 2 + r];
+    ld += log_(d);
+    const T l = sqrt_(d), il = (T)1 / l;
+    a[j * (j + 1) / 2 + j] = il;  // (the diagonal holds 1 / L_jj from here on)
+#pragma unroll
+    for (int i = j + 1; i < D; ++i) {
+      T s = a[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int r = 0; r < j; ++r) s -= a[i * (i + 1) / 2 + r] * a[j * (j + 1) / 2 + r];
+      a[i * (i + 1) / 2 + j] = s * il;
+    }
+  }
+  logdet = ld;
+  // L^-1 in place (lower): column by column
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+#pragma unroll
+    for (int i = j + 1; i < D; ++i) {
+      T s = a[i * (i + 1) / 2 + j] * a[j * (j + 1) / 2 + j];  // L_ij * inv_jj
+#pragma unroll
+      for (int r = j + 1; r < i; ++r) s += a[i * (i + 1) / 2 + r] * a[r * (r + 1) / 2 + j];
+      a[i * (i + 1) / 2 + j] = -s * a[i * (i + 1) / 2 + i];
+    }
+  }
+  // G = L^-T L^-1
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+#pragma unroll
+    for (int q = 0; q <= p; ++q) {
+      T s = 0;
+#pragma unroll
+      for (int r = p; r < D; ++r) s += a[r * (r + 1) / 2 + p] * a[r * (r + 1) / 2 + q];
+      G[p * D + q] = s;
+      G[q * D + p] = s;
+    }
+}
+
+template <typename T, int E, int D, bool JAC>
+__global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
+  using X = typename std::conditional<JAC, Dual<T>, T>::type;
+  constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* sm = reinterpret_cast<T*>(smem_raw);
+  const int M = A.M, n = A.n, K = n + A.m_act;
+  const Lds<E, D> o(M, K, JAC);
+  const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const T* z = A.z + (size_t)row * n;
+  const T* u = A.u + (size_t)row * A.m_act;
+  const int nn = A.n_non, nang = A.n_ang, na = nn + 2 * nang, enc = A.encoding;
+
+  // ---- front end, element by element, generic in the scalar type ---------------
+  auto sx = [&](int i, int j, int k) { return sx_of<X, T, E>(z, enc, i, j, k); };
+  auto mxv = [&](int i, int k) { return seed<X, T>(z[i], i, k); };
+  // E[sin], E[cos] of angle q
+  auto ang_mean = [&](int q, int k, X& es, X& ec) {
+    const int ai = A.ang[q];
+    const X damp = exp_((T)-0.5 * sx(ai, ai, k)), mu_ = mxv(ai, k);
+    es = damp * sin_(mu_);
+    ec = damp * cos_(mu_);
+  };
+  // feature mean p (p < na), action appended behind
+  auto m_of = [&](int p, int k) -> X {
+    if (p < nn) return mxv(A.non[p], k);
+    if (p < na) {
+      X es, ec;
+      ang_mean((p - nn) >> 1, k, es, ec);
+      return ((p - nn) & 1) ? ec : es;
+    }
+    return seed<X, T>(u[p - na], n + (p - na), k);
+  };
+  // feature covariance (p, q), utils/angular.py augment_moments
+  auto S_of = [&](int p, int q, int k) -> X {
+    const X zero = lift<X, T>((T)0, (T)0);
+    if (p >= na || q >= na) return zero;
+    if (p > q) { const int t_ = p; p = q; q = t_; }
+    if (q < nn) return sx(A.non[p], A.non[q], k);
+    if (p < nn) {  // x, sin / cos: C[angle, x] E[cos], -C[angle, x] E[sin]
+      const int qa = (q - nn) >> 1;
+      X es, ec;
+      ang_mean(qa, k, es, ec);
+      const X cv = sx(A.ang[qa], A.non[p], k);
+      return ((q - nn) & 1) ? -(cv * es) : cv * ec;
+    }
+    const int ka = (p - nn) >> 1, la = (q - nn) >> 1;
+    const int ia = A.ang[ka], ja = A.ang[la];
+    const X vi = sx(ia, ia, k), vj = sx(ja, ja, k), ci = sx(ia, ja, k);
+    const X lq = (T)-0.5 * (vi + vj), qq = exp_(lq);
+    const X ep = exp_(lq + ci) - qq, em = exp_(lq - ci) - qq;
+    const X mi = mxv(ia, k), mj = mxv(ja, k);
+    const bool ps = !((p - nn) & 1), qs = !((q - nn) & 1);  // sin rows
+    if (ps && qs) return (T)0.5 * (ep * cos_(mi - mj) - em * cos_(mi + mj));
+    if (!ps && !qs) return (T)0.5 * (ep * cos_(mi - mj) + em * cos_(mi + mj));
+    if (ps) return (T)0.5 * (ep * sin_(mi - mj) + em * sin_(mi + mj));  // sin_k, cos_l
+    return (T)0.5 * (ep * sin_(mj - mi) + em * sin_(mi + mj));          // cos_k, sin_l
+  };
+  // cov[x_r, feature q] (Stein's lemma)
+  auto cxf = [&](int r, int q, int k) -> X {
+    if (q < nn) return sx(r, A.non[q], k);
+    if (q >= na) return lift<X, T>((T)0, (T)0);
+    const int qa = (q - nn) >> 1;
+    X es, ec;
+    ang_mean(qa, k, es, ec);
+    const X cv = sx(r, A.ang[qa], k);
+    return ((q - nn) & 1) ? -(cv * es) : cv * ec;
+  };
+
+  // ---- A0 ------------------------------------------------------------------------
+  if (wave == 0) {
+    const int k = lane;  // tangent seed of this lane (k >= K: none)
+    for (int p = 0; p < D; ++p) {
+      const X v = m_of(p, k);
+      if (lane == 0) sm[o.m + p] = prim(v);
+      if (JAC && k < K) sm[o.dm + k * D + p] = tang(v);
+      for (int q = p; q < D; ++q) {
+        const X s = S_of(p, q, k);
+        if (lane == 0) sm[o.S + p * D + q] = sm[o.S + q * D + p] = prim(s);
+        if (JAC && k < K) sm[o.dS + k * DD + p * D + q] = sm[o.dS + k * DD + q * D + p] = tang(s);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- A1 ------------------------------------------------------------------------
+  if (wave == 0) {
+    if (lane < NS) {
+      T delta[D];
+      if (lane < E) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) delta[p] = (T)1 / A.iL[lane * D + p];
+      } else {
+        int a, b;
+        pair_of(lane - E, E, a, b);
+#pragma unroll
+        for (int p = 0; p < D; ++p) delta[p] = (T)1 / (A.iL[a * D + p] + A.iL[b * D + p]);
+      }
+      T ld;
+      spd_inverse<T, D>(sm + o.S, delta, sm + o.G + lane * DD, ld);
+      sm[o.ld + lane] = ld;
+    }
+  } else {
+    for (int e = tid - 64; e < M * D; e += kThreads - 64) sm[o.nu + e] = A.Xt[e] - sm[o.m + e % D];
+  }
+  __syncthreads();
+  for (int e = tid; e < E * M; e += kThreads) {  // log k_a(x_i, m)
+    const int a = e / M, i = e - a * M;
+    T s = 0;
+#pragma unroll
+    for (int p = 0; p < D; ++p) s += sm[o.nu + i * D + p] * sm[o.nu + i * D + p] * A.iL[a * D + p];
+    sm[o.lk + e] = log_(A.sf2[a]) - (T)0.5 * s;
+  }
+
+  // ---- A2: the mean and the input-output covariance --------------------------------
+  for (int a = wave; a < E; a += 4) {
+    const T* Ga = sm + o.G + a * DD;
+    T s0 = 0, s1[D], gg[JAC ? D * (D + 1) / 2 : 1];
+#pragma unroll
+    for (int p = 0; p < D; ++p) s1[p] = 0;
+    if (JAC) {
+#pragma unroll
+      for (int e = 0; e < D * (D + 1) / 2; ++e) gg[e] = 0;
+    }
+    for (int i = lane; i < M; i += 64) {
+      T nu[D], g[D], quad = 0;
+#pragma unroll
+      for (int p = 0; p < D; ++p) nu[p] = sm[o.nu + i * D + p];
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        T s = 0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) s += Ga[p * D + q] * nu[q];
+        g[p] = s;
+        quad += s * nu[p];
+      }
+      const T be = A.beta[a * M + i] * exp_((T)-0.5 * quad);
+      sm[o.be + a * M + i] = be;
+      s0 += be;
+#pragma unroll
+      for (int p = 0; p < D; ++p) s1[p] += be * nu[p];
+      if (JAC) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+          sm[o.g + (a * M + i) * D + p] = g[p];
+#pragma unroll
+          for (int q = 0; q <= p; ++q) gg[p * (p + 1) / 2 + q] += be * g[p] * g[q];
+        }
+      }
+    }
+    s0 = wave_sum(s0);
+#pragma unroll
+    for (int p = 0; p < D; ++p) s1[p] = wave_sum(s1[p]);
+    T sl = 0;  // sum log ell^2
+#pragma unroll
+    for (int p = 0; p < D; ++p) sl -= log_(A.iL[a * D + p]);
+    const T c = A.sf2[a] * exp_((T)-0.5 * (sm[o.ld + a] - sl));
+    const T mu = c * s0;
+    if (lane == 0) sm[o.mu + a] = mu, sm[o.c + a] = c;
+    if (lane < D) {
+      T w = 0;
+#pragma unroll
+      for (int q = 0; q < D; ++q) w += Ga[lane * D + q] * (c * s1[q]);
+      sm[o.W + a * D + lane] = w;
+      T hv = 0;  // (s1 is in every lane after the reduction; select without indexing)
+#pragma unroll
+      for (int q = 0; q < D; ++q) hv = (q == lane) ? c * s1[q] : hv;
+      sm[o.h + a * D + lane] = hv;
+      if (JAC) sm[o.gmu + a * D + lane] = w;  // d mu_a / d m = W_a
+    }
+    if (JAC) {  // d mu_a / d S = -1/2 mu_a A_a + 1/2 c sum beta e g g^T
+#pragma unroll
+      for (int p = 0; p < D; ++p)
+#pragma unroll
+        for (int q = 0; q <= p; ++q) {
+          const T v = wave_sum(gg[p * (p + 1) / 2 + q]);
+          if (lane == 0) {
+            const T r = (T)0.5 * (c * v - mu * Ga[p * D + q]);
+            sm[o.GSmu + a * DD + p * D + q] = r;
+            sm[o.GSmu + a * DD + q * D + p] = r;
+          }
+        }
+    }
+  }
+  __syncthreads();
+
+  // ---- B: the M^2 sums of every pair ---------------------------------------------
+  for (int item = wave; item < NP; item += 4) {
+    int a, b;
+    pair_of(item, E, a, b);
+    const T* Gs = sm + o.G + (E + item) * DD;
+    T iLa[D], iLb[D], lam[D];
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+      iLa[p] = A.iL[a * D + p];
+      iLb[p] = A.iL[b * D + p];
+      lam[p] = (T)1 / (iLa[p] + iLb[p]);
+    }
+    T* ub = sm + o.ub + wave * M;  // this wavefront's scratch
+    T* sj = sm + o.sj + wave * M;
+    // T x = lam x - lam G (lam x)
+    auto t_apply = [&](const T (&x)[D], T (&y)[D]) {
+      T lx[D];
+#pragma unroll
+      for (int p = 0; p < D; ++p) lx[p] = lam[p] * x[p];
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        T s = 0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) s += Gs[p * D + q] * lx[q];
+        y[p] = lx[p] - lam[p] * s;
+      }
+    };
+    // u_b[j] = log k_b(x_j, m) + 1/2 z_bj^T T z_bj
+    for (int j = lane; j < M; j += 64) {
+      T zb[D], tz[D], s = 0;
+#pragma unroll
+      for (int p = 0; p < D; ++p) zb[p] = iLb[p] * sm[o.nu + j * D + p];
+      t_apply(zb, tz);
+#pragma unroll
+      for (int p = 0; p < D; ++p) s += zb[p] * tz[p];
+      ub[j] = sm[o.lk + b * M + j] + (T)0.5 * s;
+      sj[j] = 0;
+    }
+    // (same-wavefront LDS traffic is in order; the compiler needs telling)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    T Fa = 0, y1[D], y2[JAC ? D * (D + 1) / 2 : 1];
+#pragma unroll
+    for (int p = 0; p < D; ++p) y1[p] = 0;
+    if (JAC) {
+#pragma unroll
+      for (int e = 0; e < D * (D + 1) / 2; ++e) y2[e] = 0;
+    }
+    const int tiles = (M + 63) >> 6;
+    for (int it = 0; it < tiles; ++it) {
+      const int i = it * 64 + lane;
+      const bool live = i < M;
+      const int ii = live ? i : 0;
+      T za[D], tza[D], ua = 0;
+#pragma unroll
+      for (int p = 0; p < D; ++p) za[p] = iLa[p] * sm[o.nu + ii * D + p];
+      t_apply(za, tza);
+#pragma unroll
+      for (int p = 0; p < D; ++p) ua += za[p] * tza[p];
+      ua = sm[o.lk + a * M + ii] + (T)0.5 * ua;
+      const T bai = A.beta[a * M + ii];
+      T r = 0, v[D];
+#pragma unroll
+      for (int p = 0; p < D; ++p) v[p] = 0;
+      for (int j = 0; j < M; ++j) {
+        T zb[D], e = ua + ub[j];
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+          zb[p] = iLb[p] * sm[o.nu + j * D + p];
+          e += tza[p] * zb[p];
+        }
+        T w = bai * A.beta[b * M + j];
+        if (a == b) w -= A.Kinv[((size_t)a * M + j) * M + ii];  // (symmetric: row j, coalesced)
+        T c = w * exp_(e);
+        c = live ? c : (T)0;
+        r += c;
+        if (JAC) {
+#pragma unroll
+          for (int p = 0; p < D; ++p) v[p] += c * zb[p];
+          const T col = wave_sum(c);  // column sum of this tile
+          if (lane == 0) sj[j] += col;
+        }
+      }
+      Fa += r;
+      if (JAC) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+          y1[p] += r * za[p] + v[p];
+#pragma unroll
+          for (int q = 0; q <= p; ++q)
+            y2[p * (p + 1) / 2 + q] += r * za[p] * za[q] + za[p] * v[q] + v[p] * za[q];
+        }
+      }
+    }
+    Fa = wave_sum(Fa);
+    if (lane == 0) sm[o.F + item] = Fa;
+    if (JAC) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (int j = lane; j < M; j += 64) {  // sum_j s_j z_bj z_bj^T
+        const T s = sj[j];
+        T zb[D];
+#pragma unroll
+        for (int p = 0; p < D; ++p) zb[p] = iLb[p] * sm[o.nu + j * D + p];
+#pragma unroll
+        for (int p = 0; p < D; ++p)
+#pragma unroll
+          for (int q = 0; q <= p; ++q) y2[p * (p + 1) / 2 + q] += s * zb[p] * zb[q];
+      }
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        const T t1 = wave_sum(y1[p]);
+        if (lane == 0) sm[o.Y1 + item * D + p] = t1;
+#pragma unroll
+        for (int q = 0; q <= p; ++q) {
+          const T t2 = wave_sum(y2[p * (p + 1) / 2 + q]);
+          if (lane == 0) sm[o.Y2 + item * DD + p * D + q] = sm[o.Y2 + item * DD + q * D + p] = t2;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- C: Sigma_ab and (JAC) the gradients with respect to (m, S) -------------------
+  // kappa_ab = det(R)^-1/2 = exp(-1/2 (log det(S + lam) - sum log lam))
+  auto kappa_of = [&](int item, int a, int b) {
+    T sl = 0;
+    for (int p = 0; p < D; ++p) sl -= log_(A.iL[a * D + p] + A.iL[b * D + p]);
+    return exp_((T)-0.5 * (sm[o.ld + E + item] - sl));
+  };
+  if (tid < NP) {
+    int a, b;
+    pair_of(tid, E, a, b);
+    T s = kappa_of(tid, a, b) * sm[o.F + tid] - sm[o.mu + a] * sm[o.mu + b];
+    if (a == b) s += A.sf2[a] + A.sn2[a];
+    sm[o.Sig + tid] = s;
+  }
+  if (JAC) {
+    // thread (item, p): row p of H = 1/2 G (lam Y2 lam) G and of the gradients
+    for (int e = tid; e < NP * D; e += kThreads) {
+      const int item = e / D, p = e - item * D;
+      int a, b;
+      pair_of(item, E, a, b);
+      const T* Gs = sm + o.G + (E + item) * DD;
+      const T* Y2 = sm + o.Y2 + item * DD;
+      const T kap = kappa_of(item, a, b), Fv = sm[o.F + item];
+      const T mua = sm[o.mu + a], mub = sm[o.mu + b];
+      T lam[D], tmp[D];
+#pragma unroll
+      for (int q = 0; q < D; ++q) lam[q] = (T)1 / (A.iL[a * D + q] + A.iL[b * D + q]);
+#pragma unroll
+      for (int q = 0; q < D; ++q) {  // tmp = (G lam Y2 lam)[p][:]
+        T s = 0;
+#pragma unroll
+        for (int r = 0; r < D; ++r) s += Gs[p * D + r] * lam[r] * Y2[r * D + q];
+        tmp[q] = s * lam[q];
+      }
+      T gm = 0;  // (G (lam Y1))[p]
+#pragma unroll
+      for (int r = 0; r < D; ++r) gm += Gs[p * D + r] * lam[r] * sm[o.Y1 + item * D + r];
+      sm[o.gmS + item * D + p] = kap * gm - mub * sm[o.gmu + a * D + p] - mua * sm[o.gmu + b * D + p];
+#pragma unroll
+      for (int q = 0; q < D; ++q) {
+        T hv = 0;
+#pragma unroll
+        for (int r = 0; r < D; ++r) hv += tmp[r] * Gs[r * D + q];
+        sm[o.GSS + item * DD + p * D + q] =
+            kap * ((T)0.5 * hv - (T)0.5 * Fv * Gs[p * D + q]) -
+            mub * sm[o.GSmu + a * DD + p * D + q] - mua * sm[o.GSmu + b * DD + p * D + q];
+      }
+    }
+    // tangent of W_a along input k:
+    //   dW = A [-dS W - 1/2 tr(A dS) h + c (sum_i beta e_i (g_i.dm + 1/2 g_i^T dS g_i) nu_i) - mu dm]
+    for (int task = tid; task < K * E; task += kThreads) {
+      const int k = task / E, a = task - k * E;
+      const T* Ga = sm + o.G + a * DD;
+      const T* dS = sm + o.dS + k * DD;
+      const T* dm = sm + o.dm + k * D;
+      T ds[D * (D + 1) / 2], dmv[D], acc[D];
+      T tr = 0;
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        dmv[p] = dm[p];
+        acc[p] = 0;
+#pragma unroll
+        for (int q = 0; q <= p; ++q) {
+          ds[p * (p + 1) / 2 + q] = dS[p * D + q];
+          tr += (p == q ? (T)1 : (T)2) * Ga[p * D + q] * dS[p * D + q];
+        }
+      }
+      for (int i = 0; i < M; ++i) {
+        const T* g = sm + o.g + (a * M + i) * D;
+        T gv[D], q2 = 0, gd = 0;
+#pragma unroll
+        for (int p = 0; p < D; ++p) gv[p] = g[p], gd += g[p] * dmv[p];
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+          T s = (T)0.5 * ds[p * (p + 1) / 2 + p] * gv[p];
+#pragma unroll
+          for (int q = 0; q < p; ++q) s += ds[p * (p + 1) / 2 + q] * gv[q];
+          q2 += s * gv[p];  // 1/2 g^T dS g
+        }
+        const T coef = sm[o.be + a * M + i] * (gd + q2);
+#pragma unroll
+        for (int p = 0; p < D; ++p) acc[p] += coef * sm[o.nu + i * D + p];
+      }
+      const T c = sm[o.c + a], mu = sm[o.mu + a];
+      T vec[D];
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        T s = 0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) s += dS[p * D + q] * sm[o.W + a * D + q];
+        vec[p] = -s - (T)0.5 * tr * sm[o.h + a * D + p] + c * acc[p] - mu * dmv[p];
+      }
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        T s = 0;
+#pragma unroll
+        for (int q = 0; q < D; ++q) s += Ga[p * D + q] * vec[q];
+        sm[o.dW + (k * E + a) * D + p] = s;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- A3: next mean, covariance and encoding; lane k carries input k ---------------
+  if (wave == 0 && (JAC ? lane < K : lane == 0)) {
+    const int k = lane;
+    auto contract = [&](int gm_off, int GS_off) {  // gradient . (dm_k, dS_k)
+      T s = 0;
+      if (JAC) {
+        for (int p = 0; p < D; ++p) s += sm[gm_off + p] * sm[o.dm + k * D + p];
+        for (int e = 0; e < DD; ++e) s += sm[GS_off + e] * sm[o.dS + k * DD + e];
+      }
+      return s;
+    };
+    X Mn[E], Cn[E * (E + 1) / 2];  // upper triangle, row-major: (r, c >= r)
+    auto up = [&](int r, int c) { return r * E - r * (r - 1) / 2 + (c - r); };
+    for (int a = 0; a < E; ++a)
+      Mn[a] = mxv(a, k) + lift<X, T>(sm[o.mu + a], contract(o.gmu + a * D, o.GSmu + a * DD));
+    {
+      int item = 0;
+      for (int a = 0; a < E; ++a)
+        for (int b = a; b < E; ++b, ++item)
+          Cn[up(a, b)] = sx(a, b, k) +
+                         lift<X, T>(sm[o.Sig + item], contract(o.gmS + item * D, o.GSS + item * DD));
+    }
+    for (int r = 0; r < E; ++r)
+      for (int a = 0; a < E; ++a) {  // C[r][a] = sum_q cov[x_r, f_q] W_a[q]
+        X s = lift<X, T>((T)0, (T)0);
+        for (int q = 0; q < na; ++q)
+          s = s + cxf(r, q, k) * lift<X, T>(sm[o.W + a * D + q],
+                                           JAC ? sm[o.dW + (k * E + a) * D + q] : (T)0);
+        // C + C^T on the upper triangle: (r, a) and (a, r) both land on (min, max)
+        const int lo = r < a ? r : a, hi = r < a ? a : r;
+        Cn[up(lo, hi)] = Cn[up(lo, hi)] + (r == a ? s + s : s);
+      }
+    T* out = A.z_next + (size_t)row * n;
+    auto emit = [&](int idx, X v) {
+      if (lane == 0) out[idx] = prim(v);
+      if (JAC) {
+        if (k < n) A.Fz[((size_t)row * n + idx) * n + k] = tang(v);
+        else A.Fu[((size_t)row * n + idx) * A.m_act + (k - n)] = tang(v);
+      }
+    };
+    for (int a = 0; a < E; ++a) emit(a, Mn[a]);
+    if (enc == 1) {
+      // upper Cholesky U^T U = Cn + jitter (utils/encoding.py _cholesky_upper:
+      // 1e-12, x10 while a pivot fails - per row here, per batch there)
+      T jitter = (T)1e-12;
+      X U[E * (E + 1) / 2];
+      for (int attempt = 0; attempt < 14; ++attempt) {
+        bool ok = true;
+        for (int r = 0; r < E; ++r) {
+          X d = Cn[up(r, r)] + lift<X, T>(jitter, (T)0);
+          for (int t_ = 0; t_ < r; ++t_) d = d - U[up(t_, r)] * U[up(t_, r)];
+          ok = ok && prim(d) > (T)0;
+          const X l = sqrt_(d);
+          U[up(r, r)] = l;
+          for (int c = r + 1; c < E; ++c) {
+            X s = Cn[up(r, c)];
+            for (int t_ = 0; t_ < r; ++t_) s = s - U[up(t_, r)] * U[up(t_, c)];
+            U[up(r, c)] = s / l;
+          }
+        }
+        if (ok) break;
+        jitter *= (T)10;
+      }
+      for (int e = 0; e < E * (E + 1) / 2; ++e) emit(E + e, U[e]);
+    } else if (enc == 2 || enc == 3) {
+      for (int a = 0; a < E; ++a) {
+        X v = Cn[up(a, a)];
+        if (!(prim(v) > (T)1e-12)) v = lift<X, T>((T)1e-12, (T)0);  // clamp_min
+        emit(E + a, enc == 3 ? sqrt_(v) : v);
+      }
+    }
+  }
+}
+
+template <typename T, int E, int D>
+int launch(const Args<T>& a, bool jac, hipStream_t st) {
+  const int K = a.n + a.m_act;
+  if (K > 64) return PDDP_E_UNSUPPORTED;
+  const Lds<E, D> o(a.M, K, jac);
+  const size_t bytes = (size_t)o.total * sizeof(T);
+  if (bytes > 160 * 1024) return PDDP_E_UNSUPPORTED;
+  auto kern = jac ? gp_step_kernel<T, E, D, true> : gp_step_kernel<T, E, D, false>;
+  if (bytes > 64 * 1024) {
+    const hipError_t e =
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.R), dim3(kThreads), bytes, st, a);
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int step(const pddp_gp_model* g, int R, const T* z, const T* u, T* z_next, T* Fz, T* Fu, void* stream) {
+  if (g == nullptr || R < 0 || z == nullptr || u == nullptr || z_next == nullptr) return PDDP_E_BADARG;
+  if ((Fz == nullptr) != (Fu == nullptr)) return PDDP_E_BADARG;
+  if (R == 0) return 0;
+  if (g->n_ang < 0 || g->n_ang > kMaxAng || g->n_non < 0 || g->n_non > kMaxNon) return PDDP_E_BADARG;
+  if (g->n_ang + g->n_non != g->state_size || g->M < 1 || g->action_size < 1) return PDDP_E_BADARG;
+  const int E = g->state_size, D = g->n_non + 2 * g->n_ang + g->action_size;
+  Args<T> a;
+  a.R = R;
+  a.M = g->M;
+  a.m_act = g->action_size;
+  a.n_ang = g->n_ang;
+  a.n_non = g->n_non;
+  a.encoding = g->encoding;
+  switch (g->encoding) {
+    case 1: a.n = E + E * (E + 1) / 2; break;
+    case 2:
+    case 3: a.n = 2 * E; break;
+    case 4: a.n = E; break;
+    default: return PDDP_E_UNSUPPORTED;  // FULL_COVARIANCE_MATRIX: the torch path
+  }
+  for (int i = 0; i < kMaxAng; ++i) a.ang[i] = i < g->n_ang ? g->ang[i] : 0;
+  for (int i = 0; i < kMaxNon; ++i) a.non[i] = i < g->n_non ? g->non[i] : 0;
+  for (int i = 0; i < g->n_ang; ++i)
+    if (g->ang[i] < 0 || g->ang[i] >= E) return PDDP_E_BADARG;
+  for (int i = 0; i < g->n_non; ++i)
+    if (g->non[i] < 0 || g->non[i] >= E) return PDDP_E_BADARG;
+  a.Xt = (const T*)g->Xt;
+  a.beta = (const T*)g->beta;
+  a.Kinv = (const T*)g->Kinv;
+  a.iL = (const T*)g->inv_ell2;
+  a.sf2 = (const T*)g->sf2;
+  a.sn2 = (const T*)g->sn2;
+  a.z = z;
+  a.u = u;
+  a.z_next = z_next;
+  a.Fz = Fz;
+  a.Fu = Fu;
+  const bool jac = Fz != nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  // the systems of the reference's examples: pendulum, cartpole, double cartpole
+  if (E == 2 && D == 4) return launch<T, 2, 4>(a, jac, st);
+  if (E == 4 && D == 6) return launch<T, 4, 6>(a, jac, st);
+  if (E == 6 && D == 9) return launch<T, 6, 9>(a, jac, st);
+  return PDDP_E_UNSUPPORTED;
+}
+
+}  // namespace gp
+}  // namespace pddp
+
+extern "C" {
+int pddp_gp_step_f32(const pddp_gp_model* g, int R, const float* z, const float* u, float* z_next,
+                     float* Fz, float* Fu, void* stream) {
+  return pddp::gp::step<float>(g, R, z, u, z_next, Fz, Fu, stream);
+}
+int pddp_gp_step_f64(const pddp_gp_model* g, int R, const double* z, const double* u, double* z_next,
+                     double* Fz, double* Fu, void* stream) {
+  return pddp::gp::step<double>(g, R, z, u, z_next, Fz, Fu, stream);
+}
+}

@@ -65,6 +65,7 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             self.log_sf = torch.nn.Parameter(torch.zeros(E))
             self.log_sn = torch.nn.Parameter(torch.full((E,), -2.0))
             self.fitted = False
+            self._native_cache = {}
 
         @classproperty
         def action_size(cls):
@@ -145,6 +146,7 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             self.beta = torch.cholesky_solve(Y.t().unsqueeze(-1), L).squeeze(-1)
             self.Xt = Xt.clone()
             self.fitted = True
+            self._native_cache = {}
 
         # -- prediction ---------------------------------------------------------
         def moments(self, m, S, max_bytes=1 << 29):
@@ -217,6 +219,106 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             Sig = 0.5 * (Sig + Sig.transpose(-1, -2))
             return mu, Sig, W
 
+        def __getstate__(self):
+            # (the kernel's cached view holds raw device pointers: not part of
+            # a copy or a pickle)
+            state = self.__dict__.copy()
+            state["_native_cache"] = {}
+            return state
+
+        # -- the HIP kernel (csrc/gp_step.hip) ------------------------------------
+        _NATIVE_SHAPES = ((2, 4), (4, 6), (6, 9))
+        use_native = True
+
+        def native_ok(self, z, encoding, jacobian=False):
+            """True when `pddp_gp_step_*` covers this call: device tensors of
+            f32 / f64, an encoding other than the full covariance matrix, one of
+            the built (state_size, feature + action size) pairs, a training set
+            that fits the workgroup's LDS."""
+            if not (self.use_native and self.fitted and z.is_cuda):
+                return False
+            if z.dtype not in (torch.float32, torch.float64):
+                return False
+            if int(encoding) not in (1, 2, 3, 4):
+                return False
+            if (state_size, d_in) not in self._NATIVE_SHAPES:
+                return False
+            if len(ai) > 4 or len(ni) > 8:
+                return False
+            E, M_, d = state_size, self.Xt.shape[0], d_in
+            NP = E * (E + 1) // 2
+            words = d + d * d + E + E * E + (E + NP) * d * d + (E + NP) + \
+                M_ * d + 2 * E * M_ + E + 2 * E * d + E + 2 * NP + 8 * M_
+            if jacobian:
+                n = {1: E + NP, 2: 2 * E, 3: 2 * E, 4: E}[int(encoding)]
+                K = n + action_size
+                if K > 64:
+                    return False
+                words += E * M_ * d + NP * d + NP * d * d + K * d + \
+                    K * d * d + E * d + E * d * d + NP * d + NP * d * d + \
+                    K * E * d
+            return words * z.element_size() <= 160 * 1024
+
+        def _native_model(self, dtype, device, encoding):
+            """The kernel's view of the conditioned GPs (cached per dtype; the
+            cache is dropped by `condition`)."""
+            from .. import _native
+            key = (dtype, str(device))
+            hit = self._native_cache.get(key)
+            if hit is None:
+                conv = lambda t: t.detach().to(dtype=dtype, device=device) \
+                    .contiguous()
+                keep = dict(
+                    Xt=conv(self.Xt), beta=conv(self.beta),
+                    Kinv=conv(0.5 * (self.Kinv + self.Kinv.transpose(-1, -2))),
+                    inv_ell2=conv((-2.0 * self.log_ell.double()).exp()),
+                    sf2=conv((2.0 * self.log_sf.double()).exp()),
+                    sn2=conv((2.0 * self.log_sn.double()).exp()))
+                g = _native.GpModel()
+                g.state_size, g.action_size = state_size, action_size
+                g.M = int(self.Xt.shape[0])
+                g.n_ang, g.n_non = len(ai), len(ni)
+                for k_, v in enumerate(ai):
+                    g.ang[k_] = int(v)
+                for k_, v in enumerate(ni):
+                    g.non[k_] = int(v)
+                for name, t in keep.items():
+                    setattr(g, name, _native.ptr(t))
+                hit = self._native_cache[key] = (g, keep)
+            hit[0].encoding = int(encoding)
+            return hit[0]
+
+        @torch.no_grad()
+        def native_step(self, z, u, encoding=StateEncoding.DEFAULT,
+                        jacobian=False, Fz=None, Fu=None):
+            """`forward` on the HIP kernel for rows z [R, n], u [R, m]; with
+            `jacobian` also d z' / d z [R, n, n] and d z' / d u [R, n, m]
+            (written into Fz, Fu when given: contiguous, R n n / R n m
+            elements)."""
+            import ctypes
+            from .. import _native
+            z = z.detach().contiguous()
+            u = u.detach().reshape(z.shape[0], -1).to(z.dtype).contiguous()
+            R, n = z.shape
+            g = self._native_model(z.dtype, z.device, encoding)
+            out = torch.empty_like(z)
+            if jacobian:
+                if Fz is None:
+                    Fz = torch.empty(R, n, n, dtype=z.dtype, device=z.device)
+                    Fu = torch.empty(R, n, action_size, dtype=z.dtype,
+                                     device=z.device)
+                assert Fz.is_contiguous() and Fu.is_contiguous() and \
+                    Fz.numel() == R * n * n and Fz.dtype == z.dtype and \
+                    Fu.numel() == R * n * action_size and Fu.dtype == z.dtype
+            else:
+                Fz = Fu = None
+            p = _native.ptr
+            with torch.cuda.device(z.device):
+                _native.call("pddp_gp_step", z.dtype, ctypes.byref(g), R, p(z),
+                             p(u), p(out), p(Fz), p(Fu),
+                             _native.stream_handle(z.device))
+            return (out, Fz, Fu) if jacobian else out
+
         def forward(self, z, u, i, encoding=StateEncoding.DEFAULT,
                     identical_inputs=False, **kwargs):
             """Encoded state distribution and action -> next encoded state
@@ -226,6 +328,12 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             single = z.dim() == 1
             if single:
                 z, u = z.unsqueeze(0), u.reshape(1, -1)
+            # nobody can ask autograd to differentiate this call: the kernel
+            if z.dim() == 2 and not (torch.is_grad_enabled() and (
+                    z.requires_grad or u.requires_grad)) and \
+                    self.native_ok(z, encoding):
+                out = self.native_step(z, u, encoding)
+                return out[0] if single else out
             D = state_size
             mx = decode_mean(z, encoding, state_size=D)
             Sx = decode_covar(z, encoding, state_size=D)

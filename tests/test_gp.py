@@ -185,3 +185,195 @@ def test_gp_controller_on_gpu_matches_cpu_model():
     assert torch.isfinite(Z).all() and torch.isfinite(Uo).all()
     assert min(J) < J[0] or len(J) == 1
     assert ctrl._solver.plugin is not None
+
+
+# ---- the HIP kernel of the moment-matched step (csrc/gp_step.hip) -------------
+_SYSTEMS = {"pendulum": (2, 1, [0]), "cartpole": (4, 1, [2]),
+            "double_cartpole": (6, 1, [1, 2])}
+
+
+def _system_model(system, M, dtype, seed=0):
+    D, m, ang = _SYSTEMS[system]
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(M, D, generator=g, dtype=torch.float64)
+    U = torch.randn(M, m, generator=g, dtype=torch.float64)
+    dX = 0.3 * torch.sin(X @ torch.randn(D, D, generator=g,
+                                          dtype=torch.float64)) + 0.2 * U
+    model = gp_dynamics_model_factory(D, m, ang)().double()
+    model.fit(X, U, dX)
+    return model.to(dtype).cuda(), (X, U, dX)
+
+
+def _system_rows(system, R, encoding, dtype, seed=1, spread=0.2):
+    from pddp_amd.utils.encoding import encode
+    D, m, _ = _SYSTEMS[system]
+    g = torch.Generator().manual_seed(seed)
+    mean = 0.5 * torch.randn(R, D, generator=g, dtype=torch.float64)
+    A = spread * torch.randn(R, D, D, generator=g, dtype=torch.float64)
+    C = A @ A.transpose(-1, -2) + 1e-3 * torch.eye(D, dtype=torch.float64)
+    z = encode(mean, C=C, encoding=encoding)
+    u = torch.randn(R, m, generator=g, dtype=torch.float64)
+    return z.to(dtype).cuda(), u.to(dtype).cuda()
+
+
+def _torch_step(model, z, u, encoding, jacobian):
+    """The torch module with the kernel switched off; Jacobians by autograd,
+    one replica of the row per output (controllers/plugin.py _dyn_derivs)."""
+    model.use_native = False
+    try:
+        if not jacobian:
+            with torch.no_grad():
+                return model(z, u, 0, encoding)
+        R, n = z.shape
+        m = u.shape[1]
+        rep = torch.cat([z, u], -1).unsqueeze(1).expand(R, n, n + m) \
+            .reshape(R * n, n + m).detach().clone().requires_grad_()
+        zn = model(rep[:, :n], rep[:, n:], 0, encoding)
+        eye = torch.eye(n, dtype=z.dtype, device=z.device).repeat(R, 1)
+        J, = torch.autograd.grad(zn, rep, eye)
+        J = J.reshape(R, n, n + m)
+        return zn.reshape(R, n, n)[:, 0].detach(), J[:, :, :n], J[:, :, n:]
+    finally:
+        model.use_native = True
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-300))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("system", sorted(_SYSTEMS))
+@pytest.mark.parametrize("encoding", [1, 2, 3, 4])
+@pytest.mark.parametrize("dtype,tol_step,tol_jac", [
+    (torch.float64, 1e-11, 1e-10), (torch.float32, 2e-5, 5e-4)])
+def test_gp_step_kernel_vs_torch_module(system, encoding, dtype, tol_step,
+                                        tol_jac):
+    """pddp_gp_step_* - next encoded state and its Jacobian with respect to
+    the encoded state and the action - against the torch module and autograd
+    through it: three systems, four encodings, both dtypes; 70 training points
+    (more than one tile of 64 lanes)."""
+    enc = StateEncoding(encoding)
+    model, _ = _system_model(system, 70, dtype)
+    z, u = _system_rows(system, 19, enc, dtype)
+    assert model.native_ok(z, enc, jacobian=True)
+    ref, Fz_r, Fu_r = _torch_step(model, z, u, enc, True)
+    out, Fz, Fu = model.native_step(z, u, enc, jacobian=True)
+    plain = model.native_step(z, u, enc)
+    if dtype == torch.float32:
+        # float: both are held to the module in fp64 on the same (float)
+        # inputs - the kernel may be as far from it as the float module is
+        # (x4), or within the fixed bound
+        import copy
+        m64 = copy.deepcopy(model).double()
+        m64._native_cache = {}
+        r64, Fz64, Fu64 = _torch_step(m64, z.double(), u.double(), enc, True)
+        for got, tor, exact, tol in ((out, ref, r64, tol_step),
+                                     (plain, ref, r64, tol_step),
+                                     (Fz, Fz_r, Fz64, tol_jac),
+                                     (Fu, Fu_r, Fu64, tol_jac)):
+            assert _rel(got.double(), exact) < max(
+                tol, 4.0 * _rel(tor.double(), exact))
+    else:
+        assert _rel(out, ref) < tol_step and _rel(plain, ref) < tol_step
+        assert _rel(Fz, Fz_r) < tol_jac and _rel(Fu, Fu_r) < tol_jac
+    # and `forward` itself goes through the kernel when nobody can ask for
+    # gradients
+    with torch.no_grad():
+        assert torch.equal(model(z, u, 0, enc), plain)
+        assert torch.equal(model(z[0], u[0], 0, enc), plain[0])
+
+
+@pytest.mark.gpu
+def test_gp_step_kernel_vs_numpy_port():
+    """The kernel against the independent numpy restatement
+    (oracle/gp_port.py `step`), fp64, cartpole-shaped."""
+    from pddp_amd.utils.encoding import decode_covar, decode_mean
+    model, (X, U, dX) = _system_model("cartpole", 33, torch.float64, seed=4)
+    gp, ell, sf2, sn2 = _oracle_state(model.cpu())
+    Xt = model.Xt.cpu().numpy()
+    Kinv, beta = gp.condition(Xt, dX.numpy(), ell, sf2, sn2)
+    model = model.cuda()
+    enc = StateEncoding.DEFAULT
+    z, u = _system_rows("cartpole", 5, enc, torch.float64, seed=6)
+    zn = model.native_step(z, u, enc).cpu()
+    for r in range(5):
+        mean = decode_mean(z[r].cpu(), enc, state_size=4).numpy()
+        covar = decode_covar(z[r].cpu(), enc, state_size=4).numpy()
+        Mn, Cn = gp.step(Xt, Kinv, beta, ell, sf2, sn2, mean, covar,
+                         u[r].cpu().numpy(), [2], [0, 1, 3])
+        assert np.allclose(decode_mean(zn[r], enc, state_size=4).numpy(), Mn,
+                           rtol=1e-9, atol=1e-11)
+        assert np.allclose(decode_covar(zn[r], enc, state_size=4).numpy(), Cn,
+                           rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_gp_step_kernel_refuses_what_it_does_not_cover():
+    """Full-covariance encoding and unbuilt shapes stay on the torch path
+    (native_ok False); the C entry point itself returns PDDP_E_UNSUPPORTED."""
+    from pddp_amd import _native
+    model, _ = _system_model("cartpole", 20, torch.float64)
+    enc = StateEncoding.FULL_COVARIANCE_MATRIX
+    z, u = _system_rows("cartpole", 3, enc, torch.float64)
+    assert not model.native_ok(z, enc)
+    with pytest.raises(_native.NativeError):
+        model.native_step(z, u, enc)
+    with torch.no_grad():
+        out = model(z, u, 0, enc)  # torch ops
+    assert out.shape == z.shape and torch.isfinite(out).all()
+    assert not model.native_ok(z.cpu(), StateEncoding.DEFAULT)
+
+
+@pytest.mark.gpu
+def test_gp_derivative_records_by_the_kernel_equal_autograd_records():
+    """A round of the plugin path with the GP: the kernel's Jacobians
+    (`last_derivs_path["dynamics"] == "hip"`) give the records, gains and
+    accepted nominals that autograd through the torch module gives."""
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.examples.cartpole import CartpoleCost, CartpoleDynamicsModel
+    CM = CartpoleDynamicsModel
+    g = torch.Generator().manual_seed(7)
+    true = CM(0.1).double()
+    X = torch.cat([torch.randn(50, 2, generator=g, dtype=torch.float64),
+                   3.0 + 0.8 * torch.randn(50, 1, generator=g,
+                                           dtype=torch.float64),
+                   torch.randn(50, 1, generator=g, dtype=torch.float64)], -1)
+    U = 3.0 * torch.randn(50, 1, generator=g, dtype=torch.float64)
+    with torch.no_grad():
+        dX = true(X, U, 0, StateEncoding.IGNORE_UNCERTAINTY) - X
+    model = gp_dynamics_model_factory(4, 1, CM.angular_indices,
+                                      CM.non_angular_indices)().double().cuda()
+    model.fit(X.cuda(), U.cuda(), dX.cuda())
+    model.eval()
+    enc = StateEncoding.DEFAULT
+    B, N, n, m = 6, 12, 14, 1
+    z0 = torch.stack([GaussianVariable(
+        torch.tensor([0.0, 0.0, 3.0, 0.0], dtype=torch.float64) +
+        0.05 * torch.randn(4, generator=g, dtype=torch.float64),
+        var=1e-2 * torch.ones(4, dtype=torch.float64)).encode(enc)
+        for _ in range(B)]).cuda()
+    U0 = (0.3 * torch.randn(B, N, m, generator=g, dtype=torch.float64)).cuda()
+    sol = []
+    for native in (True, False):
+        plugin = TorchProblem(model, CartpoleCost().double().cuda(), enc, {},
+                              {})
+        plugin.use_native_gp = native
+        model.use_native = native
+        s = ILQRSolver(None, B, N, torch.float64, "cuda",
+                       torch.tensor([-10.0], dtype=torch.float64),
+                       torch.tensor([10.0], dtype=torch.float64),
+                       fit_alphas(torch.float64, "cuda"), plugin=plugin, n=n,
+                       m=m)
+        s.set_nominal(z0, U0)
+        s.round(5e-6, 1e10, 1 << 30)
+        assert plugin.last_derivs_path["dynamics"] == \
+            ("hip" if native else "autograd")
+        rec = s.rec.clone()
+        s.round(5e-6, 1e10, 1 << 30)
+        sol.append((rec, s.gains.clone(), s.Z.clone(), s.U.clone(),
+                    s.J_opt.clone()))
+    model.use_native = True
+    for a, b in zip(*sol):
+        assert torch.allclose(a, b, rtol=1e-7, atol=1e-8)
