@@ -573,7 +573,7 @@ def bench_gp(args, emit=True):
     from pddp_amd.models.gp import gp_dynamics_model_factory
     world, rank, dev = init_ranks()
     CM, cost_cls = ex.DoubleCartpoleDynamicsModel, ex.DoubleCartpoleCost
-    B = args.batch or 16
+    B = args.batch or 1024
     N = args.horizon or 150
     K = args.steps if args.steps != 30 else 2
     W = args.warmup if args.warmup != 5 else 1

@@ -37,6 +37,16 @@
 namespace pddp {
 namespace gp {
 
+// Debug build (-DPDDP_GP_MARKS): wavefront 0 of every row leaves s_memtime at
+// the phase boundaries in a global buffer (pddp_debug_gp_marks)
+#ifdef PDDP_GP_MARKS
+__device__ long long g_gp_marks[8 * 8];
+#define PDDP_GP_MARK(k) \
+  do { if (tid == 0 && blockIdx.x < 8) g_gp_marks[blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PDDP_GP_MARK(k) do { } while (0)
+#endif
+
 constexpr int kThreads = 256;
 constexpr int kMaxAng = 4, kMaxNon = 8;
 
@@ -92,33 +102,56 @@ template <> PDDP_DEV double lift<double, double>(double p, double) { return p; }
 template <> PDDP_DEV Dual<float> lift<Dual<float>, float>(float p, float t) { return {p, t}; }
 template <> PDDP_DEV Dual<double> lift<Dual<double>, double>(double p, double t) { return {p, t}; }
 
-template <typename T>
-PDDP_DEV T wave_sum(T v) {
+// Sum over the wavefront, in every lane.  float: six DPP additions (within the
+// quads, the rows of 16, then row to row) and a read of lane 63; double: the
+// butterfly through ds_bpermute
+template <int CTRL, int ROWS>
+PDDP_DEV float dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROWS, 0xf, true));
+}
+PDDP_DEV float wave_sum(float v) {
+  v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1 0 3 2]
+  v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2 3 0 1]
+  v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xf>(v);  // row_mirror: every lane has its row's sum
+  v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
+  v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+PDDP_DEV double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// exp of an argument already multiplied by log2(e): one v_exp_f32 (a result
+// below the normal range is flushed to zero - such a term weighs nothing)
+PDDP_DEV float exp2_scaled(float x) { return __builtin_amdgcn_exp2f(x); }
+PDDP_DEV double exp2_scaled(double x) { return exp(x); }
+template <typename T> PDDP_DEV T exp_scale();
+template <> PDDP_DEV float exp_scale<float>() { return 1.4426950408889634f; }
+template <> PDDP_DEV double exp_scale<double>() { return 1.0; }
 
 // ---- LDS layout (in T) ---------------------------------------------------------
 template <int E, int D>
 struct Lds {
   static constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D;
-  int m, S, mx, Sx, G, ld, nu, lk, be, mu, W, h, c, F, Sig, ub, sj;  // always
-  int g, Y1, Y2, dm, dS, gmu, GSmu, gmS, GSS, dW;                // JAC
+  static constexpr int DP = (D + 3) & ~3;  // row stride of nu: 16-byte rows
+  int m, S, Sx, Cxf, G, ld, nu, lk, be, mu, W, h, c, F, Sig, ub, sj;  // always
+  int g, Y1, Y2, dm, dS, dSx, dCxf, gmu, GSmu, gmS, GSS, dW, dO;  // JAC
   int total;
   PDDP_HD Lds(int M, int K, bool jac) {
     int o = 0;
-    auto take = [&](int k) { const int r = o; o += k; return r; };
-    m = take(D); S = take(DD); mx = take(E); Sx = take(E * E);
-    G = take(NS * DD); ld = take(NS); nu = take(M * D); lk = take(E * M);
+    auto take = [&](int k) { const int r = o; o += (k + 3) & ~3; return r; };
+    m = take(D); S = take(DD); Sx = take(E * E); Cxf = take(E * D);
+    G = take(NS * DD); ld = take(NS); nu = take(M * DP); lk = take(E * M);
     be = take(E * M); mu = take(E); W = take(E * D); h = take(E * D); c = take(E);
-    F = take(NP); Sig = take(NP); ub = take(4 * M); sj = take(4 * M);
-    g = Y1 = Y2 = dm = dS = gmu = GSmu = gmS = GSS = dW = 0;
+    F = take(NP); Sig = take(NP); ub = take(4 * 2 * M); sj = take(4 * M);
+    g = Y1 = Y2 = dm = dS = dSx = dCxf = gmu = GSmu = gmS = GSS = dW = dO = 0;
     if (jac) {
       g = take(E * M * D); Y1 = take(NP * D); Y2 = take(NP * DD);
-      dm = take(K * D); dS = take(K * DD);
+      dm = take(K * D); dS = take(K * DD); dSx = take(K * E * E); dCxf = take(K * E * D);
       gmu = take(E * D); GSmu = take(E * DD); gmS = take(NP * D); GSS = take(NP * DD);
-      dW = take(K * E * D);
+      dW = take(K * E * D); dO = take(K * NS);
     }
     total = o;
   }
@@ -212,8 +245,8 @@ PDDP_DEV void spd_inverse(const T* S, const T (&delta)[D], T* G, T& logdet) {
 template <typename T, int E, int D, bool JAC>
 __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
   using X = typename std::conditional<JAC, Dual<T>, T>::type;
-  constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D;
-  extern __shared__ __align__(16) unsigned char smem_raw[];
+  constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D, DP = Lds<E, D>::DP;
+  extern __shared__ __align__(32) unsigned char smem_raw[];
   T* sm = reinterpret_cast<T*>(smem_raw);
   const int M = A.M, n = A.n, K = n + A.m_act;
   const Lds<E, D> o(M, K, JAC);
@@ -278,23 +311,52 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
     return ((q - nn) & 1) ? -(cv * es) : cv * ec;
   };
 
-  // ---- A0 ------------------------------------------------------------------------
-  if (wave == 0) {
-    const int k = lane;  // tangent seed of this lane (k >= K: none)
-    for (int p = 0; p < D; ++p) {
-      const X v = m_of(p, k);
-      if (lane == 0) sm[o.m + p] = prim(v);
-      if (JAC && k < K) sm[o.dm + k * D + p] = tang(v);
-      for (int q = p; q < D; ++q) {
-        const X s = S_of(p, q, k);
-        if (lane == 0) sm[o.S + p * D + q] = sm[o.S + q * D + p] = prim(s);
-        if (JAC && k < K) sm[o.dS + k * DD + p * D + q] = sm[o.dS + k * DD + q * D + p] = tang(s);
+  // ---- A0: one task per (entry, input k) over all threads ------------------------------
+  PDDP_GP_MARK(0);
+  {
+    constexpr int nS = D * (D + 1) / 2, nX = E * (E + 1) / 2;
+    const int n_entries = D + nS + E * D + nX, Kq = JAC ? K : 1;
+    for (int task = tid; task < n_entries * Kq; task += kThreads) {
+      // (input fastest: the lanes of a wavefront share the entry - one code path)
+      int e = JAC ? task / Kq : task;
+      const int k = JAC ? task - e * Kq : -1;
+      const bool first = !JAC || k == 0;
+      if (e < D) {
+        const X v = m_of(e, k);
+        if (first) sm[o.m + e] = prim(v);
+        if (JAC) sm[o.dm + k * D + e] = tang(v);
+        continue;
       }
+      e -= D;
+      if (e < nS) {
+        int p = 0;
+        while (e >= D - p) e -= D - p, ++p;
+        const int q = p + e;
+        const X v = S_of(p, q, k);
+        if (first) sm[o.S + p * D + q] = sm[o.S + q * D + p] = prim(v);
+        if (JAC) sm[o.dS + k * DD + p * D + q] = sm[o.dS + k * DD + q * D + p] = tang(v);
+        continue;
+      }
+      e -= nS;
+      if (e < E * D) {
+        const X v = cxf(e / D, e % D, k);
+        if (first) sm[o.Cxf + e] = prim(v);
+        if (JAC) sm[o.dCxf + k * E * D + e] = tang(v);
+        continue;
+      }
+      e -= E * D;
+      int a = 0;
+      while (e >= E - a) e -= E - a, ++a;
+      const int b = a + e;
+      const X v = sx(a, b, k);
+      if (first) sm[o.Sx + a * E + b] = sm[o.Sx + b * E + a] = prim(v);
+      if (JAC) sm[o.dSx + (k * E + a) * E + b] = sm[o.dSx + (k * E + b) * E + a] = tang(v);
     }
   }
   __syncthreads();
 
   // ---- A1 ------------------------------------------------------------------------
+  PDDP_GP_MARK(1);
   if (wave == 0) {
     if (lane < NS) {
       T delta[D];
@@ -312,18 +374,22 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       sm[o.ld + lane] = ld;
     }
   } else {
-    for (int e = tid - 64; e < M * D; e += kThreads - 64) sm[o.nu + e] = A.Xt[e] - sm[o.m + e % D];
+    for (int e = tid - 64; e < M * D; e += kThreads - 64) {
+      const int i = e / D, p = e - i * D;
+      sm[o.nu + i * DP + p] = A.Xt[e] - sm[o.m + p];
+    }
   }
   __syncthreads();
   for (int e = tid; e < E * M; e += kThreads) {  // log k_a(x_i, m)
     const int a = e / M, i = e - a * M;
     T s = 0;
 #pragma unroll
-    for (int p = 0; p < D; ++p) s += sm[o.nu + i * D + p] * sm[o.nu + i * D + p] * A.iL[a * D + p];
+    for (int p = 0; p < D; ++p) s += sm[o.nu + i * DP + p] * sm[o.nu + i * DP + p] * A.iL[a * D + p];
     sm[o.lk + e] = log_(A.sf2[a]) - (T)0.5 * s;
   }
 
   // ---- A2: the mean and the input-output covariance --------------------------------
+  PDDP_GP_MARK(2);
   for (int a = wave; a < E; a += 4) {
     const T* Ga = sm + o.G + a * DD;
     T s0 = 0, s1[D], gg[JAC ? D * (D + 1) / 2 : 1];
@@ -336,7 +402,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
     for (int i = lane; i < M; i += 64) {
       T nu[D], g[D], quad = 0;
 #pragma unroll
-      for (int p = 0; p < D; ++p) nu[p] = sm[o.nu + i * D + p];
+      for (int p = 0; p < D; ++p) nu[p] = sm[o.nu + i * DP + p];
 #pragma unroll
       for (int p = 0; p < D; ++p) {
         T s = 0;
@@ -396,6 +462,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
   __syncthreads();
 
   // ---- B: the M^2 sums of every pair ---------------------------------------------
+  PDDP_GP_MARK(3);
   for (int item = wave; item < NP; item += 4) {
     int a, b;
     pair_of(item, E, a, b);
@@ -407,7 +474,8 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       iLb[p] = A.iL[b * D + p];
       lam[p] = (T)1 / (iLa[p] + iLb[p]);
     }
-    T* ub = sm + o.ub + wave * M;  // this wavefront's scratch
+    T* ub = sm + o.ub + wave * 2 * M;  // this wavefront's scratch: (u_b[j], beta_b[j]) pairs
+    const T kx = exp_scale<T>();       // exponents in units of ln 2 for float
     T* sj = sm + o.sj + wave * M;
     // T x = lam x - lam G (lam x)
     auto t_apply = [&](const T (&x)[D], T (&y)[D]) {
@@ -426,11 +494,12 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
     for (int j = lane; j < M; j += 64) {
       T zb[D], tz[D], s = 0;
 #pragma unroll
-      for (int p = 0; p < D; ++p) zb[p] = iLb[p] * sm[o.nu + j * D + p];
+      for (int p = 0; p < D; ++p) zb[p] = iLb[p] * sm[o.nu + j * DP + p];
       t_apply(zb, tz);
 #pragma unroll
       for (int p = 0; p < D; ++p) s += zb[p] * tz[p];
-      ub[j] = sm[o.lk + b * M + j] + (T)0.5 * s;
+      ub[2 * j] = kx * (sm[o.lk + b * M + j] + (T)0.5 * s);
+      ub[2 * j + 1] = A.beta[b * M + j];
       sj[j] = 0;
     }
     // (same-wavefront LDS traffic is in order; the compiler needs telling)
@@ -451,42 +520,70 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       const int ii = live ? i : 0;
       T za[D], tza[D], ua = 0;
 #pragma unroll
-      for (int p = 0; p < D; ++p) za[p] = iLa[p] * sm[o.nu + ii * D + p];
+      for (int p = 0; p < D; ++p) za[p] = iLa[p] * sm[o.nu + ii * DP + p];
       t_apply(za, tza);
 #pragma unroll
       for (int p = 0; p < D; ++p) ua += za[p] * tza[p];
-      ua = sm[o.lk + a * M + ii] + (T)0.5 * ua;
-      const T bai = A.beta[a * M + ii];
-      T r = 0, v[D];
+      ua = kx * (sm[o.lk + a * M + ii] + (T)0.5 * ua);
+      // z_bj = L_b^-1 nu_j: the factor goes to this lane's side of the product
+      T tzb[D];
 #pragma unroll
-      for (int p = 0; p < D; ++p) v[p] = 0;
-      for (int j = 0; j < M; ++j) {
-        T zb[D], e = ua + ub[j];
+      for (int p = 0; p < D; ++p) tzb[p] = kx * tza[p] * iLb[p];
+      const T bai = live ? A.beta[a * M + ii] : (T)0;  // (a dead lane weighs nothing)
+      const T* krow = A.Kinv + (size_t)a * M * M + ii;  // (symmetric: row j, coalesced)
+      T r = 0, vn[D];
 #pragma unroll
-        for (int p = 0; p < D; ++p) {
-          zb[p] = iLb[p] * sm[o.nu + j * D + p];
-          e += tza[p] * zb[p];
+      for (int p = 0; p < D; ++p) vn[p] = 0;
+      auto body = [&](int j, T kv) {
+        using V4 = T __attribute__((ext_vector_type(4)));
+        using V2 = T __attribute__((ext_vector_type(2)));
+        const V4* nj = reinterpret_cast<const V4*>(sm + o.nu + j * DP);  // 16-byte rows
+        const V2 ubj = *reinterpret_cast<const V2*>(ub + 2 * j);
+        T nuj[DP], e = ua + ubj.x;
+#pragma unroll
+        for (int q = 0; q < DP / 4; ++q) {
+          const V4 t4 = nj[q];
+          nuj[4 * q] = t4.x, nuj[4 * q + 1] = t4.y, nuj[4 * q + 2] = t4.z, nuj[4 * q + 3] = t4.w;
         }
-        T w = bai * A.beta[b * M + j];
-        if (a == b) w -= A.Kinv[((size_t)a * M + j) * M + ii];  // (symmetric: row j, coalesced)
-        T c = w * exp_(e);
-        c = live ? c : (T)0;
+#pragma unroll
+        for (int p = 0; p < D; ++p) e += tzb[p] * nuj[p];
+        const T w = bai * ubj.y - kv;
+        const T c = w * exp2_scaled(e);
         r += c;
         if (JAC) {
 #pragma unroll
-          for (int p = 0; p < D; ++p) v[p] += c * zb[p];
+          for (int p = 0; p < D; ++p) vn[p] += c * nuj[p];
           const T col = wave_sum(c);  // column sum of this tile
           if (lane == 0) sj[j] += col;
         }
+      };
+      if (a == b) {
+        // K_a^-1[i][j] comes from HBM / L2: eight requests in flight, then
+        // eight steps (a request per step would expose its latency each time)
+        constexpr int CH = 8;
+        for (int j0 = 0; j0 < M; j0 += CH) {
+          T kv[CH];
+#pragma unroll
+          for (int c_ = 0; c_ < CH; ++c_)
+            kv[c_] = (live && j0 + c_ < M) ? krow[(size_t)(j0 + c_) * M] : (T)0;
+#pragma unroll
+          for (int c_ = 0; c_ < CH; ++c_)
+            if (j0 + c_ < M) body(j0 + c_, kv[c_]);
+        }
+      } else {
+#pragma unroll 2
+        for (int j = 0; j < M; ++j) body(j, (T)0);
       }
       Fa += r;
       if (JAC) {
 #pragma unroll
+        for (int p = 0; p < D; ++p) vn[p] *= iLb[p];  // v_i = sum_j c_ij z_bj
+#pragma unroll
         for (int p = 0; p < D; ++p) {
-          y1[p] += r * za[p] + v[p];
+          y1[p] += r * za[p] + vn[p];
 #pragma unroll
           for (int q = 0; q <= p; ++q)
-            y2[p * (p + 1) / 2 + q] += r * za[p] * za[q] + za[p] * v[q] + v[p] * za[q];
+            y2[p * (p + 1) / 2 + q] += r * za[p] * za[q] + za[p] * vn[q] + vn[p] * za[q];
         }
       }
     }
@@ -500,7 +597,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
         const T s = sj[j];
         T zb[D];
 #pragma unroll
-        for (int p = 0; p < D; ++p) zb[p] = iLb[p] * sm[o.nu + j * D + p];
+        for (int p = 0; p < D; ++p) zb[p] = iLb[p] * sm[o.nu + j * DP + p];
 #pragma unroll
         for (int p = 0; p < D; ++p)
 #pragma unroll
@@ -521,6 +618,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
   __syncthreads();
 
   // ---- C: Sigma_ab and (JAC) the gradients with respect to (m, S) -------------------
+  PDDP_GP_MARK(4);
   // kappa_ab = det(R)^-1/2 = exp(-1/2 (log det(S + lam) - sum log lam))
   auto kappa_of = [&](int item, int a, int b) {
     T sl = 0;
@@ -601,7 +699,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
         }
         const T coef = sm[o.be + a * M + i] * (gd + q2);
 #pragma unroll
-        for (int p = 0; p < D; ++p) acc[p] += coef * sm[o.nu + i * D + p];
+        for (int p = 0; p < D; ++p) acc[p] += coef * sm[o.nu + i * DP + p];
       }
       const T c = sm[o.c + a], mu = sm[o.mu + a];
       T vec[D];
@@ -621,36 +719,44 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       }
     }
   }
+  if (JAC) {
+    // tangent of mu_a (o < E) and Sigma_ab (o >= E) along input k: gradient . (dm_k, dS_k)
+    __syncthreads();
+    for (int task = tid; task < K * NS; task += kThreads) {
+      const int oo = task / K, k = task - oo * K;  // (k fastest: the gradient is a broadcast)
+      const T* gm = oo < E ? sm + o.gmu + oo * D : sm + o.gmS + (oo - E) * D;
+      const T* GS = oo < E ? sm + o.GSmu + oo * DD : sm + o.GSS + (oo - E) * DD;
+      T s0 = 0, s1 = 0;
+#pragma unroll
+      for (int p = 0; p < D; ++p) s0 += gm[p] * sm[o.dm + k * D + p];
+#pragma unroll 9
+      for (int e = 0; e < DD; ++e) s1 += GS[e] * sm[o.dS + k * DD + e];
+      sm[o.dO + k * NS + oo] = s0 + s1;
+    }
+  }
   __syncthreads();
 
   // ---- A3: next mean, covariance and encoding; lane k carries input k ---------------
+  PDDP_GP_MARK(5);
   if (wave == 0 && (JAC ? lane < K : lane == 0)) {
     const int k = lane;
-    auto contract = [&](int gm_off, int GS_off) {  // gradient . (dm_k, dS_k)
-      T s = 0;
-      if (JAC) {
-        for (int p = 0; p < D; ++p) s += sm[gm_off + p] * sm[o.dm + k * D + p];
-        for (int e = 0; e < DD; ++e) s += sm[GS_off + e] * sm[o.dS + k * DD + e];
-      }
-      return s;
-    };
     X Mn[E], Cn[E * (E + 1) / 2];  // upper triangle, row-major: (r, c >= r)
     auto up = [&](int r, int c) { return r * E - r * (r - 1) / 2 + (c - r); };
     for (int a = 0; a < E; ++a)
-      Mn[a] = mxv(a, k) + lift<X, T>(sm[o.mu + a], contract(o.gmu + a * D, o.GSmu + a * DD));
+      Mn[a] = mxv(a, k) + lift<X, T>(sm[o.mu + a], JAC ? sm[o.dO + k * NS + a] : (T)0);
     {
       int item = 0;
       for (int a = 0; a < E; ++a)
         for (int b = a; b < E; ++b, ++item)
-          Cn[up(a, b)] = sx(a, b, k) +
-                         lift<X, T>(sm[o.Sig + item], contract(o.gmS + item * D, o.GSS + item * DD));
+          Cn[up(a, b)] = lift<X, T>(sm[o.Sx + a * E + b], JAC ? sm[o.dSx + (k * E + a) * E + b] : (T)0) +
+                         lift<X, T>(sm[o.Sig + item], JAC ? sm[o.dO + k * NS + E + item] : (T)0);
     }
     for (int r = 0; r < E; ++r)
       for (int a = 0; a < E; ++a) {  // C[r][a] = sum_q cov[x_r, f_q] W_a[q]
         X s = lift<X, T>((T)0, (T)0);
         for (int q = 0; q < na; ++q)
-          s = s + cxf(r, q, k) * lift<X, T>(sm[o.W + a * D + q],
-                                           JAC ? sm[o.dW + (k * E + a) * D + q] : (T)0);
+          s = s + lift<X, T>(sm[o.Cxf + r * D + q], JAC ? sm[o.dCxf + (k * E + r) * D + q] : (T)0) *
+                      lift<X, T>(sm[o.W + a * D + q], JAC ? sm[o.dW + (k * E + a) * D + q] : (T)0);
         // C + C^T on the upper triangle: (r, a) and (a, r) both land on (min, max)
         const int lo = r < a ? r : a, hi = r < a ? a : r;
         Cn[up(lo, hi)] = Cn[up(lo, hi)] + (r == a ? s + s : s);
@@ -695,6 +801,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       }
     }
   }
+  PDDP_GP_MARK(6);
 }
 
 template <typename T, int E, int D>
@@ -766,6 +873,11 @@ int step(const pddp_gp_model* g, int R, const T* z, const T* u, T* z_next, T* Fz
 }  // namespace pddp
 
 extern "C" {
+#ifdef PDDP_GP_MARKS
+int pddp_debug_gp_marks(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::gp::g_gp_marks), sizeof(long long) * 64);
+}
+#endif
 int pddp_gp_step_f32(const pddp_gp_model* g, int R, const float* z, const float* u, float* z_next,
                      float* Fz, float* Fu, void* stream) {
   return pddp::gp::step<float>(g, R, z, u, z_next, Fz, Fu, stream);

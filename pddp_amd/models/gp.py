@@ -247,16 +247,19 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
                 return False
             E, M_, d = state_size, self.Xt.shape[0], d_in
             NP = E * (E + 1) // 2
-            words = d + d * d + E + E * E + (E + NP) * d * d + (E + NP) + \
-                M_ * d + 2 * E * M_ + E + 2 * E * d + E + 2 * NP + 8 * M_
+            NS, dd, dp = E + NP, d * d, (d + 3) & ~3
+            # (the regions of csrc/gp_step.hip `Lds`, each a multiple of four)
+            regions = [d, dd, E * E, E * d, NS * dd, NS, M_ * dp, E * M_,
+                       E * M_, E, E * d, E * d, E, NP, NP, 8 * M_, 4 * M_]
             if jacobian:
                 n = {1: E + NP, 2: 2 * E, 3: 2 * E, 4: E}[int(encoding)]
                 K = n + action_size
                 if K > 64:
                     return False
-                words += E * M_ * d + NP * d + NP * d * d + K * d + \
-                    K * d * d + E * d + E * d * d + NP * d + NP * d * d + \
-                    K * E * d
+                regions += [E * M_ * d, NP * d, NP * dd, K * d, K * dd,
+                            K * E * E, K * E * d, E * d, E * dd, NP * d,
+                            NP * dd, K * E * d, K * NS]
+            words = sum((r + 3) & ~3 for r in regions)
             return words * z.element_size() <= 160 * 1024
 
         def _native_model(self, dtype, device, encoding):

@@ -250,10 +250,10 @@ def test_gp_step_kernel_vs_torch_module(system, encoding, dtype, tol_step,
                                         tol_jac):
     """pddp_gp_step_* - next encoded state and its Jacobian with respect to
     the encoded state and the action - against the torch module and autograd
-    through it: three systems, four encodings, both dtypes; 70 training points
+    through it: three systems, four encodings, both dtypes; 66 training points
     (more than one tile of 64 lanes)."""
     enc = StateEncoding(encoding)
-    model, _ = _system_model(system, 70, dtype)
+    model, _ = _system_model(system, 66, dtype)
     z, u = _system_rows(system, 19, enc, dtype)
     assert model.native_ok(z, enc, jacobian=True)
     ref, Fz_r, Fu_r = _torch_step(model, z, u, enc, True)
