@@ -557,14 +557,14 @@ def bench_bnn(args, emit=True):
 
 def bench_gp(args, emit=True):
     """--workload double_cartpole_gp: BASELINE.json configs[3] AS STATED -
-    double cartpole (state 6) with GP dynamics, horizon 150 - on the build's
-    own GP plugin (pddp_amd/models/gp.py: squared-exponential GPs, exact
-    moment matching; the reference has no GP: PARITY UNPINNED, checker
-    oracle/gp_port.py).  The moment-matched step is batched torch (no HIP
-    kernel yet) and costs E^2 M^2 kernel evaluations per row, its Jacobians
-    come from autograd: the batch is what fits a short run (default 16
-    trajectories per GPU, 60 training points), not configs[3]'s 1024 - stated
-    in the line.  A step is one round of the fit loop."""
+    double cartpole (state 6) with GP dynamics, horizon 150, 1024 trajectories
+    per GPU - on the build's own GP plugin (pddp_amd/models/gp.py:
+    squared-exponential GPs, exact moment matching; the reference has no GP:
+    PARITY UNPINNED, checkers: the torch module + autograd and
+    oracle/gp_port.py).  The moment-matched step and its Jacobian are ONE HIP
+    kernel (csrc/gp_step.hip, pddp_gp_step_f32): the derivative rollout is a
+    single launch over all B N rows, the line search N launches of B A rows.
+    A step is one round of the fit loop."""
     import pddp_amd
     from pddp_amd.controllers.ilqr import fit_alphas
     from pddp_amd.controllers.plugin import TorchProblem
@@ -618,21 +618,45 @@ def bench_gp(args, emit=True):
     elapsed = time.perf_counter() - t0
     liveK = int(s.active.sum().item())
     attempted = live0 + int(s.n_live.sum().item()) - liveK
-    # the dominant operation: one moment-matched step of the candidate rows
+    # the dominant kernel: one moment-matched step of the line search's
+    # candidate rows (B A rows per launch, N launches per round), timed with
+    # events on the stream it is launched on (torch's current stream)
     rows = B * A
     zr = z0.repeat_interleave(A, 0)
     ur = torch.zeros(rows, m, device=dev)
+    native = bool(model.native_ok(zr, enc))
     with torch.no_grad():
         model(zr, ur, 0, enc)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(3):
+        reps = 5
+        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+        for i in range(reps):
+            e0[i].record()
             model(zr, ur, 0, enc)
+            e1[i].record()
         torch.cuda.synchronize(dev)
-        dur = (time.perf_counter() - t1) / 3
+        dur = sum(a_.elapsed_time(b_) for a_, b_ in zip(e0, e1)) / reps * 1e-3
     d_in = 9
-    # kernel evaluations' flops: Q needs ~ (2 d^2 + 4 d) flops per (a, b, i, j)
-    flop = rows * D * D * M * M * (2 * d_in * d_in + 4 * d_in)
+    NPAIR = D * (D + 1) // 2
+    # algorithmic flops of a row: the M^2 exponents of every output pair -
+    # a d-term product (2 d), two additions, the exponential counted as one,
+    # weight and accumulation (3): 2 d + 6 per (pair, i, j)
+    flop = rows * NPAIR * M * M * (2 * d_in + 6)
+    # the derivative rollout's launch (B N rows with Jacobians), once
+    jac_ms = None
+    if native:
+        zj = s.Z[:, :N].reshape(B * N, n).contiguous()
+        uj = s.U.reshape(B * N, m).contiguous()
+        Fz = torch.empty(B * N, n, n, device=dev)
+        Fu = torch.empty(B * N, n, m, device=dev)
+        model.native_step(zj, uj, enc, jacobian=True, Fz=Fz, Fu=Fu)
+        ej = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ej[0].record()
+        model.native_step(zj, uj, enc, jacobian=True, Fz=Fz, Fu=Fu)
+        ej[1].record()
+        torch.cuda.synchronize(dev)
+        jac_ms = ej[0].elapsed_time(ej[1])
+        del Fz, Fu
     out = {
         "metric": "pddp_iterations_per_sec", "value": attempted / elapsed,
         "unit": "trajectory-iterations/s", "n_gpus": world, "steps": K,
@@ -643,23 +667,30 @@ def bench_gp(args, emit=True):
             "workload": "BASELINE.json configs[3] as stated: double cartpole "
                         "(state 6, DEFAULT encoding n=27 m=1) with GP dynamics "
                         "(the build's own plugin - the reference has no GP: "
-                        "PARITY UNPINNED, checker oracle/gp_port.py), %d "
-                        "training points, exact moment matching in batched "
-                        "torch ops, autograd Jacobians, horizon=%d, batch=%d "
-                        "trajectories per GPU (REDUCED from configs[3]'s 1024 "
-                        "per GPU: no HIP kernel for the GP step yet), bounds "
-                        "+-20, 10 line-search alphas" % (M, N, B),
+                        "PARITY UNPINNED, checkers: the torch module + "
+                        "autograd, oracle/gp_port.py), %d training points, "
+                        "exact moment matching and its Jacobian in one HIP "
+                        "kernel (pddp_gp_step_f32), horizon=%d, batch=%d "
+                        "trajectories per GPU, bounds +-20, 10 line-search "
+                        "alphas; cost and control law of the line search "
+                        "still torch ops per time step" % (M, N, B),
+            "gp_step_on": "hip" if native else "torch",
+            "derivative_rollout_launch_ms": jac_ms,
             "batch_per_gpu": B, "horizon": N, "alphas": A,
             "training_points": M, "parity": "unpinned",
             "live_trajectories_start_end": [live0, liveK],
             "derivative_path": getattr(plugin, "last_derivs_path", None)},
         "roofline": {
-            "bound": "mfma", "kernel": "GP moment-matched step (torch ops: "
-                                       "einsum / solve / exp), %d candidate "
-                                       "rows" % rows,
+            # (vector arithmetic, no matrix cores: priced against the f32
+            # rate of the part, which is the same number for both)
+            "bound": "mfma", "unit_of_work": "valu",
+            "kernel": "gp_step_kernel<float, 6, 9, false>: GP moment-matched "
+                      "step, %d candidate rows (one line-search time step)"
+                      % rows,
             "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
             "avg_launch_us": dur * 1e6, "algorithmic_flop_per_launch": flop,
+            "flop_per_pair_point_point": 2 * d_in + 6,
             "traffic": None},
         "cpu_baseline": None,
     }

@@ -211,6 +211,94 @@ class TorchProblem(object):
         self.model.native_step(z, u.reshape(B * N, m), self.encoding,
                                jacobian=True, Fz=F_z, Fu=F_u)
 
+    def _gp_line_search_ok(self, s):
+        """The line search as N launches of the GP step plus ONE batched
+        evaluation of the stage costs: needs the sample problems' QR cost on
+        the model's own angle-augmented state."""
+        from ..examples._common import AugmentedQRCost
+        co, mo = self.cost, self.model
+        if not self._gp_native_ok(s) or self.cost_opts:
+            return False
+        if not isinstance(co, AugmentedQRCost) or co.model_class is None:
+            return False
+        mc = co.model_class
+        return (list(mc.angular_indices) == list(mo.angular_indices) and
+                list(mc.non_angular_indices) == list(mo.non_angular_indices)
+                and mc.state_size == mo.state_size)
+
+    @torch.no_grad()
+    def _qr_costs_batched(self, s, Zc, Uc, chunk=8):
+        """Sum over the horizon of the QR cost of every candidate rollout:
+        Zc [B, N+1, A, n], Uc [B, N, A, m] -> [B, A].  The expectation
+        E[(x~ - g)^T Q (x~ - g)] + u^T R u on the angle-augmented Gaussian state
+        (costs/quadratic.py:60-99 after utils/angular.py:47-84), taken from
+        the moments themselves: the reference's encode -> decode round trip of
+        the augmented covariance (a Cholesky factorisation per time step) is
+        the identity up to its 1e-12 jitter."""
+        from ..utils.angular import (augment_moments, augment_moments_var,
+                                     augment_state)
+        from ..utils.encoding import (StateEncoding, decode_covar,
+                                      decode_mean, decode_var)
+        co, enc = self.cost, self.encoding
+        mc = co.model_class
+        ai, ni, D = list(mc.angular_indices), list(mc.non_angular_indices), \
+            mc.state_size
+        B, N1, A, n = Zc.shape
+        J = torch.zeros(B, A, dtype=Zc.dtype, device=Zc.device)
+        for t0 in range(0, N1, chunk):
+            t1 = min(N1, t0 + chunk)
+            z = Zc[:, t0:t1]
+            mean = decode_mean(z, enc, D)
+            if enc == StateEncoding.IGNORE_UNCERTAINTY:
+                M_, spread = augment_state(mean, ai, ni), None
+            elif enc in (StateEncoding.FULL_COVARIANCE_MATRIX,
+                         StateEncoding.UPPER_TRIANGULAR_CHOLESKY):
+                M_, C_ = augment_moments(mean, decode_covar(z, enc, D), ai, ni)
+                spread = None
+            else:
+                M_, spread = augment_moments_var(mean, decode_var(z, enc, D),
+                                                 ai, ni)
+                C_ = None
+            dx = M_ - co.x_goal
+            # (the last point of the last chunk is the terminal state: Q_term)
+            parts = [(co.Q, 0, t1 - t0)]
+            if t1 == N1:
+                parts = [(co.Q, 0, t1 - t0 - 1), (co.Q_term, t1 - t0 - 1, t1 - t0)]
+            for Q, lo, hi in parts:
+                if lo >= hi:
+                    continue
+                d = dx[:, lo:hi]
+                c = ((d @ Q) * d).sum(-1)
+                if enc != StateEncoding.IGNORE_UNCERTAINTY:
+                    if spread is None:
+                        c = c + (C_[:, lo:hi] * Q.t()).sum((-2, -1))
+                    else:
+                        c = c + (spread[:, lo:hi] * torch.diagonal(Q)).sum(-1)
+                J += c.sum(1)
+        du = Uc - co.u_goal
+        J += ((du @ co.R) * du).sum(-1).sum(1)
+        return J
+
+    @torch.no_grad()
+    def _line_search_gp(self, s):
+        B, N, n, m, A = s.B, s.N, s.n, s.m, s.A
+        k, K = s.gain_views()
+        alpha = s.alphas.view(1, A, 1)
+        z = s.Z[:, 0].unsqueeze(1).expand(B, A, n).contiguous()
+        s.Zc[:, 0] = z
+        for t in range(N):
+            dz = z - s.Z[:, t].unsqueeze(1)
+            u = s.U[:, t].unsqueeze(1) + alpha * k[:, t].unsqueeze(1) + \
+                dz @ K[:, t].transpose(-1, -2)
+            if s.u_min is not None:
+                u = clamp(u, s.u_min, s.u_max)
+            z = self.model.native_step(z.reshape(B * A, n),
+                                       u.reshape(B * A, m),
+                                       self.encoding).reshape(B, A, n)
+            s.Uc[:, t] = u
+            s.Zc[:, t + 1] = z
+        s.Jc.copy_(self._qr_costs_batched(s, s.Zc, s.Uc))
+
     # -- fused BNN rollout: csrc/bnn_rollout.hip + csrc/bnn_mlp.hip -------------
     def _qr_cost_native_ok(self, s, co=None):
         """QR cost on the angle-augmented state, DEFAULT encoding, f32: value,
@@ -587,6 +675,8 @@ class TorchProblem(object):
         self.cost.eval()
         if self._bnn_native_ok(s):
             return self._line_search_bnn(s, active, use_status)
+        if self._gp_line_search_ok(s):
+            return self._line_search_gp(s)
         B, N, n, m, A = s.B, s.N, s.n, s.m, s.A
         k, K = s.gain_views()
         alpha = s.alphas.view(1, A, 1)

@@ -135,7 +135,9 @@ template <> PDDP_DEV double exp_scale<double>() { return 1.0; }
 template <int E, int D>
 struct Lds {
   static constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D;
-  static constexpr int DP = (D + 3) & ~3;  // row stride of nu: 16-byte rows
+  // nu in pairs of training points: (j, p) at (j >> 1) PS + 2 p + (j & 1) - a
+  // 16-byte read gives (p, p + 1) of two points, the operands of v_pk_fma_f32
+  static constexpr int PS = (2 * D + 3) & ~3;
   int m, S, Sx, Cxf, G, ld, nu, lk, be, mu, W, h, c, F, Sig, ub, sj;  // always
   int g, Y1, Y2, dm, dS, dSx, dCxf, gmu, GSmu, gmS, GSS, dW, dO;  // JAC
   int total;
@@ -143,9 +145,9 @@ struct Lds {
     int o = 0;
     auto take = [&](int k) { const int r = o; o += (k + 3) & ~3; return r; };
     m = take(D); S = take(DD); Sx = take(E * E); Cxf = take(E * D);
-    G = take(NS * DD); ld = take(NS); nu = take(M * DP); lk = take(E * M);
+    G = take(NS * DD); ld = take(NS); nu = take(((M + 1) >> 1) * PS); lk = take(E * M);
     be = take(E * M); mu = take(E); W = take(E * D); h = take(E * D); c = take(E);
-    F = take(NP); Sig = take(NP); ub = take(4 * 2 * M); sj = take(4 * M);
+    F = take(NP); Sig = take(NP); ub = take(4 * 4 * ((M + 1) >> 1)); sj = take(4 * 2 * ((M + 1) >> 1));
     g = Y1 = Y2 = dm = dS = dSx = dCxf = gmu = GSmu = gmS = GSS = dW = dO = 0;
     if (jac) {
       g = take(E * M * D); Y1 = take(NP * D); Y2 = take(NP * DD);
@@ -245,11 +247,12 @@ PDDP_DEV void spd_inverse(const T* S, const T (&delta)[D], T* G, T& logdet) {
 template <typename T, int E, int D, bool JAC>
 __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
   using X = typename std::conditional<JAC, Dual<T>, T>::type;
-  constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D, DP = Lds<E, D>::DP;
+  constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D, PS = Lds<E, D>::PS;
   extern __shared__ __align__(32) unsigned char smem_raw[];
   T* sm = reinterpret_cast<T*>(smem_raw);
   const int M = A.M, n = A.n, K = n + A.m_act;
   const Lds<E, D> o(M, K, JAC);
+  auto nu_at = [&](int i, int p) -> T& { return sm[o.nu + (i >> 1) * PS + 2 * p + (i & 1)]; };
   const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const T* z = A.z + (size_t)row * n;
   const T* u = A.u + (size_t)row * A.m_act;
@@ -376,15 +379,16 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
   } else {
     for (int e = tid - 64; e < M * D; e += kThreads - 64) {
       const int i = e / D, p = e - i * D;
-      sm[o.nu + i * DP + p] = A.Xt[e] - sm[o.m + p];
+      nu_at(i, p) = A.Xt[e] - sm[o.m + p];
     }
+    if ((M & 1) && tid - 64 < D) nu_at(M, tid - 64) = 0;  // the pair partner of the last point
   }
   __syncthreads();
   for (int e = tid; e < E * M; e += kThreads) {  // log k_a(x_i, m)
     const int a = e / M, i = e - a * M;
     T s = 0;
 #pragma unroll
-    for (int p = 0; p < D; ++p) s += sm[o.nu + i * DP + p] * sm[o.nu + i * DP + p] * A.iL[a * D + p];
+    for (int p = 0; p < D; ++p) s += nu_at(i, p) * nu_at(i, p) * A.iL[a * D + p];
     sm[o.lk + e] = log_(A.sf2[a]) - (T)0.5 * s;
   }
 
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
     for (int i = lane; i < M; i += 64) {
       T nu[D], g[D], quad = 0;
 #pragma unroll
-      for (int p = 0; p < D; ++p) nu[p] = sm[o.nu + i * DP + p];
+      for (int p = 0; p < D; ++p) nu[p] = nu_at(i, p);
 #pragma unroll
       for (int p = 0; p < D; ++p) {
         T s = 0;
@@ -474,9 +478,10 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       iLb[p] = A.iL[b * D + p];
       lam[p] = (T)1 / (iLa[p] + iLb[p]);
     }
-    T* ub = sm + o.ub + wave * 2 * M;  // this wavefront's scratch: (u_b[j], beta_b[j]) pairs
+    const int MP = (M + 1) >> 1;          // pairs of training points
+    T* ub = sm + o.ub + wave * 4 * MP;  // this wavefront's scratch, per pair: u_b, u_b, beta_b, beta_b
     const T kx = exp_scale<T>();       // exponents in units of ln 2 for float
-    T* sj = sm + o.sj + wave * M;
+    T* sj = sm + o.sj + wave * 2 * ((M + 1) >> 1);
     // T x = lam x - lam G (lam x)
     auto t_apply = [&](const T (&x)[D], T (&y)[D]) {
       T lx[D];
@@ -494,14 +499,15 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
     for (int j = lane; j < M; j += 64) {
       T zb[D], tz[D], s = 0;
 #pragma unroll
-      for (int p = 0; p < D; ++p) zb[p] = iLb[p] * sm[o.nu + j * DP + p];
+      for (int p = 0; p < D; ++p) zb[p] = iLb[p] * nu_at(j, p);
       t_apply(zb, tz);
 #pragma unroll
       for (int p = 0; p < D; ++p) s += zb[p] * tz[p];
-      ub[2 * j] = kx * (sm[o.lk + b * M + j] + (T)0.5 * s);
-      ub[2 * j + 1] = A.beta[b * M + j];
+      ub[4 * (j >> 1) + (j & 1)] = kx * (sm[o.lk + b * M + j] + (T)0.5 * s);
+      ub[4 * (j >> 1) + 2 + (j & 1)] = A.beta[b * M + j];
       sj[j] = 0;
     }
+    if ((M & 1) && lane == 0) ub[4 * (M >> 1) + 1] = (T)-1e30, ub[4 * (M >> 1) + 3] = 0;  // phantom: weighs nothing
     // (same-wavefront LDS traffic is in order; the compiler needs telling)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       const int ii = live ? i : 0;
       T za[D], tza[D], ua = 0;
 #pragma unroll
-      for (int p = 0; p < D; ++p) za[p] = iLa[p] * sm[o.nu + ii * DP + p];
+      for (int p = 0; p < D; ++p) za[p] = iLa[p] * nu_at(ii, p);
       t_apply(za, tza);
 #pragma unroll
       for (int p = 0; p < D; ++p) ua += za[p] * tza[p];
@@ -531,49 +537,62 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       for (int p = 0; p < D; ++p) tzb[p] = kx * tza[p] * iLb[p];
       const T bai = live ? A.beta[a * M + ii] : (T)0;  // (a dead lane weighs nothing)
       const T* krow = A.Kinv + (size_t)a * M * M + ii;  // (symmetric: row j, coalesced)
-      T r = 0, vn[D];
+      using V4 = T __attribute__((ext_vector_type(4)));
+      using V2 = T __attribute__((ext_vector_type(2)));
+      V2 r2 = {0, 0}, vn2[D], tzb2[D];
 #pragma unroll
-      for (int p = 0; p < D; ++p) vn[p] = 0;
-      auto body = [&](int j, T kv) {
-        using V4 = T __attribute__((ext_vector_type(4)));
-        using V2 = T __attribute__((ext_vector_type(2)));
-        const V4* nj = reinterpret_cast<const V4*>(sm + o.nu + j * DP);  // 16-byte rows
-        const V2 ubj = *reinterpret_cast<const V2*>(ub + 2 * j);
-        T nuj[DP], e = ua + ubj.x;
+      for (int p = 0; p < D; ++p) vn2[p] = V2{0, 0}, tzb2[p] = V2{tzb[p], tzb[p]};
+      const V2 ua2 = {ua, ua}, bai2 = {bai, bai};
+      // two training points j per step, as the two halves of packed operations
+      auto body = [&](int jp, V2 kv) {
+        const V4* nj = reinterpret_cast<const V4*>(sm + o.nu + jp * PS);
+        const V4 uq = *reinterpret_cast<const V4*>(ub + 4 * jp);
+        V2 n2[PS / 2];
 #pragma unroll
-        for (int q = 0; q < DP / 4; ++q) {
+        for (int q = 0; q < PS / 4; ++q) {
           const V4 t4 = nj[q];
-          nuj[4 * q] = t4.x, nuj[4 * q + 1] = t4.y, nuj[4 * q + 2] = t4.z, nuj[4 * q + 3] = t4.w;
+          n2[2 * q] = V2{t4.x, t4.y}, n2[2 * q + 1] = V2{t4.z, t4.w};
         }
+        V2 e = ua2 + V2{uq.x, uq.y};
 #pragma unroll
-        for (int p = 0; p < D; ++p) e += tzb[p] * nuj[p];
-        const T w = bai * ubj.y - kv;
-        const T c = w * exp2_scaled(e);
-        r += c;
-        if (JAC) {
+        for (int p = 0; p < D; ++p) e = tzb2[p] * n2[p] + e;
+        const V2 w = bai2 * V2{uq.z, uq.w} - kv;
+        const V2 ex = {exp2_scaled(e.x), exp2_scaled(e.y)};
+        if (!JAC) {
+          r2 = w * ex + r2;
+        } else {
+          const V2 c = w * ex;
+          r2 += c;
 #pragma unroll
-          for (int p = 0; p < D; ++p) vn[p] += c * nuj[p];
-          const T col = wave_sum(c);  // column sum of this tile
-          if (lane == 0) sj[j] += col;
+          for (int p = 0; p < D; ++p) vn2[p] = c * n2[p] + vn2[p];
+          const T c0 = wave_sum(c.x), c1 = wave_sum(c.y);  // column sums of this tile
+          if (lane == 0) sj[2 * jp] += c0, sj[2 * jp + 1] += c1;
         }
       };
       if (a == b) {
         // K_a^-1[i][j] comes from HBM / L2: eight requests in flight, then
-        // eight steps (a request per step would expose its latency each time)
-        constexpr int CH = 8;
-        for (int j0 = 0; j0 < M; j0 += CH) {
-          T kv[CH];
+        // four steps (a request per step would expose its latency each time)
+        constexpr int CH = 4;
+        for (int j0 = 0; j0 < MP; j0 += CH) {
+          V2 kv[CH];
+#pragma unroll
+          for (int c_ = 0; c_ < CH; ++c_) {
+            const int j = 2 * (j0 + c_);
+            kv[c_].x = (live && j < M) ? krow[(size_t)j * M] : (T)0;
+            kv[c_].y = (live && j + 1 < M) ? krow[(size_t)(j + 1) * M] : (T)0;
+          }
 #pragma unroll
           for (int c_ = 0; c_ < CH; ++c_)
-            kv[c_] = (live && j0 + c_ < M) ? krow[(size_t)(j0 + c_) * M] : (T)0;
-#pragma unroll
-          for (int c_ = 0; c_ < CH; ++c_)
-            if (j0 + c_ < M) body(j0 + c_, kv[c_]);
+            if (j0 + c_ < MP) body(j0 + c_, kv[c_]);
         }
       } else {
 #pragma unroll 2
-        for (int j = 0; j < M; ++j) body(j, (T)0);
+        for (int jp = 0; jp < MP; ++jp) body(jp, V2{0, 0});
       }
+      const T r = r2.x + r2.y;
+      T vn[D];
+#pragma unroll
+      for (int p = 0; p < D; ++p) vn[p] = vn2[p].x + vn2[p].y;
       Fa += r;
       if (JAC) {
 #pragma unroll
@@ -597,7 +616,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
         const T s = sj[j];
         T zb[D];
 #pragma unroll
-        for (int p = 0; p < D; ++p) zb[p] = iLb[p] * sm[o.nu + j * DP + p];
+        for (int p = 0; p < D; ++p) zb[p] = iLb[p] * nu_at(j, p);
 #pragma unroll
         for (int p = 0; p < D; ++p)
 #pragma unroll
@@ -699,7 +718,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
         }
         const T coef = sm[o.be + a * M + i] * (gd + q2);
 #pragma unroll
-        for (int p = 0; p < D; ++p) acc[p] += coef * sm[o.nu + i * DP + p];
+        for (int p = 0; p < D; ++p) acc[p] += coef * nu_at(i, p);
       }
       const T c = sm[o.c + a], mu = sm[o.mu + a];
       T vec[D];
@@ -742,18 +761,24 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
     const int k = lane;
     X Mn[E], Cn[E * (E + 1) / 2];  // upper triangle, row-major: (r, c >= r)
     auto up = [&](int r, int c) { return r * E - r * (r - 1) / 2 + (c - r); };
+#pragma unroll
     for (int a = 0; a < E; ++a)
       Mn[a] = mxv(a, k) + lift<X, T>(sm[o.mu + a], JAC ? sm[o.dO + k * NS + a] : (T)0);
     {
       int item = 0;
+#pragma unroll
       for (int a = 0; a < E; ++a)
+#pragma unroll
         for (int b = a; b < E; ++b, ++item)
           Cn[up(a, b)] = lift<X, T>(sm[o.Sx + a * E + b], JAC ? sm[o.dSx + (k * E + a) * E + b] : (T)0) +
                          lift<X, T>(sm[o.Sig + item], JAC ? sm[o.dO + k * NS + E + item] : (T)0);
     }
+#pragma unroll
     for (int r = 0; r < E; ++r)
+#pragma unroll
       for (int a = 0; a < E; ++a) {  // C[r][a] = sum_q cov[x_r, f_q] W_a[q]
         X s = lift<X, T>((T)0, (T)0);
+#pragma unroll
         for (int q = 0; q < na; ++q)
           s = s + lift<X, T>(sm[o.Cxf + r * D + q], JAC ? sm[o.dCxf + (k * E + r) * D + q] : (T)0) *
                       lift<X, T>(sm[o.W + a * D + q], JAC ? sm[o.dW + (k * E + a) * D + q] : (T)0);
@@ -769,6 +794,7 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
         else A.Fu[((size_t)row * n + idx) * A.m_act + (k - n)] = tang(v);
       }
     };
+#pragma unroll
     for (int a = 0; a < E; ++a) emit(a, Mn[a]);
     if (enc == 1) {
       // upper Cholesky U^T U = Cn + jitter (utils/encoding.py _cholesky_upper:
@@ -777,14 +803,18 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       X U[E * (E + 1) / 2];
       for (int attempt = 0; attempt < 14; ++attempt) {
         bool ok = true;
+#pragma unroll
         for (int r = 0; r < E; ++r) {
           X d = Cn[up(r, r)] + lift<X, T>(jitter, (T)0);
+#pragma unroll
           for (int t_ = 0; t_ < r; ++t_) d = d - U[up(t_, r)] * U[up(t_, r)];
           ok = ok && prim(d) > (T)0;
           const X l = sqrt_(d);
           U[up(r, r)] = l;
+#pragma unroll
           for (int c = r + 1; c < E; ++c) {
             X s = Cn[up(r, c)];
+#pragma unroll
             for (int t_ = 0; t_ < r; ++t_) s = s - U[up(t_, r)] * U[up(t_, c)];
             U[up(r, c)] = s / l;
           }
@@ -792,8 +822,10 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
         if (ok) break;
         jitter *= (T)10;
       }
+#pragma unroll
       for (int e = 0; e < E * (E + 1) / 2; ++e) emit(E + e, U[e]);
     } else if (enc == 2 || enc == 3) {
+#pragma unroll
       for (int a = 0; a < E; ++a) {
         X v = Cn[up(a, a)];
         if (!(prim(v) > (T)1e-12)) v = lift<X, T>((T)1e-12, (T)0);  // clamp_min

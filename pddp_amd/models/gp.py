@@ -247,10 +247,10 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
                 return False
             E, M_, d = state_size, self.Xt.shape[0], d_in
             NP = E * (E + 1) // 2
-            NS, dd, dp = E + NP, d * d, (d + 3) & ~3
+            NS, dd, ps, mp = E + NP, d * d, (2 * d + 3) & ~3, (M_ + 1) // 2
             # (the regions of csrc/gp_step.hip `Lds`, each a multiple of four)
-            regions = [d, dd, E * E, E * d, NS * dd, NS, M_ * dp, E * M_,
-                       E * M_, E, E * d, E * d, E, NP, NP, 8 * M_, 4 * M_]
+            regions = [d, dd, E * E, E * d, NS * dd, NS, mp * ps, E * M_,
+                       E * M_, E, E * d, E * d, E, NP, NP, 16 * mp, 8 * mp]
             if jacobian:
                 n = {1: E + NP, 2: 2 * E, 3: 2 * E, 4: E}[int(encoding)]
                 K = n + action_size

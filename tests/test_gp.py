@@ -336,11 +336,11 @@ def test_gp_derivative_records_by_the_kernel_equal_autograd_records():
     CM = CartpoleDynamicsModel
     g = torch.Generator().manual_seed(7)
     true = CM(0.1).double()
-    X = torch.cat([torch.randn(50, 2, generator=g, dtype=torch.float64),
-                   3.0 + 0.8 * torch.randn(50, 1, generator=g,
+    X = torch.cat([torch.randn(51, 2, generator=g, dtype=torch.float64),
+                   3.0 + 0.8 * torch.randn(51, 1, generator=g,
                                            dtype=torch.float64),
-                   torch.randn(50, 1, generator=g, dtype=torch.float64)], -1)
-    U = 3.0 * torch.randn(50, 1, generator=g, dtype=torch.float64)
+                   torch.randn(51, 1, generator=g, dtype=torch.float64)], -1)
+    U = 3.0 * torch.randn(51, 1, generator=g, dtype=torch.float64)
     with torch.no_grad():
         dX = true(X, U, 0, StateEncoding.IGNORE_UNCERTAINTY) - X
     model = gp_dynamics_model_factory(4, 1, CM.angular_indices,
@@ -377,3 +377,58 @@ def test_gp_derivative_records_by_the_kernel_equal_autograd_records():
     model.use_native = True
     for a, b in zip(*sol):
         assert torch.allclose(a, b, rtol=1e-7, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("encoding", [1, 2, 4])
+def test_gp_line_search_with_batched_costs_equals_the_generic_one(encoding):
+    """The GP line search (N launches of the kernel, stage costs of all
+    candidate points in one batched evaluation from the augmented moments)
+    against the plugin's generic line search (the cost module per time step,
+    with its encode -> decode round trip): candidate states, actions, costs."""
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.examples.cartpole import CartpoleCost, CartpoleDynamicsModel
+    from pddp_amd.utils.encoding import infer_encoded_state_size
+    CM = CartpoleDynamicsModel
+    enc = StateEncoding(encoding)
+    g = torch.Generator().manual_seed(11)
+    X = torch.cat([torch.randn(40, 2, generator=g, dtype=torch.float64),
+                   3.0 + 0.8 * torch.randn(40, 1, generator=g,
+                                           dtype=torch.float64),
+                   torch.randn(40, 1, generator=g, dtype=torch.float64)], -1)
+    U = 3.0 * torch.randn(40, 1, generator=g, dtype=torch.float64)
+    with torch.no_grad():
+        dX = CM(0.1).double()(X, U, 0, StateEncoding.IGNORE_UNCERTAINTY) - X
+    model = gp_dynamics_model_factory(4, 1, CM.angular_indices,
+                                      CM.non_angular_indices)().double().cuda()
+    model.fit(X.cuda(), U.cuda(), dX.cuda())
+    model.eval()
+    B, N, m = 5, 9, 1
+    n = infer_encoded_state_size(4, enc)
+    z0 = torch.stack([GaussianVariable(
+        torch.tensor([0.0, 0.0, 3.0, 0.0], dtype=torch.float64) +
+        0.05 * torch.randn(4, generator=g, dtype=torch.float64),
+        var=1e-2 * torch.ones(4, dtype=torch.float64)).encode(enc)
+        for _ in range(B)]).cuda()
+    U0 = (0.3 * torch.randn(B, N, m, generator=g, dtype=torch.float64)).cuda()
+    got = []
+    for fast in (True, False):
+        plugin = TorchProblem(model, CartpoleCost().double().cuda(), enc, {},
+                              {})
+        s = ILQRSolver(None, B, N, torch.float64, "cuda",
+                       torch.tensor([-10.0], dtype=torch.float64),
+                       torch.tensor([10.0], dtype=torch.float64),
+                       fit_alphas(torch.float64, "cuda"), plugin=plugin, n=n,
+                       m=m)
+        s.set_nominal(z0, U0)
+        s.derivs()
+        s.backward(active=s.active)
+        assert plugin._gp_line_search_ok(s)
+        if not fast:
+            plugin._gp_line_search_ok = lambda s_: False
+        s.line_search(active=s.active)
+        got.append((s.Zc.clone(), s.Uc.clone(), s.Jc.clone()))
+    for a, b in zip(*got):
+        assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
