@@ -538,8 +538,10 @@ int pddp_qr_cost_derivs_f32(const pddp_qr_cost* cost, void* stream);
  * (variance), 3 (standard deviation), 4 (mean only); 0 (full covariance):
  * PDDP_E_UNSUPPORTED.  Built for (state_size, features + actions) = (2, 4),
  * (4, 6), (6, 9) - pendulum, cartpole, double cartpole; n + m <= 64; the
- * training set must fit the workgroup's LDS (M <= ~300 in f32 without the
- * Jacobian, ~120 with; PDDP_E_UNSUPPORTED beyond).  All arrays on the device. */
+ * training set must fit the workgroup's 160 KB of LDS next to the inverses
+ * (double cartpole: M <= 1128 in f32 / 526 in f64 without the Jacobian, 303 /
+ * 70 with; the smaller systems several times that; PDDP_E_UNSUPPORTED beyond).
+ * All arrays on the device. */
 typedef struct pddp_gp_model {
   int state_size;        /* E: one GP per state increment */
   int action_size;       /* m */
