@@ -432,3 +432,37 @@ def test_gp_line_search_with_batched_costs_equals_the_generic_one(encoding):
         got.append((s.Zc.clone(), s.Uc.clone(), s.Jc.clone()))
     for a, b in zip(*got):
         assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_pddp_controller_with_the_gp_plugin_on_gpu():
+    """PDDPController.fit (pddp.py:61-206) with the GP plugin as the learned
+    model, end to end on the GPU: exploration trials, conditioning the GPs on
+    the collected data, iLQR on the learned model (derivative records and line
+    search on pddp_gp_step), an MPC trial, re-conditioning."""
+    from pddp_amd.examples import pendulum
+    torch.manual_seed(0)
+    np.random.seed(0)
+    PM = pendulum.PendulumDynamicsModel
+    env = pendulum.PendulumEnv(dt=0.1)
+    cost = pendulum.PendulumCost().cuda()
+    model = gp_dynamics_model_factory(2, 1, PM.angular_indices,
+                                      PM.non_angular_indices)().cuda()
+    ctrl = pddp_amd.controllers.PDDPController(
+        env, model, cost, model_opts={}, training_opts={"n_iter": 0})
+    N = 5
+    U0 = 0.1 * torch.randn(N, 1, device="cuda")
+    trials = []
+    kw = dict(encoding=StateEncoding.DEFAULT, quiet=True, n_iterations=3,
+              u_min=torch.tensor([-2.5]), u_max=torch.tensor([2.5]),
+              on_trial=lambda t, X, U: trials.append((t, X.shape, U.shape)))
+    ctrl.eval()
+    Z, U, state = ctrl.fit(U0, **kw)
+    assert Z.shape == (N + 1, 5) and U.shape == (N, 1)
+    assert model.fitted and model.Xt.shape[0] == 2 * N
+    plugin = ctrl._solver.plugin
+    assert plugin.last_derivs_path["dynamics"] == "hip"
+    ctrl.train()
+    Z, U, state = ctrl.fit(U0, max_trials=3, **kw)
+    assert trials[-1][1] == (2 * N, 2)             # MPC trial of horizon 2N
+    assert torch.isfinite(U).all() and torch.isfinite(Z).all()
