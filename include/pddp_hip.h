@@ -556,6 +556,11 @@ typedef struct pddp_gp_model {
   const void* sf2;       /* [E] signal variances */
   const void* sn2;       /* [E] noise variances */
 } pddp_gp_model;
+/* Bytes of LDS a workgroup of pddp_gp_step_* needs for `M` training points
+ * (inputs = n + m, element_size 4 or 8); the launch needs <= 160 KB.  -1: the
+ * (state_size, d) pair is not built.  Host function. */
+long long pddp_gp_step_lds_bytes(int state_size, int d, int M, int inputs, int jacobian,
+                                 int element_size);
 int pddp_gp_step_f32(const pddp_gp_model* gp, int R, const float* z, const float* u,
                      float* z_next, float* Fz, float* Fu, void* stream);
 int pddp_gp_step_f64(const pddp_gp_model* gp, int R, const double* z, const double* u,

@@ -88,6 +88,7 @@ _SIGS = {
     "pddp_bnn_jvp_moments_f32": [_P, _P],
     "pddp_qr_cost_derivs_f32": [_P, _P],
     "pddp_gp_step": [_P, c_int, _P, _P, _P, _P, _P, _P],
+    "pddp_gp_step_lds_bytes": [c_int] * 6,
     "pddp_event_create": [_P],
     "pddp_event_record": [_P, _P],
     "pddp_event_elapsed_ms": [_P, _P, _P],
@@ -134,6 +135,7 @@ def lib():
                 fn.argtypes = sig
                 fn.restype = c_int
         l.pddp_hip_arch.restype = ctypes.c_char_p
+        l.pddp_gp_step_lds_bytes.restype = ctypes.c_longlong
         _lib = l
     return _lib
 

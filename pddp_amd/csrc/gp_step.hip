@@ -910,6 +910,15 @@ int pddp_debug_gp_marks(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::gp::g_gp_marks), sizeof(long long) * 64);
 }
 #endif
+long long pddp_gp_step_lds_bytes(int state_size, int d, int M, int inputs, int jacobian,
+                                 int element_size) {
+  using namespace pddp::gp;
+  long long words = -1;
+  if (state_size == 2 && d == 4) words = Lds<2, 4>(M, inputs, jacobian != 0).total;
+  if (state_size == 4 && d == 6) words = Lds<4, 6>(M, inputs, jacobian != 0).total;
+  if (state_size == 6 && d == 9) words = Lds<6, 9>(M, inputs, jacobian != 0).total;
+  return words < 0 ? -1 : words * element_size;
+}
 int pddp_gp_step_f32(const pddp_gp_model* g, int R, const float* z, const float* u, float* z_next,
                      float* Fz, float* Fu, void* stream) {
   return pddp::gp::step<float>(g, R, z, u, z_next, Fz, Fu, stream);

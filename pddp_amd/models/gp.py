@@ -227,7 +227,6 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             return state
 
         # -- the HIP kernel (csrc/gp_step.hip) ------------------------------------
-        _NATIVE_SHAPES = ((2, 4), (4, 6), (6, 9))
         use_native = True
 
         def native_ok(self, z, encoding, jacobian=False):
@@ -241,26 +240,18 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
                 return False
             if int(encoding) not in (1, 2, 3, 4):
                 return False
-            if (state_size, d_in) not in self._NATIVE_SHAPES:
-                return False
             if len(ai) > 4 or len(ni) > 8:
                 return False
-            E, M_, d = state_size, self.Xt.shape[0], d_in
-            NP = E * (E + 1) // 2
-            NS, dd, ps, mp = E + NP, d * d, (2 * d + 3) & ~3, (M_ + 1) // 2
-            # (the regions of csrc/gp_step.hip `Lds`, each a multiple of four)
-            regions = [d, dd, E * E, E * d, NS * dd, NS, mp * ps, E * M_,
-                       E * M_, E, E * d, E * d, E, NP, NP, 16 * mp, 8 * mp]
-            if jacobian:
-                n = {1: E + NP, 2: 2 * E, 3: 2 * E, 4: E}[int(encoding)]
-                K = n + action_size
-                if K > 64:
-                    return False
-                regions += [E * M_ * d, NP * d, NP * dd, K * d, K * dd,
-                            K * E * E, K * E * d, E * d, E * dd, NP * d,
-                            NP * dd, K * E * d, K * NS]
-            words = sum((r + 3) & ~3 for r in regions)
-            return words * z.element_size() <= 160 * 1024
+            E = state_size
+            n = {1: E + E * (E + 1) // 2, 2: 2 * E, 3: 2 * E, 4: E}[
+                int(encoding)]
+            if n + action_size > 64:
+                return False
+            from .. import _native
+            fn = _native.lib().pddp_gp_step_lds_bytes
+            need = fn(E, d_in, int(self.Xt.shape[0]), n + action_size,
+                      int(bool(jacobian)), z.element_size())
+            return 0 <= need <= 160 * 1024
 
         def _native_model(self, dtype, device, encoding):
             """The kernel's view of the conditioned GPs (cached per dtype; the

@@ -466,3 +466,19 @@ def test_pddp_controller_with_the_gp_plugin_on_gpu():
     Z, U, state = ctrl.fit(U0, max_trials=3, **kw)
     assert trials[-1][1] == (2 * N, 2)             # MPC trial of horizon 2N
     assert torch.isfinite(U).all() and torch.isfinite(Z).all()
+
+
+def test_gp_step_lds_bytes_query():
+    """pddp_gp_step_lds_bytes (a host function: no GPU needed): what decides
+    whether a training set fits the kernel - grows with M, more with the
+    Jacobian, -1 for a shape that is not built; the limits DESIGN 3.11 quotes."""
+    from pddp_amd import _native
+    fn = _native.lib().pddp_gp_step_lds_bytes
+    assert fn(5, 9, 60, 28, 0, 4) == -1
+    a, b = fn(6, 9, 60, 28, 0, 4), fn(6, 9, 61, 28, 0, 4)
+    assert 0 < a <= b < fn(6, 9, 61, 28, 1, 4)
+    assert fn(6, 9, 60, 28, 1, 8) == 2 * fn(6, 9, 60, 28, 1, 4)
+    limit = 160 * 1024
+    assert fn(6, 9, 1128, 28, 0, 4) <= limit < fn(6, 9, 1130, 28, 0, 4)
+    assert fn(6, 9, 303, 28, 1, 4) <= limit < fn(6, 9, 305, 28, 1, 4)
+    assert fn(6, 9, 70, 28, 1, 8) <= limit < fn(6, 9, 72, 28, 1, 8)

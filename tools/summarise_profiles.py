@@ -64,6 +64,10 @@ stats_and_traffic("_dcbnn", "double cartpole BNN (configs[3] shard): n=27 m=1 "
                   "N=150 B=1024 fp32, [200,200] x 100 particles",
                   " --workload double_cartpole_bnn --steps 2 --warmup 1")
 
+stats_and_traffic("_dcgp", "double cartpole GP (configs[3] as stated): n=27 m=1 "
+                  "N=150 B=1024 fp32, 60 training points",
+                  " --workload double_cartpole_gp")
+
 stats_and_traffic("_cpbnn", "cartpole BNN (configs[2]): n=14 m=1 N=100 B=4096 "
                   "fp32, [200,200] x 100 particles",
                   " --workload cartpole_bnn --steps 1 --warmup 1")
