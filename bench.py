@@ -250,6 +250,7 @@ def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
 
 
 MFMA_F32_PEAK_TFLOPS = 157.0  # MI355X_MICROARCH.md: dense f32 matrix peak
+_last_gp_solver = None
 
 
 
@@ -618,6 +619,8 @@ def bench_gp(args, emit=True):
     elapsed = time.perf_counter() - t0
     liveK = int(s.active.sum().item())
     attempted = live0 + int(s.n_live.sum().item()) - liveK
+    global _last_gp_solver
+    _last_gp_solver = s  # (tests look at the state the rounds left)
     # the dominant kernel: one moment-matched step of the line search's
     # candidate rows (B A rows per launch, N launches per round), timed with
     # events on the stream it is launched on (torch's current stream)

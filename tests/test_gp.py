@@ -482,3 +482,43 @@ def test_gp_step_lds_bytes_query():
     assert fn(6, 9, 1128, 28, 0, 4) <= limit < fn(6, 9, 1130, 28, 0, 4)
     assert fn(6, 9, 303, 28, 1, 4) <= limit < fn(6, 9, 305, 28, 1, 4)
     assert fn(6, 9, 70, 28, 1, 8) <= limit < fn(6, 9, 72, 28, 1, 8)
+
+
+@pytest.mark.gpu
+def test_gp_full_size_rounds_of_configs3():
+    """BASELINE configs[3] as stated, at its full size (1024 double-cartpole
+    trajectories, N = 150, n = 27, 60 training points): two rounds on the HIP
+    path.  Size-independent properties: every accepted cost is below the
+    nominal's, the nominal rollout reproduces itself (alpha = 1 candidate of
+    zero gains = the nominal), the Jacobians of a sample of rows equal autograd
+    through the torch module."""
+    import bench
+    import argparse
+    args = argparse.Namespace(batch=1024, horizon=150, steps=1, warmup=0,
+                              scaling="weak", no_cpu_baseline=True)
+    out = bench.bench_gp(args, emit=False)
+    assert out["config"]["gp_step_on"] == "hip"
+    assert out["config"]["derivative_path"] == {"dynamics": "hip",
+                                                "cost": "hip"}
+    assert out["config"]["batch_per_gpu"] == 1024
+    assert np.isfinite(out["value"]) and out["value"] > 0
+    s = bench._last_gp_solver
+    assert torch.isfinite(s.Z).all() and torch.isfinite(s.J_opt).all()
+    J0 = s.J_opt.clone()
+    s.round(5e-6, 1e10, 1 << 30)
+    accepted = (s.state == 1) | (s.state == 5)
+    assert bool((s.J_opt[accepted] < J0[accepted]).all())
+    assert bool((s.J_opt[~accepted] == J0[~accepted]).all())
+    # Jacobians of 6 random (trajectory, step) rows against autograd
+    model = s.plugin.model
+    g = torch.Generator().manual_seed(0)
+    b = torch.randint(0, 1024, (6,), generator=g)
+    t = torch.randint(0, 150, (6,), generator=g)
+    z = s.Z[b.cuda(), t.cuda()].contiguous()
+    u = s.U[b.cuda(), t.cuda()].clamp(-20.0, 20.0).contiguous()
+    _, Fz, Fu = model.native_step(z, u, StateEncoding.DEFAULT, jacobian=True)
+    import copy
+    m64 = copy.deepcopy(model).double()
+    _, Fz64, Fu64 = _torch_step(m64, z.double(), u.double(),
+                                StateEncoding.DEFAULT, True)
+    assert _rel(Fz.double(), Fz64) < 2e-3 and _rel(Fu.double(), Fu64) < 2e-3
