@@ -621,6 +621,21 @@ def bench_gp(args, emit=True):
     attempted = live0 + int(s.n_live.sum().item()) - liveK
     global _last_gp_solver
     _last_gp_solver = s  # (tests look at the state the rounds left)
+    # the same rounds replayed as hipGraphs (ILQRSolver.fit(graph=True)):
+    # informational, `value` is the eager loop
+    graph_ms = None
+    if s.graph_ok():
+        try:
+            s.capture_round(5e-6, 1e10, 1 << 30)
+            s.replay_round(True)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(K):
+                s.replay_round(True)
+            torch.cuda.synchronize(dev)
+            graph_ms = (time.perf_counter() - t1) / K * 1e3
+        except Exception as e:  # noqa: BLE001 (reported in the line)
+            graph_ms = repr(e)[:120]
     # the dominant kernel: one moment-matched step of the line search's
     # candidate rows (B A rows per launch, N launches per round), timed with
     # events on the stream it is launched on (torch's current stream)
@@ -679,6 +694,7 @@ def bench_gp(args, emit=True):
                         "still torch ops per time step" % (M, N, B),
             "gp_step_on": "hip" if native else "torch",
             "derivative_rollout_launch_ms": jac_ms,
+            "hipgraph_replay_ms_per_step": graph_ms,
             "batch_per_gpu": B, "horizon": N, "alphas": A,
             "training_points": M, "parity": "unpinned",
             "live_trajectories_start_end": [live0, liveK],

@@ -108,8 +108,11 @@ class TorchProblem(object):
         (native BNN rollout, forward-mode Jacobians, hyper-dual cost
         derivatives): the round can then be captured into hipGraphs
         (ILQRSolver.capture_round)."""
-        return (self._bnn_native_ok(s) and self._bnn_jvp_ok(s)
-                and self._qr_cost_native_ok(s))
+        if self._bnn_native_ok(s) and self._bnn_jvp_ok(s) and \
+                self._qr_cost_native_ok(s):
+            return True
+        # GP plugin: records and line search on pddp_gp_step_*, batched costs
+        return self._gp_line_search_ok(s) and self._qr_cost_native_ok(s)
 
     def derivs(self, s, mask=None, set_state=True, in_graph=False):
         """Fills s.rec, s.L, s.J_opt (and resets s.state) for masked rows.

@@ -522,3 +522,47 @@ def test_gp_full_size_rounds_of_configs3():
     _, Fz64, Fu64 = _torch_step(m64, z.double(), u.double(),
                                 StateEncoding.DEFAULT, True)
     assert _rel(Fz.double(), Fz64) < 2e-3 and _rel(Fu.double(), Fu64) < 2e-3
+
+
+@pytest.mark.gpu
+def test_gp_rounds_replayed_as_hipgraphs_equal_eager_rounds():
+    """`ILQRSolver.fit(graph=True)` with the GP plugin: a round is HIP launches
+    and sync-free torch ops, so it is captured (plugin.capture_ok) - the
+    replayed rounds leave the state the eager rounds leave."""
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.examples.cartpole import CartpoleCost, CartpoleDynamicsModel
+    CM = CartpoleDynamicsModel
+    g = torch.Generator().manual_seed(3)
+    X = torch.cat([torch.randn(40, 2, generator=g),
+                   3.0 + 0.8 * torch.randn(40, 1, generator=g),
+                   torch.randn(40, 1, generator=g)], -1)
+    U = 3.0 * torch.randn(40, 1, generator=g)
+    with torch.no_grad():
+        dX = CM(0.1)(X, U, 0, StateEncoding.IGNORE_UNCERTAINTY) - X
+    model = gp_dynamics_model_factory(4, 1, CM.angular_indices,
+                                      CM.non_angular_indices)().cuda()
+    model.fit(X.cuda(), U.cuda(), dX.cuda())
+    model.eval()
+    enc = StateEncoding.DEFAULT
+    B, N, n, m = 8, 10, 14, 1
+    z0 = torch.stack([GaussianVariable(
+        torch.tensor([0.0, 0.0, 3.0, 0.0]) + 0.05 * torch.randn(4, generator=g),
+        var=1e-2 * torch.ones(4)).encode(enc) for _ in range(B)]).cuda()
+    U0 = (0.3 * torch.randn(B, N, m, generator=g)).cuda()
+    end = []
+    for graph in (False, True):
+        plugin = TorchProblem(model, CartpoleCost().cuda(), enc, {}, {})
+        s = ILQRSolver(None, B, N, torch.float32, "cuda",
+                       torch.tensor([-10.0]), torch.tensor([10.0]),
+                       fit_alphas(torch.float32, "cuda"), plugin=plugin, n=n,
+                       m=m)
+        s.set_nominal(z0, U0)
+        assert s.graph_ok()
+        rounds = s.fit(n_iterations=4, graph=graph, max_rounds=6)
+        end.append((rounds, s.Z.clone(), s.U.clone(), s.J_opt.clone(),
+                    s.state.clone()))
+    assert end[0][0] == end[1][0]
+    for a, b in zip(end[0][1:], end[1][1:]):
+        assert torch.equal(a, b)
