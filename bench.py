@@ -572,7 +572,10 @@ def bench_gp(args, emit=True):
     from pddp_amd.controllers.solver import ILQRSolver
     from pddp_amd.examples import double_cartpole as ex
     from pddp_amd.models.gp import gp_dynamics_model_factory
+    import torch.distributed as dist
+    from pddp_amd.parallel import post_best_rollout
     world, rank, dev = init_ranks()
+    seen = ranks_seen(world, dev)
     CM, cost_cls = ex.DoubleCartpoleDynamicsModel, ex.DoubleCartpoleCost
     B = args.batch or 1024
     N = args.horizon or 150
@@ -611,20 +614,39 @@ def bench_gp(args, emit=True):
         s.round(5e-6, 1e10, 1 << 30)
     s.n_live.zero_()
     live0 = int(s.active.sum().item())
+    # shards of configs[3]'s 8192 trajectories: rank r owns B of them, no
+    # data-path collective; the one exchange is the best rollout, per round
+    lo = rank * B
     torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
+    last_exchange = None
     for _ in range(K):
         s.round(5e-6, 1e10, 1 << 30)
+        if world > 1:
+            last_exchange = post_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
+    if last_exchange is not None:
+        last_exchange.result()
     torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
     liveK = int(s.active.sum().item())
     attempted = live0 + int(s.n_live.sum().item()) - liveK
+    total_attempted = attempted
+    if world > 1:
+        t = torch.tensor([elapsed, attempted], dtype=torch.float64, device=dev)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed, total_attempted = float(tmax[0].item()), int(t[1].item())
     global _last_gp_solver
     _last_gp_solver = s  # (tests look at the state the rounds left)
     # the same rounds replayed as hipGraphs (ILQRSolver.fit(graph=True)):
     # informational, `value` is the eager loop
     graph_ms = None
-    if s.graph_ok():
+    if world == 1 and s.graph_ok():
         try:
             s.capture_round(5e-6, 1e10, 1 << 30)
             s.replay_round(True)
@@ -676,11 +698,11 @@ def bench_gp(args, emit=True):
         jac_ms = ej[0].elapsed_time(ej[1])
         del Fz, Fu
     out = {
-        "metric": "pddp_iterations_per_sec", "value": attempted / elapsed,
+        "metric": "pddp_iterations_per_sec", "value": total_attempted / elapsed,
         "unit": "trajectory-iterations/s", "n_gpus": world, "steps": K,
         "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "rccl_ranks_seen": seen,
         "config": {
             "workload": "BASELINE.json configs[3] as stated: double cartpole "
                         "(state 6, DEFAULT encoding n=27 m=1) with GP dynamics "

@@ -1945,6 +1945,7 @@ def test_bench_two_ranks_over_rccl():
     ("cartpole", ["--batch", "512", "--repeats", "1", "--no-points",
                   "--scaling", "strong"]),
     ("double_cartpole_bnn", ["--batch", "16", "--horizon", "6"]),
+    ("double_cartpole_gp", ["--batch", "16", "--horizon", "6"]),
 ])
 def test_bench_two_ranks_rehearsal_on_one_gpu(workload, extra):
     """The whole multi-rank path of `bench.py --gpus 2` - the launcher, shard
