@@ -1,10 +1,9 @@
 """pddp_gp_step_* (csrc/gp_step.hip) against the torch module it replaces
 (pddp_amd/models/gp.py): the moment-matched step and its Jacobian by autograd,
-per system, encoding and dtype - the largest deviations, and the time per
-row."""
+per system, encoding and dtype - the largest deviations (time per row:
+tools/gp_step_time.py)."""
 import os
 import sys
-import time
 
 import torch
 
@@ -78,18 +77,3 @@ if __name__ == "__main__":
                       "Fu %.2e" % (system, str(dtype)[6:], encoding,
                                    sc(out, ref), sc(out0, ref), sc(Fz, Fz_r),
                                    sc(Fu, Fu_r)), flush=True)
-    # time per row at the bench's shape
-    for dtype in (torch.float32, torch.float64):
-        model = make("double_cartpole", 60, dtype)
-        enc = StateEncoding.DEFAULT
-        for R, jac in ((8192, False), (8192, True)):
-            z, u = rows("double_cartpole", R, enc, dtype)
-            model.native_step(z, u, enc, jacobian=jac)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(3):
-                model.native_step(z, u, enc, jacobian=jac)
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / 3
-            print("double_cartpole M=60 %s R=%d jac=%s: %.3f ms (%.2f us per "
-                  "row)" % (str(dtype)[6:], R, jac, dt * 1e3, dt / R * 1e6))
