@@ -550,7 +550,13 @@ typedef struct pddp_gp_model {
   int n_ang, n_non;
   int ang[4], non[8];    /* angular / non-angular state indices */
   const void* Xt;        /* [M][d] training inputs, d = n_non + 2 n_ang + m */
+  /* the same inputs in pairs of points, for the M^2 loop's scalar loads:
+   * [MQ/2][PS], MQ = M rounded up to a multiple of 4, PS = 2 d rounded up to a
+   * multiple of 4, element 2 p + h of row j = Xt[2 j + h][p]; zero beyond
+   * (points M .. MQ-1 and the row padding); 16-byte aligned */
+  const void* Xt_pairs;
   const void* beta;      /* [E][M]  (K_a + sn2_a I)^-1 y_a */
+  const void* beta_pairs; /* [E][MQ] = beta, rows zero-padded to MQ points */
   const void* Kinv;      /* [E][M][M] (K_a + sn2_a I)^-1, symmetric */
   const void* inv_ell2;  /* [E][d]  1 / lengthscale^2 */
   const void* sf2;       /* [E] signal variances */

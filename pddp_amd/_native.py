@@ -206,8 +206,8 @@ class GpModel(ctypes.Structure):
         [(k, ctypes.c_int32) for k in ("state_size", "action_size", "M",
                                        "encoding", "n_ang", "n_non")] +
         [("ang", ctypes.c_int32 * 4), ("non", ctypes.c_int32 * 8)] +
-        [(k, ctypes.c_void_p) for k in ("Xt", "beta", "Kinv", "inv_ell2",
-                                        "sf2", "sn2")])
+        [(k, ctypes.c_void_p) for k in ("Xt", "Xt_pairs", "beta", "beta_pairs",
+                                        "Kinv", "inv_ell2", "sf2", "sn2")])
 
 
 class QrCost(ctypes.Structure):

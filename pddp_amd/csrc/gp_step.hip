@@ -55,7 +55,9 @@ struct Args {
   int R, M, m_act, n_ang, n_non, encoding, n;
   int ang[kMaxAng], non[kMaxNon];
   const T* Xt;    // [M d]
+  const T* XtP;   // [MQ/2][PS]: (x_2j[p], x_2j+1[p]) pairs, MQ = M rounded up to 4, PS = 2 d rounded up to 4
   const T* beta;  // [E M]
+  const T* betaP; // [E][MQ/2][2]
   const T* Kinv;  // [E M M]
   const T* iL;    // [E d]  1 / lengthscale^2
   const T* sf2;   // [E]
@@ -147,7 +149,7 @@ struct Lds {
     m = take(D); S = take(DD); Sx = take(E * E); Cxf = take(E * D);
     G = take(NS * DD); ld = take(NS); nu = take(((M + 1) >> 1) * PS); lk = take(E * M);
     be = take(E * M); mu = take(E); W = take(E * D); h = take(E * D); c = take(E);
-    F = take(NP); Sig = take(NP); ub = take(4 * 4 * ((M + 1) >> 1)); sj = take(4 * 2 * ((M + 1) >> 1));
+    F = take(NP); Sig = take(NP); ub = take(4 * 2 * (((M + 3) >> 2) << 1)); sj = take(4 * 2 * (((M + 3) >> 2) << 1));
     g = Y1 = Y2 = dm = dS = dSx = dCxf = gmu = GSmu = gmS = GSS = dW = dO = 0;
     if (jac) {
       g = take(E * M * D); Y1 = take(NP * D); Y2 = take(NP * DD);
@@ -479,9 +481,10 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       lam[p] = (T)1 / (iLa[p] + iLb[p]);
     }
     const int MP = (M + 1) >> 1;          // pairs of training points
-    T* ub = sm + o.ub + wave * 4 * MP;  // this wavefront's scratch, per pair: u_b, u_b, beta_b, beta_b
+    const int MQ = ((M + 3) >> 2) << 2;    // points, padded to pairs of pairs
+    T* ub = sm + o.ub + wave * MQ;  // this wavefront's scratch: u_b of the points, in pairs
     const T kx = exp_scale<T>();       // exponents in units of ln 2 for float
-    T* sj = sm + o.sj + wave * 2 * ((M + 1) >> 1);
+    T* sj = sm + o.sj + wave * MQ;
     // T x = lam x - lam G (lam x)
     auto t_apply = [&](const T (&x)[D], T (&y)[D]) {
       T lx[D];
@@ -503,11 +506,10 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       t_apply(zb, tz);
 #pragma unroll
       for (int p = 0; p < D; ++p) s += zb[p] * tz[p];
-      ub[4 * (j >> 1) + (j & 1)] = kx * (sm[o.lk + b * M + j] + (T)0.5 * s);
-      ub[4 * (j >> 1) + 2 + (j & 1)] = A.beta[b * M + j];
+      ub[j] = kx * (sm[o.lk + b * M + j] + (T)0.5 * s);
       sj[j] = 0;
     }
-    if ((M & 1) && lane == 0) ub[4 * (M >> 1) + 1] = (T)-1e30, ub[4 * (M >> 1) + 3] = 0;  // phantom: weighs nothing
+    if (lane < MQ - M) ub[M + lane] = (T)-1e30, sj[M + lane] = 0;  // phantom points: weigh nothing
     // (same-wavefront LDS traffic is in order; the compiler needs telling)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -542,21 +544,42 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
       V2 r2 = {0, 0}, vn2[D], tzb2[D];
 #pragma unroll
       for (int p = 0; p < D; ++p) vn2[p] = V2{0, 0}, tzb2[p] = V2{tzb[p], tzb[p]};
-      const V2 ua2 = {ua, ua}, bai2 = {bai, bai};
+      // The training inputs are the same for every row and lane: they come
+      // through the SCALAR cache (constant address space: s_load_dwordx16 into
+      // SGPR pairs that v_pk_fma_f32 takes as an operand), not through LDS -
+      // six 16-byte LDS reads per step were what the loop waited for.  nu_j =
+      // x_j - m: the m part is this lane's constant, folded into u_a
+      T uam = ua;
+#pragma unroll
+      for (int p = 0; p < D; ++p) uam -= tzb[p] * sm[o.m + p];
+      const V2 ua2 = {uam, uam}, bai2 = {bai, bai};
+      typedef const __attribute__((address_space(4))) V4* CV4;
+      typedef const __attribute__((address_space(4))) V2* CV2;
+      const CV4 xp = (CV4)(uintptr_t)A.XtP;
+      const CV2 bp = (CV2)(uintptr_t)A.betaP + __builtin_amdgcn_readfirstlane(b * (MQ >> 1));
       // two training points j per step, as the two halves of packed operations
-      auto body = [&](int jp, V2 kv) {
-        const V4* nj = reinterpret_cast<const V4*>(sm + o.nu + jp * PS);
-        const V4 uq = *reinterpret_cast<const V4*>(ub + 4 * jp);
-        V2 n2[PS / 2];
+      // a step's operands (scalar registers: the training inputs and weights of
+      // two points; u_b from LDS) are requested for TWO steps before the first
+      // is computed: one scalar-load latency per two steps
+      struct Step {
+        V2 n2[PS / 2], uq, bq;
+      };
+      auto fetch = [&](int jp) {
+        Step st;
+        st.uq = *reinterpret_cast<const V2*>(ub + 2 * jp);
+        st.bq = bp[jp];
 #pragma unroll
         for (int q = 0; q < PS / 4; ++q) {
-          const V4 t4 = nj[q];
-          n2[2 * q] = V2{t4.x, t4.y}, n2[2 * q + 1] = V2{t4.z, t4.w};
+          const V4 t4 = xp[jp * (PS / 4) + q];
+          st.n2[2 * q] = V2{t4.x, t4.y}, st.n2[2 * q + 1] = V2{t4.z, t4.w};
         }
-        V2 e = ua2 + V2{uq.x, uq.y};
+        return st;
+      };
+      auto body = [&](int jp, const Step& st, V2 kv) {
+        V2 e = ua2 + st.uq;
 #pragma unroll
-        for (int p = 0; p < D; ++p) e = tzb2[p] * n2[p] + e;
-        const V2 w = bai2 * V2{uq.z, uq.w} - kv;
+        for (int p = 0; p < D; ++p) e = tzb2[p] * st.n2[p] + e;
+        const V2 w = bai2 * st.bq - kv;
         const V2 ex = {exp2_scaled(e.x), exp2_scaled(e.y)};
         if (!JAC) {
           r2 = w * ex + r2;
@@ -564,35 +587,31 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
           const V2 c = w * ex;
           r2 += c;
 #pragma unroll
-          for (int p = 0; p < D; ++p) vn2[p] = c * n2[p] + vn2[p];
+          for (int p = 0; p < D; ++p) vn2[p] = c * st.n2[p] + vn2[p];
           const T c0 = wave_sum(c.x), c1 = wave_sum(c.y);  // column sums of this tile
           if (lane == 0) sj[2 * jp] += c0, sj[2 * jp + 1] += c1;
         }
       };
-      if (a == b) {
-        // K_a^-1[i][j] comes from HBM / L2: eight requests in flight, then
-        // four steps (a request per step would expose its latency each time)
-        constexpr int CH = 4;
-        for (int j0 = 0; j0 < MP; j0 += CH) {
-          V2 kv[CH];
-#pragma unroll
-          for (int c_ = 0; c_ < CH; ++c_) {
-            const int j = 2 * (j0 + c_);
-            kv[c_].x = (live && j < M) ? krow[(size_t)j * M] : (T)0;
-            kv[c_].y = (live && j + 1 < M) ? krow[(size_t)(j + 1) * M] : (T)0;
-          }
-#pragma unroll
-          for (int c_ = 0; c_ < CH; ++c_)
-            if (j0 + c_ < MP) body(j0 + c_, kv[c_]);
+      // (the pair arrays are padded to an even number of pairs: step MP of an
+      // odd MP reads zeros - weight 0 - and u_b = -1e30)
+      const int MP2 = (MP + 1) & ~1;
+      for (int j0 = 0; j0 < MP2; j0 += 2) {
+        V2 kv0 = {0, 0}, kv1 = {0, 0};
+        if (a == b) {  // K_a^-1[i][j]: from HBM / L2, four requests in flight
+          const int j = 2 * j0;
+          kv0.x = (live && j < M) ? krow[(size_t)j * M] : (T)0;
+          kv0.y = (live && j + 1 < M) ? krow[(size_t)(j + 1) * M] : (T)0;
+          kv1.x = (live && j + 2 < M) ? krow[(size_t)(j + 2) * M] : (T)0;
+          kv1.y = (live && j + 3 < M) ? krow[(size_t)(j + 3) * M] : (T)0;
         }
-      } else {
-#pragma unroll 2
-        for (int jp = 0; jp < MP; ++jp) body(jp, V2{0, 0});
+        const Step s0 = fetch(j0), s1 = fetch(j0 + 1);
+        body(j0, s0, kv0);
+        body(j0 + 1, s1, kv1);
       }
       const T r = r2.x + r2.y;
-      T vn[D];
+      T vn[D];  // sum_j c_ij nu_j = sum_j c_ij x_j - m sum_j c_ij
 #pragma unroll
-      for (int p = 0; p < D; ++p) vn[p] = vn2[p].x + vn2[p].y;
+      for (int p = 0; p < D; ++p) vn[p] = vn2[p].x + vn2[p].y - sm[o.m + p] * r;
       Fa += r;
       if (JAC) {
 #pragma unroll
@@ -856,6 +875,8 @@ int launch(const Args<T>& a, bool jac, hipStream_t st) {
 template <typename T>
 int step(const pddp_gp_model* g, int R, const T* z, const T* u, T* z_next, T* Fz, T* Fu, void* stream) {
   if (g == nullptr || R < 0 || z == nullptr || u == nullptr || z_next == nullptr) return PDDP_E_BADARG;
+  if (!g->Xt || !g->Xt_pairs || !g->beta || !g->beta_pairs || !g->Kinv || !g->inv_ell2 || !g->sf2 || !g->sn2)
+    return PDDP_E_BADARG;
   if ((Fz == nullptr) != (Fu == nullptr)) return PDDP_E_BADARG;
   if (R == 0) return 0;
   if (g->n_ang < 0 || g->n_ang > kMaxAng || g->n_non < 0 || g->n_non > kMaxNon) return PDDP_E_BADARG;
@@ -882,6 +903,8 @@ int step(const pddp_gp_model* g, int R, const T* z, const T* u, T* z_next, T* Fz
   for (int i = 0; i < g->n_non; ++i)
     if (g->non[i] < 0 || g->non[i] >= E) return PDDP_E_BADARG;
   a.Xt = (const T*)g->Xt;
+  a.XtP = (const T*)g->Xt_pairs;
+  a.betaP = (const T*)g->beta_pairs;
   a.beta = (const T*)g->beta;
   a.Kinv = (const T*)g->Kinv;
   a.iL = (const T*)g->inv_ell2;

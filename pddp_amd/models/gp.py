@@ -262,8 +262,21 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             if hit is None:
                 conv = lambda t: t.detach().to(dtype=dtype, device=device) \
                     .contiguous()
+                # pairs of training points for the kernel's scalar loads
+                M_ = int(self.Xt.shape[0])
+                mp, ps = ((M_ + 3) // 4) * 2, (2 * d_in + 3) & ~3
+                xp = torch.zeros(2 * mp, d_in, dtype=torch.float64,
+                                 device=self.Xt.device)
+                xp[:M_] = self.Xt.detach().double()
+                xp = torch.nn.functional.pad(
+                    xp.view(mp, 2, d_in).transpose(1, 2).reshape(mp, 2 * d_in),
+                    (0, ps - 2 * d_in))
+                bp = torch.zeros(state_size, 2 * mp, dtype=torch.float64,
+                                 device=self.Xt.device)
+                bp[:, :M_] = self.beta.detach().double()
                 keep = dict(
                     Xt=conv(self.Xt), beta=conv(self.beta),
+                    Xt_pairs=conv(xp), beta_pairs=conv(bp),
                     Kinv=conv(0.5 * (self.Kinv + self.Kinv.transpose(-1, -2))),
                     inv_ell2=conv((-2.0 * self.log_ell.double()).exp()),
                     sf2=conv((2.0 * self.log_sf.double()).exp()),
