@@ -566,3 +566,20 @@ def test_gp_rounds_replayed_as_hipgraphs_equal_eager_rounds():
     assert end[0][0] == end[1][0]
     for a, b in zip(end[0][1:], end[1][1:]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M", [2, 3, 5, 63, 64, 65, 127])
+def test_gp_step_kernel_training_set_sizes(M):
+    """Edge sizes of the training set: fewer points than a step's four, odd
+    counts (the zero-weight phantom partners), exactly one lane tile, one more,
+    two tiles less one - step and Jacobian against the torch module, fp64."""
+    enc = StateEncoding.DEFAULT
+    model, _ = _system_model("cartpole", M, torch.float64, seed=M)
+    z, u = _system_rows("cartpole", 7, enc, torch.float64, seed=M + 1)
+    assert model.native_ok(z, enc, jacobian=True)
+    ref, Fz_r, Fu_r = _torch_step(model, z, u, enc, True)
+    out, Fz, Fu = model.native_step(z, u, enc, jacobian=True)
+    plain = model.native_step(z, u, enc)
+    assert _rel(out, ref) < 1e-10 and _rel(plain, ref) < 1e-10
+    assert _rel(Fz, Fz_r) < 1e-9 and _rel(Fu, Fu_r) < 1e-9
