@@ -539,8 +539,8 @@ int pddp_qr_cost_derivs_f32(const pddp_qr_cost* cost, void* stream);
  * PDDP_E_UNSUPPORTED.  Built for (state_size, features + actions) = (2, 4),
  * (4, 6), (6, 9) - pendulum, cartpole, double cartpole; n + m <= 64; the
  * training set must fit the workgroup's 160 KB of LDS next to the inverses
- * (double cartpole: M <= 1128 in f32 / 526 in f64 without the Jacobian, 303 /
- * 70 with; the smaller systems several times that; PDDP_E_UNSUPPORTED beyond).
+ * (double cartpole: M <= 1278 in f32 / 596 in f64 without the Jacobian, 318 /
+ * 74 with; the smaller systems several times that; PDDP_E_UNSUPPORTED beyond).
  * All arrays on the device. */
 typedef struct pddp_gp_model {
   int state_size;        /* E: one GP per state increment */

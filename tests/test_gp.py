@@ -479,9 +479,9 @@ def test_gp_step_lds_bytes_query():
     assert 0 < a <= b < fn(6, 9, 61, 28, 1, 4)
     assert fn(6, 9, 60, 28, 1, 8) == 2 * fn(6, 9, 60, 28, 1, 4)
     limit = 160 * 1024
-    assert fn(6, 9, 1128, 28, 0, 4) <= limit < fn(6, 9, 1130, 28, 0, 4)
-    assert fn(6, 9, 303, 28, 1, 4) <= limit < fn(6, 9, 305, 28, 1, 4)
-    assert fn(6, 9, 70, 28, 1, 8) <= limit < fn(6, 9, 72, 28, 1, 8)
+    assert fn(6, 9, 1278, 28, 0, 4) <= limit < fn(6, 9, 1282, 28, 0, 4)
+    assert fn(6, 9, 318, 28, 1, 4) <= limit < fn(6, 9, 322, 28, 1, 4)
+    assert fn(6, 9, 74, 28, 1, 8) <= limit < fn(6, 9, 78, 28, 1, 8)
 
 
 @pytest.mark.gpu
