@@ -257,9 +257,19 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             """The kernel's view of the conditioned GPs (cached per dtype; the
             cache is dropped by `condition`)."""
             from .. import _native
-            key = (dtype, str(device))
+            # (keyed by what the view was made from: a loaded state or a
+            # parameter changed in place makes a new one)
+            src = (self.Xt, self.beta, self.Kinv, self.log_ell, self.log_sf,
+                   self.log_sn)
+            key = (dtype, str(device)) + tuple(
+                (t.data_ptr(), t._version) for t in src)
             hit = self._native_cache.get(key)
             if hit is None:
+                self._native_cache.clear()
+                # (hipGraphs captured around the old view hold its pointers:
+                # ILQRSolver._graphs_fresh drops them on a new generation)
+                from .bnn import bump_generation
+                bump_generation(self)
                 conv = lambda t: t.detach().to(dtype=dtype, device=device) \
                     .contiguous()
                 # pairs of training points for the kernel's scalar loads

@@ -583,3 +583,22 @@ def test_gp_step_kernel_training_set_sizes(M):
     plain = model.native_step(z, u, enc)
     assert _rel(out, ref) < 1e-10 and _rel(plain, ref) < 1e-10
     assert _rel(Fz, Fz_r) < 1e-9 and _rel(Fu, Fu_r) < 1e-9
+
+
+@pytest.mark.gpu
+def test_gp_kernel_view_follows_a_loaded_state():
+    """The kernel's cached view of the model is keyed by the tensors it was
+    made from: after `load_state_dict` (or a parameter changed in place) the
+    kernel answers with the new model, not the cached one."""
+    enc = StateEncoding.DEFAULT
+    a, _ = _system_model("cartpole", 20, torch.float64, seed=1)
+    b, _ = _system_model("cartpole", 20, torch.float64, seed=2)
+    z, u = _system_rows("cartpole", 5, enc, torch.float64)
+    out_a, out_b = a.native_step(z, u, enc), b.native_step(z, u, enc)
+    assert not torch.allclose(out_a, out_b)
+    a.load_state_dict(b.state_dict())
+    assert torch.equal(a.native_step(z, u, enc), out_b)
+    with torch.no_grad():
+        a.log_ell.add_(0.1)
+    ref = _torch_step(a, z, u, enc, False)
+    assert _rel(a.native_step(z, u, enc), ref) < 1e-11
