@@ -247,7 +247,7 @@ PDDP_DEV void spd_inverse(const T* S, const T (&delta)[D], T* G, T& logdet) {
 }
 
 template <typename T, int E, int D, bool JAC>
-__global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
+PDDP_DEV void gp_step_body(const Args<T>& A) {
   using X = typename std::conditional<JAC, Dual<T>, T>::type;
   constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D, PS = Lds<E, D>::PS;
   extern __shared__ __align__(32) unsigned char smem_raw[];
@@ -855,6 +855,33 @@ __global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
   PDDP_GP_MARK(6);
 }
 
+template <typename T, int E, int D, bool JAC>
+__global__ __launch_bounds__(kThreads) void gp_step_kernel(const Args<T> A) {
+  gp_step_body<T, E, D, JAC>(A);
+}
+#ifndef PDDP_GP_FWD_WAVES
+#define PDDP_GP_FWD_WAVES 3
+#endif
+// The line search's kernel (float, no Jacobian) held to the registers of
+// PDDP_GP_FWD_WAVES workgroups per CU: the serial front and back end of a row
+// (A0, A1, A3: most of the workgroup waits) are filled by other rows' M^2 loops
+template <int E, int D>
+__global__ __launch_bounds__(kThreads)
+__attribute__((amdgpu_waves_per_eu(PDDP_GP_FWD_WAVES, PDDP_GP_FWD_WAVES)))
+void gp_step_fwd_f32_kernel(const Args<float> A) {
+  gp_step_body<float, E, D, false>(A);
+}
+template <typename T, int E, int D>
+struct Kernels {
+  static auto pick(bool jac) { return jac ? gp_step_kernel<T, E, D, true> : gp_step_kernel<T, E, D, false>; }
+};
+template <int E, int D>
+struct Kernels<float, E, D> {
+  static auto pick(bool jac) {
+    return jac ? gp_step_kernel<float, E, D, true> : gp_step_fwd_f32_kernel<E, D>;
+  }
+};
+
 template <typename T, int E, int D>
 int launch(const Args<T>& a, bool jac, hipStream_t st) {
   const int K = a.n + a.m_act;
@@ -862,7 +889,7 @@ int launch(const Args<T>& a, bool jac, hipStream_t st) {
   const Lds<E, D> o(a.M, K, jac);
   const size_t bytes = (size_t)o.total * sizeof(T);
   if (bytes > 160 * 1024) return PDDP_E_UNSUPPORTED;
-  auto kern = jac ? gp_step_kernel<T, E, D, true> : gp_step_kernel<T, E, D, false>;
+  auto kern = Kernels<T, E, D>::pick(jac);
   if (bytes > 64 * 1024) {
     const hipError_t e =
         hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);

@@ -353,6 +353,13 @@ def test_hot_kernels_keep_their_working_set_in_registers():
         # four times into 64 KB of LDS (N > 400 for these two problems)
         "line_search_lds_kernel<double, 4, true, 1, 1,",
         "line_search_lds_kernel<float, 2, true, 1, 1,",
+        # the GP line search's kernel, held to 168 registers for three
+        # workgroups per CU (0.81 against 1.02 ms per launch): 9 registers
+        # spilled in the per-row front end
+        "gp_step_fwd_f32_kernel<6, 9>",
+        # (fp64 Jacobian kernel at the 512-register file: ten values parked
+        # in accumulation registers, no scratch)
+        "gp_step_kernel<double, 6, 9, true>",
         # the bf16-split twin of the network kernel (opt-in): 156 registers of
         # W2 parts at the 256-register limit of an eight-wave workgroup; 5 ..
         # 25 registers spill around (not inside) the matrix-instruction loop
