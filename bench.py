@@ -646,7 +646,8 @@ def bench_gp(args, emit=True):
     # the same rounds replayed as hipGraphs (ILQRSolver.fit(graph=True)):
     # informational, `value` is the eager loop
     graph_ms = None
-    if world == 1 and s.graph_ok():
+    if world == 1 and s.graph_ok() and not getattr(args, "no_graph_replay",
+                                                    False):
         try:
             s.capture_round(5e-6, 1e10, 1 << 30)
             s.replay_round(True)
@@ -1050,6 +1051,10 @@ def main():
                     help="multi-GPU: all-gather the best rollout every E "
                          "rounds inside the timed region (SURVEY 8(e): one "
                          "exchange per iteration; 0: once, after the rounds)")
+    ap.add_argument("--no-graph-replay", action="store_true",
+                    help="double_cartpole_gp: skip the informational hipGraph "
+                         "replay (rocprofv3 --pmc and stream capture do not "
+                         "get on)")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short runs of BASELINE configs[2] / [3] / "
                          "[4] appended to the default line")

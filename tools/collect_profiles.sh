@@ -51,11 +51,11 @@ if [ "${2:-}" = "bnn" ]; then
   # configs[3] as stated (GP plugin on pddp_gp_step): the line, then per-kernel time
   python3 bench.py --workload double_cartpole_gp 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_double_cartpole_gp.json
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_dcgp -- \
-      python3 $R/bench.py --workload double_cartpole_gp --no-cpu-baseline > /dev/null 2>&1 )
+      python3 $R/bench.py --workload double_cartpole_gp --no-cpu-baseline --no-graph-replay > /dev/null 2>&1 )
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch_dcgp -- \
-      python3 $R/bench.py --workload double_cartpole_gp --no-cpu-baseline > /dev/null 2>&1 )
+      python3 $R/bench.py --workload double_cartpole_gp --no-cpu-baseline --no-graph-replay > /dev/null 2>&1 )
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_dcgp -- \
-      python3 $R/bench.py --workload double_cartpole_gp --no-cpu-baseline > /dev/null 2>&1 )
+      python3 $R/bench.py --workload double_cartpole_gp --no-cpu-baseline --no-graph-replay > /dev/null 2>&1 )
   tail -c 400 gpurun_out/${TAG}_bench_mpc_bnn.json
   # configs[3]'s shard under the profiler: per-kernel time and HBM traffic of
   # the n = 27 sweep (riccati_mfma32_kernel) and the BNN kernels
