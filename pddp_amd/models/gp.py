@@ -28,10 +28,15 @@ et al. 2003):
 and the next state x' = x + D has mean mu_x + mu, covariance S_x + S_D + C +
 C^T with C = cov[x, x~] (S + L_a)^-1 sum_i beta q nu (the state's covariance
 with its own trigonometric features is exact by Stein's lemma:
-cov[x, sin a_k] = S_x[:, k] E[cos a_k]).  All of it is batched torch on the
-device (einsum / Cholesky through rocBLAS / rocSOLVER) and differentiable, so
-the controllers' plugin path takes its Jacobians by autograd; a hand-written
-HIP kernel for q / Q is the next step.
+cov[x, sin a_k] = S_x[:, k] E[cos a_k]).  The module below is batched torch
+(einsum / solve / det) and differentiable: the definition, and the checker of
+the HIP kernel `pddp_gp_step_f32 / _f64` (csrc/gp_step.hip),
+which computes the same step and its Jacobian with respect to (z, u) in one
+launch for any number of rows.  `forward` goes through the kernel whenever
+nobody can ask autograd for gradients (`native_ok`, `native_step`); the
+controllers' plugin path takes F_z, F_u of a whole nominal from one launch
+(controllers/plugin.py `_dyn_derivs_gp`) and runs the line search on it
+(`_line_search_gp`).
 """
 import math
 
