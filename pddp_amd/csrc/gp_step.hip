@@ -33,6 +33,7 @@
 //       numbers -> column k of the Jacobian
 // Deterministic: fixed-order wave reductions, no atomics.
 #include "pddp_common.hpp"
+#include "models.hpp"  // sincos_: one range reduction for both, ~1 ulp
 
 namespace pddp {
 namespace gp {
@@ -91,8 +92,25 @@ PDDP_DEV double exp_(double x) { return exp(x); }
 PDDP_DEV float log_(float x) { return logf(x); }
 PDDP_DEV double log_(double x) { return log(x); }
 template <typename T> PDDP_DEV Dual<T> exp_(Dual<T> a) { const T e = exp_(a.p); return {e, e * a.t}; }
-template <typename T> PDDP_DEV Dual<T> sin_(Dual<T> a) { return {sin_(a.p), cos_(a.p) * a.t}; }
-template <typename T> PDDP_DEV Dual<T> cos_(Dual<T> a) { return {cos_(a.p), -sin_(a.p) * a.t}; }
+template <typename T> PDDP_DEV Dual<T> sin_(Dual<T> a) {
+  T sv, cv;
+  pddp::sincos_(a.p, sv, cv);
+  return {sv, cv * a.t};
+}
+template <typename T> PDDP_DEV Dual<T> cos_(Dual<T> a) {
+  T sv, cv;
+  pddp::sincos_(a.p, sv, cv);
+  return {cv, -sv * a.t};
+}
+// sine and cosine of one argument together
+PDDP_DEV void sincos2(float x, float& s, float& c) { pddp::sincos_(x, s, c); }
+PDDP_DEV void sincos2(double x, double& s, double& c) { pddp::sincos_(x, s, c); }
+template <typename T> PDDP_DEV void sincos2(Dual<T> a, Dual<T>& s, Dual<T>& c) {
+  T sv, cv;
+  pddp::sincos_(a.p, sv, cv);
+  s = {sv, cv * a.t};
+  c = {cv, -sv * a.t};
+}
 template <typename T> PDDP_DEV Dual<T> sqrt_(Dual<T> a) { const T s = sqrt_(a.p); return {s, a.t / ((T)2 * s)}; }
 template <typename T> PDDP_DEV T prim(T a) { return a; }
 template <typename T> PDDP_DEV T prim(Dual<T> a) { return a.p; }
@@ -267,8 +285,10 @@ PDDP_DEV void gp_step_body(const Args<T>& A) {
   auto ang_mean = [&](int q, int k, X& es, X& ec) {
     const int ai = A.ang[q];
     const X damp = exp_((T)-0.5 * sx(ai, ai, k)), mu_ = mxv(ai, k);
-    es = damp * sin_(mu_);
-    ec = damp * cos_(mu_);
+    X sv, cv;
+    sincos2(mu_, sv, cv);
+    es = damp * sv;
+    ec = damp * cv;
   };
   // feature mean p (p < na), action appended behind
   auto m_of = [&](int p, int k) -> X {
@@ -300,10 +320,13 @@ PDDP_DEV void gp_step_body(const Args<T>& A) {
     const X ep = exp_(lq + ci) - qq, em = exp_(lq - ci) - qq;
     const X mi = mxv(ia, k), mj = mxv(ja, k);
     const bool ps = !((p - nn) & 1), qs = !((q - nn) & 1);  // sin rows
-    if (ps && qs) return (T)0.5 * (ep * cos_(mi - mj) - em * cos_(mi + mj));
-    if (!ps && !qs) return (T)0.5 * (ep * cos_(mi - mj) + em * cos_(mi + mj));
-    if (ps) return (T)0.5 * (ep * sin_(mi - mj) + em * sin_(mi + mj));  // sin_k, cos_l
-    return (T)0.5 * (ep * sin_(mj - mi) + em * sin_(mi + mj));          // cos_k, sin_l
+    X sd, cd, ss_, cs_;  // of the difference and of the sum, one evaluation each
+    sincos2(mi - mj, sd, cd);
+    sincos2(mi + mj, ss_, cs_);
+    if (ps && qs) return (T)0.5 * (ep * cd - em * cs_);
+    if (!ps && !qs) return (T)0.5 * (ep * cd + em * cs_);
+    if (ps) return (T)0.5 * (ep * sd + em * ss_);  // sin_k, cos_l
+    return (T)0.5 * (em * ss_ - ep * sd);          // cos_k, sin_l: sin(m_l - m_k) = -sin(m_k - m_l)
   };
   // cov[x_r, feature q] (Stein's lemma)
   auto cxf = [&](int r, int q, int k) -> X {
