@@ -39,11 +39,12 @@ def _on_device(fn):
 
 
 def fit_alphas(dtype, device):
-    """ilqr.py:282 (the schedule `fit` actually uses).  The reference forms it
-    in its default dtype, float32, and casts (`.to(dtype=Z.dtype)`, :189): a
-    float64 run sees the float32-ROUNDED step sizes."""
-    return (1.025 ** (-torch.arange(10.0, dtype=torch.float32) ** 2)).to(
-        dtype=dtype, device=device)
+    """ilqr.py:282 (the schedule `fit` actually uses):
+    `1.025**(-torch.arange(10.0)**2).to(**tensor_opts)` - the `.to` binds to
+    the parenthesised exponent, so the (integer-valued) exponents are cast and
+    the power is taken in the RUN's dtype: a float64 run sees float64 step
+    sizes.  Formed on the host so that every device sees the same bits."""
+    return (1.025 ** (-torch.arange(10.0) ** 2).to(dtype)).to(device)
 
 
 def mpc_alphas(dtype, device):

@@ -422,7 +422,20 @@ def bnn_dynamics_model_factory(state_size, action_size, hidden_features,
                                 captured = torch.cuda.CUDAGraph()
                                 with torch.cuda.graph(captured):
                                     step(static_idx)
-                            except Exception:  # noqa: BLE001 (any capture error)
+                            except RuntimeError as err:
+                                # capture-specific failures only (an illegal
+                                # operation while the stream is capturing);
+                                # OOM, shape errors and the like are bugs and
+                                # propagate
+                                msg = str(err).lower()
+                                if not ("captur" in msg or
+                                        "streamcapture" in msg):
+                                    raise
+                                import warnings
+                                warnings.warn(
+                                    "BNN fit: the training step cannot be "
+                                    "captured into a hipGraph (%s); training "
+                                    "eagerly" % str(err).splitlines()[0])
                                 captured, use_graph = None, False
                                 torch.cuda.synchronize(X_.device)
                                 step(idx)

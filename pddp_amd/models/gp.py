@@ -151,7 +151,27 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             self.beta = torch.cholesky_solve(Y.t().unsqueeze(-1), L).squeeze(-1)
             self.Xt = Xt.clone()
             self.fitted = True
+            self._drop_native_view()
+
+        def _drop_native_view(self):
+            """The kernel's view (and every hipGraph captured around its raw
+            pointers: ILQRSolver._graphs_fresh looks at the generation BEFORE
+            it replays) dies with the tensors it was made from - eagerly, not
+            at the next eager native_step, which a graph-only controller never
+            makes."""
+            from .bnn import bump_generation
             self._native_cache = {}
+            bump_generation(self)
+
+        def _load_from_state_dict(self, *args, **kwargs):
+            super(GPDynamicsModel, self)._load_from_state_dict(*args, **kwargs)
+            self._drop_native_view()
+
+        def _apply(self, fn, *args, **kwargs):
+            # (.to / .cuda / .double replace parameters and buffers)
+            out = super(GPDynamicsModel, self)._apply(fn, *args, **kwargs)
+            self._drop_native_view()
+            return out
 
         # -- prediction ---------------------------------------------------------
         def moments(self, m, S, max_bytes=1 << 29):

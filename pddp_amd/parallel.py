@@ -27,10 +27,28 @@ def pack_best(J, Z, U, offset=0):
     exact in float32 up to 2^24 trajectories).  J [B], Z [B, N+1, n],
     U [B, N, m].  Device ops only - no host synchronisation."""
     Jc = torch.where(torch.isfinite(J), J, torch.full_like(J, float("inf")))
-    idx = torch.argmin(Jc)
-    head = torch.stack([Jc[idx], (idx + offset).to(J.dtype)])
-    return torch.cat([head, Z[idx].reshape(-1).to(J.dtype),
-                      U[idx].reshape(-1).to(J.dtype)])
+    idx = torch.argmin(Jc).reshape(1)
+    pick = lambda t: torch.index_select(t, 0, idx).reshape(-1).to(J.dtype)
+    return torch.cat([pick(Jc), (idx + offset).to(J.dtype), pick(Z), pick(U)])
+
+
+def _best_row(out):
+    """Row of lowest cost of the gathered records [world, rec] as a NEW tensor
+    (`out[argmin]` with a device index is a host round trip - `.item()` - and a
+    view into a receive buffer that a later post overwrites; index_select is
+    neither)."""
+    best = torch.argmin(out[:, 0]).reshape(1)
+    return torch.index_select(out, 0, best)[0]
+
+
+def _index_fits(dtype, n_total):
+    """The record carries the global index in the run's dtype: exact up to
+    2^24 trajectories in float32 (2^53 in float64)."""
+    limit = {torch.float32: 1 << 24, torch.float64: 1 << 53}.get(dtype)
+    if limit is None or n_total > limit:
+        raise ValueError(
+            "best-rollout record: global trajectory index %d is not exact in "
+            "%s" % (n_total, dtype))
 
 
 class BestRolloutExchange(object):
@@ -48,7 +66,8 @@ class BestRolloutExchange(object):
       events - again no host wait).
     * `result()` makes the caller's stream wait for the latest gather and
       returns (J_best, global index [0-dim tensor], Z_best, U_best),
-      identical on every rank."""
+      identical on every rank - fresh tensors (the receive buffers rotate
+      under later posts), picked without a host round trip."""
 
     def __init__(self, J, Z, U, group=None, depth=4):
         self.group = group
@@ -73,6 +92,7 @@ class BestRolloutExchange(object):
 
     def post(self, J, Z, U, offset=0):
         from . import _native
+        _index_fits(self.dtype, int(offset) + int(J.numel()))
         k = self.k = (self.k + 1) % len(self.send)
         main = torch.cuda.current_stream(self.device)
         if self.used[k] and self.world > 1:
@@ -95,8 +115,7 @@ class BestRolloutExchange(object):
         k = self.k
         if self.world > 1:
             torch.cuda.current_stream(self.device).wait_event(self.done[k])
-        out = self.recv[k]
-        row = out[torch.argmin(out[:, 0])]
+        row = _best_row(self.recv[k])
         Zb = row[2:2 + self.nz].reshape(self.zshape)
         Ub = row[2 + self.nz:].reshape(self.ushape)
         return row[0], row[1].round().to(torch.int64), Zb, Ub
@@ -129,6 +148,7 @@ def gather_best_rollout(J, Z, U, offset=0, group=None, sync=True):
             J.is_contiguous() and Z.dtype == J.dtype and U.dtype == J.dtype:
         Jb, index, Zb, Ub = post_best_rollout(J, Z, U, offset, group).result()
         return Jb, (int(index.item()) if sync else index), Zb, Ub
+    _index_fits(J.dtype, int(offset) + int(J.numel()))
     mine = pack_best(J, Z, U, offset)
     if dist.is_available() and dist.is_initialized():
         world = dist.get_world_size(group)
@@ -138,8 +158,7 @@ def gather_best_rollout(J, Z, U, offset=0, group=None, sync=True):
         out = out.view(world, -1)
     else:
         out = mine.unsqueeze(0)
-    best = torch.argmin(out[:, 0])
-    row = out[best]
+    row = _best_row(out)
     nz = Z[0].numel()
     Zb = row[2:2 + nz].reshape(Z.shape[1:]).to(Z.dtype)
     Ub = row[2 + nz:].reshape(U.shape[1:]).to(U.dtype)

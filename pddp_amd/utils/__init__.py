@@ -1,9 +1,7 @@
-"""Common utilities (reference: pddp/utils/__init__.py).  The reference's
-`trajectory` helpers and the `constrain_env` / `constrain_model` decorators are
-outside the hot path (out of scope) and are
-not provided."""
+"""Common utilities (reference: pddp/utils/__init__.py:17-22 - the same
+sub-modules under the same names)."""
 from . import (angular, autodiff, classproperty, constraint, encoding,
-               evaluation, gaussian_variable, particles)
+               evaluation, gaussian_variable, particles, trajectory)
 
 __all__ = ["angular", "autodiff", "classproperty", "constraint", "encoding",
-           "evaluation", "gaussian_variable", "particles"]
+           "evaluation", "gaussian_variable", "particles", "trajectory"]

@@ -1,7 +1,7 @@
 """Control constraints (reference: pddp/utils/constraint.py:35-48 `constrain`
 - the BNN model factory's optional action squash, modules.py:117-123 -,
-:146-147 `clamp`, :150-266 `boxqp`; the `constrain_env` / `constrain_model`
-class decorators, :51-143, are outside the hot path and not provided).
+:51-143 the `constrain_env` / `constrain_model` class decorators, :146-147
+`clamp`, :150-266 `boxqp`).
 
 The box-constrained QP lives inside the HIP backward sweep (csrc/gains.hpp
 `boxqp`, riccati_n4.hpp `QpClosed` / `BoxQp1`); `boxqp` below exposes the same
@@ -29,6 +29,45 @@ def constrain(u, min_bounds, max_bounds):
     half = (max_bounds - min_bounds) / 2.0
     centre = (max_bounds + min_bounds) / 2.0
     return half * torch.tanh(u) + centre
+
+
+def constrain_env(min_bounds, max_bounds):
+    """Class decorator: the environment's `apply` squashes its action first."""
+    def decorate(cls):
+        inner = cls.apply
+
+        def apply(self, u):
+            return inner(self, constrain(u, min_bounds, max_bounds))
+        cls.apply = apply
+        return cls
+    return decorate
+
+
+def constrain_model(min_bounds, max_bounds):
+    """Class decorator: the model's `forward` squashes its action first; the
+    instances get `min_bounds` / `max_bounds` parameters and a `constrain`
+    method (constraint.py:83-143; its `min_bounds` parameter is set from the
+    upper bound there - here it holds the lower one)."""
+    def decorate(cls):
+        init, fwd = cls.__init__, cls.forward
+
+        def __init__(self, *args, **kwargs):
+            init(self, *args, **kwargs)
+            P = lambda b: torch.nn.Parameter(
+                torch.as_tensor(b, dtype=torch.get_default_dtype()).expand(
+                    cls.action_size).clone(), requires_grad=False)
+            self.max_bounds, self.min_bounds = P(max_bounds), P(min_bounds)
+
+        def forward(self, z, u, i, encoding=None, **kwargs):
+            u = constrain(u, min_bounds, max_bounds)
+            if encoding is None:
+                return fwd(self, z, u, i, **kwargs)
+            return fwd(self, z, u, i, encoding=encoding, **kwargs)
+
+        cls.__init__, cls.forward = __init__, forward
+        cls.constrain = lambda self, u: constrain(u, min_bounds, max_bounds)
+        return cls
+    return decorate
 
 
 def clamp(u, min_bounds, max_bounds):

@@ -602,3 +602,53 @@ def test_gp_kernel_view_follows_a_loaded_state():
         a.log_ell.add_(0.1)
     ref = _torch_step(a, z, u, enc, False)
     assert _rel(a.native_step(z, u, enc), ref) < 1e-11
+
+
+@pytest.mark.gpu
+def test_gp_graphs_follow_a_refit():
+    """A captured round / rollout graph holds raw pointers into the kernel's
+    view of the GP (training points, beta, K^-1); `model.fit()` frees that view.
+    iLQRController(graph=True): fit -> model.fit(new data) -> fit must equal
+    what a fresh controller gets from the refitted model (nothing but the
+    model's generation says the graphs are stale; the GP twin of
+    test_bnn_graphs_follow_model_resample_and_refit)."""
+    from pddp_amd.controllers import iLQRController
+    from pddp_amd.examples.cartpole import CartpoleCost, CartpoleDynamicsModel
+    from pddp_amd.models.bnn import generation
+    CM = CartpoleDynamicsModel
+    enc0, enc = StateEncoding.IGNORE_UNCERTAINTY, StateEncoding.DEFAULT
+
+    def data(seed, M):
+        g = torch.Generator().manual_seed(seed)
+        X = torch.cat([torch.randn(M, 2, generator=g),
+                       3.0 + 0.8 * torch.randn(M, 1, generator=g),
+                       torch.randn(M, 1, generator=g)], -1)
+        U = 3.0 * torch.randn(M, 1, generator=g)
+        with torch.no_grad():
+            dX = CM(0.1)(X, U, 0, enc0) - X
+        return X.cuda(), U.cuda(), dX.cuda()
+    cls = gp_dynamics_model_factory(4, 1, CM.angular_indices,
+                                    CM.non_angular_indices)
+    g = torch.Generator().manual_seed(9)
+    B, N = 6, 8
+    z0 = torch.stack([GaussianVariable(
+        torch.tensor([0.0, 0.0, 3.0, 0.0]) + 0.05 * torch.randn(4, generator=g),
+        var=1e-2 * torch.ones(4)).encode(enc) for _ in range(B)]).cuda()
+    U0 = (0.3 * torch.randn(B, N, 1, generator=g)).cuda()
+    kw = dict(n_iterations=3, z0=z0, u_min=torch.tensor([-10.0]),
+              u_max=torch.tensor([10.0]), quiet=True)
+    model = cls().cuda()
+    model.fit(*data(3, 40))
+    model.eval()
+    ctrl = iLQRController(None, model, CartpoleCost().cuda(), graph=True)
+    Z1, U1, _ = ctrl.fit(U0.clone(), enc, **kw)
+    assert ctrl._solver._graph is not None
+    gen = generation(model)
+    model.fit(*data(4, 40))              # same M: same solver key, same sizes
+    assert generation(model) > gen
+    Z2, U2, _ = ctrl.fit(U0.clone(), enc, **kw)
+    fresh = iLQRController(None, model, CartpoleCost().cuda(), graph=False)
+    Zf, Uf, _ = fresh.fit(U0.clone(), enc, **kw)
+    assert torch.isfinite(Z2).all()
+    assert torch.equal(Z2, Zf) and torch.equal(U2, Uf)
+    assert not torch.equal(Z1, Z2)       # (the model did change)

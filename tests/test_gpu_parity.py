@@ -1293,6 +1293,7 @@ def test_best_rollout_exchange_on_the_device(dtype):
     Z = torch.randn(B, N + 1, n, generator=g, dtype=torch.float64).to(td).cuda()
     U = torch.randn(B, N, m, generator=g, dtype=torch.float64).to(td).cuda()
     ex = BestRolloutExchange(torch.zeros(B, dtype=td).cuda(), Z, U, depth=3)
+    kept = []  # results outlive the rotation of the buffers they came from
     for trial in range(7):
         J = torch.randn(B, generator=g, dtype=torch.float64).to(td)
         J[torch.randint(0, B, (40,), generator=g)] = float("nan")
@@ -1314,10 +1315,30 @@ def test_best_rollout_exchange_on_the_device(dtype):
             assert i == 200
         if trial == 4:
             assert i == 0
+        assert not any(Zb.data_ptr() == r.data_ptr() or Zb._is_view() and
+                       Zb._base is r for r in ex.recv)
+        kept.append((Zb, Ub, Z[i].clone(), U[i].clone()))
+    for Zb, Ub, Zr, Ur in kept:
+        assert torch.equal(Zb, Zr) and torch.equal(Ub, Ur)
     # the function form goes through the same exchange on CUDA tensors
     Jb2, idx2, Zb2, Ub2 = gather_best_rollout(J, Z, U, offset=7000, sync=False)
     assert isinstance(idx2, torch.Tensor) and int(idx2) == int(idx)
     assert torch.equal(Zb2, Zb)
+    # sync-free means capturable: pack + selection inside a hipGraph
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ex.post(J, Z, U, offset=7000).result()  # warm
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = ex.post(J, Z, U, offset=7000).result()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(out[1]) == int(idx) and torch.equal(out[2], Zb)
+    with pytest.raises(ValueError):
+        ex.post(J, Z, U, offset=1 << 53)
 
 
 @pytest.mark.parametrize("B,N", [(37, 33), (16, 100), (5, 10), (130, 47),

@@ -255,6 +255,12 @@ def test_best_rollout_single_process():
     Jb2, idx2, Zb2, Ub2 = gather_best_rollout(J, Z, U, offset=100, sync=False)
     assert isinstance(idx2, torch.Tensor) and int(idx2) == 102
     assert torch.equal(Zb2, Zb) and float(Jb2) == 1.5
+    # a copy, not a view of anything that a later exchange overwrites
+    assert not Zb2._is_view() or Zb2._base is not Z
+    assert Zb2.data_ptr() != Z[2].data_ptr()
+    # the index travels in the run's dtype: refused when it would not be exact
+    with pytest.raises(ValueError):
+        gather_best_rollout(J, Z, U, offset=1 << 24)
 
 
 @pytest.mark.parametrize("problem", ["cartpole", "pendulum"])

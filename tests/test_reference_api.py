@@ -2,8 +2,8 @@
 CPU (torch ops only - no kernel is called here): the cost algebra
 (pddp/costs/base.py:AggregateCost), QRCost's expectation under every state
 encoding (pddp/costs/quadratic.py), the autograd helpers and the single-point
-derivative evaluators (pddp/utils/autodiff.py, evaluation.py), particle
-helpers.  The behaviours are the ones the reference's own suite
+derivative evaluators (pddp/utils/autodiff.py, evaluation.py), particle and
+trajectory helpers.  The behaviours are the ones the reference's own suite
 asserts (tests/costs, tests/utils); the derivative evaluators are additionally
 held to the reference's OUTPUTS through the golden fixtures."""
 import operator
@@ -16,7 +16,7 @@ import torch
 import pddp_amd
 from pddp_amd import GaussianVariable, StateEncoding
 from pddp_amd.costs import QRCost
-from pddp_amd.utils import autodiff, evaluation, particles
+from pddp_amd.utils import autodiff, evaluation, particles, trajectory
 
 from golden_util import DT, load, rel_err
 
@@ -247,7 +247,7 @@ def test_evaluators_vs_reference_golden(problem, enc_key):
 
 
 # ---- particles, trajectories ---------------------------------------------------
-def test_particles_covar():
+def test_particles_covar_and_trajectory_helpers():
     x = torch.randn(50, 4, dtype=torch.float64)
     assert np.allclose(particles.particles_covar(x).numpy(),
                        np.cov(x.numpy().T), atol=1e-12)
@@ -257,13 +257,30 @@ def test_particles_covar():
     for b in range(3):
         assert np.allclose(Cb[b].numpy(), np.cov(xb[:, b].numpy().T),
                            atol=1e-12)
+    X = [GaussianVariable(torch.full((3,), float(i)), var=1e-6 * torch.ones(3))
+         for i in range(5)]
+    Mt = trajectory.mean_trajectory(X)
+    assert Mt.shape == (5, 3) and torch.equal(Mt[:, 0], torch.arange(5.0))
+    St = trajectory.sample_trajectory(X)
+    assert St.shape == (5, 3) and float((St - Mt).abs().max()) < 0.1
+    with pytest.raises(ValueError):
+        trajectory.mean_trajectory([])
+    with pytest.raises(ValueError):
+        trajectory.sample_trajectory([])
+    Xs, Us = torch.randn(6, 3), torch.randn(5, 2)
+    X_, dX = trajectory.trajectory_to_training_data(Xs, Us)
+    assert X_.shape == (5, 5) and dX.shape == (5, 3)
+    assert torch.equal(X_[:, :3], Xs[:-1]) and torch.equal(X_[:, 3:], Us)
+    assert torch.equal(dX, Xs[:-1] - Xs[1:])
 
 
 # ---- constraint helpers ---------------------------------------------------------
-def test_constrain_squashes_into_the_box():
+def test_constrain_and_its_decorators():
     """`constrain` squashes into the box and stays differentiable
-    (constraint.py:35-48)."""
-    from pddp_amd.utils.constraint import constrain
+    (constraint.py:35-48); the class decorators apply it in front of an
+    environment's `apply` / a model's `forward` (:51-143)."""
+    from pddp_amd.utils.constraint import (constrain, constrain_env,
+                                           constrain_model)
     lo, hi = -torch.rand(50), torch.rand(50)
     u = 10 * torch.randn(50, requires_grad=True)
     v = constrain(u, lo, hi)
@@ -272,6 +289,26 @@ def test_constrain_squashes_into_the_box():
     g, = torch.autograd.grad(v.sum(), u)
     assert bool((g >= 0).all()) and float(g.max()) > 0
 
+    class Env(object):
+        def apply(self, u):
+            return u
+
+    assert float(constrain_env(-1.0, 1.0)(Env)().apply(torch.tensor(50.0))) \
+        == pytest.approx(1.0)
+
+    from pddp_amd.examples import pendulum
+
+    @constrain_model(-2.0, 2.0)
+    class Squashed(pendulum.PendulumDynamicsModel):
+        pass
+
+    m_, base = Squashed(0.1), pendulum.PendulumDynamicsModel(0.1)
+    z, u1 = torch.tensor([0.1, -0.2]), torch.tensor([30.0])
+    enc = StateEncoding.IGNORE_UNCERTAINTY
+    assert torch.allclose(m_(z, u1, 0, enc), base(z, torch.tensor([2.0]), 0, enc),
+                          atol=1e-6)
+    assert torch.allclose(m_.constrain(u1), torch.tensor([2.0]), atol=1e-6)
+    assert m_.max_bounds.shape == (1,) and float(m_.min_bounds) == -2.0
 
 
 def test_bnn_module_names_of_the_reference():

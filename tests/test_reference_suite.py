@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.skipif(not os.path.isdir("/root/reference/tests"),
                     reason="needs /root/reference (build container only)")
 def test_reference_host_side_tests_pass_against_pddp_amd():
-    """utils (encoding, angular, gaussian_variable, autodiff,
+    """utils (encoding, angular, gaussian_variable, autodiff, trajectory,
     evaluation), costs (aggregate, quadratic), examples (costs, models, envs)
     and models/bnn of the reference's suite: everything passes except the four
     FULL_COVARIANCE_MATRIX gradchecks of tests/models/test_bnn.py that the

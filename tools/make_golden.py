@@ -67,7 +67,10 @@ ENCODINGS = {
     "fullcov": StateEncoding.FULL_COVARIANCE_MATRIX,
 }
 
-ALPHAS_FIT = lambda: 1.025**(-torch.arange(10.0)**2)  # ilqr.py:282
+# ilqr.py:282 - `.to` binds to the parenthesised EXPONENT (a trailer binds
+# tighter than **): the integer exponents are cast, the power is taken in the
+# run's dtype
+ALPHAS_FIT = lambda dt=torch.float32: 1.025**(-torch.arange(10.0)**2).to(dt)
 ALPHAS_MPC = lambda: 10.0**torch.linspace(0, -3, 11)  # ilqr.py:116
 
 
@@ -162,7 +165,8 @@ def capture_problem(name, enc_name, dtype, Ns, with_fit):
             # Line search from the branch-B (controller default) gains, reg=1.
             k, K = backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu,
                             reg=1.0, u_min=u_min, u_max=u_max, U=U)
-            for aname, alphas in (("fit", ALPHAS_FIT()), ("mpc", ALPHAS_MPC())):
+            for aname, alphas in (("fit", ALPHAS_FIT(dtype)),
+                                  ("mpc", ALPHAS_MPC())):
                 alphas = alphas.to(dtype)
                 Zb, Ub = _control_law(model, Z, U, k, K, alphas, encoding, {},
                                       u_min=u_min, u_max=u_max)
@@ -653,7 +657,7 @@ def capture_round3():
         k, K = backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu, reg=1.0,
                         u_min=um, u_max=uM, U=Ua)
         store[pre + "k"], store[pre + "K"] = np_(k), np_(K)
-        al = ALPHAS_FIT().to(dtype)
+        al = ALPHAS_FIT(dtype)
         Zn, Un = _control_law(amodel, Z, Ua, k, K, al, e, {}, u_min=um,
                               u_max=uM)
         J = _trajectory_cost(agg, Zn, Un, e, {})

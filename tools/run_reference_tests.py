@@ -5,7 +5,7 @@ needs /root/reference; nothing of it is stored in the repo).
 The reference's test files are copied to a temporary directory, `pddp` is
 aliased to `pddp_amd` in sys.modules, and the files that exercise host-side
 code (torch ops on CPU tensors) are run: utils (encoding, angular,
-gaussian_variable, autodiff, evaluation), costs (aggregate,
+gaussian_variable, autodiff, trajectory, evaluation), costs (aggregate,
 quadratic), examples (costs, models, envs), models (bnn).  The controller and
 boxqp tests need CUDA tensors in pddp_amd (no CPU fallback) and are covered by
 tests/test_gpu_parity.py instead.  `benchmark` cases (pytest-benchmark is not
@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/tests"
 FILES = ["utils/test_encoding.py", "utils/test_angular.py",
          "utils/test_gaussian_variable.py", "utils/test_autodiff.py",
-         "utils/test_evaluation.py",
+         "utils/test_trajectory.py", "utils/test_evaluation.py",
          "costs/test_aggregate.py", "costs/test_quadratic.py",
          "examples/test_costs.py", "examples/test_models.py",
          "examples/test_envs.py", "models/test_bnn.py"]
@@ -33,7 +33,7 @@ import pddp_amd
 sys.modules["pddp"] = pddp_amd
 for sub in ("utils", "utils.encoding", "utils.angular", "utils.gaussian_variable",
             "utils.autodiff", "utils.evaluation", "utils.constraint",
-            "utils.particles", "utils.classproperty",
+            "utils.trajectory", "utils.particles", "utils.classproperty",
             "costs", "costs.quadratic", "costs.base", "models", "models.base",
             "models.bnn", "controllers", "envs", "envs.base", "examples",
             "examples.cartpole", "examples.pendulum", "examples.double_cartpole",
