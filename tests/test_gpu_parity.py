@@ -1420,6 +1420,226 @@ def test_round_from_nominal_equals_round_with_records():
         y.abs().max())
 
 
+def _oracle_accept(J_opt, Jc, status, mu, delta, tol, max_reg, it, n_it):
+    """One attempt's bookkeeping as the reference writes it (ilqr.py:122-181
+    accept / converge / reject, :364-390 the mu schedule in Python floats,
+    :298-314 the fit loop's exit) on float32 costs - the test's reading of what
+    the oracle's `fit` does per attempt, so that a SINGLE launch can be
+    checked.  Returns (state, J_opt, mu, delta, live, amin)."""
+    mu_min, delta_0 = 1e-6, 2.0
+    f32 = np.float32
+
+    def increase(mu, delta):              # ilqr.py:376-390
+        delta = max(1.0, delta) * delta_0
+        mu = max(mu_min, mu * delta)
+        return mu, delta, mu >= max_reg
+
+    if status != 0:                       # RuntimeError path, :140-145
+        mu, delta, over = increase(mu, delta)
+        return (4 if over else 3), J_opt, mu, delta, not over, -1
+    amin = int(np.argmin(Jc))
+    J_new, J_opt = f32(Jc[amin]), f32(J_opt)
+    if J_new < J_opt:                     # :166
+        delta = min(1.0, delta) / delta_0  # :369-374
+        mu *= delta
+        if mu <= mu_min:
+            mu = 0.0
+        conv = f32(abs(f32(J_opt - J_new)) / J_opt) < f32(tol)
+        live = (not conv) and it < n_it
+        return (5 if conv else 1), J_new, mu, delta, live, amin
+    mu, delta, over = increase(mu, delta)
+    return (4 if over else 2), J_opt, mu, delta, not over, amin
+
+
+@pytest.mark.parametrize("rounds_before", [0, 9])
+def test_benched_round_kernels_vs_oracle(rounds_before):
+    """The two launches bench.py times at BASELINE.json configs[1] (cartpole,
+    B = 4096, N = 100, f32, bounds +-10, ten step sizes), each against the
+    oracle on a 66-trajectory sample - in the first round of a fit (mu = 0,
+    random nominal: every candidate is rejected) and in its tenth (mu has
+    grown to where steps are accepted; per-trajectory mu, nominals under way):
+
+    pddp_sweep_nominal_f32 (riccati_n4_gen_kernel; ilqr.py:529-674 with the
+    records of :393-486 evaluated in the workgroup): gains and status with the
+    fp32 bars of this file (error against the fp64 oracle within F32_RATIO of
+    the fp32 oracle's own, or the branch's floor), stage costs L and J_opt
+    against `oracle.forward`.
+
+    pddp_search_accept_f32(L = NULL) (ilqr.py:677-791 + :140-181): the ten
+    candidate costs against `oracle.control_law` + `trajectory_cost` FED THE
+    KERNEL'S GAINS (so the line search is judged on its own), the winner's Z /
+    U against the oracle's candidate of the same step size, and state, J_opt,
+    mu, delta, live flag against the accept rule applied to the kernel's own
+    costs.  Large steps from a random nominal leave the cartpole's basin and
+    roll out chaotically (the fp32 and fp64 oracle then disagree with each
+    other, NaN included): a candidate is compared where a 1e-9 relative change
+    of the feed-forward gains moves its fp64 cost by less than 3e-8 -
+    "well-conditioned"."""
+    B, N = 4096, 100
+    s, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=11)
+    s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    tol, max_reg, n_it = 5e-6, 1e10, 50
+    for _ in range(rounds_before):
+        s.round(tol, max_reg, n_it)
+    assert s.sweep_nominal()
+    assert s._nominal_sweep is True
+    o32, o64 = orc.load(np.float32), orc.load(np.float64)
+    names = ("F_z", "F_u", "L_z", "L_u", "L_zz", "L_uz", "L_uu")
+    act = s.active.bool().cpu().numpy()
+    pool = np.where(act)[0]
+    sample = np.random.RandomState(2).choice(pool, 66, replace=False).tolist()
+    k, K = s.gain_views()
+    k, K = k.cpu().numpy(), K.cpu().numpy()
+    st = s.bwd_status.cpu().numpy()
+    Lg, Jg = s.L.cpu().numpy(), s.J_opt.cpu().numpy()
+    before = {n_: getattr(s, n_).cpu().numpy().copy()
+              for n_ in ("J_opt", "mu", "delta", "iter", "Z", "U")}
+    outside, n_ok = [], 0
+    for b in sample:
+        z0b, Ub, reg = before["Z"][b, 0], before["U"][b], float(before["mu"][b])
+        f = o32.forward(op, z0b, Ub, u_min, u_max)
+        assert rel_err(before["Z"][b], f["Z"]) < 5e-6, b
+        assert rel_err(Lg[b], f["L"]) < 5e-6, b
+        assert abs(Jg[b] - f["L"].astype(np.float64).sum()) < 1e-5 * Jg[b], b
+        kw = dict(reg=reg, u_min=u_min, u_max=u_max, U=Ub)
+        kr, Kr, sr = o32.backward(*[f[nm] for nm in names], **kw)
+        assert (sr == 0) == (st[b] == 0), (b, sr, st[b])
+        if sr == 0:
+            n_ok += _check_gains("f32", k[b], K[b], kr, Kr,
+                                 [f[nm] for nm in names], kw, soft=outside,
+                                 test="benched_round", b=b, reg=reg)
+    assert n_ok >= 50
+    assert len(outside) <= 3, outside
+    assert all(r["k_hip"] < 2e-2 and r["K_hip"] < 2e-3 for r in outside), outside
+    # ---- the record-free search + accept launch
+    assert s.search_accept(tol, max_reg, n_it, records=False)
+    Jc = s.Jc.cpu().numpy()
+    after = {n_: getattr(s, n_).cpu().numpy()
+             for n_ in ("J_opt", "mu", "delta", "state", "active", "fresh",
+                        "Z", "U", "gains_acc", "gains")}
+    alphas = s.alphas.cpu().numpy()
+    n_acc = n_well = n_cand = n_winner = 0
+    e_cost, e_base, wild = [], [], []
+    for b in sample:
+        if st[b] != 0:
+            state, J_new, mu, delta, live, amin = _oracle_accept(
+                float(before["J_opt"][b]), None, int(st[b]),
+                float(before["mu"][b]), float(before["delta"][b]), tol,
+                max_reg, int(before["iter"][b]), n_it)
+        else:
+            Zn, Un = o64.control_law(op, before["Z"][b], before["U"][b], k[b],
+                                     K[b], alphas, u_min, u_max)
+            J64 = o64.trajectory_cost(op, Zn, Un)
+            Zn32, Un32 = o32.control_law(op, before["Z"][b], before["U"][b],
+                                         k[b], K[b], alphas.astype(np.float32),
+                                         u_min, u_max)
+            J32 = o32.trajectory_cost(op, Zn32, Un32)
+            # condition of each candidate: what a 1e-9 relative change of the
+            # feed-forward gains does to its cost (large steps from a random
+            # nominal leave the basin and roll out chaotically)
+            Zp, Up = o64.control_law(op, before["Z"][b], before["U"][b],
+                                     k[b].astype(np.float64) * (1 + 1e-9),
+                                     K[b], alphas, u_min, u_max)
+            Jp = o64.trajectory_cost(op, Zp, Up)
+            with np.errstate(invalid="ignore"):
+                cond = np.abs(Jp - J64) / np.abs(J64) / 1e-9
+                e_o32 = np.abs(J32 - J64) / np.abs(J64)
+                e_hip = np.abs(Jc[b] - J64) / np.abs(J64)
+                well = np.isfinite(cond) & (cond < 30.0) & np.isfinite(e_o32)
+            n_cand += len(well)
+            n_well += int(well.sum())
+            # no well-conditioned candidate wild: within 8x of what the IEEE
+            # fp32 restatement loses against fp64 on the same gains, or 1e-4;
+            # the distribution is held to the north star's 1e-5 below
+            if not np.all(e_hip[well] <= np.maximum(8 * e_o32[well], 1e-4)):
+                wild.append((b, cond.tolist(), e_hip.tolist(), e_o32.tolist()))
+            e_cost += e_hip[well].tolist()
+            e_base += e_o32[well].tolist()
+            state, J_new, mu, delta, live, amin = _oracle_accept(
+                float(before["J_opt"][b]), Jc[b], 0, float(before["mu"][b]),
+                float(before["delta"][b]), tol, max_reg,
+                int(before["iter"][b]), n_it)
+        assert after["state"][b] == state, (b, after["state"][b], state)
+        assert after["mu"][b] == mu and after["delta"][b] == delta, b
+        assert bool(after["active"][b]) == live, b
+        assert after["J_opt"][b] == np.float32(J_new), b
+        if state in (1, 5):
+            n_acc += 1
+            assert after["fresh"][b] == int(live)
+            if well[amin]:
+                n_winner += 1
+                assert rel_err(after["Z"][b], Zn[:, amin]) < 2e-5, b
+                assert rel_err(after["U"][b], Un[:, amin]) < 2e-5, b
+            assert np.array_equal(after["gains_acc"][b], after["gains"][b])
+        else:
+            assert np.array_equal(after["Z"][b], before["Z"][b])
+            assert np.array_equal(after["U"][b], before["U"][b])
+    STATS.append(dict(test="benched_round_search", rounds_before=rounds_before,
+                      accepted=n_acc, winners_compared=n_winner,
+                      candidates=n_cand, well_conditioned=n_well,
+                      cost_err_med_p99_max=_dist(e_cost),
+                      o32_cost_err_med_p99_max=_dist(e_base)))
+    assert not wild, wild
+    assert n_well >= n_cand // 4
+    # trajectory cost: the median meets the north star's 1e-5 outright; the
+    # tail is the IEEE fp32 restatement's own (same bars as the gains')
+    dc, db = _dist(e_cost), _dist(e_base)
+    assert dc[0] <= 1e-5 and dc[0] <= 2.0 * db[0] + 1e-7, (dc, db)
+    assert dc[1] <= 2.5 * db[1] + 1e-6, (dc, db)
+    if rounds_before:
+        assert n_winner >= len(sample) // 3
+
+
+def test_fit_through_the_record_free_round_vs_oracle():
+    """The whole fit loop as bench.py runs it (f32, sweep from the nominal +
+    record-free search / accept, every round) against the oracle's `fit`
+    (ilqr.py:237-316) trajectory by trajectory: per attempt the iLQRState, mu,
+    delta and cost.  An fp32 run can part from the fp64 one where an accept
+    test or a BoxQP clamp sits on a rounding knife edge (the IEEE fp32 oracle
+    does so too), so the bar is relative: the kernels' traces agree with the
+    fp64 oracle's at least as long as the fp32 oracle's do, less a margin; and
+    where they agree the costs match to 1e-4."""
+    B, N, n_it = 256, 100, 6
+    s, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=7)
+    s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    traces = _run_traced(s, n_it)
+    assert s._nominal_sweep is True and s._fused is True
+    o32, o64 = orc.load(np.float32), orc.load(np.float64)
+    alphas = s.alphas.cpu().numpy()
+
+    def agree(a, b):
+        """Attempts for which two traces make the same decisions with the same
+        regularisation."""
+        n_ = 0
+        for x, y in zip(a, b):
+            if x[0] != y[0] or x[2] != y[2] or x[3] != y[3]:
+                break
+            n_ += 1
+        return n_
+    hip_len, o32_len, total, e_J = 0, 0, 0, []
+    full = 0
+    for b in range(0, B, 4):
+        t64 = o64.fit(op, z0[b], U[b], alphas, n_iterations=n_it, u_min=u_min,
+                      u_max=u_max)[4]
+        t32 = o32.fit(op, z0[b], U[b], alphas, n_iterations=n_it, u_min=u_min,
+                      u_max=u_max)[4]
+        ref = [tuple(r[1:]) for r in t64]
+        got = [tuple(float(v) for v in r) for r in traces[b]]
+        a_hip = agree(got, ref)
+        hip_len += a_hip
+        o32_len += agree([tuple(r[1:]) for r in t32], ref)
+        total += len(ref)
+        full += int(a_hip == len(ref) == len(got))
+        e_J += [abs(got[i][1] - ref[i][1]) / abs(ref[i][1])
+                for i in range(a_hip)]
+    STATS.append(dict(test="fit_record_free", attempts=total, hip=hip_len,
+                      o32=o32_len, identical_trajectories=full,
+                      J_err_max=max(e_J)))
+    assert hip_len >= 0.9 * o32_len and hip_len >= 0.5 * total, (
+        hip_len, o32_len, total)
+    assert max(e_J) < 1e-4, max(e_J)
+
+
 @pytest.mark.parametrize("H", [64, 128, 200])
 @pytest.mark.parametrize("rows,P,in_dim,out_dim", [(1, 100, 6, 8), (37, 100, 6, 8),
                                                    (5, 7, 4, 4), (64, 33, 15, 16),
@@ -1847,9 +2067,10 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
 
     fp64: 1e-9 on every trajectory, statuses identical.
 
-    fp32 (what bench.py times: variant 25 = riccati_n4_defer_kernel<float,
-    true, ..> with v_rcp; 9, 7, 17 for the other branches): the sweep is a
-    100-step recursion through a discontinuous BoxQP, so the yardstick is the
+    fp32 (what bench.py times: "nominal" = pddp_sweep_nominal_f32, the sweep
+    that evaluates the derivative records itself - riccati_n4_gen_kernel with
+    v_rcp and the sign-bit BoxQP; 25 = the same sweep on records in HBM; 9, 7,
+    17 for the other branches): the sweep is a 100-step recursion through a discontinuous BoxQP, so the yardstick is the
     fp64 oracle and the reference point is what IEEE fp32 arithmetic in the
     reference's operation order (the fp32 oracle) loses against it.  Asserted
     per (variant, branch, reg): status flips and clamp-pattern flips against
@@ -1869,7 +2090,7 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
     f64 = dtype == "f64"
     plan = (  # branch, bounded, variants (f64 | f32)
         (0, True, (6, 8, 16, 18, 20, 24) if f64 else
-         (7, 9, 15, 16, 17, 18, 20, 21, 24, 25)),
+         (7, 9, 15, 16, 17, 18, 20, 21, 24, 25, "nominal")),
         (1, True, (6, 8, 16, 18) if f64 else (7, 8, 9, 15, 16, 17, 18)),
         (0, False, (6, 16) if f64 else (6, 7, 15, 16, 17)),
         (1, False, (6, 16) if f64 else (6, 7, 15, 16, 17)))
@@ -1893,8 +2114,22 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
             regv = torch.full((B,), reg, dtype=torch.float64, device="cuda")
             for variant in variants:
                 s.gains.zero_()
-                s.backward(reg=regv, branch=branch, bounded=bounded,
-                           variant=variant)
+                if variant == "nominal":
+                    # the record-free sweep takes everything from the nominal
+                    # (Z, U) and the controller's own mu / masks
+                    s.mu.fill_(reg)
+                    s.active.fill_(1)
+                    s.fresh.fill_(1)
+                    s.L.zero_()
+                    s.J_opt.fill_(-1.0)
+                    assert s.sweep_nominal()
+                    Lg = s.L.cpu().numpy()
+                    Lr = np.stack([fwd[b]["L"] for b in range(B)])
+                    assert rel_err(Lg, Lr) < 2e-6, rel_err(Lg, Lr)
+                    assert rel_err(s.J_opt.cpu().numpy(), Lr.sum(-1)) < 1e-5
+                else:
+                    s.backward(reg=regv, branch=branch, bounded=bounded,
+                               variant=variant)
                 k, K = s.gain_views()
                 k, K = k.cpu().numpy(), K.cpu().numpy()
                 st = s.bwd_status.cpu().numpy()
