@@ -297,6 +297,13 @@ int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
                            int32_t* status, float* L, float* J_opt,
                            void* stream);
 
+/* Which kernel pddp_sweep_nominal_f32 launches: 0 = auto (the one-wavefront
+ * kernel, csrc/riccati_n4_elem.hpp), 1 = the four-role kernel
+ * (csrc/riccati_n4_defer.hpp; needs N >= 8), 2 = the one-wavefront kernel or
+ * PDDP_E_UNSUPPORTED.  Process-wide (an A/B and test knob); -1 only queries.
+ * Returns the previous choice. */
+int pddp_sweep_nominal_kernel(int which);
+
 /* ---- one launch for the rest of a round: the line search, the accept step
  * and the derivative records of the trajectories whose nominal changed and
  * whose fit goes on.  Same arguments and semantics as the three calls; Z, U, active are

@@ -11,7 +11,10 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libpddp_hip.so")
+# (PDDP_HIP_LIB: another build of the same library - the instrumented ones of
+# tools/, e.g. -DPDDP_ELEM_MARKS)
+LIB_PATH = os.environ.get("PDDP_HIP_LIB") or os.path.join(
+    _HERE, "lib", "libpddp_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_AUG, MAX_ACTION, MAX_PARAMS = 8, 4, 8
@@ -78,6 +81,7 @@ _SIGS = {
                        _P],
     "pddp_sweep_nominal_f32": [_P, c_int, c_int] + [_P] * 5 + [c_int] +
                               [_P] * 7,
+    "pddp_sweep_nominal_kernel": [c_int],
     "pddp_bnn_mlp_precision": [c_int],
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
     "pddp_bnn_moment_step_f32": [_P, _P],

@@ -3,6 +3,7 @@
 // riccati_quad.hip) and matrix-instruction results in ordinary VGPRs
 // (-amdgpu-mfma-vgpr-form: the 4x4x1 products feed vector code directly).
 #include "riccati_n4_defer.hpp"
+#include "riccati_n4_elem.hpp"
 
 namespace pddp {
 
@@ -38,7 +39,19 @@ extern "C" int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
   a.gains = gains;
   a.status = status;
   const pddp::n4d::GenArgs<float> gen = {Z, U, L, J_opt, fresh};
+  // auto: the one-wavefront kernel (riccati_n4_elem.hpp)
+  if (pddp::nominal_kernel_choice() != 1) {
+    const int rc = pddp::launch_n4_elem(*problem, a, gen, (hipStream_t)stream);
+    if (rc != PDDP_E_UNSUPPORTED || pddp::nominal_kernel_choice() == 2)
+      return rc;
+  }
   return pddp::launch_n4_gen(*problem, a, gen, (hipStream_t)stream);
+}
+
+extern "C" int pddp_sweep_nominal_kernel(int which) {
+  const int prev = pddp::nominal_kernel_choice();
+  if (which >= 0 && which <= 2) pddp::nominal_kernel_choice() = which;
+  return prev;
 }
 
 #ifdef PDDP_QP_STATS
@@ -76,6 +89,15 @@ extern "C" int pddp_debug_defer_odd(unsigned long long* out, int reset) {
 extern "C" int pddp_debug_defer_marks(long long* out) {
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_marks), 64);
+  return 0;
+}
+#endif
+#ifdef PDDP_ELEM_MARKS
+extern "C" int pddp_debug_elem_marks(long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4e::g_elem_marks), 64);
+  long long z[8] = {};
+  hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4e::g_elem_marks), z, 64);
   return 0;
 }
 #endif

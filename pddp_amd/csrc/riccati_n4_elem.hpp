@@ -1,0 +1,528 @@
+// riccati_n4_elem.hpp - the n = 4, m = 1 bounded eig-clamp sweep (branch B,
+// ilqr.py:629-672) from the nominal trajectory, ONE wavefront per four
+// trajectories and nothing shared between wavefronts: no roles, no phase
+// barrier, no exchange buffers.
+//
+// Why: at B = 4096 every n = 4 sweep is a chain of N
+// dependent steps on wavefronts that have a SIMD to themselves, and a lone
+// wavefront issues one instruction every ~5 cycles whatever it depends on -
+// the time of a step is the instruction count of its busiest wavefront plus
+// what it waits for.  The four-role kernel (riccati_n4_defer.hpp) cut the
+// chain that crosses a step down to the scalar BoxQP, but pays an LDS
+// exchange and an s_barrier per step: ~745 cycles for ~100 instructions per
+// role.  This kernel goes the other way: the plain recursion in the
+// lane-per-matrix-element mapping of riccati_n4.hpp (16 lanes per
+// trajectory, V one register per lane, every product a v_fmac with a DPP
+// operand), with everything that made that kernel 177 instructions per step
+// removed -
+//   * the records are not streamed from HBM (no DMA ring, no vmcnt
+//     bookkeeping): every 16 steps the wavefront evaluates the next 16
+//     records of its four trajectories itself, one lane per (trajectory,
+//     step) - models.hpp record_of, the code of derivs_kernel - and lays them
+//     out in its own LDS slice in the form its lanes read them: the skewed
+//     copy of F_z as a 4x4 table whose rows are ds_read_b128 operands (2
+//     reads instead of 9), {f, L_z, L_uz} interleaved per index (2 reads
+//     instead of 5);
+//   * the BoxQP is QpLean (riccati_n4_defer.hpp: every predicate in the sign
+//     bit of a VGPR, no compare -> SGPR -> select round trips), QpClosed and
+//     the reference's loop behind it for the lanes it does not cover;
+//   * the value update is the rank-one form V' = sym(Qzz) + c Quz Quz^T,
+//     V_z' = Qz + w Quz (two FMAs) instead of the mirrored K-trees;
+//   * two transposes (ds_bpermute) instead of three, issued before the BoxQP.
+//
+// Restates pddp/controllers/ilqr.py:489-526 (Q), :529-674 (backward, branch
+// B) with the records of :393-486 evaluated in place.  Summation order
+// differs from the reference's dot products (DPP butterflies / rotations):
+// results agree to rounding.
+#pragma once
+
+#include "models.hpp"
+#include "riccati_n4_defer.hpp"
+
+namespace pddp {
+
+namespace n4e {
+
+using n4::bperm;
+using n4::dpp;
+using n4::fma_;
+using n4::group_sum;
+using n4::kGain;
+using n4::mul_nc;
+using n4d::bsel;
+using n4d::f32x4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+using n4d::GenArgs;
+using n4d::sgn;
+using n4d::splat;
+
+constexpr int kWaves = 4;    // wavefronts per workgroup (independent)
+constexpr int kTrajW = 4;    // trajectories per wavefront
+constexpr int kBlk = 16;     // steps per block = lanes of a trajectory's row
+// image of one (trajectory, step) in LDS, floats:
+//   [ 0, 16)  S[r][d] = F_z[(r + d) % 4][r]      (row r: one b128 operand)
+//   [16, 24)  {F_u[x], L_uz[x]}, x = 0..3          (read by row index)
+//   [24, 32)  {F_u[x], L_z[x]},  x = 0..3          (read by column index)
+//   [32, 48)  L_zz row-major
+//   [48, 52)  {L_uu, L_u, u_min - U, u_max - U}  (U: the un-clamped nominal
+//             action; the BoxQP's bounds, constraint.py via ilqr.py:602-603)
+// (every word of every read is used: a dead component of a wide read is a
+// register the allocator hands out again while the read is still in flight -
+// and the next write to it waits for ALL of the step's reads)
+constexpr int kImg = 52;
+// a trajectory's 16 images; + 16 floats: the four rows' reads of one step fall
+// into four different quarters of the 64 banks
+constexpr int kRowStride = kBlk * kImg + 16;
+// + the gains of a block, [step][lane]: written one word per lane and step
+// (no exec mask, no address arithmetic on the chain), stored 16 steps at a time
+constexpr int kStage = kBlk * kWave;
+constexpr int kWaveLds = kTrajW * kRowStride + kStage;  // floats per wavefront
+constexpr size_t kLdsBytes = (size_t)kWaves * kWaveLds * sizeof(float);
+
+// back-tracking step sizes of the reference's BoxQP loop as floats in global
+// memory (the loop runs on ~0.02 % of the steps: no LDS copy, no barrier)
+struct LsTableF {
+  float v[n4::kLsSteps];
+  constexpr LsTableF() : v() {
+    for (int n = 0; n < n4::kLsSteps; ++n) v[n] = (float)n4::kLs.v[n];
+  }
+};
+__device__ constexpr LsTableF kLsF{};
+
+// QpLean (riccati_n4_defer.hpp) without the third iterate: where the
+// reference's loop takes one more full Newton step from a live interior x1
+// (constraint.py:237-259, second pass), x2 = clamp(x1 + (newton - x1)) is the
+// rounded Newton point again - |x2 - x1| <= 2 ulp, both are roundings of the
+// same number - and this form returns x1.  Everything that is a DECISION of
+// the reference (the exit tests of both passes, the stale `free` flag, when
+// its back-tracking would leave the closed form) is evaluated as in QpLean.
+struct QpLean1 {
+  float x, inv;
+  int free_w, slow_w;  // flags in the sign bit
+  PDDP_DEV void solve(float x0, float Q, float c, float lo, float hi) {
+    const float d_lo = lo - x0, d_hi = x0 - hi;  // sign: x0 > lo, x0 < hi
+    const float xs = __builtin_amdgcn_fmed3f(x0, lo, hi);
+    const float hQ = 0.5f * Q;
+    inv = __builtin_amdgcn_rcpf(Q);
+    // ---- iteration 0                                        (:191-239)
+    const float g0 = fma_(Q, xs, c);
+    const int ncl0 = (sgn(d_hi) & ~sgn(d_lo) & ~sgn(g0)) | (~sgn(d_hi) & sgn(g0));
+    const int small0 = sgn(__builtin_fabsf(g0) - 1e-8f);
+    const int done0 = ncl0 | small0;
+    const float s0 = fma_(c, -inv, -xs);  // newton - xs
+    const float xa = xs + s0;
+    const float x1 = __builtin_amdgcn_fmed3f(xa, lo, hi);
+    const float d1_lo = lo - xa, d1_hi = xa - hi;  // x1 == lo <=> xa <= lo
+    const float f0 = xs * fma_(hQ, xs, c);
+    const float num = fma_(x1, fma_(hQ, x1, c), -f0);  // f1 - f0
+    // ---- iteration 1: exit tests
+    const int conv = sgn(fma_(-1e-8f, __builtin_fabsf(f0), -num));
+    const float g1 = fma_(Q, x1, c);
+    const int ncl1 = (sgn(d1_hi) & ~sgn(d1_lo) & ~sgn(g1)) | (~sgn(d1_hi) & sgn(g1));
+    const int small1 = sgn(__builtin_fabsf(g1) - 1e-8f);
+    const int stop1 = conv | ncl1 | small1;
+    x = bsel(splat(done0), xs, x1);
+    // free = (done0 & !ncl0) | (!done0 & (conv | !ncl1)), done0 = ncl0 | small0
+    free_w = ~ncl0 & (small0 | conv | ~ncl1);
+    // ---- does the reference's loop leave these paths?  (QpClosed: pass0,
+    // guard, live1 & on_bound1)
+    const float sdotg = s0 * g0;
+    const int npass = sgn(fma_(0.1f, sdotg, -num));  // !(num <= 0.1 sdotg)
+    const int pass0 = sgn(sdotg) & ~npass;
+    const int onb1 = ~(sgn(d1_lo) & sgn(d1_hi));
+    const float lhs = __builtin_fabsf(x1 - xs) * __builtin_fabsf(sdotg);
+    const float rhs = (3.0f * __builtin_fabsf(num)) * __builtin_fabsf(s0);
+    const int guard = onb1 & sgn(sdotg) & sgn(num) & ~sgn(rhs - lhs);
+    slow_w = ~done0 & (~(pass0 | guard) | (~stop1 & onb1));
+  }
+};
+
+// The products and reductions of one step, hand-scheduled: 27 instructions,
+// every DPP read at least two instructions behind the write of its source (the
+// compiler has to pad a dependent DPP chain with s_nop - nine per step when
+// these were seven separate statements; it also folds a DPP move into v_mul /
+// v_add but not into v_fmac, riccati_n4_quad.hpp).  Lane (i, j) of a row:
+//   Quu  = Luu + sum_ij f[i] V[i][j] f[j]      Qu = Lu + sum_j f[j] V_z[j]
+//   A    = F^T V:  sum_d F[(i+d)%4][i] V[(i+d)%4][j]        (row_ror by 16 - 4d)
+//   Qzz  = Lzz[i][j] + sum_d A[i][(j+d)%4] F[(j+d)%4][j]    (quad rotations)
+//   Qzc  = Lz[j] + sum_d F[(j+d)%4][j] V_z[(j+d)%4]         (column form)
+//   Quzr = Luz[i] + sum_j A[i][j] f[j]                      (row form)
+// The reductions are butterflies of ROUNDED products (separate v_mul), whose
+// results are bit-identical in every lane that holds a copy (a + b == b + a).
+struct StepCore {
+  float Quu, Qu, Qzz, Qzc, Quzr;
+};
+PDDP_DEV StepCore step_core(float V, float vc, float fr, float fc, f32x4 Fs,
+                            f32x4 Fq, float Lzz, float Lzc, float Luzr,
+                            float Luu, float Lu) {
+  StepCore o;
+  float A;
+#define PDDP_RM " row_mask:0xf bank_mask:0xf\n\t"
+  asm("v_mul_f32 %[p1], %[fr], %[V]\n\t"
+      "v_mul_f32 %[p2], %[fc], %[vc]\n\t"
+      "v_mul_f32 %[A], %[V], %[Fs0]\n\t"
+      "v_add_f32_dpp %[p1], %[p1], %[p1] row_ror:8" PDDP_RM
+      "v_add_f32_dpp %[p2], %[p2], %[p2] quad_perm:[2,3,0,1]" PDDP_RM
+      "v_fmac_f32_dpp %[A], %[V], %[Fs1] row_ror:12" PDDP_RM
+      "v_add_f32_dpp %[p1], %[p1], %[p1] row_ror:12" PDDP_RM
+      "v_add_f32_dpp %[p2], %[p2], %[p2] quad_perm:[1,0,3,2]" PDDP_RM
+      "v_fmac_f32_dpp %[A], %[V], %[Fs2] row_ror:8" PDDP_RM
+      "v_mul_f32 %[p1], %[p1], %[fc]\n\t"
+      "v_fmac_f32_dpp %[A], %[V], %[Fs3] row_ror:4" PDDP_RM
+      "v_fma_f32 %[Qzc], %[vc], %[Fq0], %[Lzc]\n\t"
+      "v_add_f32_dpp %[p1], %[p1], %[p1] quad_perm:[2,3,0,1]" PDDP_RM
+      "v_fmac_f32_dpp %[Qzc], %[vc], %[Fq1] quad_perm:[1,2,3,0]" PDDP_RM
+      "v_fma_f32 %[Qzz], %[A], %[Fq0], %[Lzz]\n\t"
+      "v_add_f32_dpp %[p1], %[p1], %[p1] quad_perm:[1,0,3,2]" PDDP_RM
+      "v_fmac_f32_dpp %[Qzz], %[A], %[Fq1] quad_perm:[1,2,3,0]" PDDP_RM
+      "v_fmac_f32_dpp %[Qzc], %[vc], %[Fq2] quad_perm:[2,3,0,1]" PDDP_RM
+      "v_mul_f32 %[q1], %[A], %[fc]\n\t"
+      "v_fmac_f32_dpp %[Qzz], %[A], %[Fq2] quad_perm:[2,3,0,1]" PDDP_RM
+      "v_fmac_f32_dpp %[Qzc], %[vc], %[Fq3] quad_perm:[3,0,1,2]" PDDP_RM
+      "v_add_f32_dpp %[q1], %[q1], %[q1] quad_perm:[2,3,0,1]" PDDP_RM
+      "v_fmac_f32_dpp %[Qzz], %[A], %[Fq3] quad_perm:[3,0,1,2]" PDDP_RM
+      "v_add_f32 %[p1], %[Luu], %[p1]\n\t"
+      "v_add_f32_dpp %[q1], %[q1], %[q1] quad_perm:[1,0,3,2]" PDDP_RM
+      "v_add_f32 %[p2], %[Lu], %[p2]\n\t"
+      "v_add_f32 %[q1], %[Luzr], %[q1]\n\t"
+      : [p1] "=&v"(o.Quu), [p2] "=&v"(o.Qu), [q1] "=&v"(o.Quzr),
+        [Qzz] "=&v"(o.Qzz), [Qzc] "=&v"(o.Qzc), [A] "=&v"(A)
+      : [V] "v"(V), [vc] "v"(vc), [fr] "v"(fr), [fc] "v"(fc),
+        [Fs0] "v"(Fs[0]), [Fs1] "v"(Fs[1]), [Fs2] "v"(Fs[2]), [Fs3] "v"(Fs[3]),
+        [Fq0] "v"(Fq[0]), [Fq1] "v"(Fq[1]), [Fq2] "v"(Fq[2]), [Fq3] "v"(Fq[3]),
+        [Lzz] "v"(Lzz), [Lzc] "v"(Lzc), [Luzr] "v"(Luzr), [Luu] "v"(Luu),
+        [Lu] "v"(Lu));
+#undef PDDP_RM
+  return o;
+}
+
+#ifdef PDDP_ELEM_MARKS
+// time marks of wavefront 0 of workgroup 0: begin, first step, last step done,
+// end (tools/elem_sweep_marks.py)
+// [4] cycles in the generator passes, [5] cycles in the steps
+__device__ long long g_elem_marks[8];
+#define PDDP_EM_MARK(I) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_elem_marks[I] = clock64(); } while (0)
+#define PDDP_EM_ACC(I, T0) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_elem_marks[I] += clock64() - (T0); } while (0)
+#define PDDP_EM_NOW() clock64()
+#else
+#define PDDP_EM_MARK(I)
+#define PDDP_EM_ACC(I, T0)
+#define PDDP_EM_NOW() 0
+#endif
+
+template <unsigned QM>
+__global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
+    RiccatiArgs<float> a, GenArgs<float> gen, ProblemT<float> prob) {
+  using T = float;
+  constexpr int MODEL = PDDP_MODEL_CARTPOLE;
+  constexpr RecLayout lay(4, 1);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  T* img = reinterpret_cast<T*>(smem_raw) + wave * kWaveLds;
+
+  const int row = lane >> 4, l = lane & 15, i = l >> 2, j = l & 3;
+  const int N = a.N;
+  const int b0 = (blockIdx.x * kWaves + wave) * kTrajW;
+  if (b0 >= a.B) return;
+  const int b = b0 + row;
+  const bool exists = b < a.B;
+  const int bc = exists ? b : a.B - 1;
+  const T* Zg = gen.Z + (size_t)bc * (size_t)(N + 1) * 4;
+  const T* Ug = gen.U + (size_t)bc * (size_t)N;
+  // the first operands before anything waits on memory: block 0's states and
+  // actions (lane = step), the terminal state
+  const int nblk = (N + kBlk - 1) / kBlk;
+  T zq[4], uq;
+  auto request = [&](int jb) {
+    int tau = N - 1 - kBlk * jb - l;
+    tau = tau < 0 ? 0 : tau;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(Zg + 4 * tau);
+    zq[0] = v[0]; zq[1] = v[1]; zq[2] = v[2]; zq[3] = v[3];
+    uq = Ug[tau];
+  };
+  request(0);
+  const f32x4 zNv = *reinterpret_cast<const f32x4*>(Zg + 4 * N);
+  const bool counted = exists && (a.active == nullptr || a.active[bc] != 0);
+  if (!__any(counted)) return;
+  PDDP_EM_MARK(0);
+  const bool sums = counted && (gen.fresh == nullptr || gen.fresh[bc] != 0);
+  const T reg = (T)a.reg[bc];
+  const T umin = a.u_min[0], umax = a.u_max[0];
+
+  // ---- LDS offsets of this lane (floats, inside a step's image)
+  const int rbase = row * kRowStride;
+  const int oA = rbase + 4 * i, oB = rbase + 4 * j, oL = rbase + 32 + l;
+  const int oTi = rbase + 16 + 2 * i, oTj = rbase + 24 + 2 * j;
+  const int tr_addr = ((lane & 48) | (j * 4 + i)) * 4;  // lane (j, i)
+
+  // ---- terminal value function: V = L_zz[N] (element (i, j)), V_z = L_z[N]
+  // in column form (element j) - evaluated by every lane of the row (the
+  // wavefront pays the instructions once either way), picked through LDS
+  T V, vc, l_term;
+  {
+    const T zN[4] = {zNv[0], zNv[1], zNv[2], zNv[3]};
+    T lz[4], lzz[16], lu[1], luu[1];
+    l_term = cost_derivs<T, MODEL>(prob, zN, nullptr, trig_of<T, MODEL>(zN),
+                                   true, lz, lzz, lu, luu);
+    T* scr = img + rbase;
+    if (l == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; k += 4)
+        *reinterpret_cast<f32x4*>(scr + k) =
+            f32x4{lzz[k], lzz[k + 1], lzz[k + 2], lzz[k + 3]};
+      *reinterpret_cast<f32x4*>(scr + 16) = f32x4{lz[0], lz[1], lz[2], lz[3]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    V = scr[l];
+    vc = scr[16 + j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (exists && l == 0) gen.L[(size_t)bc * (size_t)(N + 1) + N] = l_term;
+  }
+
+  // ---- the generator pass: lane (row, l) evaluates the record of step
+  // N - 1 - 16 jb - l of trajectory `row` and writes its image
+  T Jacc = T(0);
+  auto pass = [&](int jb) {
+    const T z[4] = {zq[0], zq[1], zq[2], zq[3]};
+    const T u = uq;
+    if (jb + 1 < nblk) request(jb + 1);
+    const int tau = N - 1 - kBlk * jb - l;
+    T w[lay.stride];
+    const T lc = record_of<T, MODEL, QM>(prob, z, &u, false, true, a.u_min,
+                                         a.u_max, w);
+    T* dst = img + rbase + l * kImg;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f32x4*>(dst + 4 * r) =
+          f32x4{w[lay.oFz + ((r + 0) & 3) * 4 + r],
+                w[lay.oFz + ((r + 1) & 3) * 4 + r],
+                w[lay.oFz + ((r + 2) & 3) * 4 + r],
+                w[lay.oFz + ((r + 3) & 3) * 4 + r]};
+#pragma unroll
+    for (int x = 0; x < 4; x += 2) {
+      *reinterpret_cast<f32x4*>(dst + 16 + 2 * x) =
+          f32x4{w[lay.oFu + x], w[lay.oLuz + x], w[lay.oFu + x + 1],
+                w[lay.oLuz + x + 1]};
+      *reinterpret_cast<f32x4*>(dst + 24 + 2 * x) =
+          f32x4{w[lay.oFu + x], w[lay.oLz + x], w[lay.oFu + x + 1],
+                w[lay.oLz + x + 1]};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      *reinterpret_cast<f32x4*>(dst + 32 + 4 * r) =
+          f32x4{w[lay.oLzz + 4 * r], w[lay.oLzz + 4 * r + 1],
+                w[lay.oLzz + 4 * r + 2], w[lay.oLzz + 4 * r + 3]};
+    *reinterpret_cast<f32x4*>(dst + 48) =
+        f32x4{w[lay.oLuu], w[lay.oLu], umin - w[lay.oU], umax - w[lay.oU]};
+    if (tau >= 0) {
+      if (exists) gen.L[(size_t)bc * (size_t)(N + 1) + tau] = lc;
+      Jacc += lc;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  // ---- one step of the sweep
+  struct Words {
+    f32x4 Fs, Fq;
+    f32x2 Ti, Tj;  // {f[i], Luz[i]}, {f[j], Lz[j]}
+    f32x4 Sc;      // Luu, Lu, lo, hi
+    T Lzz;
+  };
+  auto gather = [&](const int s) {
+    const T* p = img + s * kImg;
+    Words w;
+    w.Fs = *reinterpret_cast<const f32x4*>(p + oA);       // F_z[(i+d)%4][i]
+    w.Fq = *reinterpret_cast<const f32x4*>(p + oB);       // F_z[(j+d)%4][j]
+    w.Ti = *reinterpret_cast<const f32x2*>(p + oTi);
+    w.Tj = *reinterpret_cast<const f32x2*>(p + oTj);
+    w.Lzz = p[oL];
+    w.Sc = *reinterpret_cast<const f32x4*>(p + 48 + rbase);
+    return w;
+  };
+  T kprev = T(0);
+  int status = PDDP_BWD_OK;
+  // counted and status still OK (changes in the odd path only), as a lane mask
+  unsigned long long alive_m = __ballot(counted);
+  const unsigned long long lane_bit = 1ull << lane;
+  // gains of a block in LDS: lane (row, l < 4) holds K[l], the others k
+  T* stage = img + kTrajW * kRowStride + lane;
+
+  auto step = [&](const Words& w, const int s) {
+    const StepCore q = step_core(V, vc, w.Ti[0], w.Tj[0], w.Fs, w.Fq, w.Lzz,
+                                 w.Tj[1], w.Ti[1], w.Sc[0], w.Sc[1]);
+    const T Quu = q.Quu, Qu = q.Qu;
+    // transposes (lane (i, j) <- lane (j, i)) issued HERE: their latency under
+    // the BoxQP (left to itself the scheduler sinks them to their use)
+    const T QzzT = bperm(tr_addr, q.Qzz);
+    const T Quzc = bperm(tr_addr, q.Quzr);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- gains: e = Quu < 0 ? 1e-12 : Quu (ilqr.py:633), + reg (:634)
+    const T qp_Q = bsel(splat(sgn(Quu)), 1e-12f, Quu) + reg;
+    const T lo_b = w.Sc[2], hi_b = w.Sc[3];
+    QpLean1 ql;
+    ql.solve(kprev, qp_Q, Qu, lo_b, hi_b);
+    T kt = ql.x;
+    T sK = __int_as_float(splat(ql.free_w) & __float_as_int(ql.inv));
+    T c, wv;
+    n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, wv);
+    // anything the lean form does not cover - a non-finite Quu (0 Quu is NaN
+    // then), a Q that is not positive and finite, `slow` (all ones: a NaN) -
+    // in ONE class test: QpClosed, the reference's loop behind it, for those
+    // rows only
+    const T chk = __int_as_float(__float_as_int(fma_(Quu, T(0), qp_Q)) |
+                                 splat(ql.slow_w));
+    const unsigned long long oddm =
+        ~__builtin_amdgcn_ballot_w64(__builtin_amdgcn_classf(chk, 0x180)) &
+        alive_m;
+    if (__builtin_expect(oddm != 0, 0)) {
+      const bool take = (oddm & lane_bit) != 0;
+      int st = PDDP_BWD_OK;
+      if (!is_finite(Quu)) st = PDDP_BWD_NAN;      // eig raises (ilqr.py:631)
+      n4::QpClosed<T, true> qc;
+      qc.solve(kprev, qp_Q, Qu, lo_b, hi_b);
+      T kx = qc.x;
+      bool Kzero = !qc.free_, fail = qc.fail;
+      const bool slow = qc.slow & take;
+      if (__any(slow)) {
+        // rare: the reference's loop, one slow trajectory at a time on the
+        // whole wavefront
+        unsigned long long todo = __ballot(slow && l == 0);
+        while (todo != 0) {
+          const int src = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const n4::SlowQpOut<T> o = n4q::boxqp1_wave<T, true>(
+              __shfl(kprev, src), __shfl(qp_Q, src), __shfl(Qu, src),
+              __shfl(lo_b, src), __shfl(hi_b, src), kLsF.v, lane);
+          const bool mine = (lane >> 4) == (src >> 4);
+          kx = mine ? o.x : kx;
+          Kzero = mine ? ((o.result_free & 1) == 0) : Kzero;
+          fail = mine ? (o.result_free < 2) : fail;
+        }
+      }
+      const T sx = Kzero ? T(0) : qc.inv;
+      const int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
+      T cx, wx;
+      n4q::rank_one_coeffs(kx, sx, Quu, Qu, cx, wx);
+      kt = take ? kx : kt; sK = take ? sx : sK;
+      c = take ? cx : c; wv = take ? wx : wv;
+      const bool bad = take & (stt != PDDP_BWD_OK);
+      status = bad ? stt : status;
+      alive_m &= ~__ballot(bad);
+    }
+    // ---- gains out: K = -s Quz (column form in lanes (0, j)), k elsewhere
+    stage[s * kWave] = (l < 4) ? -(sK * Quzc) : kt;
+    kprev = kt;
+    // ---- value update (ilqr.py:664-672 with K = -s Quz):
+    // V' = sym(Qzz) + c Quz Quz^T,  V_z' = Qz + w Quz
+    // (every term symmetric in (i, j) bit for bit: a + b == b + a)
+    V = fma_(T(0.5), n4::opaque(q.Qzz + QzzT),
+             mul_nc(c, mul_nc(q.Quzr, Quzc)));
+    vc = fma_(wv, Quzc, q.Qzc);
+  };
+  // the gains of the block's first `cnt` steps (t_top, t_top - 1, ...) to
+  // HBM: lane (row, l) stores step l's five words
+  auto flush_gains = [&](int t_top, int cnt) {
+    const T* sg = img + kTrajW * kRowStride + l * kWave + row * 16;
+    const f32x4 Kv = *reinterpret_cast<const f32x4*>(sg);
+    const T kv = sg[4];
+    if (exists && l < cnt) {
+      T* g = a.gains + ((size_t)bc * (size_t)N + (size_t)(t_top - l)) * kGain;
+      g[0] = kv; g[1] = Kv[0]; g[2] = Kv[1]; g[3] = Kv[2]; g[4] = Kv[3];
+    }
+  };
+
+  PDDP_EM_MARK(1);
+  int t = N - 1;
+  for (int jb = 0; jb < nblk; ++jb) {
+    [[maybe_unused]] const long long tp0 = PDDP_EM_NOW();
+    pass(jb);
+    PDDP_EM_ACC(4, tp0);
+    [[maybe_unused]] const long long ts0 = PDDP_EM_NOW();
+    // two word sets alternate: one in use, one being read for the next step
+    Words wa = gather(0), wb = wa;
+    if (t >= kBlk - 1) {
+#pragma unroll
+      for (int s = 0; s < kBlk; s += 2) {
+        wb = gather(s + 1);
+        step(wa, s);
+        if (s + 2 < kBlk) wa = gather(s + 2);
+        step(wb, s + 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      flush_gains(t, kBlk);
+      t -= kBlk;
+    } else {
+      // the last, partial block
+      const int cnt = t + 1;
+#pragma unroll 1
+      for (int s = 0; s < cnt; ++s) {
+        const T* p = img + s * kImg;
+        Words w;
+        w.Fs = *reinterpret_cast<const f32x4*>(p + oA);
+        w.Fq = *reinterpret_cast<const f32x4*>(p + oB);
+        w.Ti = *reinterpret_cast<const f32x2*>(p + oTi);
+        w.Tj = *reinterpret_cast<const f32x2*>(p + oTj);
+        w.Lzz = p[oL];
+        w.Sc = *reinterpret_cast<const f32x4*>(p + 48 + rbase);
+        step(w, s);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      flush_gains(t, cnt);
+      t = -1;
+    }
+    // (the next pass overwrites the images: every read above has returned -
+    // its value was consumed)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    PDDP_EM_ACC(5, ts0);
+  }
+  PDDP_EM_MARK(2);
+  if (counted && l == 0) a.status[bc] = status;
+  // J_opt = sum of the stage costs and the terminal one (ilqr.py:289)
+  const T Jrow = group_sum(Jacc) + l_term;
+  if (sums && l == 0) {
+    gen.J_opt[bc] = Jrow;
+    if (gen.fresh != nullptr) gen.fresh[bc] = 0;
+  }
+  PDDP_EM_MARK(3);
+}
+
+}  // namespace n4e
+
+// 0 auto, 1 the four-role kernel (riccati_n4_defer.hpp, NP = 1), 2 this one
+inline int& nominal_kernel_choice() {
+  static int choice = 0;
+  return choice;
+}
+
+static int launch_n4_elem(const pddp_problem& p, const RiccatiArgs<float>& a,
+                          const n4d::GenArgs<float>& gen, hipStream_t st) {
+  if (p.model != PDDP_MODEL_CARTPOLE ||
+      p.encoding != PDDP_ENC_IGNORE_UNCERTAINTY || a.u_min == nullptr ||
+      a.u_max == nullptr || a.branch != PDDP_BRANCH_EIG || a.N < 1)
+    return PDDP_E_UNSUPPORTED;
+  const ProblemT<float> P = convert_problem<float>(p);
+  const size_t lds = n4e::kLdsBytes;
+  const dim3 grid((a.B + n4e::kWaves * n4e::kTrajW - 1) /
+                  (n4e::kWaves * n4e::kTrajW)),
+      block(n4e::kWaves * kWave);
+  constexpr unsigned kSparse = 0b11001u;  // CartpoleCost: {x, sin, cos}
+  const bool sparse =
+      (live_mask(p.Q, ModelDims<PDDP_MODEL_CARTPOLE>::na) & ~kSparse) == 0;
+#define PDDP_ELEM_GO(QMV)                                                     \
+  do {                                                                        \
+    auto kern = n4e::riccati_n4_elem_kernel<QMV>;                             \
+    const hipError_t e = hipFuncSetAttribute(                                 \
+        (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+        (int)lds);                                                            \
+    if (e != hipSuccess) return (int)e;                                       \
+    PDDP_LAUNCH(kern, grid, block, lds, st, a, gen, P);                       \
+  } while (0)
+  if (sparse) PDDP_ELEM_GO(kSparse);
+  else PDDP_ELEM_GO(kFullMask<PDDP_MODEL_CARTPOLE>);
+#undef PDDP_ELEM_GO
+  return launch_status();
+}
+
+}  // namespace pddp
