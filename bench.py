@@ -330,7 +330,7 @@ def profile_traffic(kernel_substr, workload_tag=None):
     cannot be read from inside this process: the summaries are of profiled
     runs of the same bench command (tools/collect_profiles.sh)."""
     import glob
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         pat = os.path.join(ROOT, "profiles", "%s_%spmc_traffic.json" % (
             rnd, (workload_tag + "_") if workload_tag else "*"))
         for path in sorted(glob.glob(pat)):
@@ -1183,8 +1183,8 @@ def main():
     # this process): taken from the committed summary of the profiled run of
     # this very command, see profiles/.
     traffic, traffic_search = None, None
-    for tname in ("r03_pmc_traffic.json", "r02_pmc_traffic.json",
-                  "r01_pmc_traffic.json"):
+    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json",
+                  "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if not (os.path.exists(tpath) and B == 4096 and N == 100
                 and args.dtype == "f32"):
@@ -1241,16 +1241,33 @@ def main():
                 "trajectory_timesteps_per_s": total_attempted * N / elapsed,
                 "live_trajectories_start_end": med["live"],
                 "backward_kernel_variant": args.kernel_variant,
+                # the timed kernels' f32 arithmetic: reciprocal by v_rcp_f32
+                # (1 ulp) where the reference divides, the BoxQP in its lean
+                # closed form (sign-bit predicates; QpClosed and the
+                # reference's loop behind it), own sincos; the IEEE-division
+                # twins are kernel variants 6 / 8 / 16 / 20 / 24
+                "arithmetic": "f32, v_rcp, lean BoxQP (fall-back: closed form "
+                              "+ the reference's loop), branch-free sincos",
             },
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("backward Riccati sweep from the nominal "
-                           "(riccati_n4_gen_kernel: the derivative records "
-                           "are evaluated inside the workgroups, in LDS - "
+                           "(riccati_n4_elem_kernel: one wavefront per four "
+                           "trajectories, the derivative records evaluated "
+                           "by its partner wavefront into LDS - "
                            "`algorithmic_bytes_per_launch` is SURVEY 8(d)'s "
                            "figure for the sweep that reads them, `traffic` "
                            "what this launch moves)") if from_nominal
                           else "backward Riccati sweep",
+                # what bounds this launch: N dependent steps on wavefronts
+                # that have a SIMD to themselves - the step's instruction
+                # count at the lone-wavefront issue rate
+                "latency_model": {
+                    "steps": N, "instructions_per_step": 104,
+                    "cycles_per_instruction_lone_wavefront": 5.0,
+                    "what": "time = N x instructions x issue interval; HBM "
+                            "and the matrix cores are idle",
+                } if from_nominal else None,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "avg_launch_us": float(d_sweep.mean()) * 1e6,

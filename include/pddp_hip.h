@@ -284,7 +284,9 @@ int pddp_pack_best_f64(int B, int nz, int nu, const double* J, const double* Z,
  * pddp_riccati_backward_* reads at B = 4096, N = 100 stay on the chip.
  * Results as pddp_derivs_* followed by pddp_riccati_backward_* (auto kernel):
  * gains [B][N][5], status [B]; L [B][N+1] the stage / terminal costs of the
- * nominal; for trajectories with fresh[b] != 0 (all, when fresh is NULL)
+ * nominal (rows of ACTIVE trajectories; the four-role kernel also refreshes
+ * inactive rows that share a workgroup with an active one - same values);
+ * for trajectories with fresh[b] != 0 (all, when fresh is NULL)
  * J_opt[b] = sum_t L[b][t] in t order (ilqr.py:289 L.sum()) and fresh[b] is
  * cleared.  Z [B][N+1][4], U [B][N] un-clamped nominal actions.  Cartpole
  * under IGNORE_UNCERTAINTY, f32, bounded (u_min, u_max non-NULL), branch
@@ -300,7 +302,9 @@ int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
 /* Which kernel pddp_sweep_nominal_f32 launches: 0 = auto (the one-wavefront
  * kernel, csrc/riccati_n4_elem.hpp), 1 = the four-role kernel
  * (csrc/riccati_n4_defer.hpp; needs N >= 8), 2 = the one-wavefront kernel or
- * PDDP_E_UNSUPPORTED.  Process-wide (an A/B and test knob); -1 only queries.
+ * PDDP_E_UNSUPPORTED, 3 / 4 = 2 with its record generator inline / on
+ * wavefronts of its own whatever the batch (auto: by batch).  Process-wide (an
+ * A/B and test knob); -1 only queries.
  * Returns the previous choice. */
 int pddp_sweep_nominal_kernel(int which);
 

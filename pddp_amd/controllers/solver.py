@@ -132,17 +132,15 @@ class ILQRSolver(object):
     def _nominal_sweep_possible(self):
         """pddp_sweep_nominal_f32's domain (include/pddp_hip.h).  At every
         batch: from 12288 trajectories on the quad sweep on records is the
-        faster SWEEP (363 against 422 us at B = 65536), but the round without
-        records is still shorter (1.05 against 1.11 ms; 0.186 against 0.220
-        at 12288)."""
+        faster SWEEP, but the round without records is still shorter (no 79 MB
+        of records written by the line search and read back)."""
         # include/pddp_problem.h: PDDP_MODEL_CARTPOLE = 1,
         # PDDP_ENC_IGNORE_UNCERTAINTY = 4
         return (self.plugin is None and self.problem is not None and
                 self.dtype == torch.float32 and self.n == 4 and self.m == 1 and
                 self.problem.model == 1 and self.problem.encoding == 4 and
                 self.u_min is not None and self.u_max is not None and
-                self.branch == BRANCH_EIG and self.kernel_variant == 0 and
-                self.N >= 8)
+                self.branch == BRANCH_EIG and self.kernel_variant == 0)
 
     @property
     def rec(self):

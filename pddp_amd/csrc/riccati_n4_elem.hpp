@@ -77,8 +77,12 @@ constexpr int kRowStride = kBlk * kImg + 16;
 // + the gains of a block, [step][lane]: written one word per lane and step
 // (no exec mask, no address arithmetic on the chain), stored 16 steps at a time
 constexpr int kStage = kBlk * kWave;
-constexpr int kWaveLds = kTrajW * kRowStride + kStage;  // floats per wavefront
-constexpr size_t kLdsBytes = (size_t)kWaves * kWaveLds * sizeof(float);
+constexpr int kImgBuf = kTrajW * kRowStride;  // a block's images, four rows
+constexpr int kTermRow = 24;  // terminal L_zz (16), L_z (4), cost, pad per row
+constexpr int kTermSh = kTrajW * kTermRow;
+// floats per wavefront (inline generator) / per (sweep, generator) pair
+constexpr int kPairLdsInl = kImgBuf + kStage + kTermSh;
+constexpr int kPairLdsOvl = 2 * kImgBuf + kStage + kTermSh;
 
 // back-tracking step sizes of the reference's BoxQP loop as floats in global
 // memory (the loop runs on ~0.02 % of the steps: no LDS copy, no barrier)
@@ -211,30 +215,56 @@ __device__ long long g_elem_marks[8];
 #define PDDP_EM_NOW() 0
 #endif
 
-template <unsigned QM>
-__global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
-    RiccatiArgs<float> a, GenArgs<float> gen, ProblemT<float> prob) {
+// OVL = false: four independent wavefronts per workgroup, each evaluates its
+// own records between its blocks of steps (LDS: 17.6 KB per wavefront - up to
+// two workgroups per CU).
+// OVL = true: eight wavefronts - four (sweep, generator) pairs, the two of a
+// pair on one SIMD.  The generator evaluates block jb + 1 into the second
+// image buffer while the sweep runs the steps of block jb; one s_barrier per
+// block (the generator sleeps there most of the time: a wavefront that has
+// its SIMD to itself uses a fifth of its issue slots, the partner's 250
+// instructions per block fit into the rest).  LDS: 31 KB per pair - one
+// workgroup per CU, for batches of up to 16 trajectories per CU.
+template <unsigned QM, bool OVL>
+__global__ __launch_bounds__((OVL ? 2 : 1) * kWaves * kWave) void
+riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
+                       ProblemT<float> prob) {
   using T = float;
   constexpr int MODEL = PDDP_MODEL_CARTPOLE;
   constexpr RecLayout lay(4, 1);
+  constexpr int kPairLds = OVL ? kPairLdsOvl : kPairLdsInl;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  T* img = reinterpret_cast<T*>(smem_raw) + wave * kWaveLds;
+  const int pair = OVL ? (wave & (kWaves - 1)) : wave;
+  const bool is_gen = OVL && wave >= kWaves;
+  T* const img0 = reinterpret_cast<T*>(smem_raw) + pair * kPairLds;
+  T* const stage_w = img0 + (OVL ? 2 : 1) * kImgBuf;
+  T* const term_w = stage_w + kStage;
 
   const int row = lane >> 4, l = lane & 15, i = l >> 2, j = l & 3;
   const int N = a.N;
-  const int b0 = (blockIdx.x * kWaves + wave) * kTrajW;
-  if (b0 >= a.B) return;
+  const int b0 = (blockIdx.x * kWaves + pair) * kTrajW;
   const int b = b0 + row;
   const bool exists = b < a.B;
   const int bc = exists ? b : a.B - 1;
   const T* Zg = gen.Z + (size_t)bc * (size_t)(N + 1) * 4;
   const T* Ug = gen.U + (size_t)bc * (size_t)N;
-  // the first operands before anything waits on memory: block 0's states and
-  // actions (lane = step), the terminal state
   const int nblk = (N + kBlk - 1) / kBlk;
-  T zq[4], uq;
+  // (both wavefronts of a pair decide alike: they own the same trajectories;
+  // s_barrier does not wait for wavefronts that have ended)
+  if (b0 >= a.B) return;
+  const bool counted = exists && (a.active == nullptr || a.active[bc] != 0);
+  if (!__any(counted)) return;
+  PDDP_EM_MARK(0);
+  const T umin = a.u_min[0], umax = a.u_max[0];
+  const int rbase = row * kRowStride;
+
+  // =============================================================== generator
+  // lane (row, l) evaluates the record of step N - 1 - 16 jb - l of
+  // trajectory `row` (models.hpp record_of: the code of derivs_kernel) and
+  // writes its image; the operands of a block are requested one block ahead
+  T zq[4], uq, Jacc = T(0), l_term = T(0);
   auto request = [&](int jb) {
     int tau = N - 1 - kBlk * jb - l;
     tau = tau < 0 ? 0 : tau;
@@ -242,49 +272,27 @@ __global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
     zq[0] = v[0]; zq[1] = v[1]; zq[2] = v[2]; zq[3] = v[3];
     uq = Ug[tau];
   };
-  request(0);
-  const f32x4 zNv = *reinterpret_cast<const f32x4*>(Zg + 4 * N);
-  const bool counted = exists && (a.active == nullptr || a.active[bc] != 0);
-  if (!__any(counted)) return;
-  PDDP_EM_MARK(0);
-  const bool sums = counted && (gen.fresh == nullptr || gen.fresh[bc] != 0);
-  const T reg = (T)a.reg[bc];
-  const T umin = a.u_min[0], umax = a.u_max[0];
-
-  // ---- LDS offsets of this lane (floats, inside a step's image)
-  const int rbase = row * kRowStride;
-  const int oA = rbase + 4 * i, oB = rbase + 4 * j, oL = rbase + 32 + l;
-  const int oTi = rbase + 16 + 2 * i, oTj = rbase + 24 + 2 * j;
-  const int tr_addr = ((lane & 48) | (j * 4 + i)) * 4;  // lane (j, i)
-
-  // ---- terminal value function: V = L_zz[N] (element (i, j)), V_z = L_z[N]
-  // in column form (element j) - evaluated by every lane of the row (the
-  // wavefront pays the instructions once either way), picked through LDS
-  T V, vc, l_term;
-  {
+  // terminal value function V = L_zz[N], V_z = L_z[N]: evaluated by every lane
+  // of the row (the wavefront pays the instructions once either way), handed
+  // over through LDS
+  auto terminal = [&]() {
+    const f32x4 zNv = *reinterpret_cast<const f32x4*>(Zg + 4 * N);
     const T zN[4] = {zNv[0], zNv[1], zNv[2], zNv[3]};
     T lz[4], lzz[16], lu[1], luu[1];
     l_term = cost_derivs<T, MODEL>(prob, zN, nullptr, trig_of<T, MODEL>(zN),
                                    true, lz, lzz, lu, luu);
-    T* scr = img + rbase;
+    T* scr = term_w + row * kTermRow;
     if (l == 0) {
 #pragma unroll
       for (int k = 0; k < 16; k += 4)
         *reinterpret_cast<f32x4*>(scr + k) =
             f32x4{lzz[k], lzz[k + 1], lzz[k + 2], lzz[k + 3]};
       *reinterpret_cast<f32x4*>(scr + 16) = f32x4{lz[0], lz[1], lz[2], lz[3]};
+      scr[20] = l_term;
+      if (counted) gen.L[(size_t)bc * (size_t)(N + 1) + N] = l_term;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    V = scr[l];
-    vc = scr[16 + j];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (exists && l == 0) gen.L[(size_t)bc * (size_t)(N + 1) + N] = l_term;
-  }
-
-  // ---- the generator pass: lane (row, l) evaluates the record of step
-  // N - 1 - 16 jb - l of trajectory `row` and writes its image
-  T Jacc = T(0);
-  auto pass = [&](int jb) {
+  };
+  auto pass = [&](int jb, T* buf) {
     const T z[4] = {zq[0], zq[1], zq[2], zq[3]};
     const T u = uq;
     if (jb + 1 < nblk) request(jb + 1);
@@ -292,7 +300,7 @@ __global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
     T w[lay.stride];
     const T lc = record_of<T, MODEL, QM>(prob, z, &u, false, true, a.u_min,
                                          a.u_max, w);
-    T* dst = img + rbase + l * kImg;
+    T* dst = buf + rbase + l * kImg;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       *reinterpret_cast<f32x4*>(dst + 4 * r) =
@@ -317,21 +325,63 @@ __global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
     *reinterpret_cast<f32x4*>(dst + 48) =
         f32x4{w[lay.oLuu], w[lay.oLu], umin - w[lay.oU], umax - w[lay.oU]};
     if (tau >= 0) {
-      if (exists) gen.L[(size_t)bc * (size_t)(N + 1) + tau] = lc;
+      if (counted) gen.L[(size_t)bc * (size_t)(N + 1) + tau] = lc;
       Jacc += lc;
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
+  // J_opt = sum of the stage costs and the terminal one (ilqr.py:289), for
+  // the trajectories whose nominal changed
+  auto finish_costs = [&]() {
+    const bool sums = counted && (gen.fresh == nullptr || gen.fresh[bc] != 0);
+    const T Jrow = group_sum(Jacc) + term_w[row * kTermRow + 20];
+    if (sums && l == 0) {
+      gen.J_opt[bc] = Jrow;
+      if (gen.fresh != nullptr) gen.fresh[bc] = 0;
+    }
+  };
+  if constexpr (OVL) {
+    if (is_gen) {
+      // (the terminal state is the sweep wavefront's, which has nothing else
+      // to do before its first block)
+      request(0);
+      pass(0, img0);
+      n4::lds_publish_barrier();  // barrier 0: block 0, the terminal state
+      for (int jb = 1; jb < nblk; ++jb) {
+        pass(jb, img0 + (jb & 1) * kImgBuf);
+        n4::lds_publish_barrier();  // barrier jb (LDS only: no vmcnt)
+      }
+      finish_costs();
+      return;
+    }
+  }
 
-  // ---- one step of the sweep
+  // =================================================================== sweep
+  const T reg = (T)a.reg[bc];
+  // LDS offsets of this lane (floats, inside a step's image)
+  const int oA = rbase + 4 * i, oB = rbase + 4 * j, oL = rbase + 32 + l;
+  const int oTi = rbase + 16 + 2 * i, oTj = rbase + 24 + 2 * j;
+  const int tr_addr = ((lane & 48) | (j * 4 + i)) * 4;  // lane (j, i)
+  if constexpr (OVL) {
+    // the sweep wins every issue slot both wavefronts of the SIMD ask for
+    __builtin_amdgcn_s_setprio(3);
+    terminal();
+    n4::lds_publish_barrier();  // barrier 0
+  } else {
+    request(0);
+    terminal();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  T V = term_w[row * kTermRow + l];
+  T vc = term_w[row * kTermRow + 16 + j];
+
   struct Words {
     f32x4 Fs, Fq;
     f32x2 Ti, Tj;  // {f[i], Luz[i]}, {f[j], Lz[j]}
     f32x4 Sc;      // Luu, Lu, lo, hi
     T Lzz;
   };
-  auto gather = [&](const int s) {
-    const T* p = img + s * kImg;
+  auto gather = [&](const T* ib, const int s) {
+    const T* p = ib + s * kImg;
     Words w;
     w.Fs = *reinterpret_cast<const f32x4*>(p + oA);       // F_z[(i+d)%4][i]
     w.Fq = *reinterpret_cast<const f32x4*>(p + oB);       // F_z[(j+d)%4][j]
@@ -347,7 +397,7 @@ __global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
   unsigned long long alive_m = __ballot(counted);
   const unsigned long long lane_bit = 1ull << lane;
   // gains of a block in LDS: lane (row, l < 4) holds K[l], the others k
-  T* stage = img + kTrajW * kRowStride + lane;
+  T* stage = stage_w + lane;
 
   auto step = [&](const Words& w, const int s) {
     const StepCore q = step_core(V, vc, w.Ti[0], w.Tj[0], w.Fs, w.Fq, w.Lzz,
@@ -373,9 +423,9 @@ __global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
     // rows only
     const T chk = __int_as_float(__float_as_int(fma_(Quu, T(0), qp_Q)) |
                                  splat(ql.slow_w));
-    const unsigned long long oddm =
-        ~__builtin_amdgcn_ballot_w64(__builtin_amdgcn_classf(chk, 0x180)) &
-        alive_m;
+    unsigned long long regular;  // (the mask straight into a scalar pair)
+    asm("v_cmp_class_f32 %0, %1, %2" : "=s"(regular) : "v"(chk), "v"(0x180));
+    const unsigned long long oddm = ~regular & alive_m;
     if (__builtin_expect(oddm != 0, 0)) {
       const bool take = (oddm & lane_bit) != 0;
       int st = PDDP_BWD_OK;
@@ -424,7 +474,7 @@ __global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
   // the gains of the block's first `cnt` steps (t_top, t_top - 1, ...) to
   // HBM: lane (row, l) stores step l's five words
   auto flush_gains = [&](int t_top, int cnt) {
-    const T* sg = img + kTrajW * kRowStride + l * kWave + row * 16;
+    const T* sg = stage_w + l * kWave + row * 16;
     const f32x4 Kv = *reinterpret_cast<const f32x4*>(sg);
     const T kv = sg[4];
     if (exists && l < cnt) {
@@ -436,18 +486,24 @@ __global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
   PDDP_EM_MARK(1);
   int t = N - 1;
   for (int jb = 0; jb < nblk; ++jb) {
-    [[maybe_unused]] const long long tp0 = PDDP_EM_NOW();
-    pass(jb);
-    PDDP_EM_ACC(4, tp0);
+    const T* ib = img0;
+    if constexpr (OVL) {
+      ib = img0 + (jb & 1) * kImgBuf;
+    } else {
+      [[maybe_unused]] const long long tp0 = PDDP_EM_NOW();
+      pass(jb, img0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PDDP_EM_ACC(4, tp0);
+    }
     [[maybe_unused]] const long long ts0 = PDDP_EM_NOW();
     // two word sets alternate: one in use, one being read for the next step
-    Words wa = gather(0), wb = wa;
+    Words wa = gather(ib, 0), wb = wa;
     if (t >= kBlk - 1) {
 #pragma unroll
       for (int s = 0; s < kBlk; s += 2) {
-        wb = gather(s + 1);
+        wb = gather(ib, s + 1);
         step(wa, s);
-        if (s + 2 < kBlk) wa = gather(s + 2);
+        if (s + 2 < kBlk) wa = gather(ib, s + 2);
         step(wb, s + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -458,14 +514,7 @@ __global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
       const int cnt = t + 1;
 #pragma unroll 1
       for (int s = 0; s < cnt; ++s) {
-        const T* p = img + s * kImg;
-        Words w;
-        w.Fs = *reinterpret_cast<const f32x4*>(p + oA);
-        w.Fq = *reinterpret_cast<const f32x4*>(p + oB);
-        w.Ti = *reinterpret_cast<const f32x2*>(p + oTi);
-        w.Tj = *reinterpret_cast<const f32x2*>(p + oTj);
-        w.Lzz = p[oL];
-        w.Sc = *reinterpret_cast<const f32x4*>(p + 48 + rbase);
+        const Words w = gather(ib, s);
         step(w, s);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -476,51 +525,61 @@ __global__ __launch_bounds__(kWaves* kWave) void riccati_n4_elem_kernel(
     // its value was consumed)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     PDDP_EM_ACC(5, ts0);
+    if constexpr (OVL) {
+      if (jb + 1 < nblk) {
+        [[maybe_unused]] const long long tb0 = PDDP_EM_NOW();
+        n4::lds_publish_barrier();  // barrier jb + 1
+        PDDP_EM_ACC(6, tb0);
+      }
+    }
   }
   PDDP_EM_MARK(2);
   if (counted && l == 0) a.status[bc] = status;
-  // J_opt = sum of the stage costs and the terminal one (ilqr.py:289)
-  const T Jrow = group_sum(Jacc) + l_term;
-  if (sums && l == 0) {
-    gen.J_opt[bc] = Jrow;
-    if (gen.fresh != nullptr) gen.fresh[bc] = 0;
-  }
+  if constexpr (!OVL) finish_costs();
   PDDP_EM_MARK(3);
 }
 
 }  // namespace n4e
 
-// 0 auto, 1 the four-role kernel (riccati_n4_defer.hpp, NP = 1), 2 this one
+// 0 auto, 1 the four-role kernel (riccati_n4_defer.hpp, NP = 1), 2 this one,
+// 3 / 4 this one with the generator inline / on wavefronts of its own
 inline int& nominal_kernel_choice() {
   static int choice = 0;
   return choice;
 }
 
 static int launch_n4_elem(const pddp_problem& p, const RiccatiArgs<float>& a,
-                          const n4d::GenArgs<float>& gen, hipStream_t st) {
+                          const n4d::GenArgs<float>& gen, hipStream_t st,
+                          int overlap = -1) {
   if (p.model != PDDP_MODEL_CARTPOLE ||
       p.encoding != PDDP_ENC_IGNORE_UNCERTAINTY || a.u_min == nullptr ||
       a.u_max == nullptr || a.branch != PDDP_BRANCH_EIG || a.N < 1)
     return PDDP_E_UNSUPPORTED;
   const ProblemT<float> P = convert_problem<float>(p);
-  const size_t lds = n4e::kLdsBytes;
-  const dim3 grid((a.B + n4e::kWaves * n4e::kTrajW - 1) /
-                  (n4e::kWaves * n4e::kTrajW)),
-      block(n4e::kWaves * kWave);
+  constexpr int kPer = n4e::kWaves * n4e::kTrajW;  // trajectories / workgroup
+  const dim3 grid((a.B + kPer - 1) / kPer);
+  // the generator on a wavefront of its own while one workgroup per CU holds
+  // the batch; beyond that the SIMDs have other wavefronts to issue from and
+  // the smaller LDS footprint (more workgroups per CU) counts
+  const bool ovl = overlap < 0 ? grid.x <= 256u : overlap != 0;
   constexpr unsigned kSparse = 0b11001u;  // CartpoleCost: {x, sin, cos}
   const bool sparse =
       (live_mask(p.Q, ModelDims<PDDP_MODEL_CARTPOLE>::na) & ~kSparse) == 0;
-#define PDDP_ELEM_GO(QMV)                                                     \
+#define PDDP_ELEM_GO(QMV, OV)                                                 \
   do {                                                                        \
-    auto kern = n4e::riccati_n4_elem_kernel<QMV>;                             \
+    auto kern = n4e::riccati_n4_elem_kernel<QMV, OV>;                         \
+    const size_t lds = (size_t)n4e::kWaves * sizeof(float) *                  \
+                       (OV ? n4e::kPairLdsOvl : n4e::kPairLdsInl);            \
     const hipError_t e = hipFuncSetAttribute(                                 \
         (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
         (int)lds);                                                            \
     if (e != hipSuccess) return (int)e;                                       \
-    PDDP_LAUNCH(kern, grid, block, lds, st, a, gen, P);                       \
+    PDDP_LAUNCH(kern, grid, dim3((OV ? 2 : 1) * n4e::kWaves * kWave), lds,    \
+                st, a, gen, P);                                               \
   } while (0)
-  if (sparse) PDDP_ELEM_GO(kSparse);
-  else PDDP_ELEM_GO(kFullMask<PDDP_MODEL_CARTPOLE>);
+  constexpr unsigned kFull = kFullMask<PDDP_MODEL_CARTPOLE>;
+  if (sparse) { if (ovl) PDDP_ELEM_GO(kSparse, true); else PDDP_ELEM_GO(kSparse, false); }
+  else { if (ovl) PDDP_ELEM_GO(kFull, true); else PDDP_ELEM_GO(kFull, false); }
 #undef PDDP_ELEM_GO
   return launch_status();
 }

@@ -1341,14 +1341,42 @@ def test_best_rollout_exchange_on_the_device(dtype):
         ex.post(J, Z, U, offset=1 << 53)
 
 
+class _nominal_kernel(object):
+    """pddp_sweep_nominal_kernel(which) for the duration of a `with` block:
+    1 the four-role kernel (riccati_n4_defer.hpp), 3 / 4 the one-wavefront
+    kernel (riccati_n4_elem.hpp) with its record generator inline / on
+    wavefronts of its own, 0 auto."""
+
+    def __init__(self, which):
+        self.which = which
+
+    def __enter__(self):
+        from pddp_amd import _native
+        self.prev = _native.lib().pddp_sweep_nominal_kernel(self.which)
+
+    def __exit__(self, *exc):
+        from pddp_amd import _native
+        _native.lib().pddp_sweep_nominal_kernel(self.prev)
+
+
+@pytest.mark.parametrize("kernel", [1, 3, 4])
 @pytest.mark.parametrize("B,N", [(37, 33), (16, 100), (5, 10), (130, 47),
-                                 (3, 8), (21, 9), (17, 12), (300, 201)])
-def test_sweep_from_nominal_equals_records_then_sweep(B, N):
+                                 (3, 8), (21, 9), (17, 12), (300, 201),
+                                 (9, 3), (2, 1), (70, 16), (33, 32), (6, 17)])
+def test_sweep_from_nominal_equals_records_then_sweep(B, N, kernel):
     """pddp_sweep_nominal_f32 (derivative records evaluated inside the sweep's
-    workgroups, never written) against pddp_derivs_f32 followed by the
-    deferred sweep on those records: gains, status, stage costs and J_opt =
-    L.sum() - ragged batches, horizons that are not a multiple of the
-    generators' four-step blocks, masked trajectories."""
+    workgroups, never written) - each of its kernels - against pddp_derivs_f32
+    followed by the deferred sweep on those records: gains, status, stage costs
+    and J_opt = L.sum() - ragged batches, horizons that are not a multiple of
+    the generators' blocks (four steps / sixteen steps), horizons shorter than
+    a block, masked trajectories."""
+    if kernel == 1 and N < 8:
+        pytest.skip("the four-role kernel needs N >= 8")
+    with _nominal_kernel(kernel):
+        _sweep_from_nominal_case(B, N, same_arithmetic=kernel == 1)
+
+
+def _sweep_from_nominal_case(B, N, same_arithmetic):
     s, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=11)
     assert s._nominal_sweep is None  # in its domain, untried
     s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
@@ -1370,18 +1398,34 @@ def test_sweep_from_nominal_equals_records_then_sweep(B, N):
     g, gr = s.gains.cpu()[live].double(), ref["gains"].cpu()[live].double()
     assert torch.isfinite(g).all()
     # (the records of the two paths agree to rounding - the same code inlined
-    # into two kernels - and a hundred steps of an f32 sweep carry that on)
-    err = float((g - gr).abs().max() / gr.abs().max())
-    assert err < 3e-4, err
+    # into two kernels - and a hundred steps of an f32 sweep carry that on.
+    # The four-role kernel is variant 25's arithmetic; the one-wavefront
+    # kernel sums in another order and runs the plain recursion - two f32
+    # sweeps then part by what f32 loses over N steps, which the oracle tests
+    # measure: here only that nothing is wild)
+    per = (g - gr).abs().amax(dim=(1, 2)) / gr.abs().max()
+    if same_arithmetic:
+        assert float(per.max()) < 3e-4, float(per.max())
+    else:
+        assert float(per.median()) < 3e-5 and float(per.max()) < 2e-2, (
+            float(per.median()), float(per.max()))
     assert torch.equal(s.bwd_status.cpu()[live], ref["bwd_status"].cpu()[live])
     assert (s.bwd_status.cpu()[~live] == -7).all()
-    assert float((s.L - ref["L"]).abs().max()) <= 1e-6 * float(
-        ref["L"].abs().max())
+    # (stage costs: rows of active trajectories; an inactive row is left alone
+    # or - the four-role kernel, for a row next to an active one - refreshed
+    # with the same values)
+    Lg, Lr = s.L.cpu(), ref["L"].cpu()
+    assert float((Lg[live] - Lr[live]).abs().max()) <= 1e-6 * float(
+        Lr.abs().max())
+    assert bool(((Lg[~live] == 0) | ((Lg[~live] - Lr[~live]).abs() <=
+                                     1e-6 * Lr.abs().max())).all())
     fr = torch.ones(B, dtype=torch.bool)
     fr[1::7] = False
     take = (live & fr)
     J, Jr = s.J_opt.cpu(), ref["J_opt"].cpu()
-    assert float((J[take] - Jr[take]).abs().max()) <= 1e-6 * float(Jr.abs().max())
+    if take.any():
+        assert float((J[take] - Jr[take]).abs().max()) <= 2e-6 * float(
+            Jr.abs().max())
     assert (J[~take] == 123.0).all()
     assert int(s.fresh.cpu()[take].sum()) == 0
     # the records themselves, on demand
@@ -1391,10 +1435,18 @@ def test_sweep_from_nominal_equals_records_then_sweep(B, N):
     assert torch.equal(rec, s.rec)
 
 
-def test_round_from_nominal_equals_round_with_records():
+@pytest.mark.parametrize("kernel", [1, 0])
+def test_round_from_nominal_equals_round_with_records(kernel):
     """ILQRSolver.round() through the sweep from the nominal (no records in
     HBM) against the same rounds through the fused launch that writes them:
-    the same decisions, nominals and regularisation, round by round."""
+    the same decisions, nominals and regularisation, round by round.  (The
+    four-role kernel has the recorded sweep's arithmetic; the one-wavefront
+    kernel - auto - sums in another order: values to 2e-2 after 14 rounds.)"""
+    with _nominal_kernel(kernel):
+        _rounds_side_by_side(1e-3 if kernel == 1 else 2e-2)
+
+
+def _rounds_side_by_side(vtol):
     B, N = 64, 40
     a, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=5)
     b, *_ = _setup("cartpole", "f32", B, N, seed=5)
@@ -1410,13 +1462,13 @@ def test_round_from_nominal_equals_round_with_records():
             assert torch.equal(getattr(a, k), getattr(b, k)), (r, k)
         for k in ("Z", "U", "gains_acc"):
             x, y = getattr(a, k).double(), getattr(b, k).double()
-            assert float((x - y).abs().max()) <= 1e-3 * float(
+            assert float((x - y).abs().max()) <= vtol * float(
                 y.abs().max().clamp_min(1.0)), (r, k)
         accepted += int(((a.state == 1) | (a.state == 5)).sum())
     assert accepted > B
     x, y = a.rec.double(), b.rec.double()  # brought up to date on access
     live = a.active.bool()
-    assert float((x[live] - y[live]).abs().max()) <= 1e-3 * float(
+    assert float((x[live] - y[live]).abs().max()) <= vtol * float(
         y.abs().max())
 
 
@@ -2067,10 +2119,11 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
 
     fp64: 1e-9 on every trajectory, statuses identical.
 
-    fp32 (what bench.py times: "nominal" = pddp_sweep_nominal_f32, the sweep
-    that evaluates the derivative records itself - riccati_n4_gen_kernel with
-    v_rcp and the sign-bit BoxQP; 25 = the same sweep on records in HBM; 9, 7,
-    17 for the other branches): the sweep is a 100-step recursion through a discontinuous BoxQP, so the yardstick is the
+    fp32 (what bench.py times: "nominal4" = pddp_sweep_nominal_f32, the sweep
+    that evaluates the derivative records itself - riccati_n4_elem_kernel with
+    its generator wavefronts, v_rcp and the sign-bit BoxQP; "nominal3" the same
+    with the generator inline, "nominal1" the four-role riccati_n4_gen_kernel;
+    25 = that sweep on records in HBM; 9, 7, 17 for the other branches): the sweep is a 100-step recursion through a discontinuous BoxQP, so the yardstick is the
     fp64 oracle and the reference point is what IEEE fp32 arithmetic in the
     reference's operation order (the fp32 oracle) loses against it.  Asserted
     per (variant, branch, reg): status flips and clamp-pattern flips against
@@ -2090,7 +2143,8 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
     f64 = dtype == "f64"
     plan = (  # branch, bounded, variants (f64 | f32)
         (0, True, (6, 8, 16, 18, 20, 24) if f64 else
-         (7, 9, 15, 16, 17, 18, 20, 21, 24, 25, "nominal")),
+         (7, 9, 15, 16, 17, 18, 20, 21, 24, 25, "nominal1", "nominal3",
+          "nominal4")),
         (1, True, (6, 8, 16, 18) if f64 else (7, 8, 9, 15, 16, 17, 18)),
         (0, False, (6, 16) if f64 else (6, 7, 15, 16, 17)),
         (1, False, (6, 16) if f64 else (6, 7, 15, 16, 17)))
@@ -2114,15 +2168,17 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
             regv = torch.full((B,), reg, dtype=torch.float64, device="cuda")
             for variant in variants:
                 s.gains.zero_()
-                if variant == "nominal":
-                    # the record-free sweep takes everything from the nominal
-                    # (Z, U) and the controller's own mu / masks
+                if str(variant).startswith("nominal"):
+                    # the record-free sweep (each of its kernels) takes
+                    # everything from the nominal (Z, U) and the controller's
+                    # own mu / masks
                     s.mu.fill_(reg)
                     s.active.fill_(1)
                     s.fresh.fill_(1)
                     s.L.zero_()
                     s.J_opt.fill_(-1.0)
-                    assert s.sweep_nominal()
+                    with _nominal_kernel(int(variant[-1])):
+                        assert s.sweep_nominal()
                     Lg = s.L.cpu().numpy()
                     Lr = np.stack([fwd[b]["L"] for b in range(B)])
                     assert rel_err(Lg, Lr) < 2e-6, rel_err(Lg, Lr)

@@ -21,9 +21,10 @@ for B in [int(v) for v in sys.argv[1:]] or [4096]:
     s.mu.fill_(1.0)
     s.derivs()
     out = {}
-    for name in ("elem", "roles", "recorded"):
+    for name in ("elem", "elem_inl", "elem_ovl", "roles", "recorded"):
         pool = bench.EventPool(lib)
-        lib.pddp_sweep_nominal_kernel({"elem": 2, "roles": 1}.get(name, 0))
+        lib.pddp_sweep_nominal_kernel({"elem": 2, "elem_inl": 3, "elem_ovl": 4,
+                                       "roles": 1}.get(name, 0))
         s.gains.zero_()
         for i in range(24):
             ev = pool.pair() if i >= 4 else None
@@ -47,20 +48,22 @@ for B in [int(v) for v in sys.argv[1:]] or [4096]:
             print("  wave M of workgroup 0: first phase after %d cycles, phases "
                   "%d cycles (%.0f each)" % (t[1] - t[0], t[2] - t[1],
                                              (t[2] - t[1]) / 102.0))
-        if name == "elem" and hasattr(raw, "pddp_debug_elem_marks"):
+        if name.startswith("elem") and hasattr(raw, "pddp_debug_elem_marks"):
             mk = (ctypes.c_longlong * 8)()  # (-DPDDP_ELEM_MARKS build)
             raw.pddp_debug_elem_marks(mk)
             t = [mk[i] for i in range(8)]
             print("  wave 0 of workgroup 0 (last launch): first block after %d "
                   "cycles, blocks %d cycles, end after %d; over the launches: "
-                  "generator passes %d cycles, steps %d (%.0f per step)" % (
+                  "generator passes %d cycles, steps %d (%.0f per step), "
+                  "block barriers %d" % (
                       t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] // 24,
-                      t[5] // 24, t[5] / 2400.0))
+                      t[5] // 24, t[5] / 2400.0, t[6] // 24))
     lib.pddp_sweep_nominal_kernel(0)
     g = {k: v[0].double() for k, v in out.items()}
     ok = (out["elem"][1] == 0) & (out["recorded"][1] == 0)
     sc = float(g["recorded"][ok].abs().max())
-    for a, b in (("elem", "recorded"), ("roles", "recorded"), ("elem", "roles")):
+    for a, b in (("elem", "recorded"), ("roles", "recorded"), ("elem", "roles"),
+                 ("elem_inl", "elem_ovl")):
         e = (g[a][ok] - g[b][ok]).abs().amax(dim=(1, 2)) / sc
         print("  gains %s vs %s: max %.2e  median %.2e   status equal: %s" % (
             a, b, float(e.max()), float(e.median()),
