@@ -1268,6 +1268,15 @@ def main():
                     "what": "time = N x instructions x issue interval; HBM "
                             "and the matrix cores are idle",
                 } if from_nominal else None,
+                # the step's dependent work alone - products, transposes, lean
+                # BoxQP, value update; operands in registers, no LDS reads, no
+                # generator, no stores: tools/probe/riccati_floor_probe.hip,
+                # profiles/r04_riccati_floor.txt (447 cycles per step: 22.75
+                # us per 100 steps, launch included)
+                "floor_us": 22.75 * N / 100.0 if from_nominal else None,
+                "frac_of_floor": (22.75 * N / 100.0) /
+                                 (float(d_sweep.mean()) * 1e6)
+                                 if from_nominal else None,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "avg_launch_us": float(d_sweep.mean()) * 1e6,
