@@ -320,6 +320,17 @@ int pddp_sweep_nominal_kernel(int which);
  * full-step candidate go there, rows next to one another, INSTEAD of
  * Zc[b][.][0][.] (the usual winner: its copy into the nominal reads whole
  * sectors there, 16 bytes out of every A n 4-byte step in Zc). */
+/* Candidates of pddp_search_accept_* in its form without records (L == NULL,
+ * rec given as scratch): 0 = auto - kept while B A (N (n + m) + n) scalars fit
+ * the Infinity Cache next to the round's other traffic (200 MB), dropped
+ * beyond; 1 = always kept; 2 = always dropped.  Dropped: Zc / Uc are scratch
+ * (contents unspecified after the call), only the costs Jc are formed; the
+ * full step's states go to `rec` as above, a winner other than the full step
+ * is rolled out a second time.  Every other output is the same to rounding.
+ * Process-wide (an A/B and test knob); -1 only queries.  Returns the previous
+ * mode. */
+int pddp_search_candidates(int mode);
+
 int pddp_search_accept_f32(const pddp_problem* problem, int B, int N, int A,
                            float* Z, float* U, const float* gains,
                            const float* alphas, const float* u_min,

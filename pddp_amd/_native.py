@@ -82,6 +82,7 @@ _SIGS = {
     "pddp_sweep_nominal_f32": [_P, c_int, c_int] + [_P] * 5 + [c_int] +
                               [_P] * 7,
     "pddp_sweep_nominal_kernel": [c_int],
+    "pddp_search_candidates": [c_int],
     "pddp_bnn_mlp_precision": [c_int],
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
     "pddp_bnn_moment_step_f32": [_P, _P],

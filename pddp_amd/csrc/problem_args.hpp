@@ -53,6 +53,14 @@ struct LineSearchArgs {
   T* Zc;
   T* Uc;
   T* Jc;
+  // Fused launch without records (pddp_search_accept_*, L == NULL, rec given
+  // as scratch) only: 1 = the candidates are NOT kept - a step size other than
+  // the full step writes nothing but its cost, the full step its compact rows
+  // in `rec`; a winner other than the full step (1 accepted attempt in 20) is
+  // rolled out a second time.  B A N (n + m) words of candidates are 82 MB at
+  // B = 4096 - absorbed by the 256 MB Infinity Cache - and 1.3 GB at B = 65536,
+  // where writing them out at ~2 TB/s WAS the launch (654 of its 654 us).
+  int drop_candidates = 0;
 };
 
 }  // namespace pddp

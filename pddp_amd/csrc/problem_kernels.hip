@@ -361,21 +361,16 @@ line_search_lds_kernel(
     if (attempted && ai == 0) acc_in = accept_load(c, b);
   }
   T Jmine = T(0);
-  if (run && hid == 0) {
-    const T alpha = a.alphas[ai];
-    const int idx = b * a.A + ai;
-    // FUSED without records, `rec` given as scratch: the FULL STEP (candidate
-    // 0, the winner of 19 accepted attempts in 20 - tools/ls_tail_profile.py)
-    // writes its states to rec[b][N + 1][n], rows next to one another, instead
-    // of Zc[b][.][0][.]: the tail's copy of the winner into the nominal then
-    // reads whole sectors instead of 16 bytes out of every 160-byte step of Zc
-    // (a per-lane stride in the address update: no instruction more)
-    const bool compact0 = FUSED && Lout == nullptr && rec != nullptr && ai == 0;
-    T* Zci = compact0 ? rec + (size_t)b * (N + 1) * n
-                      : a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
-    T* Uci = a.Uc + ((size_t)b * N * a.A + ai) * m;
-    const size_t zstep = compact0 ? (size_t)n : zstep_c, ustep = ustep_c;
-
+  // (candidates dropped: see LineSearchArgs::drop_candidates)
+  // (where the tail's short form applies: it reads the winner's compact rows)
+  const bool nocand = FUSED && Lout == nullptr && rec != nullptr &&
+                      a.drop_candidates != 0 && n <= 6 && N + 1 <= 16 * H * 4;
+  // One rollout of this lane's candidate (ilqr.py:677-723 + :764-791): states
+  // to Zci (stride zstep per step), actions to Uci (stride ustep), the cost
+  // returned.  A stride of zero makes the target a one-row scratch - the
+  // stores stay in the instruction stream (no exec mask on the chain), their
+  // line stays in L2.
+  auto rollout = [&](T alpha, T* Zci, size_t zstep, T* Uci, size_t ustep) {
     T z[n], zn[n], un[m];
 #pragma unroll
     for (int j = 0; j < n; ++j) z[j] = Zs[j];  // Z_new[0] = Z[0]  (ilqr.py:690)
@@ -422,7 +417,25 @@ line_search_lds_kernel(
     for (int j = 0; j < n; ++j) Zci[(size_t)N * zstep + j] = z[j];
     const T lf =
         cost_value<T, MODEL>(P, z, nullptr, trig_of<T, MODEL>(z), true);
-    Jmine = J + lf;  // L.sum(0) + l_f                             (ilqr.py:789)
+    return J + lf;  // L.sum(0) + l_f                              (ilqr.py:789)
+  };
+  if (run && hid == 0) {
+    const T alpha = a.alphas[ai];
+    const int idx = b * a.A + ai;
+    // FUSED without records, `rec` given as scratch: the FULL STEP (candidate
+    // 0, the winner of 19 accepted attempts in 20 - tools/ls_tail_profile.py)
+    // writes its states to rec[b][N + 1][n], rows next to one another, instead
+    // of Zc[b][.][0][.]: the tail's copy of the winner into the nominal then
+    // reads whole sectors instead of 16 bytes out of every 160-byte step of Zc
+    // (a per-lane stride in the address update: no instruction more)
+    const bool compact0 = FUSED && Lout == nullptr && rec != nullptr && ai == 0;
+    T* Zci = compact0 ? rec + (size_t)b * (N + 1) * n
+                      : a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
+    T* Uci = a.Uc + ((size_t)b * N * a.A + ai) * m;
+    // candidates dropped: every other step size overwrites ONE row of its own
+    const size_t zstep = compact0 ? (size_t)n : (nocand ? 0 : zstep_c);
+    const size_t ustep = nocand ? 0 : ustep_c;
+    Jmine = rollout(alpha, Zci, zstep, Uci, ustep);
     a.Jc[idx] = Jmine;
   }
 
@@ -454,6 +467,15 @@ line_search_lds_kernel(
     }
     amin_out = __shfl(amin_out, lane & 48);
     fresh_i = __shfl(fresh_i, lane & 48);
+    // candidates dropped and the winner is not the full step: its lane rolls
+    // it out once more, into the compact rows the tail reads (the same code on
+    // the same inputs: its states to rounding - two inlined copies of the step
+    // are not contracted alike - and its cost, Jc, from the first time)
+    if (nocand && hid == 0 && __any(amin_out > 0)) {
+      if (amin_out > 0 && ai == amin_out)
+        rollout(a.alphas[ai], rec + (size_t)b * (N + 1) * n, (size_t)n,
+                a.Uc + ((size_t)b * N * a.A + ai) * m, 0);
+    }
     if constexpr (H == 1) {
       if (!__any(amin_out >= 0)) return;
       // the candidate rows written above are read back below, by this same
@@ -490,6 +512,7 @@ line_search_lds_kernel(
       T zc[n], uc[m];
       const int t_first = ai + 16 * hid;  // rows t_first, t_first + 16 H, ...
       constexpr int KR = 4;  // rows per lane the short form below covers
+                             // (`nocand` above knows this number)
       if (n <= 6 && Lout == nullptr && N + 1 <= 16 * H * KR) {
         // No records to write (the next sweep evaluates them): the tail is
         // the winner's rows - all of this lane's requested at once, one
@@ -508,7 +531,8 @@ line_search_lds_kernel(
         // again from the nominal row in LDS - the same operations in the
         // same order as in the rollout (control_law), bit for bit.
         T zz[KR][n], uu[KR][m];
-        const bool from_rec = rec != nullptr && amin_out == 0;  // (compact0)
+        // (compact0; with the candidates dropped every winner's rows are there)
+        const bool from_rec = rec != nullptr && (amin_out == 0 || nocand);
         const T* cz = from_rec ? rec + (size_t)b * (N + 1) * n : srcz;
         const size_t czs = from_rec ? (size_t)n : zstep_c;
 #pragma unroll
@@ -814,6 +838,12 @@ static int line_search_impl(const pddp_problem* p, int B, int N, int A,
   PDDP_DISPATCH_MODEL(launch_line_search, T, p, a, (hipStream_t)stream)
 }
 
+// 0 auto (by the size of the candidates), 1 keep them, 2 drop them
+inline int& search_candidates_choice() {
+  static int choice = 0;
+  return choice;
+}
+
 template <typename T>
 static int search_accept_impl(const pddp_problem* p, int B, int N, int A, T* Z,
                               T* U, const T* gains, const T* alphas,
@@ -837,12 +867,28 @@ static int search_accept_impl(const pddp_problem* p, int B, int N, int A, T* Z,
                        state, iter, active, fresh, n_live};
   a.rec = rec;
   a.L = L;
+  // keep the candidates while they fit the Infinity Cache next to the rest of
+  // the round's traffic (256 MB; a launch's candidates: 82 MB at B = 4096,
+  // 164 MB at 8192: 50 us; 328 MB at 16384: 163 us kept, 97 us dropped)
+  const double cand_bytes =
+      (double)B * A * ((double)(N + 1) * p->encoded_size +
+                       (double)N * p->action_size) * sizeof(T);
+  const int mode = search_candidates_choice();
+  a.ls.drop_candidates =
+      (L == nullptr && rec != nullptr &&
+       (mode == 2 || (mode == 0 && cand_bytes > 200e6))) ? 1 : 0;
   PDDP_DISPATCH_MODEL(launch_search_accept, T, p, a, (hipStream_t)stream)
 }
 
 }  // namespace pddp
 
 extern "C" {
+
+int pddp_search_candidates(int mode) {
+  const int prev = pddp::search_candidates_choice();
+  if (mode >= 0 && mode <= 2) pddp::search_candidates_choice() = mode;
+  return prev;
+}
 
 int pddp_search_accept_f32(const pddp_problem* p, int B, int N, int A, float* Z,
                            float* U, const float* gains, const float* alphas,

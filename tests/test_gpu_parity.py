@@ -1472,6 +1472,61 @@ def _rounds_side_by_side(vtol):
         y.abs().max())
 
 
+@pytest.mark.parametrize("B,N", [(301, 40), (64, 100), (37, 127)])
+def test_search_accept_without_candidates(B, N):
+    """pddp_search_accept_f32(L = NULL) with the candidates dropped
+    (pddp_search_candidates(2): what `auto` does from ~10 000 cartpole
+    trajectories on, where writing B A N (n + m) words of candidates out was
+    the whole launch) against the same launch with the candidates kept, round
+    by round from the same state: costs, decisions, regularisation and masks
+    bit for bit; the new nominal bit for bit where the full step won (its
+    compact rows are the same rows), to rounding where another step size won
+    and was rolled out a second time."""
+    from pddp_amd import _native
+    lib = _native.lib()
+    a, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=3)
+    b, *_ = _setup("cartpole", "f32", B, N, seed=3)
+    a.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    b.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    other_winners = accepted = 0
+    prev = lib.pddp_search_candidates(1)
+    try:
+        for r in range(16):
+            for k in a._STATE:          # b starts every round where a does
+                getattr(b, k).copy_(getattr(a, k))
+            for s_, mode in ((a, 1), (b, 2)):
+                lib.pddp_search_candidates(mode)
+                assert s_.sweep_nominal()
+                assert s_.search_accept(5e-6, 1e10, 50, records=False)
+            torch.cuda.synchronize()
+            for k in ("Jc", "state", "iter", "active", "fresh", "mu", "delta",
+                      "J_opt", "bwd_status", "gains_acc"):
+                x, y = getattr(a, k), getattr(b, k)
+                if x.is_floating_point():  # (a diverged candidate's cost: NaN)
+                    x, y = x.view(torch.int32 if x.element_size() == 4
+                                  else torch.int64), y.view(
+                        torch.int32 if y.element_size() == 4 else torch.int64)
+                assert torch.equal(x, y), (r, k)
+            acc = (a.state == 1) | (a.state == 5)
+            amin = torch.argmin(torch.nan_to_num(a.Jc, nan=-1e30), dim=1)
+            full = acc & (amin == 0)
+            other = acc & (amin != 0)
+            assert torch.equal(a.Z[full], b.Z[full]), r
+            assert torch.equal(a.U[full], b.U[full]), r
+            assert torch.equal(a.Z[~acc], b.Z[~acc]), r
+            if other.any():
+                ez = (a.Z[other] - b.Z[other]).abs().max() / \
+                    a.Z[other].abs().max()
+                eu = (a.U[other] - b.U[other]).abs().max() / \
+                    a.U[other].abs().max().clamp_min(1e-3)
+                assert float(ez) < 1e-5 and float(eu) < 1e-5, (r, ez, eu)
+            other_winners += int(other.sum())
+            accepted += int(acc.sum())
+    finally:
+        lib.pddp_search_candidates(prev)
+    assert accepted > B and other_winners > 0, (accepted, other_winners)
+
+
 def _oracle_accept(J_opt, Jc, status, mu, delta, tol, max_reg, it, n_it):
     """One attempt's bookkeeping as the reference writes it (ilqr.py:122-181
     accept / converge / reject, :364-390 the mu schedule in Python floats,
