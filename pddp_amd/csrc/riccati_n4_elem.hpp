@@ -74,15 +74,19 @@ constexpr int kImg = 52;
 // a trajectory's 16 images; + 16 floats: the four rows' reads of one step fall
 // into four different quarters of the 64 banks
 constexpr int kRowStride = kBlk * kImg + 16;
-// + the gains of a block, [step][lane]: written one word per lane and step
-// (no exec mask, no address arithmetic on the chain), stored 16 steps at a time
-constexpr int kStage = kBlk * kWave;
 constexpr int kImgBuf = kTrajW * kRowStride;  // a block's images, four rows
+// The gains of a block go out 16 steps at a time: lane (row, l) leaves its
+// word of step s - K[l] for l < 4, k otherwise - in word l of the image of
+// (row, s), which is dead by then (its words were read into registers a step
+// earlier, and LDS executes a wavefront's operations in order): one ds_write
+// per step, no exec mask, no address arithmetic on the chain, no LDS of its own.
 constexpr int kTermRow = 24;  // terminal L_zz (16), L_z (4), cost, pad per row
 constexpr int kTermSh = kTrajW * kTermRow;
-// floats per wavefront (inline generator) / per (sweep, generator) pair
-constexpr int kPairLdsInl = kImgBuf + kStage + kTermSh;
-constexpr int kPairLdsOvl = 2 * kImgBuf + kStage + kTermSh;
+// floats per wavefront (inline generator; the terminal rows alias the images,
+// which are written after they are read: 13.25 KB - three workgroups per CU) /
+// per (sweep, generator) pair
+constexpr int kPairLdsInl = kImgBuf;
+constexpr int kPairLdsOvl = 2 * kImgBuf + kTermSh;
 
 // back-tracking step sizes of the reference's BoxQP loop as floats in global
 // memory (the loop runs on ~0.02 % of the steps: no LDS copy, no barrier)
@@ -239,8 +243,8 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
   const int pair = OVL ? (wave & (kWaves - 1)) : wave;
   const bool is_gen = OVL && wave >= kWaves;
   T* const img0 = reinterpret_cast<T*>(smem_raw) + pair * kPairLds;
-  T* const stage_w = img0 + (OVL ? 2 : 1) * kImgBuf;
-  T* const term_w = stage_w + kStage;
+  // (inline: the first rows of the image buffer, before pass 0 writes it)
+  T* const term_w = OVL ? img0 + 2 * kImgBuf : img0;
 
   const int row = lane >> 4, l = lane & 15, i = l >> 2, j = l & 3;
   const int N = a.N;
@@ -333,7 +337,8 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
   // the trajectories whose nominal changed
   auto finish_costs = [&]() {
     const bool sums = counted && (gen.fresh == nullptr || gen.fresh[bc] != 0);
-    const T Jrow = group_sum(Jacc) + term_w[row * kTermRow + 20];
+    // (OVL: the terminal cost is the sweep wavefront's; inline: our own)
+    const T Jrow = group_sum(Jacc) + (OVL ? term_w[row * kTermRow + 20] : l_term);
     if (sums && l == 0) {
       gen.J_opt[bc] = Jrow;
       if (gen.fresh != nullptr) gen.fresh[bc] = 0;
@@ -396,10 +401,10 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
   // counted and status still OK (changes in the odd path only), as a lane mask
   unsigned long long alive_m = __ballot(counted);
   const unsigned long long lane_bit = 1ull << lane;
-  // gains of a block in LDS: lane (row, l < 4) holds K[l], the others k
-  T* stage = stage_w + lane;
+  // gains of a block: word l of the (dead) image of (row, step)
+  const int ostage = rbase + l;
 
-  auto step = [&](const Words& w, const int s) {
+  auto step = [&](const Words& w, T* ib, const int s) {
     const StepCore q = step_core(V, vc, w.Ti[0], w.Tj[0], w.Fs, w.Fq, w.Lzz,
                                  w.Tj[1], w.Ti[1], w.Sc[0], w.Sc[1]);
     const T Quu = q.Quu, Qu = q.Qu;
@@ -462,7 +467,7 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
       alive_m &= ~__ballot(bad);
     }
     // ---- gains out: K = -s Quz (column form in lanes (0, j)), k elsewhere
-    stage[s * kWave] = (l < 4) ? -(sK * Quzc) : kt;
+    ib[s * kImg + ostage] = (l < 4) ? -(sK * Quzc) : kt;
     kprev = kt;
     // ---- value update (ilqr.py:664-672 with K = -s Quz):
     // V' = sym(Qzz) + c Quz Quz^T,  V_z' = Qz + w Quz
@@ -473,8 +478,8 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
   };
   // the gains of the block's first `cnt` steps (t_top, t_top - 1, ...) to
   // HBM: lane (row, l) stores step l's five words
-  auto flush_gains = [&](int t_top, int cnt) {
-    const T* sg = stage_w + l * kWave + row * 16;
+  auto flush_gains = [&](const T* ib, int t_top, int cnt) {
+    const T* sg = ib + l * kImg + rbase;
     const f32x4 Kv = *reinterpret_cast<const f32x4*>(sg);
     const T kv = sg[4];
     if (exists && l < cnt) {
@@ -486,7 +491,7 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
   PDDP_EM_MARK(1);
   int t = N - 1;
   for (int jb = 0; jb < nblk; ++jb) {
-    const T* ib = img0;
+    T* ib = img0;
     if constexpr (OVL) {
       ib = img0 + (jb & 1) * kImgBuf;
     } else {
@@ -502,12 +507,12 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
 #pragma unroll
       for (int s = 0; s < kBlk; s += 2) {
         wb = gather(ib, s + 1);
-        step(wa, s);
+        step(wa, ib, s);
         if (s + 2 < kBlk) wa = gather(ib, s + 2);
-        step(wb, s + 1);
+        step(wb, ib, s + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      flush_gains(t, kBlk);
+      flush_gains(ib, t, kBlk);
       t -= kBlk;
     } else {
       // the last, partial block
@@ -515,10 +520,10 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
 #pragma unroll 1
       for (int s = 0; s < cnt; ++s) {
         const Words w = gather(ib, s);
-        step(w, s);
+        step(w, ib, s);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      flush_gains(t, cnt);
+      flush_gains(ib, t, cnt);
       t = -1;
     }
     // (the next pass overwrites the images: every read above has returned -
