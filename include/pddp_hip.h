@@ -594,6 +594,47 @@ int pddp_gp_step_f32(const pddp_gp_model* gp, int R, const float* z, const float
 int pddp_gp_step_f64(const pddp_gp_model* gp, int R, const double* z, const double* u,
                      double* z_next, double* Fz, double* Fu, void* stream);
 
+/* ---- the GP workload's line search as a device rollout (the plugin path's
+ * counterpart of pddp_line_search_*; ilqr.py:677-723 control law + rollout,
+ * :764-791 trajectory cost): for every trajectory b and step size a, from
+ * Z_new[0] = Z[b][0],
+ *   u_t = clamp(U[b][t] + alphas[a] k[b][t] + K[b][t] (z_t - Z[b][t]))
+ *   Jc[b][a] += QR cost of (z_t, u_t);  z_{t+1} = GP step of (z_t, u_t)
+ * and the terminal cost of z_N: N + 1 launches of the moment-matched step's
+ * kernel with nothing between them (stream-ordered, capturable).  The cost is
+ * the QR cost on the angle-augmented Gaussian state (costs/quadratic.py:60-99:
+ * E[(x~ - x_goal)^T Q (x~ - x_goal)] + (u - u_goal)^T R (u - u_goal), Q_term
+ * at t = N) with the model's own angular / non-angular indices - its moments
+ * are the step's feature moments; the covariance term enters as the encoding
+ * carries it (full for 1, diagonal for 2 / 3, none for 4).  Zc [B][N+1][A][n],
+ * Uc [B][N][A][m] time-major like pddp_line_search_*; Jc [B][A].  Rows of
+ * inactive trajectories (active[b] == 0) and of failed sweeps
+ * (bwd_status[b] != 0) are skipped (both nullable).  Same model limits as
+ * pddp_gp_step_*; na = n_non + 2 n_ang <= 8, m <= 4. */
+typedef struct pddp_gp_rollout {
+  int32_t B, N, A;
+  const void* Z;        /* [B][N+1][n] nominal states */
+  const void* U;        /* [B][N][m] nominal actions (un-clamped) */
+  const void* gains;    /* [B][N][m + m n]: k | K */
+  const void* alphas;   /* [A] */
+  const void* u_min;    /* [m], nullable with u_max */
+  const void* u_max;
+  const uint8_t* active;       /* [B] nullable */
+  const int32_t* bwd_status;   /* [B] nullable */
+  void* Zc;
+  void* Uc;
+  void* Jc;
+  const void* Q;        /* [na][na] */
+  const void* Q_term;
+  const void* R;        /* [m][m] */
+  const void* x_goal;   /* [na] */
+  const void* u_goal;   /* [m] */
+} pddp_gp_rollout;
+int pddp_gp_rollout_f32(const pddp_gp_model* model, const pddp_gp_rollout* r,
+                        void* stream);
+int pddp_gp_rollout_f64(const pddp_gp_model* model, const pddp_gp_rollout* r,
+                        void* stream);
+
 /* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only
  * sees torch's current stream). Host functions. */
 int pddp_event_create(void** ev);

@@ -94,6 +94,7 @@ _SIGS = {
     "pddp_qr_cost_derivs_f32": [_P, _P],
     "pddp_gp_step": [_P, c_int, _P, _P, _P, _P, _P, _P],
     "pddp_gp_step_lds_bytes": [c_int] * 6,
+    "pddp_gp_rollout": [_P, _P, _P],
     "pddp_event_create": [_P],
     "pddp_event_record": [_P, _P],
     "pddp_event_elapsed_ms": [_P, _P, _P],
@@ -106,7 +107,7 @@ _TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
           "pddp_nominal_rollout",
           "pddp_derivs",
           "pddp_line_search", "pddp_search_accept", "pddp_accept",
-          "pddp_pack_best", "pddp_gp_step")
+          "pddp_pack_best", "pddp_gp_step", "pddp_gp_rollout")
 
 _lib = None
 
@@ -213,6 +214,16 @@ class GpModel(ctypes.Structure):
         [("ang", ctypes.c_int32 * 4), ("non", ctypes.c_int32 * 8)] +
         [(k, ctypes.c_void_p) for k in ("Xt", "Xt_pairs", "beta", "beta_pairs",
                                         "Kinv", "inv_ell2", "sf2", "sn2")])
+
+
+class GpRollout(ctypes.Structure):
+    """pddp_gp_rollout of include/pddp_hip.h."""
+    _fields_ = (
+        [(k, ctypes.c_int32) for k in ("B", "N", "A")] +
+        [(k, ctypes.c_void_p) for k in (
+            "Z", "U", "gains", "alphas", "u_min", "u_max", "active",
+            "bwd_status", "Zc", "Uc", "Jc", "Q", "Q_term", "R", "x_goal",
+            "u_goal")])
 
 
 class QrCost(ctypes.Structure):

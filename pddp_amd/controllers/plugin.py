@@ -295,8 +295,51 @@ class TorchProblem(object):
         J += ((du @ co.R) * du).sum(-1).sum(1)
         return J
 
+    use_gp_rollout = True  # pddp_gp_rollout_* (False: the per-step torch form)
+
     @torch.no_grad()
-    def _line_search_gp(self, s):
+    def _line_search_gp(self, s, active=None, use_status=True):
+        """ilqr.py:677-723 + :764-791 for every (trajectory, step size) as a
+        device rollout: control law, clamp, moment-matched GP step and stage
+        cost in the step's own kernel, N + 1 launches with nothing between
+        them (`pddp_gp_rollout_*`, csrc/gp_step.hip)."""
+        mo, co = self.model, self.cost
+        if not (self.use_gp_rollout and mo.state_size + 0 <= 6 and
+                len(mo.non_angular_indices) + 2 * len(mo.angular_indices) <= 8
+                and s.m <= 4):
+            return self._line_search_gp_torch(s)
+        import ctypes
+        g = mo._native_model(s.dtype, s.device, self.encoding)
+        key = (s.dtype, str(s.device)) + tuple(
+            (t.data_ptr(), t._version)
+            for t in (co.Q, co.Q_term, co.R, co.x_goal, co.u_goal))
+        cc = getattr(self, "_gp_cost_cache", None)
+        if cc is None or cc[0] != key:
+            conv = lambda t: t.detach().to(dtype=s.dtype,
+                                           device=s.device).contiguous()
+            cc = self._gp_cost_cache = (key, tuple(
+                conv(t) for t in (co.Q, co.Q_term, co.R, co.x_goal, co.u_goal)))
+        Q, Qt, R, xg, ug = cc[1]
+        p = _native.ptr
+        r = _native.GpRollout()
+        r.B, r.N, r.A = s.B, s.N, s.A
+        for name, t in (("Z", s.Z), ("U", s.U), ("gains", s.gains),
+                        ("alphas", s.alphas), ("u_min", s.u_min),
+                        ("u_max", s.u_max), ("active", active),
+                        ("bwd_status", s.bwd_status if use_status else None),
+                        ("Zc", s.Zc), ("Uc", s.Uc), ("Jc", s.Jc), ("Q", Q),
+                        ("Q_term", Qt), ("R", R), ("x_goal", xg),
+                        ("u_goal", ug)):
+            setattr(r, name, p(t))
+        with torch.cuda.device(s.device):
+            _native.call("pddp_gp_rollout", s.dtype, ctypes.byref(g),
+                         ctypes.byref(r), _native.stream_handle(s.device))
+
+    @torch.no_grad()
+    def _line_search_gp_torch(self, s):
+        """The same line search step by step in torch ops around
+        `pddp_gp_step_*` with one batched evaluation of the costs: the checker
+        of the rollout kernel (tests/test_gp.py)."""
         B, N, n, m, A = s.B, s.N, s.n, s.m, s.A
         k, K = s.gain_views()
         alpha = s.alphas.view(1, A, 1)
@@ -692,7 +735,7 @@ class TorchProblem(object):
         if self._bnn_native_ok(s):
             return self._line_search_bnn(s, active, use_status)
         if self._gp_line_search_ok(s):
-            return self._line_search_gp(s)
+            return self._line_search_gp(s, active, use_status)
         B, N, n, m, A = s.B, s.N, s.n, s.m, s.A
         k, K = s.gain_views()
         alpha = s.alphas.view(1, A, 1)

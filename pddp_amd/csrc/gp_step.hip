@@ -70,6 +70,36 @@ struct Args {
   T* Fu;          // [R n m] or null
 };
 
+// The line search as a device rollout (pddp_gp_rollout_*, ROLL kernels): row
+// r = (trajectory b, step size a) of time step t takes its state from the
+// candidates' own array, forms its action by the control law (ilqr.py:708-716:
+// u = clamp(U + alpha k + K (z - Z))), adds the stage cost of (z, u) - the QR
+// cost on the angle-augmented Gaussian state (costs/quadratic.py:60-99), whose
+// moments ARE the kernel's feature moments - to Jc, steps, and writes the next
+// state into the candidates' array: N launches with nothing between them, and
+// one more (terminal) for the terminal cost.
+constexpr int kMaxAct = 4;
+template <typename T>
+struct Roll {
+  int B, N, A, t, terminal, na;
+  const T* Z;       // [B][N+1][n] nominal
+  const T* U;       // [B][N][m]
+  const T* gains;   // [B][N][m + m n]: k | K
+  const T* alphas;  // [A]
+  const T* u_min;   // [m] nullable (with u_max)
+  const T* u_max;
+  const uint8_t* active;   // [B] nullable
+  const int32_t* status;   // [B] nullable: rows of a failed sweep are skipped
+  T* Zc;            // [B][N+1][A][n]
+  T* Uc;            // [B][N][A][m]
+  T* Jc;            // [B][A]
+  const T* Q;       // [na][na]
+  const T* Qt;      // [na][na] terminal
+  const T* Rm;      // [m][m]
+  const T* xg;      // [na]
+  const T* ug;      // [m]
+};
+
 // ---- dual numbers (one tangent) ----------------------------------------------
 template <typename T>
 struct Dual {
@@ -86,6 +116,8 @@ template <typename T> PDDP_DEV Dual<T> operator/(Dual<T> a, Dual<T> b) {
 }
 using pddp::cos_;
 using pddp::sin_;
+PDDP_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+PDDP_DEV double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 using pddp::sqrt_;
 PDDP_DEV float exp_(float x) { return expf(x); }
 PDDP_DEV double exp_(double x) { return exp(x); }
@@ -264,8 +296,9 @@ PDDP_DEV void spd_inverse(const T* S, const T (&delta)[D], T* G, T& logdet) {
     }
 }
 
-template <typename T, int E, int D, bool JAC>
-PDDP_DEV void gp_step_body(const Args<T>& A) {
+template <typename T, int E, int D, bool JAC, bool ROLL = false>
+PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
+  static_assert(!(JAC && ROLL), "");
   using X = typename std::conditional<JAC, Dual<T>, T>::type;
   constexpr int NP = E * (E + 1) / 2, NS = E + NP, DD = D * D, PS = Lds<E, D>::PS;
   extern __shared__ __align__(32) unsigned char smem_raw[];
@@ -276,6 +309,35 @@ PDDP_DEV void gp_step_body(const Args<T>& A) {
   const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const T* z = A.z + (size_t)row * n;
   const T* u = A.u + (size_t)row * A.m_act;
+  T* z_out = A.z_next + (size_t)row * n;
+  [[maybe_unused]] T u_loc[kMaxAct];
+  if constexpr (ROLL) {
+    const int b = row / RL.A, ai = row - b * RL.A, t = RL.t, m_ = A.m_act;
+    if (RL.active != nullptr && RL.active[b] == 0) return;
+    if (RL.status != nullptr && RL.status[b] != 0) return;
+    const T* zn = RL.Z + ((size_t)b * (RL.N + 1) + t) * n;  // nominal state
+    T* zc = RL.Zc + (((size_t)b * (RL.N + 1) + t) * RL.A + ai) * n;
+    // Z_new[0] = Z[0] (ilqr.py:690): the candidates start on the nominal
+    z = t == 0 ? zn : zc;
+    if (t == 0 && tid < n) zc[tid] = zn[tid];
+    z_out = zc + (size_t)RL.A * n;
+    // (the terminal launch has no action: its feature slot reads zeros)
+    for (int r = 0; r < kMaxAct; ++r) u_loc[r] = 0;
+    u = u_loc;
+    if (!RL.terminal) {
+      // every thread forms the action itself (n FMAs on broadcast loads)
+      const T* g = RL.gains + ((size_t)b * RL.N + t) * (m_ + m_ * n);
+      const T alpha = RL.alphas[ai];
+      for (int r = 0; r < m_; ++r) {
+        T sK = 0;
+        for (int c = 0; c < n; ++c) sK = fma_(z[c] - zn[c], g[m_ + r * n + c], sK);
+        T v = RL.U[((size_t)b * RL.N + t) * m_ + r] + fma_(alpha, g[r], sK);
+        if (RL.u_min != nullptr) v = clamp_nan(v, RL.u_min[r], RL.u_max[r]);
+        u_loc[r] = v;
+        if (tid == 0) RL.Uc[(((size_t)b * RL.N + t) * RL.A + ai) * m_ + r] = v;
+      }
+    }
+  }
   const int nn = A.n_non, nang = A.n_ang, na = nn + 2 * nang, enc = A.encoding;
 
   // ---- front end, element by element, generic in the scalar type ---------------
@@ -382,6 +444,51 @@ PDDP_DEV void gp_step_body(const Args<T>& A) {
     }
   }
   __syncthreads();
+
+  if constexpr (ROLL) {
+    // stage / terminal cost of (z, u): E[(x~ - g)^T Q (x~ - g)] + (u - ug)^T R
+    // (u - ug) on the augmented state = the first na features, whose mean and
+    // covariance the front end just left in LDS.  The covariance enters with
+    // the encoding (quadratic.py:92 and the variance-only encodings: mean only
+    // / diagonal only).  Wave 3, lane (i, j): one product each
+    if (wave == 3) {
+      const int na_ = RL.na, i = lane / 8, j = lane & 7;
+      T term = 0;
+      if (i < na_ && j < na_) {
+        const T* Qm = RL.terminal ? RL.Qt : RL.Q;
+        // (mean only: the augmented STATE, sin / cos of the mean itself -
+        // utils/angular.py augment_state - not the moment-matched features,
+        // which carry the 1e-6 placeholder variance's damping)
+        auto feat = [&](int p) -> T {
+          if (enc != 4) return sm[o.m + p];
+          if (p < nn) return z[A.non[p]];
+          T sv, cv;
+          sincos2(z[A.ang[(p - nn) >> 1]], sv, cv);
+          return ((p - nn) & 1) ? cv : sv;
+        };
+        const T di = feat(i) - RL.xg[i], dj = feat(j) - RL.xg[j];
+        T second = di * dj;
+        if (enc == 1 || ((enc == 2 || enc == 3) && i == j))
+          second += sm[o.S + i * D + j];
+        term = second * Qm[i * na_ + j];
+      }
+      if (!RL.terminal && lane >= 56) {  // (lanes 56..: i = 7 >= na or spare)
+        const int r = lane - 56, m_ = A.m_act;
+        if (r < m_) {
+          T acc = 0;
+          for (int c = 0; c < m_; ++c)
+            acc += (u_loc[c] - RL.ug[c]) * RL.Rm[c * m_ + r];
+          term += acc * (u_loc[r] - RL.ug[r]);
+        }
+      }
+      const T cost = wave_sum(term);
+      if (lane == 0) {
+        T* Jp = RL.Jc + row;
+        *Jp = (RL.t == 0 && !RL.terminal ? (T)0 : *Jp) + cost;
+      }
+    }
+    if (RL.terminal) return;
+  }
 
   // ---- A1 ------------------------------------------------------------------------
   PDDP_GP_MARK(1);
@@ -828,7 +935,7 @@ PDDP_DEV void gp_step_body(const Args<T>& A) {
         const int lo = r < a ? r : a, hi = r < a ? a : r;
         Cn[up(lo, hi)] = Cn[up(lo, hi)] + (r == a ? s + s : s);
       }
-    T* out = A.z_next + (size_t)row * n;
+    T* out = z_out;
     auto emit = [&](int idx, X v) {
       if (lane == 0) out[idx] = prim(v);
       if (JAC) {
@@ -895,6 +1002,25 @@ void gp_step_fwd_f32_kernel(const Args<float> A) {
   gp_step_body<float, E, D, false>(A);
 }
 template <typename T, int E, int D>
+__global__ __launch_bounds__(kThreads) void gp_roll_kernel(const Args<T> A, const Roll<T> RL) {
+  gp_step_body<T, E, D, false, true>(A, RL);
+}
+template <int E, int D>
+__global__ __launch_bounds__(kThreads)
+__attribute__((amdgpu_waves_per_eu(PDDP_GP_FWD_WAVES, PDDP_GP_FWD_WAVES)))
+void gp_roll_f32_kernel(const Args<float> A, const Roll<float> RL) {
+  gp_step_body<float, E, D, false, true>(A, RL);
+}
+template <typename T, int E, int D>
+struct RollKernels {
+  static auto pick() { return gp_roll_kernel<T, E, D>; }
+};
+template <int E, int D>
+struct RollKernels<float, E, D> {
+  static auto pick() { return gp_roll_f32_kernel<E, D>; }
+};
+
+template <typename T, int E, int D>
 struct Kernels {
   static auto pick(bool jac) { return jac ? gp_step_kernel<T, E, D, true> : gp_step_kernel<T, E, D, false>; }
 };
@@ -920,6 +1046,92 @@ int launch(const Args<T>& a, bool jac, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(a.R), dim3(kThreads), bytes, st, a);
   return (int)hipGetLastError();
+}
+
+template <typename T, int E, int D>
+int launch_roll(Args<T> a, Roll<T> r, hipStream_t st) {
+  if (a.n + a.m_act > 64 || r.na > 8 || r.na != a.n_non + 2 * a.n_ang || a.m_act > kMaxAct)
+    return PDDP_E_UNSUPPORTED;
+  const Lds<E, D> o(a.M, a.n + a.m_act, false);
+  const size_t bytes = (size_t)o.total * sizeof(T);
+  if (bytes > 160 * 1024) return PDDP_E_UNSUPPORTED;
+  auto kern = RollKernels<T, E, D>::pick();
+  if (bytes > 64 * 1024) {
+    const hipError_t e =
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  a.R = r.B * r.A;
+  // N steps and the terminal cost: N + 1 launches, nothing between them
+  for (int t = 0; t <= r.N; ++t) {
+    r.t = t;
+    r.terminal = t == r.N ? 1 : 0;
+    hipLaunchKernelGGL(kern, dim3(a.R), dim3(kThreads), bytes, st, a, r);
+  }
+  return (int)hipGetLastError();
+}
+
+template <typename T>
+int fill_model(const pddp_gp_model* g, Args<T>& a) {
+  if (g == nullptr) return PDDP_E_BADARG;
+  if (!g->Xt || !g->Xt_pairs || !g->beta || !g->beta_pairs || !g->Kinv || !g->inv_ell2 || !g->sf2 || !g->sn2)
+    return PDDP_E_BADARG;
+  if (g->n_ang < 0 || g->n_ang > kMaxAng || g->n_non < 0 || g->n_non > kMaxNon) return PDDP_E_BADARG;
+  if (g->n_ang + g->n_non != g->state_size || g->M < 1 || g->action_size < 1) return PDDP_E_BADARG;
+  const int E = g->state_size;
+  a.M = g->M;
+  a.m_act = g->action_size;
+  a.n_ang = g->n_ang;
+  a.n_non = g->n_non;
+  a.encoding = g->encoding;
+  switch (g->encoding) {
+    case 1: a.n = E + E * (E + 1) / 2; break;
+    case 2:
+    case 3: a.n = 2 * E; break;
+    case 4: a.n = E; break;
+    default: return PDDP_E_UNSUPPORTED;  // FULL_COVARIANCE_MATRIX: the torch path
+  }
+  for (int i = 0; i < kMaxAng; ++i) a.ang[i] = i < g->n_ang ? g->ang[i] : 0;
+  for (int i = 0; i < kMaxNon; ++i) a.non[i] = i < g->n_non ? g->non[i] : 0;
+  for (int i = 0; i < g->n_ang; ++i)
+    if (g->ang[i] < 0 || g->ang[i] >= E) return PDDP_E_BADARG;
+  for (int i = 0; i < g->n_non; ++i)
+    if (g->non[i] < 0 || g->non[i] >= E) return PDDP_E_BADARG;
+  a.Xt = (const T*)g->Xt;
+  a.XtP = (const T*)g->Xt_pairs;
+  a.betaP = (const T*)g->beta_pairs;
+  a.beta = (const T*)g->beta;
+  a.Kinv = (const T*)g->Kinv;
+  a.iL = (const T*)g->inv_ell2;
+  a.sf2 = (const T*)g->sf2;
+  a.sn2 = (const T*)g->sn2;
+  a.z = nullptr; a.u = nullptr; a.z_next = nullptr; a.Fz = nullptr; a.Fu = nullptr;
+  return 0;
+}
+
+template <typename T>
+int rollout(const pddp_gp_model* g, const pddp_gp_rollout* q, void* stream) {
+  if (q == nullptr || q->B <= 0 || q->N <= 0 || q->A <= 0 || !q->Z || !q->U || !q->gains ||
+      !q->alphas || !q->Zc || !q->Uc || !q->Jc || !q->Q || !q->Q_term || !q->R || !q->x_goal ||
+      !q->u_goal || ((q->u_min == nullptr) != (q->u_max == nullptr)))
+    return PDDP_E_BADARG;
+  Args<T> a;
+  if (int rc = fill_model<T>(g, a)) return rc;
+  Roll<T> r;
+  r.B = q->B; r.N = q->N; r.A = q->A; r.t = 0; r.terminal = 0;
+  r.na = g->n_non + 2 * g->n_ang;
+  r.Z = (const T*)q->Z; r.U = (const T*)q->U; r.gains = (const T*)q->gains;
+  r.alphas = (const T*)q->alphas; r.u_min = (const T*)q->u_min; r.u_max = (const T*)q->u_max;
+  r.active = q->active; r.status = q->bwd_status;
+  r.Zc = (T*)q->Zc; r.Uc = (T*)q->Uc; r.Jc = (T*)q->Jc;
+  r.Q = (const T*)q->Q; r.Qt = (const T*)q->Q_term; r.Rm = (const T*)q->R;
+  r.xg = (const T*)q->x_goal; r.ug = (const T*)q->u_goal;
+  const int E = g->state_size, D = g->n_non + 2 * g->n_ang + g->action_size;
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 2 && D == 4) return launch_roll<T, 2, 4>(a, r, st);
+  if (E == 4 && D == 6) return launch_roll<T, 4, 6>(a, r, st);
+  if (E == 6 && D == 9) return launch_roll<T, 6, 9>(a, r, st);
+  return PDDP_E_UNSUPPORTED;
 }
 
 template <typename T>
@@ -999,5 +1211,11 @@ int pddp_gp_step_f32(const pddp_gp_model* g, int R, const float* z, const float*
 int pddp_gp_step_f64(const pddp_gp_model* g, int R, const double* z, const double* u, double* z_next,
                      double* Fz, double* Fu, void* stream) {
   return pddp::gp::step<double>(g, R, z, u, z_next, Fz, Fu, stream);
+}
+int pddp_gp_rollout_f32(const pddp_gp_model* g, const pddp_gp_rollout* r, void* stream) {
+  return pddp::gp::rollout<float>(g, r, stream);
+}
+int pddp_gp_rollout_f64(const pddp_gp_model* g, const pddp_gp_rollout* r, void* stream) {
+  return pddp::gp::rollout<double>(g, r, stream);
 }
 }

@@ -414,9 +414,13 @@ def test_gp_line_search_with_batched_costs_equals_the_generic_one(encoding):
         for _ in range(B)]).cuda()
     U0 = (0.3 * torch.randn(B, N, m, generator=g, dtype=torch.float64)).cuda()
     got = []
-    for fast in (True, False):
+    for fast in ("rollout", "per_step", False):
         plugin = TorchProblem(model, CartpoleCost().double().cuda(), enc, {},
                               {})
+        # "rollout": pddp_gp_rollout_* (control law, clamp, step and stage
+        # cost in the step's kernel); "per_step": torch ops around
+        # pddp_gp_step_* + batched costs; False: the generic line search
+        plugin.use_gp_rollout = fast == "rollout"
         s = ILQRSolver(None, B, N, torch.float64, "cuda",
                        torch.tensor([-10.0], dtype=torch.float64),
                        torch.tensor([10.0], dtype=torch.float64),
@@ -430,8 +434,74 @@ def test_gp_line_search_with_batched_costs_equals_the_generic_one(encoding):
             plugin._gp_line_search_ok = lambda s_: False
         s.line_search(active=s.active)
         got.append((s.Zc.clone(), s.Uc.clone(), s.Jc.clone()))
+    for other in got[1:]:
+        for a, b in zip(got[0], other):
+            assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("system", ["pendulum", "double_cartpole"])
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_gp_rollout_kernel_vs_per_step_line_search(system, dtype):
+    """pddp_gp_rollout_* on the other two systems (E = 2 and E = 6: eight
+    augmented features, the full 8 x 8 lane map of the cost), DEFAULT encoding,
+    with masked trajectories and failed sweeps: candidates, actions and costs
+    against the per-step torch form; skipped rows untouched."""
+    import pddp_amd.examples as ex
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    mod = getattr(ex, system)
+    cost_cls = [getattr(mod, k) for k in dir(mod) if k.endswith("Cost") and
+                k not in ("AugmentedQRCost", "QRCost")][0]
+    enc = StateEncoding.DEFAULT
+    # (the GP on the example model's own angular / non-angular indices: the
+    # cost's augmented state must be the model's features)
+    MC = [getattr(mod, k) for k in dir(mod) if k.endswith("DynamicsModel") and
+          k != "DynamicsModel"][0]
+    E, m = MC.state_size, 1
+    g = torch.Generator().manual_seed(2)
+    Md = 24
+    Xd = torch.randn(Md, E, generator=g, dtype=torch.float64)
+    Ud = torch.randn(Md, m, generator=g, dtype=torch.float64)
+    dXd = 0.1 * torch.randn(Md, E, generator=g, dtype=torch.float64)
+    model = gp_dynamics_model_factory(E, m, MC.angular_indices,
+                                      MC.non_angular_indices)().double().cuda()
+    model.fit(Xd.cuda(), Ud.cuda(), dXd.cuda())
+    model = model.to(dtype).eval()
+    n = E + E * (E + 1) // 2
+    B, N = 7, 6
+    z0 = torch.stack([GaussianVariable(
+        0.3 * torch.randn(E, generator=g, dtype=torch.float64),
+        var=1e-2 * torch.ones(E, dtype=torch.float64)).encode(enc)
+        for _ in range(B)]).to(dtype).cuda()
+    U0 = (0.3 * torch.randn(B, N, m, generator=g)).to(dtype).cuda()
+    bound = torch.tensor([2.0], dtype=dtype)
+    got = []
+    for roll in (True, False):
+        plugin = TorchProblem(model, cost_cls().to(dtype).cuda(), enc, {}, {})
+        plugin.use_gp_rollout = roll
+        s = ILQRSolver(None, B, N, dtype, "cuda", -bound, bound,
+                       fit_alphas(dtype, "cuda"), plugin=plugin, n=n, m=m)
+        s.set_nominal(z0, U0)
+        s.derivs()
+        s.mu.fill_(1.0)
+        s.backward(active=s.active)
+        assert plugin._gp_line_search_ok(s)
+        s.active[2] = 0
+        s.bwd_status[4] = 3
+        s.Zc.fill_(-7.0)
+        s.Jc.fill_(-7.0)
+        s.line_search(active=s.active)
+        got.append((s.Zc.clone(), s.Uc.clone(), s.Jc.clone()))
+    live = torch.ones(B, dtype=torch.bool)
+    live[2] = live[4] = False
+    tol = 1e-9 if dtype == torch.float64 else 2e-4
     for a, b in zip(*got):
-        assert torch.allclose(a, b, rtol=1e-9, atol=1e-9)
+        assert torch.allclose(a[live], b[live], rtol=tol, atol=tol), \
+            float((a[live] - b[live]).abs().max())
+    assert bool((got[0][0][~live] == -7.0).all())   # skipped rows: untouched
+    assert bool((got[0][2][~live] == -7.0).all())
 
 
 @pytest.mark.gpu
