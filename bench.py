@@ -726,19 +726,22 @@ def bench_gp(args, emit=True):
             # (vector arithmetic, no matrix cores: priced against the f32
             # rate of the part, which is the same number for both)
             "bound": "mfma", "unit_of_work": "valu",
-            "kernel": "gp_step_kernel<float, 6, 9, false>: GP moment-matched "
-                      "step, %d candidate rows (one line-search time step)"
+            "kernel": "gp_roll_f32_kernel<6, 9> (gp_step_body: control law, "
+                      "GP moment-matched step and stage cost of %d candidate "
+                      "rows - one line-search time step)"
                       % rows,
             "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
             "avg_launch_us": dur * 1e6, "algorithmic_flop_per_launch": flop,
             "flop_per_pair_point_point": 2 * d_in + 6,
-            "traffic": None},
+            "traffic": profile_traffic("gp_roll_f32_kernel<6, 9>", "dcgp") or
+                       profile_traffic("gp_step_fwd_f32_kernel<6, 9>", "dcgp")},
         "cpu_baseline": None,
     }
     if world == 1:
         from pddp_amd import _native
-        out["roofline"]["other_kernels"] = [sweep_roofline_of(s, _native.lib())]
+        out["roofline"]["other_kernels"] = [sweep_roofline_of(
+            s, _native.lib(), traffic_tag="dcgp")]
         if not args.no_cpu_baseline:
             import copy
             cpu = copy.deepcopy(model).cpu()
@@ -902,8 +905,10 @@ def bench_mpc_bnn(args, emit=True):
             "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
             "avg_launch_us": dur * 1e6, "algorithmic_flop_per_launch": flop,
-            "traffic": None,
-            "other_kernels": [sweep_roofline_of(sv, _native.lib())]}
+            "traffic": profile_traffic("bnn_mlp_kernel<200, 8, 8", "mpc") or
+                       profile_traffic("bnn_mlp_kernel<200, 8, 8", "cpbnn"),
+            "other_kernels": [sweep_roofline_of(sv, _native.lib(),
+                                                traffic_tag="cpbnn")]}
         if not args.no_cpu_baseline:
             cb = bnn_cpu_baseline(model, enc, N, 14, 1, 11,
                                   {"use_predicted_std": False,
@@ -1327,15 +1332,17 @@ def main():
             out["cpu_baseline"] = None
         if world == 1 and not args.no_secondary and B == 4096 and N == 100 \
                 and args.dtype == "f32":
-            # BASELINE configs[2] / [3] (one GPU's shard) / [4], shortened, in
-            # the driver's line: 2 rounds, 2 rounds, 20 control steps
+            # BASELINE configs[2] / [3] (one GPU's shard, BNN and GP) / [4] in
+            # the driver's line: five timed rounds each, configs[4] in full
+            # (200 control steps of all 256 restarts)
             import copy
             del s
             torch.cuda.empty_cache()
             sec = []
-            for wl, k, w in (("cartpole_bnn", 2, 1),
-                             ("double_cartpole_bnn", 2, 1),
-                             ("double_cartpole_gp", 1, 1), ("mpc_bnn", 20, 2)):
+            for wl, k, w in (("cartpole_bnn", 5, 1),
+                             ("double_cartpole_bnn", 5, 1),
+                             ("double_cartpole_gp", 5, 1),
+                             ("mpc_bnn", 200, 2)):
                 a2 = copy.copy(args)
                 a2.workload, a2.steps, a2.warmup = wl, k, w
                 a2.batch = a2.horizon = None
