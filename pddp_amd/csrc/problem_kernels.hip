@@ -363,8 +363,9 @@ line_search_lds_kernel(
   T Jmine = T(0);
   // (candidates dropped: see LineSearchArgs::drop_candidates)
   // (where the tail's short form applies: it reads the winner's compact rows)
-  const bool nocand = FUSED && Lout == nullptr && rec != nullptr &&
-                      a.drop_candidates != 0 && n <= 6 && N + 1 <= 16 * H * 4;
+  // (n <= 4: a second inlined copy of the larger models' step spills)
+  const bool nocand = FUSED && n <= 4 && Lout == nullptr && rec != nullptr &&
+                      a.drop_candidates != 0 && N + 1 <= 16 * H * 4;
   // One rollout of this lane's candidate (ilqr.py:677-723 + :764-791): states
   // to Zci (stride zstep per step), actions to Uci (stride ustep), the cost
   // returned.  A stride of zero makes the target a one-row scratch - the
@@ -471,10 +472,12 @@ line_search_lds_kernel(
     // it out once more, into the compact rows the tail reads (the same code on
     // the same inputs: its states to rounding - two inlined copies of the step
     // are not contracted alike - and its cost, Jc, from the first time)
-    if (nocand && hid == 0 && __any(amin_out > 0)) {
-      if (amin_out > 0 && ai == amin_out)
-        rollout(a.alphas[ai], rec + (size_t)b * (N + 1) * n, (size_t)n,
-                a.Uc + ((size_t)b * N * a.A + ai) * m, 0);
+    if constexpr (n <= 4) {
+      if (nocand && hid == 0 && __any(amin_out > 0)) {
+        if (amin_out > 0 && ai == amin_out)
+          rollout(a.alphas[ai], rec + (size_t)b * (N + 1) * n, (size_t)n,
+                  a.Uc + ((size_t)b * N * a.A + ai) * m, 0);
+      }
     }
     if constexpr (H == 1) {
       if (!__any(amin_out >= 0)) return;

@@ -35,6 +35,23 @@ def test_abi_library_exports_every_declared_symbol():
     assert lay.stride % 4 == 0 and lay.stride >= 2 * 27 * 27 + 3 * 27 + 3
 
 
+def test_no_new_spilling_kernel():
+    """Register spills / scratch of every kernel in the built library against
+    the reviewed list (profiles/kernel_resources_allowed.csv): a kernel that
+    starts to spill, or spills more, fails here - on the CPU, from the code
+    object's metadata (tools/kernel_resources.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import kernel_resources as kr
+    finally:
+        sys.path.pop(0)
+    rows = kr.kernel_resources()
+    assert len(rows) > 100  # (the metadata was found)
+    bad = kr.check(rows)
+    assert not bad, bad
+
+
 def test_no_cpu_fallback():
     """The product path refuses CPU tensors instead of silently computing."""
     import pddp_amd
@@ -363,6 +380,7 @@ def test_hot_kernels_keep_their_working_set_in_registers():
         # workgroups per CU (0.81 against 1.02 ms per launch): 9 registers
         # spilled in the per-row front end
         "gp_step_fwd_f32_kernel<6, 9>",
+        "gp_roll_f32_kernel<6, 9>",             # the same body behind the rollout's front end
         # (fp64 Jacobian kernel at the 512-register file: ten values parked
         # in accumulation registers, no scratch)
         "gp_step_kernel<double, 6, 9, true>",
