@@ -304,6 +304,9 @@ class TorchProblem(object):
         cost in the step's own kernel, N + 1 launches with nothing between
         them (`pddp_gp_rollout_*`, csrc/gp_step.hip)."""
         mo, co = self.model, self.cost
+        import os
+        if os.environ.get("PDDP_NO_GP_ROLLOUT"):
+            return self._line_search_gp_torch(s)
         if not (self.use_gp_rollout and mo.state_size + 0 <= 6 and
                 len(mo.non_angular_indices) + 2 * len(mo.angular_indices) <= 8
                 and s.m <= 4):
