@@ -4,7 +4,7 @@
 # Writes raw output under gpurun_out/<tag>_* ; tools/summarise_profiles.py then
 # condenses it into profiles/ (tracked).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 if [ "${2:-}" != "bnn" ]; then
