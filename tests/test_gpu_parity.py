@@ -2651,6 +2651,58 @@ def test_bnn_training_step_vs_reference_golden():
         assert e < 1e-9, (n, e)
 
 
+def test_bnn_fit_itself_vs_reference_golden(monkeypatch):
+    """`BNNDynamicsModel.fit()` - its own normalisation, shuffled mini-batch
+    loop, likelihood + regulariser and Adam(amsgrad) (modules.py:131-198) -
+    against the reference's parameters after three full-batch steps with held
+    masks (group train/ of round3_extras.npz).  The held concrete-dropout
+    noise is per (row, unit): the fixture's rows are in data order, so the
+    epoch's permutation is replayed as the identity (`torch.randperm`
+    patched for the call).  The captured-step path is held to this one by
+    test_bnn_training_graph_equals_eager."""
+    monkeypatch.setattr(torch, "randperm",
+                        lambda n, **kw: torch.arange(n, **kw))
+    from pddp_amd.examples.cartpole import CartpoleDynamicsModel as CM
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    g = _round3()
+    dt = torch.float64
+    t = lambda a: torch.as_tensor(np.asarray(a), dtype=dt).cuda()
+    X, U, dX = t(g["train/X"]), t(g["train/U"]), t(g["train/dX"])
+    Nd = X.shape[0]
+    model = bnn_dynamics_model_factory(4, 1, [32, 24], CM.angular_indices,
+                                       CM.non_angular_indices)(
+        n_particles=10).to(dt).cuda()
+    mlp = model.model
+    ours = {"model.fc_0.weight": mlp.hidden[0].weight,
+            "model.fc_0.bias": mlp.hidden[0].bias,
+            "model.drop_0.logit_p": mlp.drops[0].logit_p,
+            "model.fc_1.weight": mlp.hidden[1].weight,
+            "model.fc_1.bias": mlp.hidden[1].bias,
+            "model.drop_1.logit_p": mlp.drops[1].logit_p,
+            "model.fc_out.weight": mlp.out.weight,
+            "model.fc_out.bias": mlp.out.bias}
+    names = [str(n) for n in g["train/param_names"]]
+    with torch.no_grad():
+        for n in names:
+            ours[n].copy_(t(g["train/init/" + n]).reshape(ours[n].shape))
+        for k in (0, 1):
+            mlp.drops[k].noise = t(g["train/state/drop_%d.noise" % k])
+            mlp.drops[k].temperature.copy_(
+                t(g["train/state/drop_%d.temperature" % k]))
+    model.fit(X, U, dX, n_iter=3, batch_size=Nd,
+              reg_scale=float(g["train/reg_scale"]),
+              learning_rate=float(g["train/lr"]), resample=False,
+              normalize=True, quiet=True, graph=False)
+    assert model.last_fit_used_graph is False
+    for nm in ("X_mean", "X_std", "dX_mean", "dX_std"):
+        assert rel_err(getattr(model, nm).cpu().numpy(),
+                       g["train/state/" + nm]) < 1e-12, nm
+    for n in names:
+        e = rel_err(ours[n].detach().cpu().numpy().reshape(-1),
+                    g["train/after3/" + n].reshape(-1))
+        assert e < 1e-9, (n, e)
+
+
 def test_pddp_controller_fit_vs_reference_golden():
     """PDDPController.fit (pddp.py:61-206) against the reference's own run
     (group pddp/): a deterministic plant (the true cartpole model, no noise),
