@@ -284,13 +284,12 @@ int pddp_pack_best_f64(int B, int nz, int nu, const double* J, const double* Z,
  * pddp_riccati_backward_* reads at B = 4096, N = 100 stay on the chip.
  * Results as pddp_derivs_* followed by pddp_riccati_backward_* (auto kernel):
  * gains [B][N][5], status [B]; L [B][N+1] the stage / terminal costs of the
- * nominal (rows of ACTIVE trajectories; the four-role kernel also refreshes
- * inactive rows that share a workgroup with an active one - same values);
+ * nominal (rows of ACTIVE trajectories);
  * for trajectories with fresh[b] != 0 (all, when fresh is NULL)
  * J_opt[b] = sum_t L[b][t] in t order (ilqr.py:289 L.sum()) and fresh[b] is
  * cleared.  Z [B][N+1][4], U [B][N] un-clamped nominal actions.  Cartpole
  * under IGNORE_UNCERTAINTY, f32, bounded (u_min, u_max non-NULL), branch
- * PDDP_BRANCH_EIG, N >= 8: PDDP_E_UNSUPPORTED otherwise (make the two calls
+ * PDDP_BRANCH_EIG: PDDP_E_UNSUPPORTED otherwise (make the two calls
  * then).  `L` of pddp_search_accept_* may be NULL with this sweep. */
 int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
                            const float* Z, const float* U, const float* u_min,
@@ -299,13 +298,11 @@ int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
                            int32_t* status, float* L, float* J_opt,
                            void* stream);
 
-/* Which kernel pddp_sweep_nominal_f32 launches: 0 = auto (the one-wavefront
- * kernel, csrc/riccati_n4_elem.hpp), 1 = the four-role kernel
- * (csrc/riccati_n4_defer.hpp; needs N >= 8), 2 = the one-wavefront kernel or
- * PDDP_E_UNSUPPORTED, 3 / 4 = 2 with its record generator inline / on
- * wavefronts of its own whatever the batch (auto: by batch).  Process-wide (an
- * A/B and test knob); -1 only queries.
- * Returns the previous choice. */
+/* How pddp_sweep_nominal_f32 (csrc/riccati_n4_elem.hpp) generates its records:
+ * 0 = auto (on wavefronts of their own while one workgroup per CU holds the
+ * batch, inline beyond), 3 = inline, 4 = on wavefronts of their own; results
+ * are bit-identical.  Other values are ignored.  Process-wide (an A/B and
+ * test knob); -1 only queries.  Returns the previous choice. */
 int pddp_sweep_nominal_kernel(int which);
 
 /* ---- one launch for the rest of a round: the line search, the accept step

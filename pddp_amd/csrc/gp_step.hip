@@ -310,13 +310,11 @@ PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
   const T* z = A.z + (size_t)row * n;
   const T* u = A.u + (size_t)row * A.m_act;
   T* z_out = A.z_next + (size_t)row * n;
-  // (ROLL: the action, formed here.  Indexed at run time, so it lives in 16
-  // bytes of scratch; the form with four scalars and a select chain was built
-  // in round 4 and is NOT kept: with it the GPU suite died of a hardware
-  // exception - reported against a later torch kernel - in four runs of four,
-  // with this form in none of four; no difference was found in the code the
-  // compiler emits for either beyond the scratch set-up)
-  [[maybe_unused]] T u_loc[kMaxAct];
+  // (ROLL: the action, formed here and kept in four scalars - an array indexed
+  // at run time would live in scratch)
+  static_assert(kMaxAct == 4, "act() below selects among four scalars");
+  [[maybe_unused]] T ua0 = 0, ua1 = 0, ua2 = 0, ua3 = 0;
+  [[maybe_unused]] auto act = [&](int r) -> T { return r == 0 ? ua0 : r == 1 ? ua1 : r == 2 ? ua2 : ua3; };
   if constexpr (ROLL) {
     const int b = row / RL.A, ai = row - b * RL.A, t = RL.t, m_ = A.m_act;
     if (RL.active != nullptr && RL.active[b] == 0) return;
@@ -328,8 +326,6 @@ PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
     if (t == 0 && tid < n) zc[tid] = zn[tid];
     z_out = zc + (size_t)RL.A * n;
     // (the terminal launch has no action: its feature slot reads zeros)
-    for (int r = 0; r < kMaxAct; ++r) u_loc[r] = 0;
-    u = u_loc;
     if (!RL.terminal) {
       // every thread forms the action itself (n FMAs on broadcast loads)
       const T* g = RL.gains + ((size_t)b * RL.N + t) * (m_ + m_ * n);
@@ -339,7 +335,10 @@ PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
         for (int c = 0; c < n; ++c) sK = fma_(z[c] - zn[c], g[m_ + r * n + c], sK);
         T v = RL.U[((size_t)b * RL.N + t) * m_ + r] + fma_(alpha, g[r], sK);
         if (RL.u_min != nullptr) v = clamp_nan(v, RL.u_min[r], RL.u_max[r]);
-        u_loc[r] = v;
+        ua0 = r == 0 ? v : ua0;
+        ua1 = r == 1 ? v : ua1;
+        ua2 = r == 2 ? v : ua2;
+        ua3 = r == 3 ? v : ua3;
         if (tid == 0) RL.Uc[(((size_t)b * RL.N + t) * RL.A + ai) * m_ + r] = v;
       }
     }
@@ -366,7 +365,8 @@ PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
       ang_mean((p - nn) >> 1, k, es, ec);
       return ((p - nn) & 1) ? ec : es;
     }
-    return seed<X, T>(u[p - na], n + (p - na), k);
+    if constexpr (ROLL) return seed<X, T>(act(p - na), n + (p - na), k);
+    else return seed<X, T>(u[p - na], n + (p - na), k);
   };
   // feature covariance (p, q), utils/angular.py augment_moments
   auto S_of = [&](int p, int q, int k) -> X {
@@ -483,8 +483,8 @@ PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
         if (r < m_) {
           T acc = 0;
           for (int c = 0; c < m_; ++c)
-            acc += (u_loc[c] - RL.ug[c]) * RL.Rm[c * m_ + r];
-          term += acc * (u_loc[r] - RL.ug[r]);
+            acc += (act(c) - RL.ug[c]) * RL.Rm[c * m_ + r];
+          term += acc * (act(r) - RL.ug[r]);
         }
       }
       const T cost = wave_sum(term);

@@ -213,32 +213,10 @@ PDDP_DEV void solve3(const T (&A)[3][3], T (&B)[3][NR]) {
     }
 }
 
-// A caller may pass a callable that is invoked at a few points of the longer
-// evaluations below - about every hundred instructions - and do nothing by
-// default.  The sweep that evaluates its records itself (riccati_n4_defer.hpp,
-// generator wavefronts) puts its phase barrier there: a record evaluation is
-// several phases long and every wavefront of the workgroup has to arrive at
-// the barrier of every phase.
-// A sync point is numbered (an integral_constant: the callee may act on a
-// subset) and names the values the segment before it produced - the callee
-// can pin them (pin_value) so that the compiler keeps that segment's
-// arithmetic on its side of the barrier.
-struct NoSync {
-  template <class K, class... A>
-  PDDP_DEV void operator()(K, A&...) const {}
-};
-template <int K>
-using SyncPoint = std::integral_constant<int, K>;
-template <class T>
-PDDP_DEV void pin_value(T& x) {
-  asm volatile("" : "+v"(x));
-}
-
 // z_next = model(z, u); if JAC also F_z [n][n] and F_u [n][m] (row-major).
-template <typename T, int MODEL, bool JAC, class Sync = NoSync>
+template <typename T, int MODEL, bool JAC>
 PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
-                       const Trig<T, MODEL>& tr, T* zn, T* Fz, T* Fu,
-                       Sync&& sync = Sync()) {
+                       const Trig<T, MODEL>& tr, T* zn, T* Fz, T* Fu) {
   using D = ModelDims<MODEL>;
   constexpr int n = D::n, m = D::m;
   const T dt = P.dt;
@@ -257,7 +235,6 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
     T a1 = g * s;
     T a2 = F - mu * xd;
     T a3 = T(4) * (mc + mp) - T(3) * mp * c * c;
-    if constexpr (JAC) sync(SyncPoint<5>{}, a0, a1, a2, a3);
     T num_t = a0 * c + T(2) * ((mc + mp) * a1 + a2 * c);
     // one reciprocal of a3 serves both accelerations (and the Jacobians)
     T ia3 = inv_(a3);
@@ -272,7 +249,6 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
     zn[2] = th + nthd * dt;
     zn[3] = nthd;
     if constexpr (JAC) {
-      sync(SyncPoint<1>{}, a0, a1, a2, a3, num_t, num_x, ia3);
       T da0_th = mp * l * thd * thd * c;
       T da0_thd = T(2) * mp * l * thd * s;
       const T da1_th = g * c;
@@ -286,13 +262,11 @@ PDDP_DEV void dynamics(const ProblemT<T>& P, const T* z, const T* u,
       const T dnx_xd = T(-4) * mu;
       const T dnx_F = T(4);
       const T kt = T(-3) * il;
-      sync(SyncPoint<2>{}, da0_thd, da3_th, dnt_th, dnt_thd, dnx_th);
       const T dthdd_xd = kt * dnt_xd * ia3;
       const T dthdd_th = kt * (dnt_th * a3 - num_t * da3_th) * ia3 * ia3;
       const T dthdd_thd = kt * dnt_thd * ia3;
       const T dthdd_F = kt * dnt_F * ia3;
       T dthdd_thp = dthdd_th, dthdd_xdp = dthdd_xd, dthdd_thdp = dthdd_thd;
-      sync(SyncPoint<6>{}, dthdd_thp, dthdd_xdp, dthdd_thdp);
       const T dxdd_xd = dnx_xd * ia3;
       const T dxdd_th = (dnx_th * a3 - num_x * da3_th) * ia3 * ia3;
       const T dxdd_thd = dnx_thd * ia3;
@@ -494,11 +468,10 @@ PDDP_DEV T cost_value(const ProblemT<T>& P, const T* z, const T* u,
 // Cost with gradient and Hessian w.r.t. (z, u) (ilqr.py:464-465,471-473).
 // l_uz is identically zero for QRCost and is not returned.  QM as in
 // cost_value: rows / columns outside it only ever contribute exact zeros.
-template <typename T, int MODEL, unsigned QM = kFullMask<MODEL>,
-          class Sync = NoSync>
+template <typename T, int MODEL, unsigned QM = kFullMask<MODEL>>
 PDDP_DEV T cost_derivs(const ProblemT<T>& P, const T* z, const T* u,
                        const Trig<T, MODEL>& tr, bool terminal, T* l_z,
-                       T* l_zz, T* l_u, T* l_uu, Sync&& sync = Sync()) {
+                       T* l_zz, T* l_u, T* l_uu) {
   using D = ModelDims<MODEL>;
   constexpr int na = D::na, n = D::n, m = D::m;
   const T* Q = terminal ? P.Qt : P.Q;
@@ -532,9 +505,6 @@ PDDP_DEV T cost_derivs(const ProblemT<T>& P, const T* z, const T* u,
 #pragma unroll
   for (int i = 0; i < na; ++i)
     if ((QM >> i) & 1u) l_z[D::col[i]] += d[i] * g[i];
-  if constexpr (n == 4 && na == 5)
-    sync(SyncPoint<4>{}, cost, g[0], g[1], g[2], g[3], g[4], l_z[0], l_z[1],
-         l_z[2], l_z[3]);
 #pragma unroll
   for (int i = 0; i < n * n; ++i) l_zz[i] = T(0);
 #pragma unroll
@@ -547,9 +517,6 @@ PDDP_DEV T cost_derivs(const ProblemT<T>& P, const T* z, const T* u,
             d[i] *
             ((Q[i * PDDP_MAX_AUG + k] + Q[k * PDDP_MAX_AUG + i]) * d[k]);
   }
-  if constexpr (n == 4 && na == 5)
-    sync(SyncPoint<7>{}, l_zz[0], l_zz[2], l_zz[8], l_zz[10], l_zz[3],
-         l_zz[12], l_zz[15]);
   // second derivative of the augmentation: d2 sin = -sin, d2 cos = -cos
 #pragma unroll
   for (int i = 0; i < na; ++i)
@@ -587,11 +554,10 @@ PDDP_DEV T cost_derivs(const ProblemT<T>& P, const T* z, const T* u,
 // bounds (ilqr.py:457-473, 602-603).  QM: live rows of the STAGE cost matrix
 // (a terminal row is evaluated in full whatever QM says when `terminal` is a
 // run-time flag shared by both; pass the full mask then).
-template <typename T, int MODEL, unsigned QM = kFullMask<MODEL>,
-          class Sync = NoSync>
+template <typename T, int MODEL, unsigned QM = kFullMask<MODEL>>
 PDDP_DEV T record_of(const ProblemT<T>& P, const T* z, const T* un,
                      bool terminal, bool bounded, const T* u_min,
-                     const T* u_max, T* w, Sync&& sync = Sync()) {
+                     const T* u_max, T* w) {
   using D = ModelDims<MODEL>;
   constexpr int n = D::n, m = D::m;
   constexpr RecLayout lay(n, m);
@@ -606,22 +572,16 @@ PDDP_DEV T record_of(const ProblemT<T>& P, const T* z, const T* un,
 #pragma unroll
   for (int j = 0; j < m * m; ++j) luu[j] = T(0);
   Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
-  sync(SyncPoint<0>{}, tr.s[0], tr.c[0]);
   if (!terminal) {
-    dynamics<T, MODEL, true>(P, z, u, tr, zn, Fz, Fu, sync);
+    dynamics<T, MODEL, true>(P, z, u, tr, zn, Fz, Fu);
   } else {
 #pragma unroll
     for (int j = 0; j < n * n; ++j) Fz[j] = T(0);
 #pragma unroll
     for (int j = 0; j < n * m; ++j) Fu[j] = T(0);
   }
-  // (all of F: a callee that stores them here takes their evaluation along)
-  if constexpr (n == 4 && m == 1)
-    sync(SyncPoint<3>{}, Fz[0], Fz[1], Fz[2], Fz[3], Fz[4], Fz[5], Fz[6],
-         Fz[7], Fz[8], Fz[9], Fz[10], Fz[11], Fz[12], Fz[13], Fz[14], Fz[15],
-         Fu[0], Fu[1], Fu[2], Fu[3]);
   const T l =
-      cost_derivs<T, MODEL, QM>(P, z, u, tr, terminal, lz, lzz, lu, luu, sync);
+      cost_derivs<T, MODEL, QM>(P, z, u, tr, terminal, lz, lzz, lu, luu);
 #pragma unroll
   for (int j = 0; j < n * n; ++j) w[lay.oFz + j] = Fz[j];
 #pragma unroll

@@ -39,19 +39,17 @@ extern "C" int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
   a.gains = gains;
   a.status = status;
   const pddp::n4d::GenArgs<float> gen = {Z, U, L, J_opt, fresh};
-  // auto: the one-wavefront kernel (riccati_n4_elem.hpp)
+  // riccati_n4_elem.hpp: its record generator inline, on wavefronts of its
+  // own, or (auto) by batch
   const int choice = pddp::nominal_kernel_choice();
-  if (choice != 1) {
-    const int rc = pddp::launch_n4_elem(*problem, a, gen, (hipStream_t)stream,
-                                        choice == 3 ? 0 : choice == 4 ? 1 : -1);
-    if (rc != PDDP_E_UNSUPPORTED || choice >= 2) return rc;
-  }
-  return pddp::launch_n4_gen(*problem, a, gen, (hipStream_t)stream);
+  return pddp::launch_n4_elem(*problem, a, gen, (hipStream_t)stream,
+                              choice == 3 ? 0 : choice == 4 ? 1 : -1);
 }
 
 extern "C" int pddp_sweep_nominal_kernel(int which) {
   const int prev = pddp::nominal_kernel_choice();
-  if (which >= 0 && which <= 4) pddp::nominal_kernel_choice() = which;
+  if (which == 0 || which == 3 || which == 4)
+    pddp::nominal_kernel_choice() = which;
   return prev;
 }
 

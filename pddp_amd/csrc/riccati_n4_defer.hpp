@@ -232,34 +232,16 @@ struct GenArgs {
   uint8_t* fresh;  // [B] nullable: "the nominal changed"; cleared
 };
 
-// NP = 0: role P streams the records from `a.rec` by LDS-DMA (above).
-// NP > 0: nothing is read from `a.rec`.  NP GENERATOR wavefronts evaluate the
-// records of the nominal (gen.Z, gen.U) with the sample problem's closed
-// forms (models.hpp record_of - the code of derivs_kernel and of the fused
-// line search's tail) straight into the ring: one lane per (trajectory, step),
-// a wavefront = a BLOCK of four consecutive steps of the sixteen trajectories.
-// A block takes a generator 4 NP phases (its evaluation is cut into segments
-// by the phase barrier: the sync points of models.hpp, which also pin the
-// segment's results so that the compiler keeps the arithmetic between the
-// barriers it was written between); block j = records N-1-4j .. N-4-4j is
-// first read in phase 4j - 1, written in phase 4j - 2, and its slots are dead
-// from phase 4j + 5 - R on: R >= 4 NP + 6 ring slots.  Built: one generator,
-// twelve slots (two generators and sixteen slots were measured too: the fifth
-// wavefront costs every phase barrier more than the shorter segments save).
-// Role Q evaluates the terminal record before the first phase; generator 0
-// sums the stage costs (J_opt) in the phases after its last block.  The 79 MB
-// of records per launch at B = 4096 are then neither written by the line
-// search's tail nor read here.
-template <typename T, bool FAST, int R, int NP, unsigned QM>
-PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
-                         const ProblemT<T>& prob) {
+// Role P streams the records from `a.rec` by LDS-DMA (above).  (Round 3's
+// form with a generator wavefront instead of role P - the sweep from the
+// nominal - is superseded by riccati_n4_elem.hpp and gone; GenArgs stays: it is
+// that kernel's argument block.)
+template <typename T, bool FAST, int R>
+PDDP_DEV void defer_body(const RiccatiArgs<T>& a) {
   using G = n4q::QuadGeom<T>;
-  constexpr bool GEN = NP > 0;
-  constexpr int kThreads = (3 + (GEN ? NP : 1)) * kWave;
+  constexpr int kThreads = 4 * kWave;
   constexpr int NI = G::NI, RPI = G::RPI, CH = G::CH, CB = G::CB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  // GEN: terminal L_zz (16) and L_z (4) of every trajectory
-  __shared__ __attribute__((aligned(16))) T term_sh[GEN ? kTraj : 1][20];
   // exchange buffers, two parities each (written in phase p, read in p + 1)
   __shared__ __attribute__((aligned(16))) T xq[2][kTraj][4];   // Q: k, s, c, w
   __shared__ __attribute__((aligned(16))) T xin[2][kTraj][4];  // M: A00 | Y: G0, g2, B00
@@ -285,28 +267,6 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
   const int b = b0 + tr;
   const bool exists = b < a.B;
   const int bc = exists ? b : a.B - 1;
-  // GEN: the first operands of this wavefront's role - the generator's first
-  // block, role Q's terminal state - requested before anything waits on
-  // memory (`active` below): one memory latency at the start, not two (in
-  // the fit loop the nominal was written by the launch before: not in L2)
-  T pre_z[4] = {T(0), T(0), T(0), T(0)}, pre_u = T(0);
-  if constexpr (GEN) {
-    const int gt = lane & 15;
-    const int gb = b0 + gt < a.B ? b0 + gt : a.B - 1;
-    int row = -1;
-    if (role >= 3) {
-      row = N - 1 - 4 * (role - 3) - (lane >> 4);
-      row = row < 0 ? 0 : row;
-    } else if (role == 1 && lane < kTraj) {
-      row = N;
-    }
-    if (row >= 0) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(
-          gen.Z + ((size_t)gb * (size_t)(N + 1) + row) * 4);
-      pre_z[0] = v[0]; pre_z[1] = v[1]; pre_z[2] = v[2]; pre_z[3] = v[3];
-      if (row < N) pre_u = gen.U[(size_t)gb * (size_t)N + row];
-    }
-  }
   // (identical in the four waves: they own the same sixteen trajectories)
   const bool counted = exists && (a.active == nullptr || a.active[bc] != 0);
   if (!__any(counted)) return;
@@ -316,176 +276,7 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
   PDDP_DW_DECL
   if (role == 0) PDDP_DW_MARK(0, 0);
 
-  // GEN: stage costs of the sixteen trajectories, [kTraj][N + 1], behind the ring
-  T* Lsh = ring + R * G::SLOT;
-  if constexpr (GEN) {
-    if (role >= 3) {
-      // =========================================================== generator
-      constexpr int MODEL = PDDP_MODEL_CARTPOLE;
-      const int g = role - 3;
-      const int gt = lane & 15, sb = lane >> 4;
-      const bool gex = b0 + gt < a.B;
-      const int gb = gex ? b0 + gt : a.B - 1;
-      const int grbase = (gt / RPI) * G::GS + (gt % RPI) * kRec;
-      const T* Zg = gen.Z + (size_t)gb * (size_t)(N + 1) * 4;
-      const T* Ug = gen.U + (size_t)gb * (size_t)N;
-      const int nblk = (N + 3) / 4;
-      // (asked now: needed after the last block only)
-      const bool sums = gex && (a.active == nullptr || a.active[gb] != 0) &&
-                        (gen.fresh == nullptr || gen.fresh[gb] != 0);
-      // A pass = one block = four phases: block j is evaluated in the phases
-      // 4j - 5 .. 4j - 2 and first read in phase 4j - 1.  Block 0 is
-      // evaluated before the first phase (its sync points do nothing), block
-      // 1 starts before it too: the first sync point of its pass is the
-      // workgroup's start barrier, the others are phase barriers - of which
-      // every wavefront of the workgroup executes exactly P.  The three
-      // kinds of pass are three instantiations (MODE): a state machine in
-      // the barrier cost the pass a hundred scalar instructions.
-      static_assert(NP == 1, "one generator (see above for two)");
-      constexpr int SP = 4;
-      // the sync points of record_of (models.hpp) this generator stops at:
-      // SP - 1 (the pass ends with one more, after the LDS writes)
-#ifndef PDDP_GEN_STOPS
-#define PDDP_GEN_STOPS 0b00011010u
-#endif
-      constexpr unsigned kStops = PDDP_GEN_STOPS;
-      static_assert(__builtin_popcount(kStops) == SP - 1, "");
-      int p = 0;
-      T* dst = ring;  // this pass's slot, this lane's record (set by pass)
-      // operands of the block evaluated next, requested one pass ahead
-      T zq[4], uq;
-      auto request = [&](int j) {
-        int tau = N - 1 - 4 * j - sb;
-        tau = tau < 0 ? 0 : tau;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(Zg + 4 * tau);
-        zq[0] = v[0]; zq[1] = v[1]; zq[2] = v[2]; zq[3] = v[3];
-        uq = Ug[tau];
-      };
-      // MODE 0: before the first phase; 1: the pass that crosses the start
-      // barrier; 2: steady state
-      auto pass = [&](auto mode, int j) {
-        constexpr int MODE = decltype(mode)::value;
-        int nsync = 0;
-        auto barrier = [&]() {
-          if constexpr (MODE == 2) {
-            if (p < P) {  // (always: block j's pass ends with phase 4j - 2)
-              PDDP_DW_STAMP(nsync & 3);  // (stats build: segment lengths)
-              PDDP_DW_BARRIER();
-              ++p;
-            }
-          } else if constexpr (MODE == 1) {
-            if (nsync == 0) {
-              __syncthreads();
-            } else if (p < P) {
-              PDDP_DW_BARRIER();
-              ++p;
-            }
-          }
-          ++nsync;
-        };
-        auto sync = [&](auto point, auto&... vals) {
-          constexpr int K = decltype(point)::value;
-          if constexpr (K == 3) {
-            // F_z, F_u: into the ring as soon as they exist - left to itself
-            // the compiler sinks the whole evaluation to the stores at the
-            // end of the pass, into one segment as long as two phases
-            const T f[] = {vals...};
-            static_assert(sizeof...(vals) == 20, "");
-#pragma unroll
-            for (int k = 0; k < 16; k += 4)
-              *reinterpret_cast<f32x4*>(dst + k) =
-                  f32x4{f[k], f[k + 1], f[k + 2], f[k + 3]};
-            *reinterpret_cast<f32x4*>(dst + 32) =
-                f32x4{f[16], f[17], f[18], f[19]};
-            asm volatile("" ::: "memory");
-          }
-          if constexpr ((kStops >> K) & 1u) {
-            if constexpr (K != 3) (pin_value(vals), ...);
-            barrier();
-          }
-        };
-        const T z[4] = {zq[0], zq[1], zq[2], zq[3]};
-        const T u = uq;
-        if (j + 1 < nblk) request(j + 1);
-        const int tau = N - 1 - 4 * j - sb;
-        T w[kRec];
-        // the block's slots: record tau lives in slot (N - 1 - tau) % R
-        dst = ring + ((4 * j + sb) % R) * G::SLOT + grbase;
-        const T l = record_of<T, MODEL, QM>(prob, z, &u, false, true, a.u_min,
-                                            a.u_max, w, sync);
-        // (words 0..15 and 32..35, F_z and F_u, went out at sync point 3;
-        // 36..39, L_uz, are zero in every record: written the first time a
-        // slot is used only)
-#pragma unroll
-        for (int k = 16; k < kRec; k += 4)
-          if (k != 32 && k != 36)
-            *reinterpret_cast<f32x4*>(dst + k) =
-                f32x4{w[k], w[k + 1], w[k + 2], w[k + 3]};
-        if (MODE != 2 || j < R / 4)
-          *reinterpret_cast<f32x4*>(dst + 36) = f32x4{T(0), T(0), T(0), T(0)};
-        if (tau >= 0) Lsh[gt * (N + 1) + tau] = l;  // (to `L` at the end)
-        barrier();  // SP-th: the block is visible from the next phase on
-      };
-      PDDP_DW_MARK(1, 0);
-      zq[0] = pre_z[0]; zq[1] = pre_z[1]; zq[2] = pre_z[2]; zq[3] = pre_z[3];
-      uq = pre_u;  // (block 0: requested at the top of the kernel)
-      pass(std::integral_constant<int, 0>{}, 0);
-      PDDP_DW_MARK(1, 1);
-      if (nblk > 1) pass(std::integral_constant<int, 1>{}, 1);
-      else __syncthreads();
-#pragma unroll 1
-      for (int j = 2; j < nblk; ++j) pass(std::integral_constant<int, 2>{}, j);
-      // every stage cost is in LDS now (the last block's barrier is behind
-      // us): J_opt = L.sum() in t order, in the phases this wavefront would
-      // otherwise idle through.  The LDS reads sixteen at a time - one read
-      // per add would expose the LDS latency a hundred times.
-      if (g == 0 && lane < kTraj && sums) {
-        T Jacc = T(0);
-        const T* Lt = Lsh + gt * (N + 1);
-        int t = 0;
-        for (; t + 16 <= N + 1; t += 16) {
-          T v[16];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = Lt[t + i];
-#pragma unroll
-          for (int i = 0; i < 16; ++i) Jacc += v[i];
-        }
-        for (; t <= N; ++t) Jacc += Lt[t];
-        gen.J_opt[gb] = Jacc;
-        if (gen.fresh != nullptr) gen.fresh[gb] = 0;
-      }
-      // the stage costs to `L`, whole rows (one word at a time from the
-      // passes they were 4-byte writes into 400 000 different sectors, still
-      // draining when the kernel was over: 2 us)
-      {
-        // (L is [B][N + 1]: the sixteen trajectories' rows are one run)
-        const int cnt = ((a.B - b0 < kTraj) ? a.B - b0 : kTraj) * (N + 1);
-        T* Lw = gen.L + (size_t)b0 * (size_t)(N + 1);
-        for (int i0 = lane; i0 < cnt; i0 += 8 * kWave) {
-          T v[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int i = i0 + k * kWave;
-            v[k] = Lsh[i < cnt ? i : 0];
-          }
-#pragma unroll
-          for (int k = 0; k < 8; ++k) {
-            const int i = i0 + k * kWave;
-            if (i < cnt) Lw[i] = v[k];
-          }
-        }
-      }
-      while (p < P) {
-        PDDP_DW_BARRIER();
-        ++p;
-      }
-      PDDP_DW_MARK(1, 2);
-      PDDP_DW_MARK(1, 3);
-      PDDP_DW_END(3);
-      return;
-    }
-  }
-  if (!GEN && role == 3) {
+  if (role == 3) {
     // =================================================================== P
     const char* rec_w = reinterpret_cast<const char*>(
         a.rec + (size_t)b0 * (size_t)(N + 1) * kRec);
@@ -544,23 +335,6 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
     T A0p = T(0), B0p = T(0), g1 = T(0), g1sq = T(0);
     T lo_b = T(0), hi_b = T(0);  // bounds of step tq's BoxQP: u_min/max - U
     int status = PDDP_BWD_OK;
-    if constexpr (GEN) {
-      // the terminal record (L_zz, L_z of z_N: what roles M and Y start
-      // from), while the generators evaluate the first blocks
-      if (lane < kTraj) {
-        constexpr int MODEL = PDDP_MODEL_CARTPOLE;
-        const T zN[4] = {pre_z[0], pre_z[1], pre_z[2], pre_z[3]};
-        T lz[4], lzz[16], lu[1], luu[1];
-        const T l = cost_derivs<T, MODEL>(prob, zN, nullptr,
-                                          trig_of<T, MODEL>(zN), true, lz, lzz,
-                                          lu, luu);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) term_sh[lane][i] = lzz[i];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) term_sh[lane][16 + i] = lz[i];
-        Lsh[lane * (N + 1) + N] = l;
-      }
-    }
     __syncthreads();
     int p = 0;
     // The exact path of one step: QpClosed, the reference's loop behind it.
@@ -681,7 +455,7 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
     // yp = y'_tq (everything of y_tq but the c_{tq+1} term); r0n = r0_{tq-1}
     T y1 = T(0), y1c = T(0), y1cc = T(0), g1a = T(0), g1b = T(0), yp = T(0);
     T r0n = T(0);
-    if constexpr (!GEN) {
+    {
       const T* term = a.rec + ((size_t)bc * (size_t)(N + 1) + N) * kRec;
       r0n = term[40 + q];  // r0_N = L_z[N]
     }
@@ -700,7 +474,6 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
       return o;
     };
     __syncthreads();
-    if constexpr (GEN) r0n = term_sh[tr][16 + q];
     int p = 0;
     // on entry to phase p: o_cur = record t = N - 1 - p (the package step),
     // o_prev = record tq - 1 = N - p (in phase 0 it does not exist: okA false)
@@ -805,16 +578,12 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
   };
   // S0_{t+1}, column q ("S0_N": the terminal value function, ilqr.py:581-583)
   Acc4<T> S0 = {T(0), T(0), T(0), T(0)};
-  if constexpr (!GEN) {
+  {
     const T* term = a.rec + ((size_t)bc * (size_t)(N + 1) + N) * kRec;
     S0.v0 = term[16 + 0 + q]; S0.v1 = term[16 + 4 + q];
     S0.v2 = term[16 + 8 + q]; S0.v3 = term[16 + 12 + q];
   }
   __syncthreads();
-  if constexpr (GEN) {
-    S0.v0 = term_sh[tr][0 + q]; S0.v1 = term_sh[tr][4 + q];
-    S0.v2 = term_sh[tr][8 + q]; S0.v3 = term_sh[tr][12 + q];
-  }
   int p = 0;
   PDDP_DW_MARK(0, 1);
   Words wn = gather(0);  // record N - 1
@@ -891,15 +660,7 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
 template <typename T, bool FAST, int R>
 __global__ __launch_bounds__(kThreads) void riccati_n4_defer_kernel(
     RiccatiArgs<T> a) {
-  defer_body<T, FAST, R, 0, 0u>(a, GenArgs<T>{}, ProblemT<T>{});
-}
-
-constexpr int kGenWaves = 1;   // generator wavefronts
-constexpr int kGenRing = 12;   // ring slots = three blocks (>= 4 NP + 6)
-template <unsigned QM>
-__global__ __launch_bounds__((3 + kGenWaves) * kWave) void riccati_n4_gen_kernel(
-    RiccatiArgs<float> a, GenArgs<float> gen, ProblemT<float> P) {
-  defer_body<float, true, kGenRing, kGenWaves, QM>(a, gen, P);
+  defer_body<T, FAST, R>(a);
 }
 
 }  // namespace n4d
@@ -926,38 +687,6 @@ static int launch_n4_defer(const RiccatiArgs<T>& a, hipStream_t st,
   if (fast_math && sizeof(T) == 4) PDDP_DF_GO(true);
   else PDDP_DF_GO(false);
 #undef PDDP_DF_GO
-  return launch_status();
-}
-
-// The same sweep from the nominal trajectory of a cartpole problem (f32,
-// bounded, eig-clamp branch): records evaluated in the workgroup, none read.
-static int launch_n4_gen(const pddp_problem& p, const RiccatiArgs<float>& a,
-                         const n4d::GenArgs<float>& gen, hipStream_t st) {
-  using G = n4q::QuadGeom<float>;
-  if (p.model != PDDP_MODEL_CARTPOLE ||
-      p.encoding != PDDP_ENC_IGNORE_UNCERTAINTY || a.u_min == nullptr ||
-      a.u_max == nullptr || a.branch != PDDP_BRANCH_EIG || a.N < 8)
-    return PDDP_E_UNSUPPORTED;
-  const ProblemT<float> P = convert_problem<float>(p);
-  const size_t lds = ((size_t)n4d::kGenRing * G::SLOT +
-                      (size_t)n4d::kTraj * (a.N + 1)) * sizeof(float);
-  if (lds > 150 * 1024) return PDDP_E_UNSUPPORTED;
-  const dim3 grid((a.B + 15) / 16), block((3 + n4d::kGenWaves) * kWave);
-  constexpr unsigned kSparse = 0b11001u;  // CartpoleCost: {x, sin, cos}
-  const bool sparse =
-      (live_mask(p.Q, ModelDims<PDDP_MODEL_CARTPOLE>::na) & ~kSparse) == 0;
-#define PDDP_GEN_GO(QMV)                                                      \
-  do {                                                                        \
-    auto kern = n4d::riccati_n4_gen_kernel<QMV>;                              \
-    const hipError_t e = hipFuncSetAttribute(                                 \
-        (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-        (int)lds);                                                            \
-    if (e != hipSuccess) return (int)e;                                       \
-    PDDP_LAUNCH(kern, grid, block, lds, st, a, gen, P);                       \
-  } while (0)
-  if (sparse) PDDP_GEN_GO(kSparse);
-  else PDDP_GEN_GO(kFullMask<PDDP_MODEL_CARTPOLE>);
-#undef PDDP_GEN_GO
   return launch_status();
 }
 

@@ -546,8 +546,9 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
 
 }  // namespace n4e
 
-// 0 auto, 1 the four-role kernel (riccati_n4_defer.hpp, NP = 1), 2 this one,
-// 3 / 4 this one with the generator inline / on wavefronts of its own
+// 0 auto (by batch), 3 / 4: the record generator inline / on wavefronts of
+// its own (the numbers of round 4's A/B knob: 1 was the four-role kernel of
+// round 3, removed)
 inline int& nominal_kernel_choice() {
   static int choice = 0;
   return choice;

@@ -46,6 +46,7 @@ from .base import DynamicsModel
 from ..utils.angular import augment_moments, augment_state
 from ..utils.classproperty import classproperty
 from ..utils.encoding import StateEncoding, decode_covar, decode_mean, encode
+from ..utils.linalg import cholesky_solve
 
 
 def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
@@ -104,7 +105,7 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             K = K + ((2.0 * self.log_sn).exp() + self.jitter)[:, None, None] * \
                 torch.eye(M, dtype=Xt.dtype, device=Xt.device)
             L = torch.linalg.cholesky(K)
-            a_ = torch.cholesky_solve(Y.t().unsqueeze(-1), L).squeeze(-1)
+            a_ = cholesky_solve(Y.t().unsqueeze(-1), L).squeeze(-1)
             return (0.5 * (Y.t() * a_).sum() +
                     torch.diagonal(L, dim1=-2, dim2=-1).log().sum() +
                     0.5 * M * Y.shape[1] * math.log(2 * math.pi))
@@ -147,8 +148,8 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             L = torch.linalg.cholesky(K)
             eye = torch.eye(M, dtype=Xt.dtype, device=Xt.device).expand(
                 state_size, M, M)
-            self.Kinv = torch.cholesky_solve(eye, L)
-            self.beta = torch.cholesky_solve(Y.t().unsqueeze(-1), L).squeeze(-1)
+            self.Kinv = cholesky_solve(eye, L)
+            self.beta = cholesky_solve(Y.t().unsqueeze(-1), L).squeeze(-1)
             self.Xt = Xt.clone()
             self.fitted = True
             self._drop_native_view()

@@ -10,6 +10,7 @@ device routines as a callable: batches of problems with up to four dimensions.
 import torch
 
 from .. import _native
+from .linalg import cholesky_solve
 
 BOXQP_RESULTS = {
     -1: "Hessian is not positive definite",
@@ -110,7 +111,7 @@ def _boxqp_torch(x0, Q, c, lower, upper, max_iter=100, min_grad=1e-8,
             break
         g_c = Q @ (x * clamped.to(x.dtype)) + c
         step_dir = torch.zeros_like(x)
-        step_dir[free] = -torch.cholesky_solve(
+        step_dir[free] = -cholesky_solve(
             g_c[free].unsqueeze(1), Ufree, upper=True).squeeze(1) - x[free]
         slope = (step_dir * g).sum()
         step = 1.0

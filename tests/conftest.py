@@ -35,3 +35,16 @@ def pytest_sessionfinish(session, exitstatus):
         import json
         with open(path, "w") as fh:
             json.dump(mod.STATS, fh)
+
+
+@pytest.fixture(autouse=True)
+def _sync_after_each_gpu_test(request):
+    """PDDP_SYNC_EACH=1: a device synchronisation after every test, so that an
+    asynchronous GPU fault is reported in the test that caused it (a debugging
+    aid; off by default)."""
+    yield
+    if os.environ.get("PDDP_SYNC_EACH"):
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            print("[synced after %s]" % request.node.name, flush=True)

@@ -722,3 +722,57 @@ def test_gp_graphs_follow_a_refit():
     assert torch.isfinite(Z2).all()
     assert torch.equal(Z2, Zf) and torch.equal(U2, Uf)
     assert not torch.equal(Z1, Z2)       # (the model did change)
+
+
+def test_cholesky_solve_helper_is_torch_cholesky_solve():
+    """utils/linalg.py cholesky_solve (two triangular solves; what the GP
+    conditioning and the torch BoxQP call instead of torch.cholesky_solve):
+    the same numbers, lower and upper factors, batched and broadcast."""
+    from pddp_amd.utils.linalg import cholesky_solve
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(3, 7, 7, generator=g, dtype=torch.float64)
+    K = A @ A.transpose(-1, -2) + torch.eye(7, dtype=torch.float64)
+    Bm = torch.randn(3, 7, 2, generator=g, dtype=torch.float64)
+    eye = torch.eye(7, dtype=torch.float64).expand(3, 7, 7)
+    L = torch.linalg.cholesky(K)
+    U = torch.linalg.cholesky(K, upper=True)
+    for rhs in (Bm, eye):
+        assert torch.allclose(cholesky_solve(rhs, L),
+                              torch.cholesky_solve(rhs, L), rtol=1e-12, atol=1e-12)
+        assert torch.allclose(cholesky_solve(rhs, U, upper=True),
+                              torch.cholesky_solve(rhs, U, upper=True),
+                              rtol=1e-12, atol=1e-12)
+    assert torch.allclose(cholesky_solve(Bm[0], L[0]),
+                          torch.cholesky_solve(Bm[0], L[0]),
+                          rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gp_fit_on_the_device_leaves_other_tensors_alone():
+    """GPDynamicsModel.fit on the device, among many small live tensors: none
+    of them changes.  (torch.cholesky_solve's batched path on this ROCm build
+    wrote outside its outputs: cached index tensors came back scaled by 1 / L_ii
+    and a GPU exception followed many launches later -
+    tools/dbg/torch_potrs_canary.py; the conditioning now runs on triangular
+    solves, utils/linalg.py.)"""
+    dev = torch.device("cuda", 0)
+    keep = []
+    for r in range(3000):
+        n = (64, 30, 128, 256, 100, 512)[r % 6]
+        keep.append(torch.full((n,), 3 + (r % 5), dtype=torch.int64, device=dev))
+    keep = [t for i, t in enumerate(keep) if i % 3]   # holes between them
+    g = torch.Generator().manual_seed(0)
+    for it in range(40):
+        for E, ai, ni, Md in ((2, [0], [1], 24), (4, [2], [0, 1, 3], 24),
+                              (6, [1, 2], [0, 3, 4, 5], 24),
+                              (6, [1, 2], [0, 3, 4, 5], 21), (4, [2], [0, 1, 3], 5)):
+            X = torch.randn(Md, E, generator=g, dtype=torch.float64)
+            U = torch.randn(Md, 1, generator=g, dtype=torch.float64)
+            dX = 0.1 * torch.randn(Md, E, generator=g, dtype=torch.float64)
+            model = gp_dynamics_model_factory(E, 1, ai, ni)().double().to(dev)
+            model.fit(X.to(dev), U.to(dev), dX.to(dev))
+    torch.cuda.synchronize()
+    bad = [i for i, t in enumerate(keep)
+           if not bool((t == t.flatten()[-1]).all()) or
+           int(t.flatten()[-1]) not in (3, 4, 5, 6, 7)]
+    assert not bad, bad[:10]

@@ -1343,9 +1343,8 @@ def test_best_rollout_exchange_on_the_device(dtype):
 
 class _nominal_kernel(object):
     """pddp_sweep_nominal_kernel(which) for the duration of a `with` block:
-    1 the four-role kernel (riccati_n4_defer.hpp), 3 / 4 the one-wavefront
-    kernel (riccati_n4_elem.hpp) with its record generator inline / on
-    wavefronts of its own, 0 auto."""
+    3 / 4 the record generator of riccati_n4_elem.hpp inline / on wavefronts
+    of its own, 0 auto (by batch)."""
 
     def __init__(self, which):
         self.which = which
@@ -1359,7 +1358,7 @@ class _nominal_kernel(object):
         _native.lib().pddp_sweep_nominal_kernel(self.prev)
 
 
-@pytest.mark.parametrize("kernel", [1, 3, 4])
+@pytest.mark.parametrize("kernel", [3, 4])
 @pytest.mark.parametrize("B,N", [(37, 33), (16, 100), (5, 10), (130, 47),
                                  (3, 8), (21, 9), (17, 12), (300, 201),
                                  (9, 3), (2, 1), (70, 16), (33, 32), (6, 17)])
@@ -1370,10 +1369,8 @@ def test_sweep_from_nominal_equals_records_then_sweep(B, N, kernel):
     and J_opt = L.sum() - ragged batches, horizons that are not a multiple of
     the generators' blocks (four steps / sixteen steps), horizons shorter than
     a block, masked trajectories."""
-    if kernel == 1 and N < 8:
-        pytest.skip("the four-role kernel needs N >= 8")
     with _nominal_kernel(kernel):
-        _sweep_from_nominal_case(B, N, same_arithmetic=kernel == 1)
+        _sweep_from_nominal_case(B, N, same_arithmetic=False)
 
 
 def _sweep_from_nominal_case(B, N, same_arithmetic):
@@ -1399,10 +1396,10 @@ def _sweep_from_nominal_case(B, N, same_arithmetic):
     assert torch.isfinite(g).all()
     # (the records of the two paths agree to rounding - the same code inlined
     # into two kernels - and a hundred steps of an f32 sweep carry that on.
-    # The four-role kernel is variant 25's arithmetic; the one-wavefront
-    # kernel sums in another order and runs the plain recursion - two f32
-    # sweeps then part by what f32 loses over N steps, which the oracle tests
-    # measure: here only that nothing is wild)
+    # Variant 25 is the deferred rank-one form; the one-wavefront kernel sums
+    # in another order and runs the plain recursion - two f32 sweeps then part
+    # by what f32 loses over N steps, which the oracle tests measure: here
+    # only that nothing is wild)
     per = (g - gr).abs().amax(dim=(1, 2)) / gr.abs().max()
     if same_arithmetic:
         assert float(per.max()) < 3e-4, float(per.max())
@@ -1411,9 +1408,7 @@ def _sweep_from_nominal_case(B, N, same_arithmetic):
             float(per.median()), float(per.max()))
     assert torch.equal(s.bwd_status.cpu()[live], ref["bwd_status"].cpu()[live])
     assert (s.bwd_status.cpu()[~live] == -7).all()
-    # (stage costs: rows of active trajectories; an inactive row is left alone
-    # or - the four-role kernel, for a row next to an active one - refreshed
-    # with the same values)
+    # (stage costs: rows of active trajectories; an inactive row is left alone)
     Lg, Lr = s.L.cpu(), ref["L"].cpu()
     assert float((Lg[live] - Lr[live]).abs().max()) <= 1e-6 * float(
         Lr.abs().max())
@@ -1435,15 +1430,15 @@ def _sweep_from_nominal_case(B, N, same_arithmetic):
     assert torch.equal(rec, s.rec)
 
 
-@pytest.mark.parametrize("kernel", [1, 0])
+@pytest.mark.parametrize("kernel", [0, 3])
 def test_round_from_nominal_equals_round_with_records(kernel):
     """ILQRSolver.round() through the sweep from the nominal (no records in
     HBM) against the same rounds through the fused launch that writes them:
     the same decisions, nominals and regularisation, round by round.  (The
-    four-role kernel has the recorded sweep's arithmetic; the one-wavefront
-    kernel - auto - sums in another order: values to 2e-2 after 14 rounds.)"""
+    recorded sweep is the deferred rank-one form, the sweep from the nominal
+    the plain recursion: values to 2e-2 after 14 rounds.)"""
     with _nominal_kernel(kernel):
-        _rounds_side_by_side(1e-3 if kernel == 1 else 2e-2)
+        _rounds_side_by_side(2e-2)
 
 
 def _rounds_side_by_side(vtol):
@@ -1566,7 +1561,7 @@ def test_benched_round_kernels_vs_oracle(rounds_before):
     random nominal: every candidate is rejected) and in its tenth (mu has
     grown to where steps are accepted; per-trajectory mu, nominals under way):
 
-    pddp_sweep_nominal_f32 (riccati_n4_gen_kernel; ilqr.py:529-674 with the
+    pddp_sweep_nominal_f32 (riccati_n4_elem_kernel; ilqr.py:529-674 with the
     records of :393-486 evaluated in the workgroup): gains and status with the
     fp32 bars of this file (error against the fp64 oracle within F32_RATIO of
     the fp32 oracle's own, or the branch's floor), stage costs L and J_opt
@@ -2177,8 +2172,8 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
     fp32 (what bench.py times: "nominal4" = pddp_sweep_nominal_f32, the sweep
     that evaluates the derivative records itself - riccati_n4_elem_kernel with
     its generator wavefronts, v_rcp and the sign-bit BoxQP; "nominal3" the same
-    with the generator inline, "nominal1" the four-role riccati_n4_gen_kernel;
-    25 = that sweep on records in HBM; 9, 7, 17 for the other branches): the sweep is a 100-step recursion through a discontinuous BoxQP, so the yardstick is the
+    with the generator inline; 25 = the deferred four-role sweep on records in
+    HBM; 9, 7, 17 for the other branches): the sweep is a 100-step recursion through a discontinuous BoxQP, so the yardstick is the
     fp64 oracle and the reference point is what IEEE fp32 arithmetic in the
     reference's operation order (the fp32 oracle) loses against it.  Asserted
     per (variant, branch, reg): status flips and clamp-pattern flips against
@@ -2198,8 +2193,7 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
     f64 = dtype == "f64"
     plan = (  # branch, bounded, variants (f64 | f32)
         (0, True, (6, 8, 16, 18, 20, 24) if f64 else
-         (7, 9, 15, 16, 17, 18, 20, 21, 24, 25, "nominal1", "nominal3",
-          "nominal4")),
+         (7, 9, 15, 16, 17, 18, 20, 21, 24, 25, "nominal3", "nominal4")),
         (1, True, (6, 8, 16, 18) if f64 else (7, 8, 9, 15, 16, 17, 18)),
         (0, False, (6, 16) if f64 else (6, 7, 15, 16, 17)),
         (1, False, (6, 16) if f64 else (6, 7, 15, 16, 17)))

@@ -398,7 +398,8 @@ def test_hot_kernels_keep_their_working_set_in_registers():
     assert not bad, bad
     hot = ("riccati_n4_qpipe_kernel<float", "riccati_n4_quad_kernel<float",
            "line_search_lds_kernel<float, 1, true, 4, 2, 25u>",
-           "riccati_n4_gen_kernel<25u>", "riccati_n4_defer_kernel<float",
+           "riccati_n4_elem_kernel<25u, true>", "riccati_n4_elem_kernel<25u, false>",
+           "riccati_n4_defer_kernel<float",
            "bnn_mlp_kernel<200", "riccati_mfma16_kernel<", "riccati_mfma32_kernel<",
            "bnn_moment_step_kernel<4>", "bnn_moment_step_kernel<6>",
            "bnn_jvp_moments_kernel<16, 4, true>", "qr_cost_derivs_kernel<")

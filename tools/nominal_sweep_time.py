@@ -1,8 +1,8 @@
-"""Duration of the sweep from the nominal (pddp_sweep_nominal_f32) - the
-one-wavefront kernel (riccati_n4_elem.hpp) and the four-role kernel
-(riccati_n4_defer.hpp) - and of the recorded deferred sweep (variant 25) on the
-same fresh nominal, events on the dispatches; gains of the three against each
-other:  python tools/nominal_sweep_time.py [B ...]"""
+"""Duration of the sweep from the nominal (pddp_sweep_nominal_f32,
+riccati_n4_elem.hpp: generator inline / on wavefronts of its own / auto) and of
+the recorded deferred sweep (variant 25) on the same fresh nominal, events on
+the dispatches; gains against each other:
+python tools/nominal_sweep_time.py [B ...]"""
 import ctypes
 import os
 import sys
@@ -21,10 +21,9 @@ for B in [int(v) for v in sys.argv[1:]] or [4096]:
     s.mu.fill_(1.0)
     s.derivs()
     out = {}
-    for name in ("elem", "elem_inl", "elem_ovl", "roles", "recorded"):
+    for name in ("elem", "elem_inl", "elem_ovl", "recorded"):
         pool = bench.EventPool(lib)
-        lib.pddp_sweep_nominal_kernel({"elem": 2, "elem_inl": 3, "elem_ovl": 4,
-                                       "roles": 1}.get(name, 0))
+        lib.pddp_sweep_nominal_kernel({"elem_inl": 3, "elem_ovl": 4}.get(name, 0))
         s.gains.zero_()
         for i in range(24):
             ev = pool.pair() if i >= 4 else None
@@ -41,13 +40,6 @@ for B in [int(v) for v in sys.argv[1:]] or [4096]:
         print("B %6d %-9s mean %.1f us  min %.1f us  (status != 0: %d)" % (
             B, name, d.mean(), d.min(), int((s.bwd_status != 0).sum())))
         raw = ctypes.CDLL(_native.LIB_PATH)
-        if name == "roles" and hasattr(raw, "pddp_debug_defer_marks"):
-            mk = (ctypes.c_longlong * 8)()  # (-DPDDP_QP_MARKS build)
-            raw.pddp_debug_defer_marks(mk)
-            t = [mk[i] for i in range(4)]
-            print("  wave M of workgroup 0: first phase after %d cycles, phases "
-                  "%d cycles (%.0f each)" % (t[1] - t[0], t[2] - t[1],
-                                             (t[2] - t[1]) / 102.0))
         if name.startswith("elem") and hasattr(raw, "pddp_debug_elem_marks"):
             mk = (ctypes.c_longlong * 8)()  # (-DPDDP_ELEM_MARKS build)
             raw.pddp_debug_elem_marks(mk)
@@ -62,13 +54,12 @@ for B in [int(v) for v in sys.argv[1:]] or [4096]:
     g = {k: v[0].double() for k, v in out.items()}
     ok = (out["elem"][1] == 0) & (out["recorded"][1] == 0)
     sc = float(g["recorded"][ok].abs().max())
-    for a, b in (("elem", "recorded"), ("roles", "recorded"), ("elem", "roles"),
-                 ("elem_inl", "elem_ovl")):
+    for a, b in (("elem", "recorded"), ("elem_inl", "elem_ovl")):
         e = (g[a][ok] - g[b][ok]).abs().amax(dim=(1, 2)) / sc
         print("  gains %s vs %s: max %.2e  median %.2e   status equal: %s" % (
             a, b, float(e.max()), float(e.median()),
             bool(torch.equal(out[a][1], out[b][1]))))
-    print("  L elem vs roles: %.2e   J_opt: %.2e" % (
-        float((out["elem"][2] - out["roles"][2]).abs().max()),
-        float(((out["elem"][3] - out["roles"][3]).abs() /
-               out["roles"][3].abs()).max())))
+    print("  L inline vs overlapped: %.2e   J_opt: %.2e" % (
+        float((out["elem_inl"][2] - out["elem_ovl"][2]).abs().max()),
+        float(((out["elem_inl"][3] - out["elem_ovl"][3]).abs() /
+               out["elem_ovl"][3].abs()).max())))
