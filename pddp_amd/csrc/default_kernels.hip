@@ -1,5 +1,5 @@
 // default_kernels.hip - the sample problems (cartpole, pendulum, double
-// cartpole) under StateEncoding.DEFAULT = UPPER_TRIANGULAR_CHOLESKY:
+// cartpole; round 4: rendezvous, see kCarriesCovar) under StateEncoding.DEFAULT = UPPER_TRIANGULAR_CHOLESKY:
 // z = mean (D) | triu(upper Cholesky factor U of the covariance, U^T U = C),
 // n = D + D (D + 1) / 2 = 14 / 5 / 27.
 //
@@ -169,6 +169,79 @@ PDDP_DEV T chol_jitter_of(const T (&C)[NA][NA]) {
   return T(-1);
 }
 
+// Rendezvous (8 states, 4 actions, no angles) carries the input's FULL
+// covariance through its dynamics (pddp/examples/rendezvous/model.py:94,110:
+// encode(mean', C = decode_covar(z))), where the other sample models keep the
+// variances only:
+//   Cholesky   chol' = the jittered upper Cholesky of U^T U (encoding.py:99-141,
+//              536-564), a re-factorisation - the identity up to its 1e-12
+//              jitter when U has a positive diagonal, not otherwise
+//   full       C' = C, every entry      variance / std   as the other models
+template <int MODEL>
+constexpr bool kCarriesCovar = (MODEL == PDDP_MODEL_RENDEZVOUS);
+
+template <typename T>
+struct FDual {  // forward dual number: value, one tangent
+  T v, d;
+};
+template <typename T> PDDP_DEV FDual<T> operator+(FDual<T> x, FDual<T> y) { return {x.v + y.v, x.d + y.d}; }
+template <typename T> PDDP_DEV FDual<T> operator-(FDual<T> x, FDual<T> y) { return {x.v - y.v, x.d - y.d}; }
+template <typename T> PDDP_DEV FDual<T> operator*(FDual<T> x, FDual<T> y) { return {x.v * y.v, x.d * y.v + x.v * y.d}; }
+template <typename T> PDDP_DEV FDual<T> operator/(FDual<T> x, FDual<T> y) {
+  const T q = x.v / y.v;
+  return {q, (x.d - q * y.d) / y.v};
+}
+template <typename T> PDDP_DEV FDual<T> sqrt_x(FDual<T> x) {
+  const T r = sqrt_(x.v);
+  return {r, x.d / (r + r)};
+}
+template <typename T> PDDP_DEV T sqrt_x(T x) { return sqrt_(x); }
+template <typename T> PDDP_DEV T val(FDual<T> x) { return x.v; }
+
+// R = upper Cholesky factor of U^T U + jitter I, both as the row-major upper
+// triangles the encoding stores (utils/encoding.py _cholesky_upper: jitter
+// 1e-12, x10 while a pivot fails - per batch there, per row here); X = T or
+// FDual<T>.  False when no jitter up to 10 makes it positive-definite (the
+// reference raises).
+template <typename X, typename T, int D>
+PDDP_DEV bool rechol_upper(const X (&U)[D * (D + 1) / 2],
+                           X (&R)[D * (D + 1) / 2]) {
+  auto tri = [](int k, int i) { return k * D - k * (k - 1) / 2 + (i - k); };
+  X C[D * (D + 1) / 2];  // U^T U, upper triangle
+#pragma unroll
+  for (int r = 0; r < D; ++r)
+#pragma unroll
+    for (int c = r; c < D; ++c) {
+      X v = U[tri(0, r)] * U[tri(0, c)];
+#pragma unroll
+      for (int k = 1; k <= r; ++k) v = v + U[tri(k, r)] * U[tri(k, c)];
+      C[tri(r, c)] = v;
+    }
+  double jit = 1e-12;
+  while (jit <= 10.0) {
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+      for (int j = i; j < D; ++j) {
+        X s = C[tri(i, j)];
+        if (i == j) s = s + X{(T)jit};
+#pragma unroll
+        for (int q = 0; q < i; ++q) s = s - R[tri(q, i)] * R[tri(q, j)];
+        if (i == j) {
+          if (!(val(s) > T(0))) ok = false;
+          R[tri(i, i)] = sqrt_x(s);
+        } else {
+          R[tri(i, j)] = s / R[tri(i, i)];
+        }
+      }
+    }
+    if (ok) return true;
+    jit *= 10.0;
+  }
+  return false;
+}
+
 // l(z, u) on the augmented Gaussian moments; X = T (value) or HDual<T>.
 // mu [D], oth [NO] the encoding's second block, u [m] (clamped).
 template <typename X, typename T, int MODEL, int ENC>
@@ -285,7 +358,14 @@ PDDP_DEV void step_default(const ProblemT<T>& P,
   T next[D];
   const Trig<T, MODEL> tr = trig_of<T, MODEL>(mean);
   dynamics<T, MODEL, false>(P, mean, u, tr, next, nullptr, nullptr);
-  if constexpr (ENC == kChol) {
+  if constexpr (kCarriesCovar<MODEL> && ENC == kChol) {
+    T R[G::NO];
+    const bool ok = rechol_upper<T, T, D>(oth, R);
+#pragma unroll
+    for (int j = 0; j < G::NO; ++j) oth[j] = ok ? R[j] : (T)__builtin_nan("");
+  } else if constexpr (kCarriesCovar<MODEL> && ENC == kFull) {
+    // C' = C
+  } else if constexpr (ENC == kChol) {
     T sd[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -453,7 +533,11 @@ __global__ __launch_bounds__(kWave) void derivs_default_kernel(
       if (r < D && c < D) {
         v = sFx[r * D + c];
       } else if (r >= D && c >= D) {
-        if constexpr (ENC == kChol) {
+        if constexpr (kCarriesCovar<MODEL> && ENC == kChol) {
+          continue;  // d chol' / d chol: by dual numbers, below
+        } else if constexpr (kCarriesCovar<MODEL> && ENC == kFull) {
+          v = (r == c) ? T(1) : T(0);  // C' = C
+        } else if constexpr (ENC == kChol) {
           // encoded row r = upper-triangle entry (ri, rj); only the diagonal
           // entries of chol' are non-zero functions of the input:
           // d sqrt(V_i + j) / dU[k][i] = U[k][i] / sqrt(V_i + j)
@@ -476,6 +560,22 @@ __global__ __launch_bounds__(kWave) void derivs_default_kernel(
       }
     }
     w[lay.oFz + e] = v;
+  }
+  if constexpr (kCarriesCovar<MODEL> && ENC == kChol) {
+    // column D + e of F_z: the re-factorisation in dual numbers seeded at
+    // entry e of the input factor (what the reference's autograd returns
+    // through torch.linalg.cholesky_ex)
+    // (the terminal record's block is zeros, written above)
+    for (int e = lane; e < NO && !terminal; e += kWave) {
+      using X = FDual<T>;
+      X U_[NO], R_[NO];
+#pragma unroll
+      for (int c = 0; c < NO; ++c) U_[c] = X{oth[c], c == e ? T(1) : T(0)};
+      const bool ok = rechol_upper<X, T, D>(U_, R_);
+#pragma unroll
+      for (int r = 0; r < NO; ++r)
+        w[lay.oFz + (D + r) * n + (D + e)] = ok ? R_[r].d : (T)__builtin_nan("");
+    }
   }
   for (int e = lane; e < n * m; e += kWave) {
     const int r = e / m, c = e - r * m;
@@ -584,7 +684,8 @@ static int check_default(const pddp_problem& p) {
     case PDDP_MODEL_CARTPOLE:
     case PDDP_MODEL_DOUBLE_CARTPOLE:
     case PDDP_MODEL_PENDULUM:
-      return 0;  // (rendezvous carries the full covariance: plugin path)
+    case PDDP_MODEL_RENDEZVOUS:  // (carries the full covariance: kCarriesCovar)
+      return 0;
   }
   return PDDP_E_UNSUPPORTED;
 }
@@ -606,6 +707,10 @@ static int check_default(const pddp_problem& p) {
     } break;                                                                 \
     case PDDP_MODEL_PENDULUM: {                                              \
       constexpr int MODEL = PDDP_MODEL_PENDULUM;                             \
+      PDDP_DEFAULT_ENC(__VA_ARGS__)                                            \
+    } break;                                                                 \
+    case PDDP_MODEL_RENDEZVOUS: {                                            \
+      constexpr int MODEL = PDDP_MODEL_RENDEZVOUS;                           \
       PDDP_DEFAULT_ENC(__VA_ARGS__)                                            \
     } break;                                                                 \
     default: {                                                               \

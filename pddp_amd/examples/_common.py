@@ -31,19 +31,15 @@ def build_problem(name, model, cost, encoding, param_names):
     """Flattens a sample (model, cost) pair into include/pddp_problem.h: the
     problems the HIP kernels evaluate in closed form - every sample problem
     under IGNORE_UNCERTAINTY (csrc/problem_kernels.hip) and cartpole, pendulum,
-    double cartpole under DEFAULT = UPPER_TRIANGULAR_CHOLESKY, VARIANCE_ONLY and
-    STANDARD_DEVIATION_ONLY and FULL_COVARIANCE_MATRIX (csrc/default_kernels.hip;
-    rendezvous carries a full covariance through its dynamics and stays on the
-    plugin path).  None otherwise."""
-    if encoding in (StateEncoding.UPPER_TRIANGULAR_CHOLESKY,
-                    StateEncoding.VARIANCE_ONLY,
-                    StateEncoding.STANDARD_DEVIATION_ONLY):
-        if name == "rendezvous":
-            return None
-    elif encoding == StateEncoding.FULL_COVARIANCE_MATRIX:
-        if name == "rendezvous":
-            return None
-    elif encoding != StateEncoding.IGNORE_UNCERTAINTY:
+    double cartpole, rendezvous under DEFAULT = UPPER_TRIANGULAR_CHOLESKY,
+    VARIANCE_ONLY, STANDARD_DEVIATION_ONLY and FULL_COVARIANCE_MATRIX
+    (csrc/default_kernels.hip; rendezvous carries the full covariance through
+    its dynamics, `kCarriesCovar` there).  None otherwise."""
+    if encoding not in (StateEncoding.UPPER_TRIANGULAR_CHOLESKY,
+                        StateEncoding.VARIANCE_ONLY,
+                        StateEncoding.STANDARD_DEVIATION_ONLY,
+                        StateEncoding.FULL_COVARIANCE_MATRIX,
+                        StateEncoding.IGNORE_UNCERTAINTY):
         return None
     if not isinstance(cost, AugmentedQRCost) or \
             cost.model_class is not type(model):

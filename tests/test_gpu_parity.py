@@ -646,7 +646,9 @@ def test_plugin_path_equals_native_path():
     ("cartpole", "default"), ("pendulum", "default"),
     ("cartpole", "variance"), ("pendulum", "variance"),
     ("cartpole", "std"), ("pendulum", "std"), ("cartpole", "fullcov"),
-    ("pendulum", "fullcov"), ("double_cartpole", "fullcov")])
+    ("pendulum", "fullcov"), ("double_cartpole", "fullcov"),
+    ("rendezvous", "default"), ("rendezvous", "variance"),
+    ("rendezvous", "std"), ("rendezvous", "fullcov")])
 def test_default_encoding_vs_reference_golden(problem, enc_key):
     """The Gaussian state encodings - DEFAULT (upper-triangular Cholesky, n =
     14 / 5), VARIANCE_ONLY, STANDARD_DEVIATION_ONLY (n = 8 / 4) and
@@ -656,7 +658,10 @@ def test_default_encoding_vs_reference_golden(problem, enc_key):
     a full fit, against the reference's own outputs (fp64 goldens,
     tools/make_golden.py [--other-encodings]).  All of it on the native path
     (csrc/default_kernels.hip: closed-form dynamics Jacobian, hyper-dual cost
-    derivatives, line-search kernel) - asserted below."""
+    derivatives, line-search kernel) - asserted below.  Round 4: rendezvous
+    (8 states, 4 actions; it carries the FULL covariance through its dynamics,
+    rendezvous/model.py:94,110): n = 44 / 16 / 16 / 72, horizons 5 and 12
+    (tools/make_golden.py --rendezvous-gaussian)."""
     import pddp_amd
     from pddp_amd import StateEncoding
     from pddp_amd.controllers.ilqr import _control_law, backward, forward
@@ -784,7 +789,7 @@ def test_double_cartpole_full_covariance_fit_native_vs_plugin():
                                       "FULL_COVARIANCE_MATRIX"])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", ["cartpole", "pendulum",
-                                     "double_cartpole"])
+                                     "double_cartpole", "rendezvous"])
 def test_default_encoding_native_vs_plugin_path(problem, dtype, enc_name):
     """The native Gaussian-encoding kernels (csrc/default_kernels.hip: DEFAULT =
     upper-triangular Cholesky, VARIANCE_ONLY, STANDARD_DEVIATION_ONLY) against
@@ -793,7 +798,10 @@ def test_default_encoding_native_vs_plugin_path(problem, dtype, enc_name):
     (controllers/plugin.py; pinned to the reference's goldens by
     tests/test_host_cpu.py and, for cartpole / pendulum, by the test above):
     nominal rollout, every derivative, the candidates and their costs.  Covers
-    double cartpole (n = 27, no golden captured) and float32."""
+    double cartpole (n = 27, no golden captured) and float32.  Rendezvous
+    starts from a FULL upper factor here (the goldens' is diagonal): its
+    re-factorisation chol(U^T U + 1e-12 I) and the Jacobian of that, by dual
+    numbers in the kernel, against autograd through torch.linalg.cholesky_ex."""
     import pddp_amd
     from pddp_amd.controllers.ilqr import _make_solver
     mod = getattr(pddp_amd.examples, problem)
@@ -819,7 +827,7 @@ def test_default_encoding_native_vs_plugin_path(problem, dtype, enc_name):
     U = (0.5 * torch.randn(B, N, m, generator=g, dtype=torch.float64)).to(
         td).cuda()
     bound = BOUND[problem]
-    u_min, u_max = torch.tensor([-bound]), torch.tensor([bound])
+    u_min, u_max = torch.full((m,), -bound), torch.full((m,), bound)
     sols = []
     for force in (False, True):
         s = _make_solver(model, cost, enc, B, N, n, td, "cuda", u_min, u_max,

@@ -699,6 +699,14 @@ def main():
         capture_problem("double_cartpole", "fullcov", torch.float64, [5, 12],
                         with_fit=6)
         return
+    if "--rendezvous-gaussian" in sys.argv:
+        # round 4: rendezvous (8 states, 4 actions) carries the FULL covariance
+        # through its dynamics (rendezvous/model.py:94,110): n = 44 under the
+        # Cholesky encoding, 72 under the full covariance matrix
+        for enc in ("default", "fullcov", "variance", "std"):
+            capture_problem("rendezvous", enc, torch.float64, [5, 12],
+                            with_fit=6)
+        return
     if "--default-only" in sys.argv:
         capture_problem("cartpole", "default", torch.float64, [5, 25],
                         with_fit=12)
