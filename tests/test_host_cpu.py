@@ -368,6 +368,10 @@ def test_hot_kernels_keep_their_working_set_in_registers():
         "bnn_jvp_moments_kernel<32, 6, false>",
         "derivs_default_kernel<double, 2, 1>",  # double cartpole, hyper-dual on 27 inputs
         "derivs_default_kernel<float, 2, 1>",
+        # rendezvous, Cholesky encoding, fp64: the 36-entry re-factorisation in
+        # dual numbers at the 512-register file, two values parked in
+        # accumulation registers (no scratch); not on a benchmarked path
+        "derivs_default_kernel<double, 4, 1>",
         "line_search_default_kernel<float, 2, 2>",
         "line_search_kernel<double, 2>",
         "line_search_lds_kernel<double, 2, true, 4, 2,",
