@@ -1,0 +1,419 @@
+// riccati_mfma32s.hpp - riccati_mfma32.hpp's sweep (15 <= n <= 30, m = 1, fp32)
+// with ONE TRAJECTORY'S STEP SPLIT OVER TWO WAVEFRONTS on different SIMDs
+// (task 5).  At configs[3]'s 1024 trajectories per GPU the
+// one-wave form leaves every SIMD with one wavefront whose 2048 matrix-core
+// cycles and ~460 vector instructions per step serialise (the vector work
+// depends on the products).  Here wavefront w of a pair owns 16 of the 32
+// columns; both products are done on v_mfma_f32_16x16x4_f32 (16 instructions of
+// 32 cycles per product and wave instead of 16 of 64), the vector work halves,
+// and a SIMD holds halves of two trajectories: one's vector work runs under
+// the other's products.
+//
+//   X = V F~ (32 x 32, X[:, 31] = V_z), Q~ = L~ + F~^T X as in
+//   riccati_mfma32.hpp.  Lane (c, g) = (lane & 15, lane >> 4); rho(rb, r, g) =
+//   16 rb + 4 g + r is the row that register (rb, r) of an accumulator block
+//   holds in lane group g (the C/D layout of the 16x16 form).
+//
+//   wave w keeps  Vw[(rb, r)]  = V[rho][16 w + c]   (= V[16 w + c][rho]: symmetric)
+//                 Vzw[r]       = V_z[16 w + 4 g + r]
+//   product 1, ROWS 16 w ..: X[16 w + i][:] = sum_rho V[16 w + i][rho] F~[rho][:]
+//              A of k-slice (rb, r) = Vw[(rb, r)] as it stands; B = F~[rho][16 cb + c]
+//              gathered from the record in LDS (16 words: Fg[cb][(rb, r)])
+//   exchange:  the 16 x 16 block of X the partner's columns need, through LDS
+//   product 2, COLUMNS 16 w ..: Q~[:, 16 w + c] = L~ + sum_rho F~[rho][:]^T X[rho][16 w + c]
+//              B of k-slice (rb, r) = the accumulator registers of X (own rows:
+//              own registers; the partner's rows: the exchanged block);
+//              A = F~[rho][16 ob + c] = the SAME 16 gathered words
+//   Q~'s block lands in the layout of Vw: V' = sym(Q~) + c Quz^T Quz needs the
+//   transposed entries and row n, both through a 32 x 32 tile in LDS that the
+//   two waves fill together.
+//
+// Two workgroup barriers per step (X exchanged - tile filled, which is also
+// "the next record has landed": the producer wavefront of riccati_mfma32.hpp
+// waits for it before that barrier); the next step's operands are gathered
+// right behind the second, under the BoxQP and the value update.
+// Eig-clamp branches (B, D: the controller's default); the Cholesky branches
+// stay on the one-wave kernel.
+#pragma once
+
+#include "riccati_mfma32.hpp"
+
+namespace pddp {
+namespace m32s {
+
+constexpr int kTraj = 1;                 // trajectories per workgroup
+constexpr int kSweep = 2 * kTraj;        // sweeping wavefronts
+constexpr int kThreads = kWave * (kSweep + 1);
+constexpr int kRing = 2;
+constexpr int kTileLd = 36;
+constexpr int kTile = 32 * kTileLd;
+constexpr int kXch = 2 * kWave * 4;      // two 16 x 16 blocks, lane-linear
+
+// FORM 0: three barriers per step (record landed - X exchanged - tile filled),
+// operands gathered at the top of the step; FORM 1: two (the last one doubles
+// as "the next record has landed"), the next step's operands gathered behind it
+template <bool BOUNDED, bool FAST, int NDMA, int FORM>
+__global__ __launch_bounds__(kThreads) void riccati_mfma32s_kernel(
+    RiccatiArgs<float> a) {
+  using T = float;
+  using m16::f32x4;
+  constexpr int kSlotWords = NDMA * kWave * 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  constexpr int per_traj = kRing * kSlotWords + kTile + kXch;
+  float* ls_tail = smem + kTraj * per_traj;
+  if constexpr (BOUNDED) {
+    for (int q = threadIdx.x; q < n4::kLsSteps; q += kThreads)
+      ls_tail[q] = (T)n4::kLs.v[q];
+  }
+  const T lstep0 = (T)n4::kLs.v[lane & 15];
+  const int n = a.n, N = a.N;
+  const RecLayout lay(n, 1);
+  const int S = lay.stride;
+  const int chunks = S / 4;
+  const int nd_live = (chunks + kWave - 1) / kWave;
+  auto live_of = [&](int bb) {
+    return bb < a.B && (a.active == nullptr || a.active[bb] != 0);
+  };
+  auto step_barrier = [] { asm volatile("s_barrier" ::: "memory"); };
+  auto publish_barrier = [] {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+
+  if (wv == kSweep) {
+    // ===================================================================
+    // producer (riccati_mfma32.hpp): record t of both trajectories has landed
+    // before the first barrier of step t; the two other barriers of a step
+    // are the sweeping waves' own
+    // ===================================================================
+    uint32_t qoff[NDMA];
+#pragma unroll
+    for (int r = 0; r < NDMA; ++r) qoff[r] = (uint32_t)(lane + kWave * r) * 16u;
+    const uint32_t qoff_last = (uint32_t)(lane + kWave * (nd_live - 1)) * 16u;
+    const bool in_tail = lane + kWave * (nd_live - 1) < chunks;
+    auto dma = [&](int w, int slot, int t) {
+      const int bb = blockIdx.x * kTraj + w;
+      if (!live_of(bb) || t < 0) return;  // (wave-uniform)
+      const char* rec_b = reinterpret_cast<const char*>(
+          a.rec + (size_t)bb * (size_t)(N + 1) * S);
+      const uint32_t base = (uint32_t)t * (uint32_t)(S * sizeof(T));
+      const uint32_t lbase = __builtin_amdgcn_readfirstlane(
+          n4::lds_addr(smem + w * per_traj + slot * kSlotWords));
+#pragma unroll
+      for (int r = 0; r < NDMA - 1; ++r) {
+        if (r < nd_live - 1)
+          n4::lds_dma16(rec_b, base + qoff[r], lbase + r * kWave * 16);
+      }
+      if (in_tail)
+        n4::lds_dma16(rec_b, base + qoff_last,
+                      lbase + (uint32_t)(nd_live - 1) * kWave * 16);
+    };
+    __syncthreads();  // the sweeping waves have zeroed their slots' padding
+#pragma unroll
+    for (int w = 0; w < kTraj; ++w) dma(w, 0, N - 1);
+    if constexpr (FORM == 0) {
+      for (int t = N - 1; t >= 0; --t) {
+        n4::wait_vmcnt<0>();
+        step_barrier();  // (1) record t landed
+        const int slot_next = (N - t) & 1;
+#pragma unroll
+        for (int w = 0; w < kTraj; ++w) dma(w, slot_next, t - 1);
+        step_barrier();  // (2) X exchanged
+        step_barrier();  // (3) tile filled
+      }
+    } else {
+      n4::wait_vmcnt<0>();
+      step_barrier();  // (0) record N - 1 landed
+#pragma unroll
+      for (int w = 0; w < kTraj; ++w) dma(w, 1, N - 2);
+      for (int t = N - 1; t >= 0; --t) {
+        // (2) of step t: the sweeping waves have gathered record t (they did
+        // before their first product) - its slot takes record t - 2
+        step_barrier();
+        n4::wait_vmcnt<0>();  // record t - 1, requested a step ago
+        step_barrier();  // (3) of step t = "record t - 1 landed"
+        // (the requests go out behind (3): an LDS-DMA instruction parks this
+        // wave for ~90 cycles and there are up to 16)
+        const int slot_t = (N - 1 - t) & 1;
+#pragma unroll
+        for (int w = 0; w < kTraj; ++w) dma(w, slot_t, t - 2);
+      }
+    }
+    return;
+  }
+
+  const int tw = wv >> 1;  // trajectory of the workgroup
+  const int w = wv & 1;    // column half
+  float* ring = smem + tw * per_traj;
+  float* tile = ring + kRing * kSlotWords;
+  float* xch = tile + kTile;
+  // zero the padding of both slots once (the pair shares the ring: half each)
+  for (int sl = 0; sl < kRing; ++sl)
+    for (int wd = S + lane + kWave * w; wd < kSlotWords; wd += 2 * kWave)
+      ring[sl * kSlotWords + wd] = T(0);
+  __syncthreads();
+
+  const int b = blockIdx.x * kTraj + tw;
+  if (!live_of(b)) {  // keep step with the workgroup's barriers
+    if constexpr (FORM == 1) step_barrier();
+    for (int t = N - 1; t >= 0; --t) {
+      if constexpr (FORM == 0) step_barrier();
+      step_barrier();
+      step_barrier();
+    }
+    return;
+  }
+  const int c = lane & 15, g = lane >> 4;
+  const int jcol = 16 * w + c;  // this lane's column of X (product 2) / Q~ / V
+  const T reg = (T)a.reg[b];
+  T umin = T(0), umax = T(0);
+  if constexpr (BOUNDED) { umin = a.u_min[0]; umax = a.u_max[0]; }
+
+  // ---- word offsets of this lane's operands inside a record; entries
+  // outside the matrices read the slot's zeroed padding (word S)
+  auto rho = [&](int s) { return 16 * (s >> 2) + 4 * g + (s & 3); };
+  int oF[2][8], oL[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int k = rho(s);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int j = 16 * cb + c;
+      const int f = (k < n) ? (j < n ? lay.oFz + k * n + j
+                                     : (j == n ? lay.oFu + k : -1))
+                            : -1;
+      oF[cb][s] = f < 0 ? S : f;
+    }
+    int o = -1;
+    if (k < n) {
+      if (jcol < n) o = lay.oLzz + k * n + jcol;
+      else if (jcol == n) o = lay.oLuz + k;  // L_uz^T
+      else if (jcol == 31) o = lay.oLz + k;
+    } else if (k == n) {
+      if (jcol < n) o = lay.oLuz + jcol;
+      else if (jcol == n) o = lay.oLuu;
+      else if (jcol == 31) o = lay.oLu;
+    }
+    oL[s] = o < 0 ? S : o;
+  }
+
+  // ---- terminal value function (ilqr.py:581-583)
+  T Vw[8], Vzw[4];
+  {
+    const T* term = a.rec + ((size_t)b * (size_t)(N + 1) + N) * S;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = rho(s);
+      Vw[s] = (k < n && jcol < n) ? term[lay.oLzz + k * n + jcol] : T(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * w + 4 * g + r;
+      Vzw[r] = (k < n) ? term[lay.oLz + k] : T(0);
+    }
+  }
+
+  T* gains_b = a.gains + (size_t)b * (size_t)N * lay.gstride;
+  T kprev = T(0);
+  int status = PDDP_BWD_OK;
+  // row n of Q~ sits in the registers of lane group (n & 15) >> 2
+  const int gn = (n & 15) >> 2;
+  static_assert(kRing == 2, "the step is instantiated once per ring slot");
+  // this lane's operands of a step, gathered from the record's slot: 16 words
+  // of F~ (both products), 8 of L~ (this wave's columns), the nominal action
+  T Fg[2][8], Li[8], Un = T(0);
+  auto gather = [&](const T* R) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      Fg[0][s] = R[oF[0][s]];
+      Fg[1][s] = R[oF[1][s]];
+      Li[s] = R[oL[s]];
+    }
+    if constexpr (BOUNDED) Un = R[lay.oU];
+  };
+  if constexpr (FORM == 1) {
+    step_barrier();  // (0) record N - 1 has landed
+    gather(ring);
+  }
+  // Two barriers per step: (2) X exchanged, (3) tile filled AND the next
+  // record landed - its gathers are issued right behind (3), under the BoxQP
+  // and the value update
+  auto step = [&](auto slot_c, int t) {
+    constexpr int slot = decltype(slot_c)::value;
+    if constexpr (FORM == 0) {
+      step_barrier();  // (1) record t has landed
+      gather(ring + slot * kSlotWords);
+    }
+    // ---- product 1: rows 16 w .. of X = V F~, both column blocks
+    // (a wave that feeds the matrix pipe goes first: it needs one issue slot
+    // in 32 cycles, and the other wavefront of the SIMD - another trajectory -
+    // fills the rest with its vector work)
+    f32x4 X0 = {0, 0, 0, 0}, X1 = {0, 0, 0, 0};
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      X0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vw[s], Fg[0][s], X0, 0, 0, 0);
+      X1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Vw[s], Fg[1][s], X1, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // X[:, 31] = V_z (lanes c = 15 of column block 1)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) X1[r] = (c == 15) ? Vzw[r] : X1[r];
+    // the partner's columns of my rows go to it; mine of its rows come back
+    {
+      const f32x4 give = w == 0 ? X1 : X0;
+      *reinterpret_cast<f32x4*>(xch + (w * kWave + lane) * 4) = give;
+    }
+    publish_barrier();  // (2)
+    const f32x4 Xo =
+        *reinterpret_cast<const f32x4*>(xch + ((1 - w) * kWave + lane) * 4);
+    const f32x4 Xm = w == 0 ? X0 : X1;
+    // ---- product 2: columns 16 w .. of Q~ = L~ + F~^T X, both row blocks.
+    // k-slices (rb, r): rows 16 rb + 4 g + r of X[:, 16 w + c]; rb = 0 are wave
+    // 0's rows (w is wave-uniform: selects, no indexing)
+    f32x4 Q0 = {Li[0], Li[1], Li[2], Li[3]}, Q1 = {Li[4], Li[5], Li[6], Li[7]};
+    const T Un_t = Un;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const T xk = s < 4 ? (w == 0 ? Xm[s & 3] : Xo[s & 3])
+                         : (w == 0 ? Xo[s & 3] : Xm[s & 3]);
+      if (s == 0) __builtin_amdgcn_s_setprio(3);
+      Q0 = __builtin_amdgcn_mfma_f32_16x16x4f32(Fg[0][s], xk, Q0, 0, 0, 0);
+      Q1 = __builtin_amdgcn_mfma_f32_16x16x4f32(Fg[1][s], xk, Q1, 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    // transpose tile: T[col][row] = Q~[row][col]
+    *reinterpret_cast<f32x4*>(tile + jcol * kTileLd + 4 * g) = Q0;
+    *reinterpret_cast<f32x4*>(tile + jcol * kTileLd + 16 + 4 * g) = Q1;
+    publish_barrier();  // (3)
+
+    // ---- everything the rest of the step reads from the tile, requested at
+    // once; then the next step's operands (its record has landed)
+    const T Quu = tile[n * kTileLd + n];
+    const T Qu = tile[31 * kTileLd + n];
+    const T Quz_j = tile[jcol * kTileLd + n];  // Q~[n][16 w + c]
+    T QT[8], Qk[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      QT[s] = tile[rho(s) * kTileLd + jcol];  // Q~[16 w + c][rho]
+      Qk[s] = tile[rho(s) * kTileLd + n];     // Q~[n][rho]
+    }
+    const f32x4 Qz = *reinterpret_cast<const f32x4*>(
+        tile + 31 * kTileLd + 16 * w + 4 * g);  // Q~[16 w + 4 g + r][31]
+    if constexpr (FORM == 1) {
+      if (t > 0) gather(ring + (1 - slot) * kSlotWords);
+    }
+
+    // ---- gains (every lane the same scalars)                 (ilqr.py:629-657)
+    int st = PDDP_BWD_OK;
+    if (!is_finite(Quu)) st = PDDP_BWD_NAN;     // eig raises (ilqr.py:631)
+    const T e = (Quu < T(0)) ? T(1e-12) : Quu;  // ilqr.py:633
+    const T qp_Q = e + reg;                     // ilqr.py:634
+    T kt, sE;
+    int stt = st;
+    if constexpr (BOUNDED) {
+      n4::QpClosed<T, FAST> qc;
+      qc.solve(kprev, qp_Q, Qu, umin - Un_t, umax - Un_t);
+      kt = qc.x;
+      bool Kz = !qc.free_, fail = qc.fail;
+      if (__builtin_amdgcn_ballot_w64(qc.slow) != 0) {
+        const n4::SlowQpOut<T> o = n4::boxqp1_outlined<T, FAST>(
+            kprev, qp_Q, Qu, umin - Un_t, umax - Un_t, lstep0, ls_tail, lane);
+        kt = o.x;
+        Kz = (o.result_free & 1) == 0;
+        fail = o.result_free < 2;
+      }
+      if (fail) stt = PDDP_BWD_BOXQP_FAILED;
+      if constexpr (FAST) sE = Kz ? T(0) : qc.inv;
+      else sE = Kz ? T(0) : n4::div_<false>(n4::div_<false>(T(1), qc.U), qc.U);
+    } else {
+      sE = n4::div_<FAST>(T(1), qp_Q);  // (E / e) E^T             (ilqr.py:636)
+      kt = -(sE * Qu);
+      // NaN in k or K raises (ilqr.py:639-640)
+      const bool nanK = (g == gn) && (jcol < n) && (sE * Quz_j != sE * Quz_j);
+      // (the partner sees its own columns only: the statuses are merged below)
+      if (kt != kt || __builtin_amdgcn_ballot_w64(nanK) != 0) stt = PDDP_BWD_NAN;
+    }
+    if (status == PDDP_BWD_OK && stt != PDDP_BWD_OK) status = stt;
+    kprev = kt;
+    const T cc = sE * (sE * Quu - T(2));
+    const T wc = kt - sE * (Qu + Quu * kt);
+
+    // ---- k, K of step t: this wave's columns of row n
+    {
+      const T val = (jcol < n) ? -(sE * Quz_j) : kt;
+      T* dst = gains_b + (size_t)t * lay.gstride + (jcol < n ? 1 + jcol : 0);
+      if (g == gn && jcol <= n) *dst = val;
+    }
+
+    // ---- V' = sym(Q_zz) + c Q_uz^T Q_uz,  V_z' = Q_z + Q_uz^T w
+    // (no masks: entries outside the n x n block meet zero rows / columns of
+    // F~ in both products of the next step - riccati_mfma32.hpp)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const T q = s < 4 ? Q0[s & 3] : Q1[s & 3];
+      const T sym = T(0.5) * (q + QT[s]);
+      Vw[s] = __builtin_fmaf(cc * Qk[s], Quz_j, sym);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const T qk = w == 0 ? Qk[r] : Qk[4 + r];  // rows 16 w + 4 g + r
+      Vzw[r] = __builtin_fmaf(qk, wc, Qz[r]);
+    }
+  };
+  for (int t = N - 1; t >= 0; t -= 2) {
+    step(std::integral_constant<int, 0>{}, t);
+    if (t >= 1) step(std::integral_constant<int, 1>{}, t - 1);
+  }
+  n4::wait_vmcnt<0>();
+  // both halves hold the same status except for the unbounded branch's NaN
+  // test of K, which each makes on its own columns: the first non-zero wins,
+  // column half 0 first (one writer per trajectory: wave 0 after the exchange)
+  if (lane == 0) xch[w] = __int_as_float(status);
+  publish_barrier();
+  if (w == 0 && lane == 0) {
+    const int other = __float_as_int(xch[1]);
+    a.status[b] = status != PDDP_BWD_OK ? status : other;
+  }
+}
+
+}  // namespace m32s
+
+// 15 <= n <= 30, m = 1, fp32, eig-clamp branches; PDDP_E_UNSUPPORTED otherwise
+static int launch_mfma32s(const RiccatiArgs<float>& a, hipStream_t st,
+                          bool fast_math, int form = 0) {
+  if (a.n < 15 || a.n > 30) return PDDP_E_UNSUPPORTED;
+  if (a.branch == PDDP_BRANCH_CHOLESKY) return PDDP_E_UNSUPPORTED;
+  const RecLayout lay(a.n, 1);
+  const int chunks = lay.stride / 4;
+  const int ndma = chunks / kWave + 1 <= 4 ? 4 : 8;
+  if (chunks >= ndma * kWave) return PDDP_E_UNSUPPORTED;
+  const size_t lds =
+      sizeof(float) * ((size_t)m32s::kTraj * (m32s::kRing * ndma * kWave * 4 +
+                                              m32s::kTile + m32s::kXch) +
+                       n4::kLsSteps);
+  const dim3 grid((a.B + m32s::kTraj - 1) / m32s::kTraj), block(m32s::kThreads);
+  const bool bounded = a.u_min != nullptr;
+#define PDDP_M32S(Bd, F, ND)                                                   \
+  do {                                                                         \
+    auto kern = form == 0 ? m32s::riccati_mfma32s_kernel<Bd, F, ND, 0>         \
+                          : m32s::riccati_mfma32s_kernel<Bd, F, ND, 1>;        \
+    const hipError_t e_ = hipFuncSetAttribute(                                 \
+        (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,         \
+        (int)lds);                                                             \
+    if (e_ != hipSuccess) return (int)e_;                                      \
+    PDDP_LAUNCH(kern, grid, block, lds, st, a);                                \
+  } while (0)
+#define PDDP_M32S_ND(Bd, F)                                                    \
+  do {                                                                         \
+    if (ndma == 4) PDDP_M32S(Bd, F, 4); else PDDP_M32S(Bd, F, 8);              \
+  } while (0)
+  if (bounded) { if (fast_math) PDDP_M32S_ND(true, true); else PDDP_M32S_ND(true, false); }
+  else { if (fast_math) PDDP_M32S_ND(false, true); else PDDP_M32S_ND(false, false); }
+#undef PDDP_M32S_ND
+#undef PDDP_M32S
+  return launch_status();
+}
+
+}  // namespace pddp

@@ -1130,7 +1130,9 @@ def test_backward_large_state_vs_oracle(n, m, dtype):
                                  (9, 6)])
 def test_matrix_core_sweeps_with_active_mask_and_ragged_batches(n, B):
     """The matrix-core sweeps (riccati_mfma16.hpp; riccati_mfma32.hpp with its
-    producer wavefront: two trajectories per workgroup, one barrier per step)
+    producer wavefront: two trajectories per workgroup, one barrier per step;
+    riccati_mfma32s.hpp: a trajectory's step on two wavefronts, auto on the
+    eig-clamp branch)
     on batch sizes that leave a workgroup half empty and under an `active`
     mask: active trajectories get exactly the un-masked launch's gains,
     inactive ones are not touched (gains and status), and the result is the
@@ -1176,6 +1178,17 @@ def test_matrix_core_sweeps_with_active_mask_and_ragged_batches(n, B):
         assert torch.equal(part[a], full[a])
         assert bool((part[~a] == 7.0).all()) and bool((sp[~a] == -5).all())
         assert float((full - ref).abs().max() / ref.abs().max()) < 2e-5
+        # every form by its number: the one-wave kernel (14 / 15) and, on the
+        # eig-clamp branch, the two-wavefront split (riccati_mfma32s.hpp:
+        # 26 / 27 three barriers per step, 28 / 29 two)
+        if n >= 15:
+            for variant in (14, 15) + ((26, 27, 28, 29) if branch == 0 else ()):
+                gv, sv = run(None, variant, branch)
+                pv, spv = run(act, variant, branch)
+                assert int(sv.abs().max()) == 0, variant
+                assert float((gv - ref).abs().max() / ref.abs().max()) < 2e-5, variant
+                assert torch.equal(pv[a], gv[a]), variant
+                assert bool((pv[~a] == 7.0).all()) and bool((spv[~a] == -5).all())
 
 
 def test_graph_replay_equals_eager_rounds():
