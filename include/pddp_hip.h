@@ -108,10 +108,9 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  * division; auto for those shapes other than n = 4); f64: n <= 14 on the f64
  * matrix cores, variant 14 only (15 and n > 14: PDDP_E_UNSUPPORTED; auto then
  * takes the generic kernel).
- * 26 / 27 (IEEE / approximate division), 28 / 29: 15 <= n <= 30, m = 1, f32,
- * eig-clamp branches with one trajectory's step split over two wavefronts
- * (three / two workgroup barriers per step); auto for those shapes and
- * branches: 29 up to 1536 trajectories, 27 beyond.
+ * 26 / 27 (IEEE / approximate division): 15 <= n <= 30, m = 1, f32, eig-clamp
+ * branches with one trajectory's step split over two wavefronts; auto for
+ * those shapes and branches: 27.
  * Auto for n = 4, m = 1: bounded eig-clamp branch: f32 below 12288
  * trajectories -> 25, up to 16383 -> 21, f64 up to 8192 -> 20; f32 from 12288
  * trajectories on -> 17; bounded Cholesky branch f32 below that -> 9; otherwise

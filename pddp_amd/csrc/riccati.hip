@@ -103,15 +103,13 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   //          f32 from 12288 trajectories on (other branches; all from 16384)
   //          -> 17; bounded Cholesky branch f32 below that -> 9; otherwise 7
   //          (f32) / 6 (f64); other shapes with m = 1, n <= 30 (f64: n <= 14)
-  //          -> 15 / 14 (f32, 15 <= n <= 30, eig-clamp branches: 29 up to 1536
-  //          trajectories, 27 beyond); everything else -> 1
+  //          -> 15 / 14 (f32, 15 <= n <= 30, eig-clamp branches: 27); everything else -> 1
   //          26 / 27: 15 <= n <= 30, m = 1, f32, eig-clamp branches with one
   //          trajectory's step split over two wavefronts (riccati_mfma32s.hpp)
-  //          (28 / 29: its two-barrier form)
-  if (variant >= 26 && variant <= 29) {
+  if (variant == 26 || variant == 27) {
     if constexpr (sizeof(T) == 4) {
       if (m != 1) return PDDP_E_UNSUPPORTED;
-      return launch_mfma32s(a, st, (variant & 1) != 0, variant >= 28 ? 1 : 0);
+      return launch_mfma32s(a, st, variant == 27);
     } else {
       return PDDP_E_UNSUPPORTED;
     }
@@ -126,7 +124,7 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
       // trajectories per GPU, 1385 -> 1217 at 4096); its two-barrier form
       // while a CU holds at most four trajectories
       if (variant == 0 && branch != PDDP_BRANCH_CHOLESKY)
-        return launch_mfma32s(a, st, true, B <= 1536 ? 1 : 0);
+        return launch_mfma32s(a, st, true);
       return launch_mfma32(a, st, variant != 14);
     } else {
       if (variant == 15 || n > 14) return PDDP_E_UNSUPPORTED;
