@@ -4,10 +4,10 @@
 // one-wave form leaves every SIMD with one wavefront whose 2048 matrix-core
 // cycles and ~460 vector instructions per step serialise (the vector work
 // depends on the products).  Here wavefront w of a pair owns 16 of the 32
-// columns; both products are done on v_mfma_f32_16x16x4_f32 (16 instructions of
-// 32 cycles per product and wave instead of 16 of 64), the vector work halves,
-// and a SIMD holds halves of two trajectories: one's vector work runs under
-// the other's products.
+// columns; both products are done on v_mfma_f32_16x16x4_f32 (at most 16
+// instructions of 32 cycles per product and wave instead of 16 of 64; the
+// k-slices that hold only zero rows of F~ are skipped, see the permutation
+// below), the vector work halves, and a SIMD holds halves of two trajectories.
 //
 //   X = V F~ (32 x 32, X[:, 31] = V_z), Q~ = L~ + F~^T X as in
 //   riccati_mfma32.hpp.  Lane (c, g) = (lane & 15, lane >> 4); rho(rb, r, g) =
@@ -38,7 +38,8 @@
 // waves never do the same thing - 340 us: the f32 matrix instruction runs on
 // the vector unit's own multipliers, its rate IS the packed vector rate, and a
 // SIMD's second wave does not advance under it; what a SIMD has to issue per
-// step pair, 2 x (1024 + ~900) cycles, is what the sweep takes.)
+// step pair - 2 x (896 matrix + ~800 other) cycles at n = 27 - is what the
+// sweep takes.)
 // Eig-clamp branches (B, D: the controller's default); the Cholesky branches
 // stay on the one-wave kernel.
 #pragma once
