@@ -1127,7 +1127,8 @@ def test_backward_large_state_vs_oracle(n, m, dtype):
 
 
 @pytest.mark.parametrize("n,B", [(27, 37), (20, 9), (15, 2), (30, 5), (14, 7),
-                                 (9, 6)])
+                                 (9, 6), (16, 8), (17, 3), (18, 4), (19, 2),
+                                 (23, 2), (24, 5), (25, 3), (28, 6), (29, 3)])
 def test_matrix_core_sweeps_with_active_mask_and_ragged_batches(n, B):
     """The matrix-core sweeps (riccati_mfma16.hpp; riccati_mfma32.hpp with its
     producer wavefront: two trajectories per workgroup, one barrier per step;
