@@ -87,7 +87,6 @@ template <typename T, bool BOUNDED, bool FAST, bool CHOL, int NDMA>
 __global__ __launch_bounds__(kWave * kWaves) void riccati_mfma16_kernel(
     RiccatiArgs<T> a) {
   constexpr int slot_words = NDMA * kWave * (16 / (int)sizeof(T));
-  constexpr int ndma = NDMA;
   using TL = Tile<T>;
   using Acc = typename TL::Acc;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
