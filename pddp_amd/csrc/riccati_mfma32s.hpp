@@ -327,7 +327,8 @@ __global__ __launch_bounds__(kThreads) void riccati_mfma32s_kernel(
         Kz = (o.result_free & 1) == 0;
         fail = o.result_free < 2;
       }
-      if (fail) stt = PDDP_BWD_BOXQP_FAILED;
+      // (a NaN Q_uu fails `eig` before the BoxQP is reached, ilqr.py:631)
+      if (fail && st == PDDP_BWD_OK) stt = PDDP_BWD_BOXQP_FAILED;
       if constexpr (FAST) sE = Kz ? T(0) : qc.inv;
       else sE = Kz ? T(0) : n4::div_<false>(n4::div_<false>(T(1), qc.U), qc.U);
     } else {

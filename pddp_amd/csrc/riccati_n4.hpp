@@ -753,7 +753,7 @@ __global__ __launch_bounds__(kWave * WPB) void riccati_n4_kernel(
       // closed form and after the rare loop call) so that the two paths only
       // merge at the step boundary.
       auto tail = [&]() {
-        int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
+        int stt = st != PDDP_BWD_OK ? st : (fail ? (int)PDDP_BWD_BOXQP_FAILED : (int)PDDP_BWD_OK);
         // K in row and column form, same arithmetic on transposed copies
         T Kr, Kc;
         if (by_inv) {

@@ -370,7 +370,7 @@ PDDP_DEV void defer_body(const RiccatiArgs<T>& a) {
       if constexpr (FAST) sx = qc.inv;
       else sx = T(1) / qp_Q;
       sx = Kzero ? T(0) : sx;
-      const int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
+      const int stt = st != PDDP_BWD_OK ? st : (fail ? (int)PDDP_BWD_BOXQP_FAILED : (int)PDDP_BWD_OK);
       T cx, wx;
       n4q::rank_one_coeffs(kx, sx, Quu, Qu, cx, wx);
       kt = take ? kx : kt; sK = take ? sx : sK;

@@ -457,7 +457,7 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
         }
       }
       const T sx = Kzero ? T(0) : qc.inv;
-      const int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
+      const int stt = st != PDDP_BWD_OK ? st : (fail ? (int)PDDP_BWD_BOXQP_FAILED : (int)PDDP_BWD_OK);
       T cx, wx;
       n4q::rank_one_coeffs(kx, sx, Quu, Qu, cx, wx);
       kt = take ? kx : kt; sK = take ? sx : sK;

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kQpThreads) void riccati_n4_qpipe_kernel(
       if constexpr (FAST) sK = qc.inv;
       else sK = T(1) / qp_Q;
       sK = Kzero ? T(0) : sK;
-      const int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
+      const int stt = st != PDDP_BWD_OK ? st : (fail ? (int)PDDP_BWD_BOXQP_FAILED : (int)PDDP_BWD_OK);
       // the rank-one value update of this step, for role M and for the next
       // phase's affine update
       T c, w;

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(kWave * WPB) void riccati_n4_quad_kernel(
     }
     // the rest of the step given the minimiser: K, status, stores, value update
     auto tail = [&]() {
-      int stt = fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
+      int stt = st != PDDP_BWD_OK ? st : (fail ? (int)PDDP_BWD_BOXQP_FAILED : (int)PDDP_BWD_OK);
       T Kq;
       if (by_inv) {
         Kq = -(inv * Quzg);

@@ -205,7 +205,8 @@ __global__ __launch_bounds__(kSplitThreads) void riccati_n4_split_kernel(
       q.sK = qc.free_ ? (FAST ? qc.inv : qc.U) : (T)__builtin_nan("");
       q.Quu = Quu;
       q.Qu = Qu;
-      int stt = qc.fail ? (int)PDDP_BWD_BOXQP_FAILED : st;
+      int stt = st != PDDP_BWD_OK ? st
+                                   : (qc.fail ? (int)PDDP_BWD_BOXQP_FAILED : (int)PDDP_BWD_OK);
       if (__builtin_amdgcn_ballot_w64(qc.slow & alive) != 0) {
         // rare: the reference's loop as written
         const SlowQpOut<T> o = boxqp1_outlined<T, FAST>(
@@ -215,7 +216,8 @@ __global__ __launch_bounds__(kSplitThreads) void riccati_n4_split_kernel(
         q.kt = o.x;
         q.sK = (o.result_free & 1) ? (FAST ? qc.inv : o.U)
                                    : (T)__builtin_nan("");
-        stt = (o.result_free < 2) ? (int)PDDP_BWD_BOXQP_FAILED : st;
+        stt = st != PDDP_BWD_OK ? st
+                               : ((o.result_free < 2) ? (int)PDDP_BWD_BOXQP_FAILED : (int)PDDP_BWD_OK);
       }
       {
         T* pq = &xq[s & 1][lane][0];

@@ -1192,6 +1192,74 @@ def test_matrix_core_sweeps_with_active_mask_and_ragged_batches(n, B):
                 assert bool((pv[~a] == 7.0).all()) and bool((spv[~a] == -5).all())
 
 
+@pytest.mark.parametrize("n", [27, 20, 15, 14, 4])
+def test_matrix_core_sweeps_report_failures_like_the_generic_kernel(n):
+    """A non-finite record (NaN in L_uu of one step: Q_uu is NaN from there on,
+    `eig` raises, ilqr.py:631) in some trajectories: the matrix-core sweeps -
+    one wave per trajectory (15) and its step split over two (27: both halves
+    see the same scalars, one writes the status) - report the status the
+    generic kernel reports, bounded and unbounded, and leave the other
+    trajectories' gains what they are without the fault.  (n = 14: the 16 x 16
+    matrix-core kernel; n = 4: the specialised sweeps on records.  All of them
+    used to report "BoxQP failed" here - the closed-form BoxQP fails on a NaN
+    too, and its status overwrote the earlier one.)"""
+    from pddp_amd import _native
+    dt = torch.float32
+    B, N, m = 6, 9, 1
+    lay = _native.record_layout(n, m)
+    g = torch.Generator(device="cuda").manual_seed(100 + n)
+    r = lambda *s: torch.randn(*s, generator=g, device="cuda", dtype=dt)
+    eye = torch.eye(n, device="cuda")
+    F_z, F_u = eye + 0.05 * r(B, N, n, n), 0.3 * r(B, N, n, m)
+    L_z, L_u = r(B, N + 1, n), r(B, N, m)
+    R = 0.2 * r(B, N + 1, n, n)
+    L_zz = eye + R @ R.transpose(-1, -2)
+    L_uz = 0.05 * r(B, N, m, n)
+    L_uu = 1.0 + 0.04 * r(B, N, m, m) ** 2
+    U = 0.5 * r(B, N, m)
+    p, st = _native.ptr, _native.stream_handle(F_z.device)
+
+    def pack(L_uu_):
+        rec = torch.empty(B, N + 1, lay.stride, dtype=dt, device="cuda")
+        _native.call("pddp_pack_records", dt, B, N, n, m, p(F_z), p(F_u),
+                     p(L_z), p(L_u), p(L_zz), p(L_uz), p(L_uu_), p(U), p(rec),
+                     st)
+        return rec
+
+    bad = L_uu.clone()
+    bad[1, 4] = float("nan")
+    bad[4, 0] = float("nan")
+    rec_ok, rec_bad = pack(L_uu), pack(bad)
+    u_min, u_max = -torch.ones(m, device="cuda"), torch.ones(m, device="cuda")
+    reg = torch.full((B,), 1e-3, dtype=torch.float64, device="cuda")
+
+    def run(rec, variant, bounded):
+        gains = torch.full((B, N, lay.gain_stride), 7.0, device="cuda")
+        status = torch.full((B,), -5, dtype=torch.int32, device="cuda")
+        _native.call("pddp_riccati_backward_variant", dt, B, N, n, m, p(rec),
+                     p(u_min) if bounded else None,
+                     p(u_max) if bounded else None, p(reg), 0, None, p(gains),
+                     p(status), st, variant)
+        torch.cuda.synchronize()
+        return gains, status
+
+    fine = torch.tensor([True, False, True, True, False, True])
+    for bounded in (True, False):
+        ref_g, ref_s = run(rec_bad, 1, bounded)
+        assert ref_s.cpu().tolist()[1] != 0 and ref_s.cpu().tolist()[4] != 0
+        assert int(ref_s.cpu()[fine].abs().max()) == 0
+        variants = {27: (0, 15, 27), 20: (0, 15, 27), 15: (0, 15, 27),
+                    14: (0, 15),
+                    # n = 4: every specialised sweep (7 sixteen lanes, 17 quad;
+                    # bounded only: 9 split, 21 three wavefronts, 25 deferred)
+                    4: (0, 7, 17) + ((9, 21, 25) if bounded else ())}[n]
+        for variant in variants:
+            g_bad, s_bad = run(rec_bad, variant, bounded)
+            g_ok, _ = run(rec_ok, variant, bounded)
+            assert torch.equal(s_bad.cpu(), ref_s.cpu()), (variant, bounded)
+            assert torch.equal(g_bad[fine], g_ok[fine]), (variant, bounded)
+
+
 def test_graph_replay_equals_eager_rounds():
     """ILQRSolver.capture_round(): a fit driven by hipGraph replays ends in
     exactly the eager result (same kernels, same order, same buffers), also
