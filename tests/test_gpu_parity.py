@@ -1226,38 +1226,57 @@ def test_matrix_core_sweeps_report_failures_like_the_generic_kernel(n):
                      st)
         return rec
 
-    bad = L_uu.clone()
-    bad[1, 4] = float("nan")
-    bad[4, 0] = float("nan")
-    rec_ok, rec_bad = pack(L_uu), pack(bad)
     u_min, u_max = -torch.ones(m, device="cuda"), torch.ones(m, device="cuda")
     reg = torch.full((B,), 1e-3, dtype=torch.float64, device="cuda")
 
-    def run(rec, variant, bounded):
+    def run(rec, variant, bounded, branch):
         gains = torch.full((B, N, lay.gain_stride), 7.0, device="cuda")
         status = torch.full((B,), -5, dtype=torch.int32, device="cuda")
         _native.call("pddp_riccati_backward_variant", dt, B, N, n, m, p(rec),
                      p(u_min) if bounded else None,
-                     p(u_max) if bounded else None, p(reg), 0, None, p(gains),
-                     p(status), st, variant)
+                     p(u_max) if bounded else None, p(reg), branch, None,
+                     p(gains), p(status), st, variant)
         torch.cuda.synchronize()
         return gains, status
 
+    rec_ok = pack(L_uu)
     fine = torch.tensor([True, False, True, True, False, True])
-    for bounded in (True, False):
-        ref_g, ref_s = run(rec_bad, 1, bounded)
-        assert ref_s.cpu().tolist()[1] != 0 and ref_s.cpu().tolist()[4] != 0
-        assert int(ref_s.cpu()[fine].abs().max()) == 0
-        variants = {27: (0, 15, 27), 20: (0, 15, 27), 15: (0, 15, 27),
-                    14: (0, 15),
+    # NaN: both branches; a large negative L_uu: Q_uu_reg is not positive
+    # definite - `potrf` fails on the unbounded Cholesky branch (ilqr.py:595),
+    # the BoxQP on the bounded one; the eig-clamp branch clamps it and goes on
+    for fault, value in (("nan", float("nan")), ("negative", -1e4)):
+        bad = L_uu.clone()
+        bad[1, 4] = value
+        bad[4, 0] = value
+        rec_bad = pack(bad)
+        for branch in (0, 1):
+            for bounded in (True, False):
+                ref_g, ref_s = run(rec_bad, 1, bounded, branch)
+                got = ref_s.cpu().tolist()
+                if fault == "nan":
+                    assert got[1] != 0 and got[4] != 0, (fault, branch,
+                                                          bounded, got)
+                # (a negative Q_uu: the eig-clamp branch goes on with e = 1e-12
+                # + reg, the bounded Cholesky branch may end with every action
+                # clamped - whatever the generic kernel says)
+                assert int(ref_s.cpu()[fine].abs().max()) == 0
+                if n >= 15:
+                    variants = (0, 15) + ((27,) if branch == 0 else ())
+                elif n == 14:
+                    variants = (0, 15)
+                else:
                     # n = 4: every specialised sweep (7 sixteen lanes, 17 quad;
-                    # bounded only: 9 split, 21 three wavefronts, 25 deferred)
-                    4: (0, 7, 17) + ((9, 21, 25) if bounded else ())}[n]
-        for variant in variants:
-            g_bad, s_bad = run(rec_bad, variant, bounded)
-            g_ok, _ = run(rec_ok, variant, bounded)
-            assert torch.equal(s_bad.cpu(), ref_s.cpu()), (variant, bounded)
-            assert torch.equal(g_bad[fine], g_ok[fine]), (variant, bounded)
+                    # bounded: 9 split; bounded eig-clamp only: 21 three
+                    # wavefronts, 25 deferred)
+                    variants = (0, 7, 17) + ((9,) if bounded else ()) + (
+                        (21, 25) if bounded and branch == 0 else ())
+                for variant in variants:
+                    g_bad, s_bad = run(rec_bad, variant, bounded, branch)
+                    g_ok, _ = run(rec_ok, variant, bounded, branch)
+                    key = (fault, branch, bounded, variant)
+                    assert torch.equal(s_bad.cpu(), ref_s.cpu()), (
+                        key, s_bad.cpu().tolist(), ref_s.cpu().tolist())
+                    assert torch.equal(g_bad[fine], g_ok[fine]), key
 
 
 def test_graph_replay_equals_eager_rounds():
