@@ -1482,6 +1482,37 @@ def test_sweep_from_nominal_equals_records_then_sweep(B, N, kernel):
         _sweep_from_nominal_case(B, N, same_arithmetic=False)
 
 
+@pytest.mark.parametrize("kernel", [3, 4])
+def test_sweep_from_nominal_reports_a_nan_nominal(kernel):
+    """A NaN in the nominal controls of some trajectories: the sweep from the
+    nominal reports what the records path (pddp_derivs_f32 + the generic
+    kernel) reports - PDDP_BWD_NAN, `eig` on a NaN Q_uu (ilqr.py:631) - and
+    the other trajectories of the same wavefront are not disturbed."""
+    B, N = 24, 40
+    with _nominal_kernel(kernel):
+        s, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=3)
+        U = U.copy()
+        U[2, 17] = np.nan
+        U[9, 0] = np.nan
+        U[10, N - 1] = np.nan
+        s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+        s.mu.fill_(1.0)
+        s.derivs()
+        s.backward(active=s.active, variant=1)
+        ref_s, ref_g = s.bwd_status.clone(), s.gains.clone()
+        assert [int(v) for v in ref_s.cpu()[[2, 9, 10]]] == [1, 1, 1]
+        s.bwd_status.fill_(-7)
+        s.gains.zero_()
+        s.fresh.fill_(1)
+        assert s.sweep_nominal()
+        torch.cuda.synchronize()
+        assert torch.equal(s.bwd_status.cpu(), ref_s.cpu())
+        ok = (ref_s == 0).cpu()
+        g, gr = s.gains.cpu()[ok].double(), ref_g.cpu()[ok].double()
+        per = (g - gr).abs().amax(dim=(1, 2)) / gr.abs().max()
+        assert torch.isfinite(g).all() and float(per.max()) < 2e-2
+
+
 def _sweep_from_nominal_case(B, N, same_arithmetic):
     s, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=11)
     assert s._nominal_sweep is None  # in its domain, untried
