@@ -593,6 +593,19 @@ int pddp_gp_step_f32(const pddp_gp_model* gp, int R, const float* z, const float
                      float* z_next, float* Fz, float* Fu, void* stream);
 int pddp_gp_step_f64(const pddp_gp_model* gp, int R, const double* z, const double* u,
                      double* z_next, double* Fz, double* Fu, void* stream);
+/* The same with a mask over groups of `rows_per_mask` consecutive rows
+ * (row_mask [ceil(R / rows_per_mask)], nullable = every row): rows of a group
+ * with row_mask[group] == 0 are skipped - nothing of theirs is read or
+ * written.  The derivative rollout of a round passes the trajectories whose
+ * nominal is new (rows_per_mask = N): the records of the others stand
+ * (ilqr.py:125-139: a rejected step retries with a larger mu on the same
+ * nominal). */
+int pddp_gp_step_masked_f32(const pddp_gp_model* gp, int R, const float* z, const float* u,
+                            float* z_next, float* Fz, float* Fu, const uint8_t* row_mask,
+                            int rows_per_mask, void* stream);
+int pddp_gp_step_masked_f64(const pddp_gp_model* gp, int R, const double* z, const double* u,
+                            double* z_next, double* Fz, double* Fu, const uint8_t* row_mask,
+                            int rows_per_mask, void* stream);
 
 /* ---- the GP workload's line search as a device rollout (the plugin path's
  * counterpart of pddp_line_search_*; ilqr.py:677-723 control law + rollout,

@@ -93,6 +93,7 @@ _SIGS = {
     "pddp_bnn_jvp_moments_f32": [_P, _P],
     "pddp_qr_cost_derivs_f32": [_P, _P],
     "pddp_gp_step": [_P, c_int, _P, _P, _P, _P, _P, _P],
+    "pddp_gp_step_masked": [_P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P],
     "pddp_gp_step_lds_bytes": [c_int] * 6,
     "pddp_gp_rollout": [_P, _P, _P],
     "pddp_event_create": [_P],
@@ -107,7 +108,8 @@ _TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
           "pddp_nominal_rollout",
           "pddp_derivs",
           "pddp_line_search", "pddp_search_accept", "pddp_accept",
-          "pddp_pack_best", "pddp_gp_step", "pddp_gp_rollout")
+          "pddp_pack_best", "pddp_gp_step", "pddp_gp_step_masked",
+          "pddp_gp_rollout")
 
 _lib = None
 

@@ -147,7 +147,9 @@ class TorchProblem(object):
         elif gp_dyn:
             # GP plugin: every (trajectory, step) row of the nominal in ONE
             # launch of the moment-matched step with its Jacobian
-            self._dyn_derivs_gp(s, F_z, F_u)
+            # (rows of the trajectories whose nominal stands are skipped:
+            # their records are kept below)
+            self._dyn_derivs_gp(s, F_z, F_u, mask)
             native_dyn = True
         self.last_derivs_path = {"dynamics": "hip" if native_dyn else "autograd",
                                  "cost": "hip" if native_cost else "autograd"}
@@ -203,16 +205,21 @@ class TorchProblem(object):
         return bool(mo.native_ok(s.Z[:, 0], self.encoding, jacobian=True))
 
     @torch.no_grad()
-    def _dyn_derivs_gp(self, s, F_z, F_u):
+    def _dyn_derivs_gp(self, s, F_z, F_u, mask=None):
         """F_z [B N n n], F_u [B N n m] of the nominal: d z' / d (z, u) at the
-        clamped actions (ilqr.py:443-470), by `pddp_gp_step_*`."""
+        clamped actions (ilqr.py:443-470), by `pddp_gp_step_*`; with `mask`
+        [B] only for its trajectories (`pddp_gp_step_masked_*`)."""
         B, N, n, m = s.B, s.N, s.n, s.m
         z = s.Z[:, :N].reshape(B * N, n)
         u = s.U
         if s.u_min is not None:
             u = clamp(u, s.u_min, s.u_max)
+        rm = None
+        if mask is not None:
+            rm = mask.to(torch.uint8).contiguous()
         self.model.native_step(z, u.reshape(B * N, m), self.encoding,
-                               jacobian=True, Fz=F_z, Fu=F_u)
+                               jacobian=True, Fz=F_z, Fu=F_u, row_mask=rm,
+                               rows_per_mask=N)
 
     def _gp_line_search_ok(self, s):
         """The line search as N launches of the GP step plus ONE batched

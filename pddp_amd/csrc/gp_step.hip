@@ -54,6 +54,10 @@ constexpr int kMaxAng = 4, kMaxNon = 8;
 template <typename T>
 struct Args {
   int R, M, m_act, n_ang, n_non, encoding, n;
+  // rows of group r / rows_per_mask are skipped where row_mask[group] == 0
+  // (nullable: every row)
+  const uint8_t* row_mask;
+  int rows_per_mask;
   int ang[kMaxAng], non[kMaxNon];
   const T* Xt;    // [M d]
   const T* XtP;   // [MQ/2][PS]: (x_2j[p], x_2j+1[p]) pairs, MQ = M rounded up to 4, PS = 2 d rounded up to 4
@@ -307,6 +311,9 @@ PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
   const Lds<E, D> o(M, K, JAC);
   auto nu_at = [&](int i, int p) -> T& { return sm[o.nu + (i >> 1) * PS + 2 * p + (i & 1)]; };
   const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if constexpr (!ROLL) {
+    if (A.row_mask != nullptr && A.row_mask[row / A.rows_per_mask] == 0) return;
+  }
   const T* z = A.z + (size_t)row * n;
   const T* u = A.u + (size_t)row * A.m_act;
   T* z_out = A.z_next + (size_t)row * n;
@@ -1112,6 +1119,7 @@ int fill_model(const pddp_gp_model* g, Args<T>& a) {
   a.sf2 = (const T*)g->sf2;
   a.sn2 = (const T*)g->sn2;
   a.z = nullptr; a.u = nullptr; a.z_next = nullptr; a.Fz = nullptr; a.Fu = nullptr;
+  a.row_mask = nullptr; a.rows_per_mask = 1;
   return 0;
 }
 
@@ -1141,11 +1149,13 @@ int rollout(const pddp_gp_model* g, const pddp_gp_rollout* q, void* stream) {
 }
 
 template <typename T>
-int step(const pddp_gp_model* g, int R, const T* z, const T* u, T* z_next, T* Fz, T* Fu, void* stream) {
+int step(const pddp_gp_model* g, int R, const T* z, const T* u, T* z_next, T* Fz, T* Fu, void* stream,
+         const uint8_t* row_mask = nullptr, int rows_per_mask = 1) {
   if (g == nullptr || R < 0 || z == nullptr || u == nullptr || z_next == nullptr) return PDDP_E_BADARG;
   if (!g->Xt || !g->Xt_pairs || !g->beta || !g->beta_pairs || !g->Kinv || !g->inv_ell2 || !g->sf2 || !g->sn2)
     return PDDP_E_BADARG;
   if ((Fz == nullptr) != (Fu == nullptr)) return PDDP_E_BADARG;
+  if (row_mask != nullptr && rows_per_mask < 1) return PDDP_E_BADARG;
   if (R == 0) return 0;
   if (g->n_ang < 0 || g->n_ang > kMaxAng || g->n_non < 0 || g->n_non > kMaxNon) return PDDP_E_BADARG;
   if (g->n_ang + g->n_non != g->state_size || g->M < 1 || g->action_size < 1) return PDDP_E_BADARG;
@@ -1183,6 +1193,8 @@ int step(const pddp_gp_model* g, int R, const T* z, const T* u, T* z_next, T* Fz
   a.z_next = z_next;
   a.Fz = Fz;
   a.Fu = Fu;
+  a.row_mask = row_mask;
+  a.rows_per_mask = rows_per_mask;
   const bool jac = Fz != nullptr;
   hipStream_t st = (hipStream_t)stream;
   // the systems of the reference's examples: pendulum, cartpole, double cartpole
@@ -1217,6 +1229,16 @@ int pddp_gp_step_f32(const pddp_gp_model* g, int R, const float* z, const float*
 int pddp_gp_step_f64(const pddp_gp_model* g, int R, const double* z, const double* u, double* z_next,
                      double* Fz, double* Fu, void* stream) {
   return pddp::gp::step<double>(g, R, z, u, z_next, Fz, Fu, stream);
+}
+int pddp_gp_step_masked_f32(const pddp_gp_model* g, int R, const float* z, const float* u,
+                            float* z_next, float* Fz, float* Fu, const uint8_t* row_mask,
+                            int rows_per_mask, void* stream) {
+  return pddp::gp::step<float>(g, R, z, u, z_next, Fz, Fu, stream, row_mask, rows_per_mask);
+}
+int pddp_gp_step_masked_f64(const pddp_gp_model* g, int R, const double* z, const double* u,
+                            double* z_next, double* Fz, double* Fu, const uint8_t* row_mask,
+                            int rows_per_mask, void* stream) {
+  return pddp::gp::step<double>(g, R, z, u, z_next, Fz, Fu, stream, row_mask, rows_per_mask);
 }
 int pddp_gp_rollout_f32(const pddp_gp_model* g, const pddp_gp_rollout* r, void* stream) {
   return pddp::gp::rollout<float>(g, r, stream);

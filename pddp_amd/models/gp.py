@@ -333,11 +333,14 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
 
         @torch.no_grad()
         def native_step(self, z, u, encoding=StateEncoding.DEFAULT,
-                        jacobian=False, Fz=None, Fu=None):
+                        jacobian=False, Fz=None, Fu=None, row_mask=None,
+                        rows_per_mask=1):
             """`forward` on the HIP kernel for rows z [R, n], u [R, m]; with
             `jacobian` also d z' / d z [R, n, n] and d z' / d u [R, n, m]
             (written into Fz, Fu when given: contiguous, R n n / R n m
-            elements)."""
+            elements).  `row_mask` (uint8, one entry per `rows_per_mask`
+            consecutive rows): rows of a zero entry are skipped, their outputs
+            left as they are."""
             import ctypes
             from .. import _native
             z = z.detach().contiguous()
@@ -357,9 +360,18 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
                 Fz = Fu = None
             p = _native.ptr
             with torch.cuda.device(z.device):
-                _native.call("pddp_gp_step", z.dtype, ctypes.byref(g), R, p(z),
-                             p(u), p(out), p(Fz), p(Fu),
-                             _native.stream_handle(z.device))
+                if row_mask is None:
+                    _native.call("pddp_gp_step", z.dtype, ctypes.byref(g), R,
+                                 p(z), p(u), p(out), p(Fz), p(Fu),
+                                 _native.stream_handle(z.device))
+                else:
+                    assert row_mask.dtype == torch.uint8 and \
+                        row_mask.is_contiguous() and row_mask.numel() * \
+                        int(rows_per_mask) >= R
+                    _native.call("pddp_gp_step_masked", z.dtype,
+                                 ctypes.byref(g), R, p(z), p(u), p(out), p(Fz),
+                                 p(Fu), p(row_mask), int(rows_per_mask),
+                                 _native.stream_handle(z.device))
             return (out, Fz, Fu) if jacobian else out
 
         def forward(self, z, u, i, encoding=StateEncoding.DEFAULT,

@@ -776,3 +776,38 @@ def test_gp_fit_on_the_device_leaves_other_tensors_alone():
            if not bool((t == t.flatten()[-1]).all()) or
            int(t.flatten()[-1]) not in (3, 4, 5, 6, 7)]
     assert not bad, bad[:10]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_gp_step_with_a_row_mask(dtype):
+    """pddp_gp_step_masked_*: groups of rows with a zero mask entry are skipped
+    - their outputs (step and Jacobians) are left as they were - and the other
+    rows are the unmasked launch's, bit for bit."""
+    model, _ = _system_model("cartpole", 30, dtype)
+    enc = StateEncoding.DEFAULT
+    g = torch.Generator().manual_seed(5)
+    groups, per = 5, 3
+    R = groups * per - 1   # (a ragged last group)
+    z = torch.stack([GaussianVariable(
+        0.3 * torch.randn(4, generator=g, dtype=torch.float64),
+        var=1e-2 * torch.ones(4, dtype=torch.float64)).encode(enc)
+        for _ in range(R)]).to(dtype).cuda()
+    u = (0.3 * torch.randn(R, 1, generator=g)).to(dtype).cuda()
+    n = z.shape[1]
+    full = [t.clone() for t in model.native_step(z, u, enc, jacobian=True)]
+    mask = torch.tensor([1, 0, 1, 0, 1], dtype=torch.uint8, device="cuda")
+    Fz = torch.full((R, n, n), 7.0, dtype=dtype, device="cuda")
+    Fu = torch.full((R, n, 1), 7.0, dtype=dtype, device="cuda")
+    out, Fz2, Fu2 = model.native_step(z, u, enc, jacobian=True, Fz=Fz, Fu=Fu,
+                                      row_mask=mask, rows_per_mask=per)
+    rows = torch.arange(R, device="cuda") // per
+    live = mask[rows].bool()
+    assert torch.equal(out[live], full[0][live])
+    assert torch.equal(Fz2[live], full[1][live])
+    assert torch.equal(Fu2[live], full[2][live])
+    assert bool((Fz2[~live] == 7.0).all()) and bool((Fu2[~live] == 7.0).all())
+    # forward only (another kernel: against its own unmasked launch)
+    full_f = model.native_step(z, u, enc).clone()
+    out_f = model.native_step(z, u, enc, row_mask=mask, rows_per_mask=per)
+    assert torch.equal(out_f[live], full_f[live])
