@@ -393,6 +393,17 @@ int pddp_bnn_mlp_f32(int R, int P, int in_dim, int H, int out_dim,
                      const float* M1, const float* W2, const float* b2,
                      const float* M2, const float* W3, const float* b3,
                      float* Y, void* stream);
+/* The same on the first min(R, *live_rows) rows only (live_rows: one int32 on
+ * the device, read by the kernel - no host synchronisation; nullable = R): the
+ * launch is sized for R, workgroups without a tile leave at once.  The rows
+ * beyond are neither read nor written.  For a line search whose live
+ * candidates are packed to the front (pddp_bnn_step.slot): a round of retries
+ * with three of 256 restarts alive runs the network on 3 / 256 of the rows. */
+int pddp_bnn_mlp_rows_f32(int R, int P, int in_dim, int H, int out_dim,
+                          const float* X, const float* W1, const float* b1,
+                          const float* M1, const float* W2, const float* b2,
+                          const float* M2, const float* W3, const float* b3,
+                          float* Y, const int32_t* live_rows, void* stream);
 
 /* ---- one time step of the moment-matched line-search rollout under a BNN
  * dynamics model, everything but the network: ilqr.py:677-723 (_control_law),
@@ -442,6 +453,12 @@ typedef struct pddp_bnn_step {
    * t - 1, [P][D]; then X_t += exp(net_out[:, D + d] + log dX_std[d]) *
    * eps_out[p][d] and out_dim >= 2 D.  NULL: the predicted std is not used. */
   const float* eps_out;
+  /* [B] nullable: the rank of trajectory b among the live ones (active and
+   * bwd_status == 0; anything for the others).  Given, the network-facing rows
+   * - F and net_out - of candidate (b, a) are (slot[b] A + a) P + p instead of
+   * (b A + a) P + p: the network then runs on the first (live count) A P rows
+   * only (pddp_bnn_mlp_rows_f32).  The other arrays keep their indexing. */
+  const int32_t* slot;
 } pddp_bnn_step;
 int pddp_bnn_moment_step_f32(const pddp_bnn_step* step, void* stream);
 

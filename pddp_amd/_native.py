@@ -85,6 +85,7 @@ _SIGS = {
     "pddp_search_candidates": [c_int],
     "pddp_bnn_mlp_precision": [c_int],
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
+    "pddp_bnn_mlp_rows_f32": [c_int] * 5 + [_P] * 12,
     "pddp_bnn_moment_step_f32": [_P, _P],
     "pddp_bnn_mlp_jvp_f32": [c_int] * 6 + [_P] * 11,
     "pddp_bnn_mlp_jvp_live_f32": [c_int] * 7 + [_P] * 11,
@@ -191,7 +192,7 @@ class BnnStep(ctypes.Structure):
             "Z", "U", "gains", "alphas", "u_min", "u_max", "active",
             "bwd_status", "Q", "Q_term", "R", "x_goal", "u_goal", "X_mean",
             "X_std_inv", "dX_mean", "dX_std", "net_out", "Xp", "F", "Zc", "Uc",
-            "J", "Jc", "eps_out")])
+            "J", "Jc", "eps_out", "slot")])
 
 
 class BnnJvp(ctypes.Structure):

@@ -721,6 +721,22 @@ class TorchProblem(object):
                         ("F", F), ("Zc", Zc), ("Uc", Uc), ("J", J),
                         ("Jc", Jc)):
             setattr(st, name, p(t))
+        # The live trajectories' candidates are packed to the front of the
+        # network's rows (slot = rank among the live ones) and the network runs
+        # on those rows only - a count it reads on the device: a round of
+        # retries with three of 256 restarts alive costs 3 / 256 of the
+        # network time (sync-free: capturable)
+        live_rows = slot = None
+        if active is not None or status is not None:
+            alive = torch.ones(B, dtype=torch.bool, device=s.device)
+            if active is not None:
+                alive &= active != 0
+            if status is not None:
+                alive &= status == 0
+            rank = torch.cumsum(alive.to(torch.int32), 0, dtype=torch.int32)
+            slot = (rank - 1).contiguous()
+            live_rows = (rank[-1:] * (A * P)).to(torch.int32)
+            st.slot = p(slot)
         lib, stream = _native.lib(), _native.stream_handle(s.device)
         out = None
         eps_keep = [self._eps_out(i, P, D, opts) for i in range(N)] if ups \
@@ -733,7 +749,7 @@ class TorchProblem(object):
                                                        stream),
                           "pddp_bnn_moment_step_f32")
             if t < N:
-                out = mo.model._forward_native(F, out_dim)
+                out = mo.model._forward_native(F, out_dim, live_rows=live_rows)
         mo.output = {}  # the particle caches of a torch-path rollout: stale
         return Jc
 

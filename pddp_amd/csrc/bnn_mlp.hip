@@ -84,6 +84,7 @@ struct BnnMlpArgs {
   const float* W3;
   const float* b3;
   float* Y;
+  const int32_t* live_rows;  // nullable: rows beyond *live_rows are left out
 };
 
 constexpr int kMlpThreads = 512;
@@ -189,7 +190,12 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int P = a.P, IN = a.in_dim, OUT = a.out_dim, R = a.R;
+  const int P = a.P, IN = a.in_dim, OUT = a.out_dim;
+  int R = a.R;
+  if (a.live_rows != nullptr) {  // (one scalar load: the count is device data)
+    const int lr = *a.live_rows;
+    R = lr < R ? (lr > 0 ? lr : 0) : R;
+  }
 
   const int ntiles = (R + TROWS - 1) / TROWS;
   // tile row rt (MFMA column) of tile `tile` -> memory row; rows of padding
@@ -215,6 +221,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   // grid is never larger than the number of tiles)
   const int my = blockIdx.x < ntiles
                      ? (ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+  if (my == 0) return;  // (live_rows: fewer tiles than the launch was sized for)
   // LDS only: the tile barrier must not wait for the finisher's row stores
   auto tile_barrier = [] {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -696,8 +703,22 @@ int pddp_bnn_mlp_f32(int R, int P, int in_dim, int H, int out_dim,
     return PDDP_E_BADARG;
   if (in_dim >= pddp::kMlpW1Max || out_dim > pddp::kMlpMaxOut)
     return PDDP_E_UNSUPPORTED;
+  return pddp_bnn_mlp_rows_f32(R, P, in_dim, H, out_dim, X, W1, b1, MT1, W2, b2,
+                               MT2, W3, b3, Y, nullptr, stream);
+}
+
+int pddp_bnn_mlp_rows_f32(int R, int P, int in_dim, int H, int out_dim,
+                          const float* X, const float* W1, const float* b1,
+                          const float* MT1, const float* W2, const float* b2,
+                          const float* MT2, const float* W3, const float* b3,
+                          float* Y, const int32_t* live_rows, void* stream) {
+  if (R <= 0 || P <= 0 || in_dim <= 0 || H <= 0 || out_dim <= 0 || !X || !W1 ||
+      !b1 || !MT1 || !W2 || !b2 || !MT2 || !W3 || !b3 || !Y)
+    return PDDP_E_BADARG;
+  if (in_dim >= pddp::kMlpW1Max || out_dim > pddp::kMlpMaxOut)
+    return PDDP_E_UNSUPPORTED;
   const pddp::BnnMlpArgs a{R, P, in_dim, H, out_dim, X, W1, b1, MT1, W2,
-                           b2, MT2, W3, b3, Y};
+                           b2, MT2, W3, b3, Y, live_rows};
   hipStream_t st = (hipStream_t)stream;
   switch (H) {
     case 64: return pddp::launch_bnn_mlp<64>(a, st);
@@ -721,7 +742,7 @@ static int bnn_mlp_jvp_impl(int R, int P, int group, int live, int in_dim,
   if (in_dim >= pddp::kMlpW1Max || out_dim > pddp::kMlpMaxOut)
     return PDDP_E_UNSUPPORTED;
   const pddp::BnnMlpArgs a{R, P, in_dim, H, out_dim, X, W1, b1, MT1, W2,
-                           b2, MT2, W3, b3, Y};
+                           b2, MT2, W3, b3, Y, nullptr};
   hipStream_t st = (hipStream_t)stream;
 #define PDDP_MLP_H(G, L)                                             \
   switch (H) {                                                       \

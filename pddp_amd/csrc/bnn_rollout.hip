@@ -102,6 +102,10 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
   // wavefront per workgroup, a barrier only orders its LDS traffic)
   if (s.active != nullptr && s.active[b] == 0) return;
   if (s.bwd_status != nullptr && s.bwd_status[b] != 0) return;
+  // rows of the network's input / output: the candidate's own, or - with
+  // `slot` - those of its trajectory's rank among the live ones, so that the
+  // network runs on the live candidates' rows only
+  const int cc = s.slot != nullptr ? s.slot[b] * s.A + ai : c;
   const int D = DT > 0 ? DT : s.D;
   const int P = s.P, m = s.m, N = s.N, t = s.t;
   const int n = D + D * (D + 1) / 2;
@@ -116,6 +120,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     const int p = lane + kBnnGroup * q;
     has[q] = p < P;
     const size_t row = (size_t)c * P + (has[q] ? p : 0);
+    const size_t nrow = (size_t)cc * P + (has[q] ? p : 0);  // (network rows)
     // rows of D (and out_dim = D or 2 D) floats: 8-byte vector accesses when D
     // is a compile-time even number (rows are then 8-byte aligned)
     constexpr bool kVec = DT > 0 && DT % 2 == 0;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
       typedef float f32x2 __attribute__((ext_vector_type(2)));
       const f32x2* xr = reinterpret_cast<const f32x2*>(s.Xp + row * D);
       const f32x2* nr = reinterpret_cast<const f32x2*>(
-          s.net_out + row * s.out_dim);  // (dereferenced for t > 0 only)
+          s.net_out + nrow * s.out_dim);  // (dereferenced for t > 0 only)
 #pragma unroll
       for (int d2 = 0; d2 < DX / 2; ++d2) {
         const f32x2 a = xr[d2];
@@ -147,8 +152,8 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
         if (d >= D) break;
         xin[d] = s.Xp[row * D + d];
         if (t > 0) {
-          net[d] = s.net_out[row * s.out_dim + d];
-          if (s.eps_out != nullptr) nls[d] = s.net_out[row * s.out_dim + D + d];
+          net[d] = s.net_out[nrow * s.out_dim + d];
+          if (s.eps_out != nullptr) nls[d] = s.net_out[nrow * s.out_dim + D + d];
         }
       }
     }
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
   // dimension (a static register index) to the feature slot the `non` / `ang`
   // lists give it - the other way round is a dynamic index into x, i.e.
   // scratch memory
-  float* frow = s.F + ((size_t)c * P + lane) * s.in_dim;
+  float* frow = s.F + ((size_t)cc * P + lane) * s.in_dim;
   const size_t qstep = (size_t)kBnnGroup * s.in_dim;
 #pragma unroll
   for (int d = 0; d < DX; ++d) {

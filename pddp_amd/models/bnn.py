@@ -219,9 +219,11 @@ class BayesianMLP(torch.nn.Module):
             cache[k] = (key, m.contiguous())
         return cache[k][1]
 
-    def _forward_native(self, x, out_rows=None):
+    def _forward_native(self, x, out_rows=None, live_rows=None):
         """`out_rows`: only the first rows of fc_out (the mean increments when
-        the predicted std is not used, modules.py:262)."""
+        the predicted std is not used, modules.py:262).  `live_rows`: an int32
+        device scalar - only that many leading rows are computed (the kernel
+        reads it: no host synchronisation), the others are left alone."""
         from .. import _native
         P, in_dim = x.shape[-2], x.shape[-1]
         H = self.hidden[0].out_features
@@ -232,12 +234,13 @@ class BayesianMLP(torch.nn.Module):
         m1, m2 = self._mask_t(0, P, xc), self._mask_t(1, P, xc)
         c = lambda t: t.detach().contiguous()
         p = _native.ptr
-        rc = _native.lib().pddp_bnn_mlp_f32(
+        rc = _native.lib().pddp_bnn_mlp_rows_f32(
             R, P, in_dim, H, out_dim, p(xc), p(c(self.hidden[0].weight)),
             p(c(self.hidden[0].bias)), p(m1), p(c(self.hidden[1].weight)),
             p(c(self.hidden[1].bias)), p(m2), p(c(self.out.weight[:out_dim])),
-            p(c(self.out.bias[:out_dim])), p(y), _native.stream_handle(x.device))
-        _native.check(rc, "pddp_bnn_mlp_f32")
+            p(c(self.out.bias[:out_dim])), p(y), p(live_rows),
+            _native.stream_handle(x.device))
+        _native.check(rc, "pddp_bnn_mlp_rows_f32")
         return y
 
     def _jvp_native(self, F, P, out_rows, group=16, live=None):
