@@ -661,12 +661,15 @@ class TorchProblem(object):
 
     @torch.no_grad()
     def _line_search_bnn(self, s, active, use_status):
-        Jc = self._bnn_rollouts(s, s.A, s.alphas, s.gains, s.Zc, s.Uc, active,
-                                s.bwd_status if use_status else None)
-        s.Jc.copy_(Jc.view(s.B, s.A))
+        # (costs straight into s.Jc: rows of skipped trajectories stay as they
+        # are, like their candidates)
+        self._bnn_rollouts(s, s.A, s.alphas, s.gains, s.Zc, s.Uc, active,
+                           s.bwd_status if use_status else None,
+                           Jc_out=s.Jc.view(-1))
 
     @torch.no_grad()
-    def _bnn_rollouts(self, s, A, alphas, gains, Zc, Uc, active, status):
+    def _bnn_rollouts(self, s, A, alphas, gains, Zc, Uc, active, status,
+                      Jc_out=None):
         """A moment-matched rollouts per trajectory under the control law
         u = clamp(U + alpha k + K (z - Z)): N + 1 moment-step launches with the
         fused network kernel in between.  Returns the costs [B A]."""
@@ -696,7 +699,7 @@ class TorchProblem(object):
         Xp = X0.unsqueeze(1).expand(B, A, P, D).contiguous()
         F = torch.zeros(B * A, P, in_dim, **opts)
         J = torch.zeros(B * A, **opts)
-        Jc = torch.zeros(B * A, **opts)
+        Jc = torch.zeros(B * A, **opts) if Jc_out is None else Jc_out
         keep = [vec(mo.X_mean, in_dim), vec(mo.X_std_inv, in_dim),
                 vec(mo.dX_mean, D), vec(mo.dX_std, D), mat(co.Q),
                 mat(co.Q_term), mat(co.R), vec(co.x_goal, na),

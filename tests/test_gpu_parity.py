@@ -2020,6 +2020,81 @@ def test_bnn_native_line_search_vs_torch_path(problem, H, P, model_opts):
     assert float((Za[:, 1:] - Zb[:, :1]).abs().max()) > 1e-4  # it did move
 
 
+@pytest.mark.parametrize("problem,H,P", [("cartpole", 200, 100),
+                                         ("double_cartpole", 128, 70)])
+def test_bnn_line_search_on_the_live_rows_only(problem, H, P):
+    """The BNN line search with trajectories masked out and sweeps that failed:
+    the live trajectories' candidates are packed to the front of the network's
+    rows (pddp_bnn_step.slot) and the network runs on that many rows
+    (pddp_bnn_mlp_rows_f32, the count read on the device).  Their states,
+    actions and costs are the all-live launch's bit for bit - a row's result
+    does not depend on where it sits - and the others' are not touched; also
+    with nothing alive and with everything alive under a mask."""
+    import pddp_amd
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    torch.manual_seed(7)
+    mod = getattr(pddp_amd.examples, problem)
+    KM = [getattr(mod, k) for k in dir(mod) if k.endswith("DynamicsModel")
+          and k != "DynamicsModel"][0]
+    cost = [getattr(mod, k) for k in dir(mod) if k.endswith("Cost")
+            and k != "AugmentedQRCost"][0]().cuda()
+    D, m = KM.state_size, KM.action_size
+    cls = bnn_dynamics_model_factory(D, m, [H, H], KM.angular_indices,
+                                     KM.non_angular_indices)
+    model = cls(n_particles=P).cuda().eval()
+    with torch.no_grad():
+        model.model.out.weight.mul_(0.05)
+        model.model.out.bias.mul_(0.05)
+    enc = pddp_amd.StateEncoding.DEFAULT
+    B, N = 13, 7
+    n = D + D * (D + 1) // 2
+    bound = BOUND[problem]
+    plugin = TorchProblem(model, cost, enc, {}, {})
+    s = ILQRSolver(None, B, N, torch.float32, "cuda", torch.full((m,), -bound),
+                   torch.full((m,), bound), fit_alphas(torch.float32, "cuda"),
+                   plugin=plugin, n=n, m=m)
+    g = torch.Generator().manual_seed(1)
+    mean = torch.tensor(MEAN0[problem], dtype=torch.float32)
+    z0 = torch.stack([pddp_amd.GaussianVariable(
+        mean + 1e-2 * torch.randn(D, generator=g),
+        var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).cuda()
+    U = (0.1 * torch.randn(B, N, m, generator=g)).cuda()
+    s.set_nominal(z0, U)
+    s.gains.copy_(1e-1 * torch.randn(s.gains.shape, generator=g).cuda())
+    with torch.no_grad():
+        assert plugin._bnn_native_ok(s)
+    s.active.fill_(1)
+    s.bwd_status.zero_()
+    s.line_search(active=None, use_status=False)     # no mask: rows in place
+    ref = (s.Zc.clone(), s.Uc.clone(), s.Jc.clone())
+    assert torch.isfinite(ref[2]).all()
+    cases = []
+    a1 = torch.ones(B, dtype=torch.uint8)
+    a1[1::3] = 0
+    st1 = torch.zeros(B, dtype=torch.int32)
+    st1[2] = 3
+    st1[11] = 1
+    cases.append((a1, st1))
+    cases.append((torch.ones(B, dtype=torch.uint8), torch.zeros(B, dtype=torch.int32)))
+    cases.append((torch.zeros(B, dtype=torch.uint8), torch.zeros(B, dtype=torch.int32)))
+    only = torch.zeros(B, dtype=torch.uint8)
+    only[B - 1] = 1
+    cases.append((only, torch.zeros(B, dtype=torch.int32)))
+    for act, stat in cases:
+        s.active.copy_(act.cuda())
+        s.bwd_status.copy_(stat.cuda())
+        for t in (s.Zc, s.Uc, s.Jc):
+            t.fill_(-7.0)
+        s.line_search(active=s.active)
+        live = (act != 0) & (stat == 0)
+        for got, want in zip((s.Zc, s.Uc, s.Jc), ref):
+            assert torch.equal(got[live.cuda()], want[live.cuda()])
+            assert bool((got[(~live).cuda()] == -7.0).all())
+
+
 @pytest.mark.parametrize("G,live", [(8, None), (16, None), (32, None), (8, 6),
                                     (8, 4), (8, 5), (8, 3)])
 @pytest.mark.parametrize("H", [64, 200])
