@@ -486,6 +486,14 @@ int pddp_bnn_mlp_jvp_live_f32(int R, int P, int group, int live, int in_dim,
                               const float* W2, const float* b2, const float* M2,
                               const float* W3, const float* b3, float* Y,
                               void* stream);
+/* The same on the first min(R, *live_rows) rows (a device scalar, nullable =
+ * R; whole groups): see pddp_bnn_mlp_rows_f32 and pddp_bnn_jvp.slot. */
+int pddp_bnn_mlp_jvp_rows_f32(int R, int P, int group, int live, int in_dim,
+                              int H, int out_dim, const float* X,
+                              const float* W1, const float* b1, const float* M1,
+                              const float* W2, const float* b2, const float* M2,
+                              const float* W3, const float* b3, float* Y,
+                              const int32_t* live_rows, void* stream);
 
 /* ---- Jacobians F_z, F_u of one moment-matched BNN step (modules.py:287-386
  * under DEFAULT encoding) in forward mode, around pddp_bnn_mlp_jvp_f32:
@@ -531,6 +539,13 @@ typedef struct pddp_bnn_jvp {
    * (modules.py:256-258). */
   const float* eps_out;
   int32_t independent_noise;
+  /* [B] nullable: trajectories with slot[b] < 0 are skipped (nothing of theirs
+   * is read or written); the others' network-facing rows - F and net_out - are
+   * those of trajectory slot[b] (their rank among the ones that run), so that
+   * the network launch in between covers the first (count) P 8 rows only
+   * (pddp_bnn_mlp_jvp_rows_f32).  The derivative rollout of a round passes the
+   * trajectories whose nominal is new. */
+  const int32_t* slot;
 } pddp_bnn_jvp;
 int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* step, void* stream);
 int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* step, void* stream);

@@ -89,6 +89,7 @@ _SIGS = {
     "pddp_bnn_moment_step_f32": [_P, _P],
     "pddp_bnn_mlp_jvp_f32": [c_int] * 6 + [_P] * 11,
     "pddp_bnn_mlp_jvp_live_f32": [c_int] * 7 + [_P] * 11,
+    "pddp_bnn_mlp_jvp_rows_f32": [c_int] * 7 + [_P] * 12,
     "pddp_bnn_jvp_group": [c_int, c_int],
     "pddp_bnn_jvp_features_f32": [_P, _P],
     "pddp_bnn_jvp_moments_f32": [_P, _P],
@@ -206,7 +207,7 @@ class BnnJvp(ctypes.Structure):
             "Z", "U", "u_min", "u_max", "X_mean", "X_std_inv", "dX_mean",
             "dX_std", "net_out", "Xp", "Xp_next", "eps", "F", "Z_next", "F_z",
             "F_u", "eps_out")] +
-        [("independent_noise", ctypes.c_int32)])
+        [("independent_noise", ctypes.c_int32), ("slot", ctypes.c_void_p)])
 
 
 class GpModel(ctypes.Structure):

@@ -143,7 +143,8 @@ class TorchProblem(object):
         native_cost = self._qr_cost_native_ok(s)
         # which code produced the records (tests assert on it)
         if native_dyn:
-            self._dyn_derivs_bnn(s, F_z, F_u)
+            # (rows of the trajectories whose nominal stands are skipped)
+            self._dyn_derivs_bnn(s, F_z, F_u, mask)
         elif gp_dyn:
             # GP plugin: every (trajectory, step) row of the nominal in ONE
             # launch of the moment-matched step with its Jacobian
@@ -540,7 +541,7 @@ class TorchProblem(object):
                 _native.lib().pddp_bnn_jvp_group(mo.state_size, s.m) != 0)
 
     @torch.no_grad()
-    def _dyn_derivs_bnn(self, s, F_z, F_u):
+    def _dyn_derivs_bnn(self, s, F_z, F_u, mask=None):
         """F_z, F_u of the whole nominal in forward mode: per time step one
         feature launch, the fused network in JVP mode on B P 8 rows, one
         moment launch (csrc/bnn_jvp.hip, csrc/bnn_mlp.hip) - instead of
@@ -589,6 +590,16 @@ class TorchProblem(object):
                         ("u_max", s.u_max), ("eps", eps), ("F", F),
                         ("F_z", F_z), ("F_u", F_u)):
             setattr(st, name, p(t))
+        # with a mask: only its trajectories, their network rows packed to the
+        # front and the network on that many rows (a device count; sync-free)
+        live_rows = slot = None
+        if mask is not None:
+            run = mask != 0
+            rank = torch.cumsum(run.to(torch.int32), 0, dtype=torch.int32)
+            slot = torch.where(run, rank - 1,
+                               torch.full_like(rank, -1)).contiguous()
+            live_rows = (rank[-1:] * (P * G)).to(torch.int32)
+            st.slot = p(slot)
         lib, stream = _native.lib(), _native.stream_handle(s.device)
         for t in range(N):
             st.t = t
@@ -596,7 +607,8 @@ class TorchProblem(object):
             _native.check(lib.pddp_bnn_jvp_features_f32(ctypes.byref(st),
                                                         stream),
                           "pddp_bnn_jvp_features_f32")
-            Y = mo.model._jvp_native(F, P, out_rows, G, live=1 + D + s.m)
+            Y = mo.model._jvp_native(F, P, out_rows, G, live=1 + D + s.m,
+                                     live_rows=live_rows)
             st.net_out = p(Y)
             st.eps_out = p(eps_keep[t]) if ups else None
             _native.check(lib.pddp_bnn_jvp_moments_f32(ctypes.byref(st),

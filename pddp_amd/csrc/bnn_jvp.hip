@@ -54,6 +54,10 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   const int bp = blockIdx.x * (64 / kJvpRows) + lane / kJvpRows;  // (b, p)
   if (bp >= s.B * s.P) return;
   const int b = bp / s.P;
+  // (slot: skipped trajectories leave; the others' network rows are packed)
+  const int sb = s.slot != nullptr ? s.slot[b] : b;
+  if (sb < 0) return;
+  const int sbp = sb * s.P + (bp - b * s.P);
   const int D = EXACT ? kJvpMaxD : s.D;
   const int m = s.m, n = D + D * (D + 1) / 2;
   const float* z = s.Z + ((size_t)b * (s.N + 1) + s.t) * n;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   // row k >= 1: direction mean_{k-1} (k - 1 < D) or u_{k-1-D}.  By state
   // dimension c (a static index) to the feature slot the `non` / `ang` lists
   // give it.
-  float* f = s.F + ((size_t)bp * kJvpRows + k) * s.in_dim;
+  float* f = s.F + ((size_t)sbp * kJvpRows + k) * s.in_dim;
 #pragma unroll
   for (int c = 0; c < kJvpMaxD; ++c) {
     if (c >= D) break;
@@ -118,10 +122,12 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   const int slice = lane / kJvpRows;
   const int b = blockIdx.x;
   if (b >= s.B) return;
+  const int sb = s.slot != nullptr ? s.slot[b] : b;
+  if (sb < 0) return;
   const int D = EXACT ? kJvpMaxD : s.D;
   const int P = s.P, m = s.m, n = D + D * (D + 1) / 2;
   const int OUT = s.out_dim;
-  const float* Y = s.net_out + (size_t)b * P * kNetRows * OUT;
+  const float* Y = s.net_out + (size_t)sb * P * kNetRows * OUT;
   auto across_slices = [&](float v) {
 #pragma unroll
     for (int o = kJvpRows; o < 64; o <<= 1) v += __shfl_xor(v, o);

@@ -732,7 +732,8 @@ static int bnn_mlp_jvp_impl(int R, int P, int group, int live, int in_dim,
                             int H, int out_dim, const float* X, const float* W1,
                             const float* b1, const float* MT1, const float* W2,
                             const float* b2, const float* MT2, const float* W3,
-                            const float* b3, float* Y, void* stream) {
+                            const float* b3, float* Y, void* stream,
+                            const int32_t* live_rows = nullptr) {
   if (R <= 0 || P <= 0 || in_dim <= 0 || H <= 0 || out_dim <= 0 || !X || !W1 ||
       !b1 || !MT1 || !W2 || !b2 || !MT2 || !W3 || !b3 || !Y)
     return PDDP_E_BADARG;
@@ -742,7 +743,7 @@ static int bnn_mlp_jvp_impl(int R, int P, int group, int live, int in_dim,
   if (in_dim >= pddp::kMlpW1Max || out_dim > pddp::kMlpMaxOut)
     return PDDP_E_UNSUPPORTED;
   const pddp::BnnMlpArgs a{R, P, in_dim, H, out_dim, X, W1, b1, MT1, W2,
-                           b2, MT2, W3, b3, Y, nullptr};
+                           b2, MT2, W3, b3, Y, live_rows};
   hipStream_t st = (hipStream_t)stream;
 #define PDDP_MLP_H(G, L)                                             \
   switch (H) {                                                       \
@@ -783,6 +784,16 @@ int pddp_bnn_mlp_jvp_live_f32(int R, int P, int group, int live, int in_dim,
                               void* stream) {
   return bnn_mlp_jvp_impl(R, P, group, live, in_dim, H, out_dim, X, W1, b1, MT1,
                           W2, b2, MT2, W3, b3, Y, stream);
+}
+
+int pddp_bnn_mlp_jvp_rows_f32(int R, int P, int group, int live, int in_dim,
+                              int H, int out_dim, const float* X,
+                              const float* W1, const float* b1, const float* MT1,
+                              const float* W2, const float* b2, const float* MT2,
+                              const float* W3, const float* b3, float* Y,
+                              const int32_t* live_rows, void* stream) {
+  return bnn_mlp_jvp_impl(R, P, group, live, in_dim, H, out_dim, X, W1, b1, MT1,
+                          W2, b2, MT2, W3, b3, Y, stream, live_rows);
 }
 
 }  // extern "C"

@@ -243,7 +243,7 @@ class BayesianMLP(torch.nn.Module):
         _native.check(rc, "pddp_bnn_mlp_rows_f32")
         return y
 
-    def _jvp_native(self, F, P, out_rows, group=16, live=None):
+    def _jvp_native(self, F, P, out_rows, group=16, live=None, live_rows=None):
         """Forward-mode pass of csrc/bnn_mlp.hip: F [(states P) group, in_dim],
         groups of 8 / 16 / 32 rows = primal input + tangent rows; returns the
         first `out_rows` outputs per row (include/pddp_hip.h
@@ -257,14 +257,16 @@ class BayesianMLP(torch.nn.Module):
         m1, m2 = self._mask_t(0, P, F), self._mask_t(1, P, F)
         c = lambda t: t.detach().contiguous()
         p = _native.ptr
-        rc = _native.lib().pddp_bnn_mlp_jvp_live_f32(
+        # (`live_rows`: an int32 device scalar - only that many leading rows)
+        rc = _native.lib().pddp_bnn_mlp_jvp_rows_f32(
             R, P, int(group), int(group if live is None else live), in_dim, H,
             out_rows, p(F),
             p(c(self.hidden[0].weight)),
             p(c(self.hidden[0].bias)), p(m1), p(c(self.hidden[1].weight)),
             p(c(self.hidden[1].bias)), p(m2), p(c(self.out.weight[:out_rows])),
-            p(c(self.out.bias[:out_rows])), p(Y), _native.stream_handle(F.device))
-        _native.check(rc, "pddp_bnn_mlp_jvp_live_f32")
+            p(c(self.out.bias[:out_rows])), p(Y), p(live_rows),
+            _native.stream_handle(F.device))
+        _native.check(rc, "pddp_bnn_mlp_jvp_rows_f32")
         return Y
 
     def forward(self, x, resample=False):

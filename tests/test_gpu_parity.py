@@ -2095,6 +2095,64 @@ def test_bnn_line_search_on_the_live_rows_only(problem, H, P):
             assert bool((got[(~live).cuda()] == -7.0).all())
 
 
+@pytest.mark.parametrize("problem,H,P", [("cartpole", 200, 100),
+                                         ("double_cartpole", 128, 70)])
+def test_bnn_derivative_rollout_of_the_new_nominals_only(problem, H, P):
+    """derivs(mask) under a BNN model: the forward-mode rollout runs for the
+    masked trajectories only - their network rows packed to the front
+    (pddp_bnn_jvp.slot, pddp_bnn_mlp_jvp_rows_f32) - and their records are the
+    unmasked launch's bit for bit; the other trajectories' records, stage costs
+    and J_opt stand."""
+    import pddp_amd
+    from pddp_amd.controllers.ilqr import fit_alphas
+    from pddp_amd.controllers.plugin import TorchProblem
+    from pddp_amd.controllers.solver import ILQRSolver
+    from pddp_amd.models.bnn import bnn_dynamics_model_factory
+    torch.manual_seed(7)
+    mod = getattr(pddp_amd.examples, problem)
+    KM = [getattr(mod, k) for k in dir(mod) if k.endswith("DynamicsModel")
+          and k != "DynamicsModel"][0]
+    cost = [getattr(mod, k) for k in dir(mod) if k.endswith("Cost")
+            and k != "AugmentedQRCost"][0]().cuda()
+    D, m = KM.state_size, KM.action_size
+    cls = bnn_dynamics_model_factory(D, m, [H, H], KM.angular_indices,
+                                     KM.non_angular_indices)
+    model = cls(n_particles=P).cuda().eval()
+    with torch.no_grad():
+        model.model.out.weight.mul_(0.05)
+        model.model.out.bias.mul_(0.05)
+    enc = pddp_amd.StateEncoding.DEFAULT
+    B, N = 11, 6
+    n = D + D * (D + 1) // 2
+    bound = BOUND[problem]
+    plugin = TorchProblem(model, cost, enc, {}, {})
+    s = ILQRSolver(None, B, N, torch.float32, "cuda", torch.full((m,), -bound),
+                   torch.full((m,), bound), fit_alphas(torch.float32, "cuda"),
+                   plugin=plugin, n=n, m=m)
+    g = torch.Generator().manual_seed(1)
+    mean = torch.tensor(MEAN0[problem], dtype=torch.float32)
+    z0 = torch.stack([pddp_amd.GaussianVariable(
+        mean + 1e-2 * torch.randn(D, generator=g),
+        var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).cuda()
+    U = (0.1 * torch.randn(B, N, m, generator=g)).cuda()
+    s.set_nominal(z0, U)
+    s.derivs()
+    assert plugin.last_derivs_path["dynamics"] == "hip"
+    ref = {k: getattr(s, k).clone() for k in ("rec", "L", "J_opt")}
+    for mask in (torch.tensor([1, 0, 0, 1, 1, 0, 1, 0, 0, 0, 1]),
+                 torch.ones(B, dtype=torch.int64),
+                 torch.tensor([0] * (B - 1) + [1])):
+        sel = mask.bool().cuda()
+        s.rec.fill_(-7.0)
+        s.L.fill_(-7.0)
+        s.J_opt.fill_(-7.0)
+        s.derivs(mask=mask.to(torch.uint8).cuda())
+        for k in ("rec", "L", "J_opt"):
+            got, want = getattr(s, k), ref[k]
+            assert torch.equal(got[sel], want[sel]), k
+            assert bool((got[~sel] == -7.0).all()), k
+
+
 @pytest.mark.parametrize("G,live", [(8, None), (16, None), (32, None), (8, 6),
                                     (8, 4), (8, 5), (8, 3)])
 @pytest.mark.parametrize("H", [64, 200])
