@@ -290,15 +290,27 @@ int pddp_pack_best_f64(int B, int nz, int nu, const double* J, const double* Z,
  * nominal (rows of ACTIVE trajectories);
  * for trajectories with fresh[b] != 0 (all, when fresh is NULL)
  * J_opt[b] = sum_t L[b][t] in t order (ilqr.py:289 L.sum()) and fresh[b] is
- * cleared.  Z [B][N+1][4], U [B][N] un-clamped nominal actions.  Cartpole
- * under IGNORE_UNCERTAINTY, f32, bounded (u_min, u_max non-NULL), branch
- * PDDP_BRANCH_EIG: PDDP_E_UNSUPPORTED otherwise (make the two calls
- * then).  `L` of pddp_search_accept_* may be NULL with this sweep. */
+ * cleared.  Z [B][N+1][n], U [B][N] un-clamped nominal actions.  Under
+ * IGNORE_UNCERTAINTY:
+ *   cartpole          f32, bounded (u_min, u_max non-NULL), PDDP_BRANCH_EIG
+ *                     (csrc/riccati_n4_elem.hpp);
+ *   pendulum, double cartpole   f32 and f64, both branches, bounded or not
+ *                     (csrc/riccati_mfma16_nominal.hpp: the 16 x 16
+ *                     matrix-core sweep, its records generated block by block
+ *                     in the wavefront);
+ * PDDP_E_UNSUPPORTED otherwise (make the two calls then).  `L` of
+ * pddp_search_accept_* may be NULL with this sweep. */
 int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
                            const float* Z, const float* U, const float* u_min,
                            const float* u_max, const double* reg, int branch,
                            const uint8_t* active, uint8_t* fresh, float* gains,
                            int32_t* status, float* L, float* J_opt,
+                           void* stream);
+int pddp_sweep_nominal_f64(const pddp_problem* problem, int B, int N,
+                           const double* Z, const double* U, const double* u_min,
+                           const double* u_max, const double* reg, int branch,
+                           const uint8_t* active, uint8_t* fresh, double* gains,
+                           int32_t* status, double* L, double* J_opt,
                            void* stream);
 
 /* How pddp_sweep_nominal_f32 (csrc/riccati_n4_elem.hpp) generates its records:

@@ -79,8 +79,8 @@ _SIGS = {
                    [_P] * 12,
     "pddp_pack_best": [c_int, c_int, c_int, _P, _P, _P, ctypes.c_longlong, _P,
                        _P],
-    "pddp_sweep_nominal_f32": [_P, c_int, c_int] + [_P] * 5 + [c_int] +
-                              [_P] * 7,
+    "pddp_sweep_nominal": [_P, c_int, c_int] + [_P] * 5 + [c_int] +
+                          [_P] * 7,
     "pddp_sweep_nominal_kernel": [c_int],
     "pddp_search_candidates": [c_int],
     "pddp_bnn_mlp_precision": [c_int],
@@ -110,7 +110,8 @@ _TYPED = ("pddp_riccati_backward", "pddp_riccati_backward_variant",
           "pddp_nominal_rollout",
           "pddp_derivs",
           "pddp_line_search", "pddp_search_accept", "pddp_accept",
-          "pddp_pack_best", "pddp_gp_step", "pddp_gp_step_masked",
+          "pddp_pack_best", "pddp_sweep_nominal", "pddp_gp_step",
+          "pddp_gp_step_masked",
           "pddp_gp_rollout")
 
 _lib = None

@@ -125,22 +125,42 @@ class ILQRSolver(object):
         # nominal (pddp_sweep_nominal_f32): None untried, then True / False.
         # With it `rec` is not kept up to date by round(); `sync_records()`
         # brings it up to date for whoever reads it.
-        self._nominal_sweep = None if self._nominal_sweep_possible() else False
+        self._nominal_sweep = None if (self._nominal_sweep_possible() and
+                                       self._nominal_sweep_pays()) else False
         self._rec_stale = False
         self._pp = None if problem is None else ctypes.addressof(problem)
 
     def _nominal_sweep_possible(self):
-        """pddp_sweep_nominal_f32's domain (include/pddp_hip.h).  At every
+        """pddp_sweep_nominal_*'s domain (include/pddp_hip.h).  At every
         batch: from 12288 trajectories on the quad sweep on records is the
         faster SWEEP, but the round without records is still shorter (no 79 MB
         of records written by the line search and read back)."""
         # include/pddp_problem.h: PDDP_MODEL_CARTPOLE = 1,
         # PDDP_ENC_IGNORE_UNCERTAINTY = 4
-        return (self.plugin is None and self.problem is not None and
-                self.dtype == torch.float32 and self.n == 4 and self.m == 1 and
-                self.problem.model == 1 and self.problem.encoding == 4 and
-                self.u_min is not None and self.u_max is not None and
-                self.branch == BRANCH_EIG and self.kernel_variant == 0)
+        if not (self.plugin is None and self.problem is not None and
+                self.m == 1 and self.problem.encoding == 4 and
+                self.kernel_variant == 0):
+            return False
+        if self.problem.model == 1:  # cartpole: csrc/riccati_n4_elem.hpp
+            return (self.dtype == torch.float32 and self.n == 4 and
+                    self.u_min is not None and self.u_max is not None and
+                    self.branch == BRANCH_EIG)
+        # pendulum (3), double cartpole (2): csrc/riccati_mfma16_nominal.hpp -
+        # f32 and f64, both branches, bounded or not
+        return self.problem.model in (2, 3) and \
+            (self.u_min is None) == (self.u_max is None)
+
+    def _nominal_sweep_pays(self):
+        """Where round() takes the sweep from the nominal by itself (measured,
+        tools/nominal_round_time.py, 4096 trajectories): cartpole f32 1.37x
+        the round on records, pendulum f32 1.04x; pendulum f64 0.95x and the
+        double cartpole 0.65x (f32) / 0.74x (f64) - its record is ~1500
+        instructions against a step of ~150, and a block of them in LDS leaves
+        one workgroup per CU.  `sweep_nominal()` itself works wherever
+        `_nominal_sweep_possible()` says so; set `_nominal_sweep = None` to
+        make round() use it regardless."""
+        return self.problem.model == 1 or (self.problem.model == 3 and
+                                           self.dtype == torch.float32)
 
     @property
     def rec(self):
@@ -309,11 +329,11 @@ class ILQRSolver(object):
         p = _native.ptr
         if events is not None:
             _native.lib().pddp_attach_events(*events)
-        fn = _native.lib().pddp_sweep_nominal_f32
-        rc = fn(self._pp, self.B, self.N, p(self.Z), p(self.U), p(self.u_min),
-                p(self.u_max), p(self.mu), int(self.branch), p(self.active),
-                p(self.fresh), p(self.gains), p(self.bwd_status), p(self.L),
-                p(self.J_opt), self._s())
+        rc = _native.call_rc(
+            "pddp_sweep_nominal", self.dtype, self._pp, self.B, self.N,
+            p(self.Z), p(self.U), p(self.u_min), p(self.u_max), p(self.mu),
+            int(self.branch), p(self.active), p(self.fresh), p(self.gains),
+            p(self.bwd_status), p(self.L), p(self.J_opt), self._s())
         if rc == _native.E_UNSUPPORTED:
             if events is not None:
                 _native.lib().pddp_attach_events(None, None)

@@ -4,6 +4,7 @@
 // (-amdgpu-mfma-vgpr-form: the 4x4x1 products feed vector code directly).
 #include "riccati_n4_defer.hpp"
 #include "riccati_n4_elem.hpp"
+#include "riccati_mfma16_nominal.hpp"
 
 namespace pddp {
 
@@ -29,6 +30,8 @@ extern "C" int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
       reg == nullptr || gains == nullptr || status == nullptr ||
       L == nullptr || J_opt == nullptr)
     return PDDP_E_BADARG;
+  if (branch != PDDP_BRANCH_EIG && branch != PDDP_BRANCH_CHOLESKY)
+    return PDDP_E_BADARG;
   pddp::RiccatiArgs<float> a;
   a.B = B; a.N = N; a.n = 4;
   a.rec = nullptr;
@@ -39,11 +42,45 @@ extern "C" int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
   a.gains = gains;
   a.status = status;
   const pddp::n4d::GenArgs<float> gen = {Z, U, L, J_opt, fresh};
+  if (problem->model != PDDP_MODEL_CARTPOLE) {
+    // pendulum, double cartpole: the 16 x 16 matrix-core sweep with its
+    // records generated in the wavefront (riccati_mfma16_nominal.hpp)
+    a.n = problem->state_size;
+    return pddp::launch_m16_nominal<float>(*problem, a, gen,
+                                           (hipStream_t)stream);
+  }
   // riccati_n4_elem.hpp: its record generator inline, on wavefronts of its
   // own, or (auto) by batch
   const int choice = pddp::nominal_kernel_choice();
   return pddp::launch_n4_elem(*problem, a, gen, (hipStream_t)stream,
                               choice == 3 ? 0 : choice == 4 ? 1 : -1);
+}
+
+extern "C" int pddp_sweep_nominal_f64(const pddp_problem* problem, int B, int N,
+                                      const double* Z, const double* U,
+                                      const double* u_min, const double* u_max,
+                                      const double* reg, int branch,
+                                      const uint8_t* active, uint8_t* fresh,
+                                      double* gains, int32_t* status, double* L,
+                                      double* J_opt, void* stream) {
+  if (problem == nullptr || B <= 0 || N <= 0 || Z == nullptr || U == nullptr ||
+      reg == nullptr || gains == nullptr || status == nullptr ||
+      L == nullptr || J_opt == nullptr)
+    return PDDP_E_BADARG;
+  if (branch != PDDP_BRANCH_EIG && branch != PDDP_BRANCH_CHOLESKY)
+    return PDDP_E_BADARG;
+  pddp::RiccatiArgs<double> a;
+  a.B = B; a.N = N; a.n = problem->state_size;
+  a.rec = nullptr;
+  a.u_min = u_min; a.u_max = u_max;
+  a.reg = reg;
+  a.branch = branch;
+  a.active = active;
+  a.gains = gains;
+  a.status = status;
+  const pddp::n4d::GenArgs<double> gen = {Z, U, L, J_opt, fresh};
+  return pddp::launch_m16_nominal<double>(*problem, a, gen,
+                                          (hipStream_t)stream);
 }
 
 extern "C" int pddp_sweep_nominal_kernel(int which) {

@@ -1482,6 +1482,71 @@ def test_sweep_from_nominal_equals_records_then_sweep(B, N, kernel):
         _sweep_from_nominal_case(B, N, same_arithmetic=False)
 
 
+@pytest.mark.parametrize("branch", [0, 1])
+@pytest.mark.parametrize("bounded", [True, False])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("problem,B,N", [("pendulum", 21, 50),
+                                         ("pendulum", 5, 3),
+                                         ("double_cartpole", 13, 60),
+                                         ("double_cartpole", 6, 70),
+                                         ("double_cartpole", 3, 1)])
+def test_sweep_from_nominal_of_the_other_problems(problem, B, N, dtype, bounded,
+                                                  branch):
+    """pddp_sweep_nominal_f32 / _f64 for pendulum and double cartpole
+    (csrc/riccati_mfma16_nominal.hpp: the 16 x 16 matrix-core sweep with its
+    records generated block by block in the wavefront; horizons longer and
+    shorter than a block, not a multiple of it) against pddp_derivs_* followed
+    by the sweep on those records: gains, status, stage costs, J_opt of the
+    fresh nominals, masked trajectories left alone - both gain branches,
+    bounded and not, fp64 to 1e-9 (the same record code, the same step) and
+    fp32 to what two f32 sweeps of the same step agree to."""
+    s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N, seed=4)
+    if not bounded:
+        s.u_min = s.u_max = None
+    s.branch = branch
+    assert s._nominal_sweep_possible()
+    s._nominal_sweep = None  # (round() takes it by itself only where it pays)
+    s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    s.mu.fill_(1.0)
+    s.active[::4] = 0
+    s.derivs()
+    s.backward(active=s.active, bounded=bounded)
+    ref = {k: getattr(s, k).clone() for k in ("gains", "bwd_status", "L",
+                                              "J_opt")}
+    s.gains.zero_()
+    s.bwd_status.fill_(-7)
+    s.L.zero_()
+    s.J_opt.fill_(123.0)
+    s.fresh.fill_(1)
+    s.fresh[1::5] = 0
+    assert s.sweep_nominal()
+    torch.cuda.synchronize()
+    live = s.active.bool().cpu()
+    # (some branches fail on the pendulum's negative curvature at this
+    # regularisation - in both paths alike; gains are compared where the sweep
+    # went through)
+    assert torch.equal(s.bwd_status.cpu()[live], ref["bwd_status"].cpu()[live])
+    assert (s.bwd_status.cpu()[~live] == -7).all()
+    ok = live & (ref["bwd_status"].cpu() == 0)
+    if bool(ok.any()):
+        g, gr = s.gains.cpu()[ok].double(), ref["gains"].cpu()[ok].double()
+        tol = 1e-9 if dtype == "f64" else 2e-4
+        assert float((g - gr).abs().max()) <= tol * float(gr.abs().max())
+    assert bool((s.gains.cpu()[~live] == 0).all())
+    Lg, Lr = s.L.cpu().double(), ref["L"].cpu().double()
+    assert float((Lg[live] - Lr[live]).abs().max()) <= (
+        1e-12 if dtype == "f64" else 1e-6) * float(Lr.abs().max())
+    assert bool((Lg[~live] == 0).all())
+    fresh = torch.ones(B, dtype=torch.bool)
+    fresh[1::5] = False
+    Jg, Jr = s.J_opt.cpu().double(), ref["J_opt"].cpu().double()
+    sel = live & fresh
+    assert float((Jg[sel] - Jr[sel]).abs().max()) <= (
+        1e-12 if dtype == "f64" else 1e-5) * float(Jr.abs().max())
+    assert bool((Jg[~sel] == 123.0).all())
+    assert int(s.fresh.cpu()[sel].max()) == 0
+
+
 @pytest.mark.parametrize("kernel", [3, 4])
 def test_sweep_from_nominal_reports_a_nan_nominal(kernel):
     """A NaN in the nominal controls of some trajectories: the sweep from the
@@ -1581,10 +1646,22 @@ def test_round_from_nominal_equals_round_with_records(kernel):
         _rounds_side_by_side(2e-2)
 
 
-def _rounds_side_by_side(vtol):
-    B, N = 64, 40
-    a, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=5)
-    b, *_ = _setup("cartpole", "f32", B, N, seed=5)
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("problem,N", [("pendulum", 50), ("double_cartpole", 36)])
+def test_rounds_from_nominal_of_the_other_problems(problem, N, dtype):
+    """round() forced through pddp_sweep_nominal_* for pendulum and double
+    cartpole (riccati_mfma16_nominal.hpp; round() takes it by itself only where
+    it is the faster round) against the rounds on records: the same decisions
+    and regularisation round by round; nominals equal to rounding in fp64."""
+    _rounds_side_by_side(1e-8 if dtype == "f64" else 2e-2, problem, dtype, N)
+
+
+def _rounds_side_by_side(vtol, problem="cartpole", dtype="f32", N=40):
+    B = 64
+    a, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N, seed=5)
+    b, *_ = _setup(problem, dtype, B, N, seed=5)
+    assert a._nominal_sweep_possible()
+    a._nominal_sweep = None
     b._nominal_sweep = False
     for s in (a, b):
         s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
