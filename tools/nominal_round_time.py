@@ -26,8 +26,10 @@ for problem, (dt_, N, bound, mean0) in CASES.items():
             s = ILQRSolver(prob, B, N, td, "cuda", torch.full((m,), -bound, dtype=td), torch.full((m,), bound, dtype=td))
             if not nominal:
                 s._nominal_sweep = False
-            elif s._nominal_sweep is False:
+            elif not s._nominal_sweep_possible():
                 continue
+            else:
+                s._nominal_sweep = None  # (also where round() would not take it)
             z0 = torch.from_numpy(np.asarray(mean0) + 1e-2 * rng.randn(B, n)).to(td).cuda()
             U = torch.from_numpy(0.1 * rng.randn(B, N, m)).to(td).cuda()
             s.set_nominal(z0, U)
