@@ -342,6 +342,14 @@ int pddp_sweep_nominal_kernel(int which);
  * Process-wide (an A/B and test knob); -1 only queries.  Returns the previous
  * mode. */
 int pddp_search_candidates(int mode);
+/* Which form of pddp_search_accept_* runs (f32, n <= 4): 0 = auto - the paired
+ * form (a helper wavefront per rollout wavefront, the nominal's 4 KB per
+ * trajectory in LDS, two workgroups per CU), from 8193 to 49152 trajectories
+ * the dense form (gains only in LDS, no helpers, four workgroups per CU); 1 =
+ * always the paired form; 2 = the dense form wherever it is built.  Results are
+ * bit-identical.  Process-wide (an A/B and test knob); -1 only queries.
+ * Returns the previous mode. */
+int pddp_search_form(int mode);
 
 int pddp_search_accept_f32(const pddp_problem* problem, int B, int N, int A,
                            float* Z, float* U, const float* gains,

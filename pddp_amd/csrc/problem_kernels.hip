@@ -289,12 +289,20 @@ PDDP_DEV void control_law(const T* z, const T* zr, const T* gr, const T* us,
 // same LDS slice) helps with the staging, sleeps at a barrier through the
 // rollouts, and takes every other row of the tail.
 // QM: live rows / columns of the stage cost matrix (models.hpp live_mask).
+// DENSE (FUSED, H = 1; round 4): for the batches that do not fit a CU's two
+// resident workgroups of the paired form (from 8193 trajectories on, where the
+// launch ran one and a half rounds of workgroups: DESIGN.md 3.4).  Only the
+// gains are staged in LDS (2 KB per trajectory instead of 4: the nominal's
+// states and actions are read from global memory - with three or four rollout
+// wavefronts on a SIMD their latency is covered), there is no helper wavefront
+// (the tail's short form takes eight rows per lane instead of four), and four
+// workgroups of four wavefronts share a CU.
 template <typename T, int MODEL, bool FUSED, int WPB, int H = 1,
-          unsigned QM = kFullMask<MODEL>>
+          unsigned QM = kFullMask<MODEL>, bool DENSE = false>
 // (f32, n <= 4: at most 128 VGPRs, so that two workgroups of eight waves share
 // a CU at the batches that have more than 256 workgroups)
 __global__ __launch_bounds__(kWave * WPB * H) __attribute__((
-    amdgpu_waves_per_eu(WPB * H >= 8 && sizeof(T) == 4 &&
+    amdgpu_waves_per_eu((WPB * H >= 8 || DENSE) && sizeof(T) == 4 &&
                                 ModelDims<MODEL>::n <= 4
                             ? 4
                             : 1))) void
@@ -304,6 +312,8 @@ line_search_lds_kernel(
   constexpr int n = D::n, m = D::m;
   constexpr int GS = m + m * n;
   static_assert(H == 1 || (H == 2 && FUSED), "");
+  static_assert(!DENSE || (FUSED && H == 1), "");
+  constexpr int kTailRows = DENSE ? 8 : 4;  // rows per lane of the short tail
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __shared__ int sh_dec[WPB][4][2];  // H = 2: {amin_out, fresh} per trajectory
   const int lane = threadIdx.x & (kWave - 1);
@@ -312,7 +322,8 @@ line_search_lds_kernel(
   const int hid = H == 1 ? 0 : wave_all / WPB;  // 0 rollout wave, 1 helper
   const int grp = lane >> 4, ai = lane & 15;
   const int N = a.N;
-  const int per = (N + 1) * n + N * m + N * GS;  // scalars per trajectory
+  // scalars per trajectory in LDS (DENSE: the gains only)
+  const int per = DENSE ? N * GS : (N + 1) * n + N * m + N * GS;
   T* smem = reinterpret_cast<T*>(smem_raw) + (size_t)wave * 4 * per;
   const int b0 = (blockIdx.x * WPB + wave) * 4;
 
@@ -326,10 +337,14 @@ line_search_lds_kernel(
     const T* zs = a.Z + (size_t)bg * (N + 1) * n;
     const T* us = a.U + (size_t)bg * N * m;
     const T* gs = a.gains + (size_t)bg * N * GS;
-    for (int o = lane; o < (N + 1) * n; o += kWave) dst[o] = zs[o];
-    for (int o = lane; o < N * m; o += kWave) dst[(N + 1) * n + o] = us[o];
-    for (int o = lane; o < N * GS; o += kWave)
-      dst[(N + 1) * n + N * m + o] = gs[o];
+    if constexpr (DENSE) {
+      for (int o = lane; o < N * GS; o += kWave) dst[o] = gs[o];
+    } else {
+      for (int o = lane; o < (N + 1) * n; o += kWave) dst[o] = zs[o];
+      for (int o = lane; o < N * m; o += kWave) dst[(N + 1) * n + o] = us[o];
+      for (int o = lane; o < N * GS; o += kWave)
+        dst[(N + 1) * n + N * m + o] = gs[o];
+    }
   }
   __syncthreads();
 
@@ -350,9 +365,11 @@ line_search_lds_kernel(
     umin[r] = bounded ? a.u_min[r] : -(T)__builtin_inff();
     umax[r] = bounded ? a.u_max[r] : (T)__builtin_inff();
   }
-  const T* Zs = smem + (size_t)grp * per;
-  const T* Us = Zs + (N + 1) * n;
-  const T* Gs = Us + N * m;
+  // the nominal's rows: LDS copies (DENSE: states and actions in place)
+  const T* Zs = DENSE ? a.Z + (size_t)bc * (N + 1) * n
+                      : smem + (size_t)grp * per;
+  const T* Us = DENSE ? a.U + (size_t)bc * N * m : Zs + (N + 1) * n;
+  const T* Gs = DENSE ? smem + (size_t)grp * per : Us + N * m;
   const size_t zstep_c = (size_t)a.A * n, ustep_c = (size_t)a.A * m;
   // the state machine's inputs, requested now: their latency hides behind
   // the rollout
@@ -365,7 +382,7 @@ line_search_lds_kernel(
   // (where the tail's short form applies: it reads the winner's compact rows)
   // (n <= 4: a second inlined copy of the larger models' step spills)
   const bool nocand = FUSED && n <= 4 && Lout == nullptr && rec != nullptr &&
-                      a.drop_candidates != 0 && N + 1 <= 16 * H * 4;
+                      a.drop_candidates != 0 && N + 1 <= 16 * H * kTailRows;
   // One rollout of this lane's candidate (ilqr.py:677-723 + :764-791): states
   // to Zci (stride zstep per step), actions to Uci (stride ustep), the cost
   // returned.  A stride of zero makes the target a one-row scratch - the
@@ -514,8 +531,8 @@ line_search_lds_kernel(
       T* Ga = c.gains_acc + (size_t)b * N * GS;
       T zc[n], uc[m];
       const int t_first = ai + 16 * hid;  // rows t_first, t_first + 16 H, ...
-      constexpr int KR = 4;  // rows per lane the short form below covers
-                             // (`nocand` above knows this number)
+      constexpr int KR = kTailRows;  // rows per lane the short form below
+                                     // covers (`nocand` above knows it)
       if (n <= 6 && Lout == nullptr && N + 1 <= 16 * H * KR) {
         // No records to write (the next sweep evaluates them): the tail is
         // the winner's rows - all of this lane's requested at once, one
@@ -545,7 +562,7 @@ line_search_lds_kernel(
 #pragma unroll
           for (int j = 0; j < n; ++j) zz[k][j] = cz[(size_t)tz * czs + j];
         }
-        const T* Gl = smem + (size_t)grp * per + (N + 1) * n + N * m;
+        const T* Gl = Gs;  // (the staged gains)
         for (int o = ai + 16 * hid; o < N * GS; o += 16 * H) Ga[o] = Gl[o];
         const T alpha_w = a.alphas[amin_out];
 #pragma unroll
@@ -728,6 +745,11 @@ struct SearchAcceptArgs {
   T* rec;
   T* L;
 };
+// 0 auto (by batch), 1 the paired form always, 2 the dense form where built
+inline int& search_form_choice() {
+  static int choice = 0;
+  return choice;
+}
 template <typename T, int MODEL>
 static int launch_search_accept(const pddp_problem& p, SearchAcceptArgs<T> a,
                                 hipStream_t st) {
@@ -739,6 +761,32 @@ static int launch_search_accept(const pddp_problem& p, SearchAcceptArgs<T> a,
   if (a.ls.A > 16 || lds > 64 * 1024) return PDDP_E_UNSUPPORTED;
   a.ac.n = D::n;
   a.ac.m = D::m;
+  if constexpr (sizeof(T) == 4 && D::n <= 4) {
+    // the dense form (see the kernel): from the batch on that the paired
+    // form's two workgroups per CU no longer hold at once
+    const int mode = search_form_choice();
+    const size_t lds_dense =
+        16 * (size_t)a.ls.N * (D::m + D::m * D::n) * sizeof(T);
+    // (measured, tools/dbg/search_form_scan.py: 100.5 -> 90.7 us at 12288
+    // trajectories, 117.8 -> 105.5 at 16384, 206.7 -> 192.1 at 32768; slower
+    // at 8192 and below - 50.5 -> 60.3 - and at 65536 - 406 -> 483)
+    const bool dense =
+        mode == 2 || (mode == 0 && a.ls.B > 8192 && a.ls.B <= 49152);
+    if (dense && 4 * lds <= 64 * 1024 && lds_dense <= 40 * 1024 &&
+        a.ls.N + 1 <= 128) {
+      if (stage_cost_on<MODEL, kSparseMask<MODEL>>(p))
+        PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 4, 1,
+                                            kSparseMask<MODEL>, true>),
+                    dim3((a.ls.B + 15) / 16), dim3(kWave * 4), lds_dense, st,
+                    P, a.ls, a.ac, a.rec, a.L);
+      else
+        PDDP_LAUNCH((line_search_lds_kernel<T, MODEL, true, 4, 1,
+                                            kFullMask<MODEL>, true>),
+                    dim3((a.ls.B + 15) / 16), dim3(kWave * 4), lds_dense, st,
+                    P, a.ls, a.ac, a.rec, a.L);
+      return launch_status();
+    }
+  }
   if (4 * lds <= 64 * 1024) {
     // four rollout waves (one per SIMD of a CU) + their four helpers
     if (stage_cost_on<MODEL, kSparseMask<MODEL>>(p))
@@ -887,6 +935,11 @@ static int search_accept_impl(const pddp_problem* p, int B, int N, int A, T* Z,
 
 extern "C" {
 
+int pddp_search_form(int mode) {
+  const int prev = pddp::search_form_choice();
+  if (mode >= 0 && mode <= 2) pddp::search_form_choice() = mode;
+  return prev;
+}
 int pddp_search_candidates(int mode) {
   const int prev = pddp::search_candidates_choice();
   if (mode >= 0 && mode <= 2) pddp::search_candidates_choice() = mode;

@@ -1739,6 +1739,49 @@ def test_search_accept_without_candidates(B, N):
     assert accepted > B and other_winners > 0, (accepted, other_winners)
 
 
+@pytest.mark.parametrize("cand", [1, 2])
+@pytest.mark.parametrize("B,N", [(301, 40), (64, 100), (37, 127), (50, 7)])
+def test_search_accept_dense_form(B, N, cand):
+    """The dense form of pddp_search_accept_f32 (pddp_search_form(2): gains only
+    in LDS, the nominal's states and actions read in place, no helper
+    wavefronts, four workgroups per CU - what `auto` takes from 8193
+    trajectories on) against the paired form, round by round from the same
+    state, with the candidates kept and dropped: costs, decisions,
+    regularisation, masks and the new nominals bit for bit (the same rollout
+    and tail arithmetic; only where the operands come from differs)."""
+    from pddp_amd import _native
+    lib = _native.lib()
+    a, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=3)
+    b, *_ = _setup("cartpole", "f32", B, N, seed=3)
+    a.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    b.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    accepted = 0
+    prev_c = lib.pddp_search_candidates(cand)
+    prev_f = lib.pddp_search_form(1)
+    try:
+        for r in range(16):
+            for k in a._STATE:          # b starts every round where a does
+                getattr(b, k).copy_(getattr(a, k))
+            for s_, form in ((a, 1), (b, 2)):
+                lib.pddp_search_form(form)
+                assert s_.sweep_nominal()
+                assert s_.search_accept(5e-6, 1e10, 50, records=False)
+            torch.cuda.synchronize()
+            for k in ("Jc", "state", "iter", "active", "fresh", "mu", "delta",
+                      "J_opt", "bwd_status", "gains_acc", "Z", "U"):
+                x, y = getattr(a, k), getattr(b, k)
+                if x.is_floating_point():  # (a diverged candidate's cost: NaN)
+                    x, y = x.view(torch.int32 if x.element_size() == 4
+                                  else torch.int64), y.view(
+                        torch.int32 if y.element_size() == 4 else torch.int64)
+                assert torch.equal(x, y), (r, k)
+            accepted += int(((a.state == 1) | (a.state == 5)).sum())
+    finally:
+        lib.pddp_search_candidates(prev_c)
+        lib.pddp_search_form(prev_f)
+    assert accepted > B, accepted
+
+
 def _oracle_accept(J_opt, Jc, status, mu, delta, tol, max_reg, it, n_it):
     """One attempt's bookkeeping as the reference writes it (ilqr.py:122-181
     accept / converge / reject, :364-390 the mu schedule in Python floats,
