@@ -424,6 +424,19 @@ int pddp_bnn_mlp_rows_f32(int R, int P, int in_dim, int H, int out_dim,
                           const float* M1, const float* W2, const float* b2,
                           const float* M2, const float* W3, const float* b3,
                           float* Y, const int32_t* live_rows, void* stream);
+/* The same network in double precision (modules.py runs in the dtype of its
+ * inputs) on v_mfma_f64_16x16x4_f64, weights-stationary, four wavefronts per
+ * CU (csrc/bnn_mlp_f64.hip); arguments as above with double data. */
+int pddp_bnn_mlp_f64(int R, int P, int in_dim, int H, int out_dim,
+                     const double* X, const double* W1, const double* b1,
+                     const double* M1, const double* W2, const double* b2,
+                     const double* M2, const double* W3, const double* b3,
+                     double* Y, void* stream);
+int pddp_bnn_mlp_rows_f64(int R, int P, int in_dim, int H, int out_dim,
+                          const double* X, const double* W1, const double* b1,
+                          const double* M1, const double* W2, const double* b2,
+                          const double* M2, const double* W3, const double* b3,
+                          double* Y, const int32_t* live_rows, void* stream);
 
 /* ---- one time step of the moment-matched line-search rollout under a BNN
  * dynamics model, everything but the network: ilqr.py:677-723 (_control_law),
@@ -481,6 +494,39 @@ typedef struct pddp_bnn_step {
   const int32_t* slot;
 } pddp_bnn_step;
 int pddp_bnn_moment_step_f32(const pddp_bnn_step* step, void* stream);
+/* double precision: the same fields, double data */
+typedef struct pddp_bnn_step_f64 {
+  int32_t B, A, P, D, m, N, t;
+  int32_t n_ang, ang[2], n_non, non[8];
+  int32_t in_dim, out_dim;
+  const double* Z;
+  const double* U;
+  const double* gains;
+  const double* alphas;
+  const double* u_min;
+  const double* u_max;
+  const uint8_t* active;
+  const int32_t* bwd_status;
+  const double* Q;
+  const double* Q_term;
+  const double* R;
+  const double* x_goal;
+  const double* u_goal;
+  const double* X_mean;
+  const double* X_std_inv;
+  const double* dX_mean;
+  const double* dX_std;
+  const double* net_out;
+  double* Xp;
+  double* F;
+  double* Zc;
+  double* Uc;
+  double* J;
+  double* Jc;
+  const double* eps_out;
+  const int32_t* slot;
+} pddp_bnn_step_f64;
+int pddp_bnn_moment_step_f64(const pddp_bnn_step_f64* step, void* stream);
 
 /* ---- the same network in forward mode (JVP), for the derivative rollout
  * (ilqr.py:457-468 -> utils/evaluation.py:203-235 batch_eval_dynamics, which
@@ -513,6 +559,14 @@ int pddp_bnn_mlp_jvp_rows_f32(int R, int P, int group, int live, int in_dim,
                               const float* W1, const float* b1, const float* M1,
                               const float* W2, const float* b2, const float* M2,
                               const float* W3, const float* b3, float* Y,
+                              const int32_t* live_rows, void* stream);
+/* double precision (group = 8 or 16; 32: PDDP_E_UNSUPPORTED) */
+int pddp_bnn_mlp_jvp_rows_f64(int R, int P, int group, int live, int in_dim,
+                              int H, int out_dim, const double* X,
+                              const double* W1, const double* b1,
+                              const double* M1, const double* W2,
+                              const double* b2, const double* M2,
+                              const double* W3, const double* b3, double* Y,
                               const int32_t* live_rows, void* stream);
 
 /* ---- Jacobians F_z, F_u of one moment-matched BNN step (modules.py:287-386
@@ -569,6 +623,33 @@ typedef struct pddp_bnn_jvp {
 } pddp_bnn_jvp;
 int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* step, void* stream);
 int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* step, void* stream);
+/* double precision: the same fields, double data */
+typedef struct pddp_bnn_jvp_f64 {
+  int32_t B, P, D, m, N, t;
+  int32_t n_ang, ang[2], n_non, non[8];
+  int32_t in_dim, out_dim;
+  const double* Z;
+  const double* U;
+  const double* u_min;
+  const double* u_max;
+  const double* X_mean;
+  const double* X_std_inv;
+  const double* dX_mean;
+  const double* dX_std;
+  const double* net_out;
+  const double* Xp;
+  double* Xp_next;
+  double* eps;
+  double* F;
+  double* Z_next;
+  double* F_z;
+  double* F_u;
+  const double* eps_out;
+  int32_t independent_noise;
+  const int32_t* slot;
+} pddp_bnn_jvp_f64;
+int pddp_bnn_jvp_features_f64(const pddp_bnn_jvp_f64* step, void* stream);
+int pddp_bnn_jvp_moments_f64(const pddp_bnn_jvp_f64* step, void* stream);
 
 /* ---- value, gradient and Hessian of the QR cost on the angle-augmented
  * Gaussian state under DEFAULT encoding, every (trajectory, time step) in one
@@ -599,6 +680,27 @@ typedef struct pddp_qr_cost {
   float* L_uu;          /* [B][N][m][m] */
 } pddp_qr_cost;
 int pddp_qr_cost_derivs_f32(const pddp_qr_cost* cost, void* stream);
+/* double precision: the same fields, double data */
+typedef struct pddp_qr_cost_f64 {
+  int32_t B, N, D, m;
+  int32_t n_ang, ang[2], n_non, non[8];
+  const double* Z;
+  const double* U;
+  const double* u_min;
+  const double* u_max;
+  const double* Q;
+  const double* Q_term;
+  const double* R;
+  const double* x_goal;
+  const double* u_goal;
+  double* L;
+  double* L_z;
+  double* L_u;
+  double* L_zz;
+  double* L_uz;
+  double* L_uu;
+} pddp_qr_cost_f64;
+int pddp_qr_cost_derivs_f64(const pddp_qr_cost_f64* cost, void* stream);
 
 /* ---- pddp_amd/models/gp.py (the build's own plugin behind models/base.py:24-83
  * `DynamicsModel.forward(z, u, i, encoding)`; the reference has no GP - PARITY

@@ -87,6 +87,13 @@ _SIGS = {
     "pddp_bnn_mlp_precision": [c_int],
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
     "pddp_bnn_mlp_rows_f32": [c_int] * 5 + [_P] * 12,
+    "pddp_bnn_mlp_f64": [c_int] * 5 + [_P] * 11,
+    "pddp_bnn_mlp_rows_f64": [c_int] * 5 + [_P] * 12,
+    "pddp_bnn_moment_step_f64": [_P, _P],
+    "pddp_bnn_mlp_jvp_rows_f64": [c_int] * 7 + [_P] * 12,
+    "pddp_bnn_jvp_features_f64": [_P, _P],
+    "pddp_bnn_jvp_moments_f64": [_P, _P],
+    "pddp_qr_cost_derivs_f64": [_P, _P],
     "pddp_bnn_moment_step_f32": [_P, _P],
     "pddp_bnn_mlp_jvp_f32": [c_int] * 6 + [_P] * 11,
     "pddp_bnn_mlp_jvp_live_f32": [c_int] * 7 + [_P] * 11,

@@ -405,8 +405,8 @@ class TorchProblem(object):
         mc = getattr(co, "model_class", None)
         if not getattr(self, "use_native_cost", True) or self.cost_opts:
             return False
-        if s.dtype != torch.float32 or type(co).forward is not \
-                _augmented_forward() or mc is None:
+        if s.dtype not in (torch.float32, torch.float64) or \
+                type(co).forward is not _augmented_forward() or mc is None:
             return False
         if int(self.encoding) != int(StateEncoding.UPPER_TRIANGULAR_CHOLESKY):
             return False
@@ -528,9 +528,8 @@ class TorchProblem(object):
                         ("L_u", L_u), ("L_zz", L_zz), ("L_uz", L_uz),
                         ("L_uu", L_uu)):
             setattr(st, name, p(t))
-        _native.check(_native.lib().pddp_qr_cost_derivs_f32(
-            ctypes.byref(st), _native.stream_handle(s.device)),
-            "pddp_qr_cost_derivs_f32")
+        _native.call("pddp_qr_cost_derivs", s.dtype, ctypes.byref(st),
+                     _native.stream_handle(s.device))
 
     def _bnn_jvp_ok(self, s):
         """The forward-mode kernels cover D <= 6 with D + m <= 7 network
@@ -604,16 +603,14 @@ class TorchProblem(object):
         for t in range(N):
             st.t = t
             st.Xp, st.Xp_next = p(Xp), p(Xn)
-            _native.check(lib.pddp_bnn_jvp_features_f32(ctypes.byref(st),
-                                                        stream),
-                          "pddp_bnn_jvp_features_f32")
+            _native.call("pddp_bnn_jvp_features", s.dtype, ctypes.byref(st),
+                         stream)
             Y = mo.model._jvp_native(F, P, out_rows, G, live=1 + D + s.m,
                                      live_rows=live_rows)
             st.net_out = p(Y)
             st.eps_out = p(eps_keep[t]) if ups else None
-            _native.check(lib.pddp_bnn_jvp_moments_f32(ctypes.byref(st),
-                                                       stream),
-                          "pddp_bnn_jvp_moments_f32")
+            _native.call("pddp_bnn_jvp_moments", s.dtype, ctypes.byref(st),
+                         stream)
             Xp, Xn = Xn, Xp
         mo.output = {}  # the particle caches of a torch-path rollout: stale
 
@@ -627,7 +624,7 @@ class TorchProblem(object):
         mo, co = self.model, self.cost
         if not getattr(self, "use_native_bnn", True):
             return False
-        if s.dtype != torch.float32 or self.cost_opts:
+        if s.dtype not in (torch.float32, torch.float64) or self.cost_opts:
             return False
         if int(self.encoding) != int(StateEncoding.UPPER_TRIANGULAR_CHOLESKY):
             return False
@@ -760,9 +757,8 @@ class TorchProblem(object):
             st.t = t
             st.net_out = p(out)
             st.eps_out = p(eps_keep[t - 1]) if ups and t > 0 else None
-            _native.check(lib.pddp_bnn_moment_step_f32(ctypes.byref(st),
-                                                       stream),
-                          "pddp_bnn_moment_step_f32")
+            _native.call("pddp_bnn_moment_step", s.dtype, ctypes.byref(st),
+                         stream)
             if t < N:
                 out = mo.model._forward_native(F, out_dim, live_rows=live_rows)
         mo.output = {}  # the particle caches of a torch-path rollout: stale

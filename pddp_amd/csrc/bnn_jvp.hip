@@ -46,8 +46,43 @@ constexpr int kNetRows = 8;  // network rows per (state, particle)
 // EXACT: D == kJvpMaxD, known at compile time - every small matrix below is
 // then indexed statically and lives in registers (under a runtime D they sat in
 // scratch memory: 160 .. 1024 bytes per lane, and the kernels waited for it).
-template <int kJvpMaxD, bool EXACT>
-__global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
+PDDP_DEV float jvp_exp(float x) { return expf(x); }
+PDDP_DEV double jvp_exp(double x) { return exp(x); }
+PDDP_DEV float jvp_log(float x) { return logf(x); }
+PDDP_DEV double jvp_log(double x) { return log(x); }
+
+// pddp_bnn_jvp / pddp_bnn_jvp_f64 (include/pddp_hip.h) with the scalar type as
+// a parameter: the two structs differ in the pointee type only
+template <typename T>
+struct BnnJvpV {
+  int32_t B, P, D, m, N, t;
+  int32_t n_ang, ang[2], n_non, non[8];
+  int32_t in_dim, out_dim;
+  const T* Z;
+  const T* U;
+  const T* u_min;
+  const T* u_max;
+  const T* X_mean;
+  const T* X_std_inv;
+  const T* dX_mean;
+  const T* dX_std;
+  const T* net_out;
+  const T* Xp;
+  T* Xp_next;
+  T* eps;
+  T* F;
+  T* Z_next;
+  T* F_z;
+  T* F_u;
+  const T* eps_out;
+  int32_t independent_noise;
+  const int32_t* slot;
+};
+static_assert(sizeof(BnnJvpV<float>) == sizeof(pddp_bnn_jvp) &&
+              sizeof(BnnJvpV<double>) == sizeof(pddp_bnn_jvp_f64), "");
+
+template <typename T, int kJvpMaxD, bool EXACT>
+__global__ __launch_bounds__(64) void bnn_jvp_features_kernel(BnnJvpV<T> s) {
   constexpr int kJvpRows = kNetRows;
   const int lane = threadIdx.x;
   const int k = lane & (kJvpRows - 1);  // row of the group
@@ -60,10 +95,10 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   const int sbp = sb * s.P + (bp - b * s.P);
   const int D = EXACT ? kJvpMaxD : s.D;
   const int m = s.m, n = D + D * (D + 1) / 2;
-  const float* z = s.Z + ((size_t)b * (s.N + 1) + s.t) * n;
-  const float* xp = s.Xp + (size_t)bp * D;
+  const T* z = s.Z + ((size_t)b * (s.N + 1) + s.t) * n;
+  const T* xp = s.Xp + (size_t)bp * D;
   // eps = (X - mean) U^-1: forward substitution against the upper factor
-  float U[kJvpMaxD][kJvpMaxD], eps[kJvpMaxD], x[kJvpMaxD];
+  T U[kJvpMaxD][kJvpMaxD], eps[kJvpMaxD], x[kJvpMaxD];
   {
     int o = D;
     for (int i = 0; i < D; ++i)
@@ -71,7 +106,7 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   }
   for (int j = 0; j < D; ++j) {
     x[j] = xp[j];
-    float v = x[j] - z[j];
+    T v = x[j] - z[j];
     for (int i = 0; i < j; ++i) v -= eps[i] * U[i][j];
     eps[j] = v / U[j][j];
   }
@@ -80,11 +115,11 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   // row k >= 1: direction mean_{k-1} (k - 1 < D) or u_{k-1-D}.  By state
   // dimension c (a static index) to the feature slot the `non` / `ang` lists
   // give it.
-  float* f = s.F + ((size_t)sbp * kJvpRows + k) * s.in_dim;
+  T* f = s.F + ((size_t)sbp * kJvpRows + k) * s.in_dim;
 #pragma unroll
   for (int c = 0; c < kJvpMaxD; ++c) {
     if (c >= D) break;
-    const float dXc = (k - 1 == c) ? 1.f : 0.f;
+    const T dXc = (k - 1 == c) ? 1.f : 0.f;
     int o = -1, oa = -1;
     for (int i = 0; i < s.n_non; ++i) o = s.non[i] == c ? i : o;
     for (int a = 0; a < s.n_ang; ++a) oa = s.ang[a] == c ? s.n_non + 2 * a : oa;
@@ -92,7 +127,7 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
       f[o] = k == 0 ? (x[c] - s.X_mean[o]) * s.X_std_inv[o]
                     : dXc * s.X_std_inv[o];
     if (oa >= 0) {
-      float sn, cs;
+      T sn, cs;
       sincos_(x[c], sn, cs);
       f[oa] = k == 0 ? (sn - s.X_mean[oa]) * s.X_std_inv[oa]
                      : (cs * dXc) * s.X_std_inv[oa];
@@ -104,7 +139,7 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   for (int r = 0; r < m; ++r, ++o) {
     // derivatives AT the clamped action (ilqr.py:461-462: the clamp is not
     // differentiated through)
-    float u = s.U[((size_t)b * s.N + s.t) * m + r];
+    T u = s.U[((size_t)b * s.N + s.t) * m + r];
     if (s.u_min != nullptr && s.u_max != nullptr)
       u = clamp1(u, s.u_min[r], s.u_max[r]);
     f[o] = k == 0 ? (u - s.X_mean[o]) * s.X_std_inv[o]
@@ -112,8 +147,8 @@ __global__ __launch_bounds__(64) void bnn_jvp_features_kernel(pddp_bnn_jvp s) {
   }
 }
 
-template <int kJvpRows, int kJvpMaxD, bool EXACT>
-__global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
+template <typename T, int kJvpRows, int kJvpMaxD, bool EXACT>
+__global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(BnnJvpV<T> s) {
   // one wavefront per trajectory: lane = (particle slice, direction k); the
   // NS = 64 / G slices split the particle loop and meet in xor butterflies
   constexpr int NS = 64 / kJvpRows;
@@ -127,8 +162,8 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   const int D = EXACT ? kJvpMaxD : s.D;
   const int P = s.P, m = s.m, n = D + D * (D + 1) / 2;
   const int OUT = s.out_dim;
-  const float* Y = s.net_out + (size_t)sb * P * kNetRows * OUT;
-  auto across_slices = [&](float v) {
+  const T* Y = s.net_out + (size_t)sb * P * kNetRows * OUT;
+  auto across_slices = [&](T v) {
 #pragma unroll
     for (int o = kJvpRows; o < 64; o <<= 1) v += __shfl_xor(v, o);
     return v;
@@ -147,51 +182,51 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
           if (o == d) { yrow = 1 + bb; ea = aa; }
     }
   }
-  const float* Xin = s.Xp + (size_t)b * P * D;
-  float sd[kJvpMaxD], mu[kJvpMaxD];
+  const T* Xin = s.Xp + (size_t)b * P * D;
+  T sd[kJvpMaxD], mu[kJvpMaxD];
   for (int d = 0; d < D; ++d) { sd[d] = s.dX_std[d]; mu[d] = s.dX_mean[d]; }
 
   // ---- primal moments (every lane of the group, same arithmetic)
-  float M[kJvpMaxD];
+  T M[kJvpMaxD];
   for (int d = 0; d < D; ++d) M[d] = 0.f;
   // use_predicted_std (modules.py:242-260): + exp(log_std + log dX_std) eps
   const bool ups = s.eps_out != nullptr;
-  float lsd[kJvpMaxD];
-  for (int d = 0; d < D; ++d) lsd[d] = ups ? logf(sd[d]) : 0.f;
-  auto primal_out = [&](int p, int d, float& stdeps) {
-    const float* y = Y + (size_t)p * kNetRows * OUT;
-    float dx = y[d] * sd[d] + mu[d];
+  T lsd[kJvpMaxD];
+  for (int d = 0; d < D; ++d) lsd[d] = ups ? jvp_log(sd[d]) : 0.f;
+  auto primal_out = [&](int p, int d, T& stdeps) {
+    const T* y = Y + (size_t)p * kNetRows * OUT;
+    T dx = y[d] * sd[d] + mu[d];
     stdeps = 0.f;
     if (ups) {
-      stdeps = expf(y[D + d] + lsd[d]) * s.eps_out[p * D + d];
+      stdeps = jvp_exp(y[D + d] + lsd[d]) * s.eps_out[p * D + d];
       dx = dx + stdeps;
     }
     return Xin[p * D + d] + dx;
   };
   for (int p = slice; p < P; p += NS)
     for (int d = 0; d < D; ++d) {
-      float unused;
+      T unused;
       M[d] += primal_out(p, d, unused);
     }
-  for (int d = 0; d < D; ++d) M[d] = across_slices(M[d]) / (float)P;
+  for (int d = 0; d < D; ++d) M[d] = across_slices(M[d]) / (T)P;
 
   // ---- covariance, and this lane's tangent sums
-  float C[kJvpMaxD][kJvpMaxD], S[kJvpMaxD][kJvpMaxD], dM[kJvpMaxD];
+  T C[kJvpMaxD][kJvpMaxD], S[kJvpMaxD][kJvpMaxD], dM[kJvpMaxD];
   for (int i = 0; i < D; ++i) {
     dM[i] = 0.f;
     for (int j = 0; j < D; ++j) { C[i][j] = 0.f; S[i][j] = 0.f; }
   }
   for (int p = slice; p < P; p += NS) {
-    float dev[kJvpMaxD], dout[kJvpMaxD];
+    T dev[kJvpMaxD], dout[kJvpMaxD];
     // tangent of X for the base direction: e_b (mean_b / U_ab), 0 (u); scale
-    const float sc = ea < 0 ? 1.f : s.eps[((size_t)b * P + p) * D + ea];
+    const T sc = ea < 0 ? 1.f : s.eps[((size_t)b * P + p) * D + ea];
     for (int d = 0; d < D; ++d) {
-      float stdeps;
-      const float out = primal_out(p, d, stdeps);
+      T stdeps;
+      const T out = primal_out(p, d, stdeps);
       dev[d] = out - M[d];
-      const float dXd = (yrow >= 1 && yrow <= D && yrow - 1 == d) ? 1.f : 0.f;
-      const float* yt = Y + ((size_t)p * kNetRows + yrow) * OUT;
-      float dnet = yt[d] * sd[d];
+      const T dXd = (yrow >= 1 && yrow <= D && yrow - 1 == d) ? 1.f : 0.f;
+      const T* yt = Y + ((size_t)p * kNetRows + yrow) * OUT;
+      T dnet = yt[d] * sd[d];
       // d exp(log_std + c) eps = std eps d log_std
       if (ups && s.independent_noise == 0) dnet = dnet + stdeps * yt[D + d];
       dout[d] = sc * (dXd + dnet);
@@ -207,16 +242,16 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
     }
   }
   for (int i = 0; i < D; ++i) {
-    dM[i] = across_slices(dM[i]) / (float)P;
+    dM[i] = across_slices(dM[i]) / (T)P;
     for (int j = 0; j < D; ++j) {
-      C[i][j] = across_slices(C[i][j]) / (float)(P - 1);
+      C[i][j] = across_slices(C[i][j]) / (T)(P - 1);
       S[i][j] = across_slices(S[i][j]);
     }
   }
   if (slice != 0) return;  // (every slice holds the totals; one writes)
 
   // ---- U' = chol(C + jitter I), upper (encoding.py:536-564)
-  float Uc[kJvpMaxD][kJvpMaxD];
+  T Uc[kJvpMaxD][kJvpMaxD];
   bool ok = false;
   {
     double jit = 1e-12;
@@ -231,12 +266,12 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
 #pragma unroll
         for (int j = i; j < kJvpMaxD; ++j) {
           if (j >= D) break;
-          float v = C[i][j] + (i == j ? (float)jit : 0.f);
+          T v = C[i][j] + (i == j ? (T)jit : 0.f);
 #pragma unroll
           for (int q = 0; q < i; ++q) v -= Uc[q][i] * Uc[q][j];
           if (i == j) {
             if (!(v > 0.f)) ok = false;
-            Uc[i][i] = sqrtf(v);
+            Uc[i][i] = sqrt_(v);
           } else {
             Uc[i][j] = v / Uc[i][i];
           }
@@ -248,31 +283,31 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
       for (int j = 0; j < i; ++j) Uc[i][j] = 0.f;
   }
 
-  float dU[kJvpMaxD][kJvpMaxD];
+  T dU[kJvpMaxD][kJvpMaxD];
   for (int i = 0; i < D; ++i)
     for (int j = 0; j < D; ++j) dU[i][j] = 0.f;
   if (ok) {
     // dC = (S + S^T) / (P - 1);  W = U'^-T dC U'^-1;  dU' = Phi(W) U'
-    float dC[kJvpMaxD][kJvpMaxD], T1[kJvpMaxD][kJvpMaxD], W[kJvpMaxD][kJvpMaxD];
+    T dC[kJvpMaxD][kJvpMaxD], T1[kJvpMaxD][kJvpMaxD], W[kJvpMaxD][kJvpMaxD];
     for (int i = 0; i < D; ++i)
-      for (int j = 0; j < D; ++j) dC[i][j] = (S[i][j] + S[j][i]) / (float)(P - 1);
+      for (int j = 0; j < D; ++j) dC[i][j] = (S[i][j] + S[j][i]) / (T)(P - 1);
     // T1 = U'^-T dC: solve U'^T T1 = dC (U'^T lower): forward substitution
     for (int c = 0; c < D; ++c)
       for (int i = 0; i < D; ++i) {
-        float v = dC[i][c];
+        T v = dC[i][c];
         for (int q = 0; q < i; ++q) v -= Uc[q][i] * T1[q][c];
         T1[i][c] = v / Uc[i][i];
       }
     // W = T1 U'^-1: solve W U' = T1 row by row, forward in the column index
     for (int r = 0; r < D; ++r)
       for (int j = 0; j < D; ++j) {
-        float v = T1[r][j];
+        T v = T1[r][j];
         for (int q = 0; q < j; ++q) v -= W[r][q] * Uc[q][j];
         W[r][j] = v / Uc[j][j];
       }
     for (int i = 0; i < D; ++i)
       for (int j = i; j < D; ++j) {
-        float v = 0.f;
+        T v = 0.f;
         for (int q = i; q <= j; ++q)
           v += (q == i ? 0.5f * W[i][i] : W[i][q]) * Uc[q][j];
         dU[i][j] = v;
@@ -281,16 +316,16 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
     // encode()'s fall-back: the diagonal of standard deviations
     // (modules.py:380-386 -> encoding.py:99-141)
     for (int i = 0; i < D; ++i) {
-      const float sdev = sqrtf(C[i][i]);
+      const T sdev = sqrt_(C[i][i]);
       Uc[i][i] = sdev;
-      dU[i][i] = (S[i][i] + S[i][i]) / (float)(P - 1) / (2.f * sdev);
+      dU[i][i] = (S[i][i] + S[i][i]) / (T)(P - 1) / (2.f * sdev);
     }
   }
 
   // ---- outputs: the next encoded state (lane 0) and column k - 1 of (F_z|F_u)
   if (k == 0) {
     if (s.Z_next != nullptr) {
-      float* zn = s.Z_next + (size_t)b * n;
+      T* zn = s.Z_next + (size_t)b * n;
       for (int d = 0; d < D; ++d) zn[d] = M[d];
       int o = D;
       for (int i = 0; i < D; ++i)
@@ -300,7 +335,7 @@ __global__ __launch_bounds__(64) void bnn_jvp_moments_kernel(pddp_bnn_jvp s) {
   }
   const int col = k - 1;
   if (col >= n + m) return;
-  float* dst;
+  T* dst;
   int ld;
   if (col < n) {
     dst = s.F_z + ((size_t)b * s.N + s.t) * n * n + col;
@@ -328,7 +363,12 @@ int pddp_bnn_jvp_group(int D, int m) {
   return 0;
 }
 
-static int bnn_jvp_check(const pddp_bnn_jvp* s) {
+}  // extern "C"
+
+namespace pddp {
+
+template <typename T>
+static int bnn_jvp_check(const BnnJvpV<T>* s) {
   if (s == nullptr) return PDDP_E_BADARG;
   if (s->B <= 0 || s->P <= 1 || s->N <= 0 || s->t < 0 || s->t >= s->N ||
       !s->Z || !s->U || !s->X_mean || !s->X_std_inv || !s->dX_mean ||
@@ -336,7 +376,7 @@ static int bnn_jvp_check(const pddp_bnn_jvp* s) {
     return PDDP_E_BADARG;
   const int n = s->D + s->D * (s->D + 1) / 2;
   if (s->D < 1 || s->D > 6 || s->m < 1 || n + s->m > 31 ||
-      s->D + s->m > pddp::kNetRows - 1 || s->n_ang < 0 || s->n_ang > 2 ||
+      s->D + s->m > kNetRows - 1 || s->n_ang < 0 || s->n_ang > 2 ||
       s->n_non < 0 || s->n_non + s->n_ang != s->D ||
       s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D ||
       (s->eps_out != nullptr && s->out_dim < 2 * s->D))
@@ -344,40 +384,59 @@ static int bnn_jvp_check(const pddp_bnn_jvp* s) {
   return 0;
 }
 
-int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* s, void* stream) {
+template <typename T>
+static int bnn_jvp_features(const BnnJvpV<T>* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
   const dim3 grid((s->B * s->P + 7) / 8), block(64);
   hipStream_t st = (hipStream_t)stream;
   switch (s->D) {
-    case 2: PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<2, true>), grid, block, 0, st, *s); break;
-    case 4: PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<4, true>), grid, block, 0, st, *s); break;
-    case 6: PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<6, true>), grid, block, 0, st, *s); break;
+    case 2: PDDP_LAUNCH((bnn_jvp_features_kernel<T, 2, true>), grid, block, 0, st, *s); break;
+    case 4: PDDP_LAUNCH((bnn_jvp_features_kernel<T, 4, true>), grid, block, 0, st, *s); break;
+    case 6: PDDP_LAUNCH((bnn_jvp_features_kernel<T, 6, true>), grid, block, 0, st, *s); break;
     default:
       if (s->D <= 4)
-        PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<4, false>), grid, block, 0, st, *s);
+        PDDP_LAUNCH((bnn_jvp_features_kernel<T, 4, false>), grid, block, 0, st, *s);
       else
-        PDDP_LAUNCH((pddp::bnn_jvp_features_kernel<6, false>), grid, block, 0, st, *s);
+        PDDP_LAUNCH((bnn_jvp_features_kernel<T, 6, false>), grid, block, 0, st, *s);
   }
-  return pddp::launch_status();
+  return launch_status();
 }
 
-int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* s, void* stream) {
+template <typename T>
+static int bnn_jvp_moments(const BnnJvpV<T>* s, void* stream) {
   if (int rc = bnn_jvp_check(s)) return rc;
   if (!s->net_out || !s->F_z || !s->F_u) return PDDP_E_BADARG;
   const dim3 grid(s->B), block(64);
   hipStream_t st = (hipStream_t)stream;
   const bool g16 = pddp_bnn_jvp_group(s->D, s->m) == 16;
   if (g16 && s->D == 2)
-    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<16, 2, true>), grid, block, 0, st, *s);
+    PDDP_LAUNCH((bnn_jvp_moments_kernel<T, 16, 2, true>), grid, block, 0, st, *s);
   else if (g16 && s->D == 4)
-    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<16, 4, true>), grid, block, 0, st, *s);
+    PDDP_LAUNCH((bnn_jvp_moments_kernel<T, 16, 4, true>), grid, block, 0, st, *s);
   else if (g16)
-    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<16, 4, false>), grid, block, 0, st, *s);
+    PDDP_LAUNCH((bnn_jvp_moments_kernel<T, 16, 4, false>), grid, block, 0, st, *s);
   else if (s->D == 6)
-    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<32, 6, true>), grid, block, 0, st, *s);
+    PDDP_LAUNCH((bnn_jvp_moments_kernel<T, 32, 6, true>), grid, block, 0, st, *s);
   else
-    PDDP_LAUNCH((pddp::bnn_jvp_moments_kernel<32, 6, false>), grid, block, 0, st, *s);
-  return pddp::launch_status();
+    PDDP_LAUNCH((bnn_jvp_moments_kernel<T, 32, 6, false>), grid, block, 0, st, *s);
+  return launch_status();
+}
+
+}  // namespace pddp
+
+extern "C" {
+
+int pddp_bnn_jvp_features_f32(const pddp_bnn_jvp* s, void* stream) {
+  return pddp::bnn_jvp_features(reinterpret_cast<const pddp::BnnJvpV<float>*>(s), stream);
+}
+int pddp_bnn_jvp_moments_f32(const pddp_bnn_jvp* s, void* stream) {
+  return pddp::bnn_jvp_moments(reinterpret_cast<const pddp::BnnJvpV<float>*>(s), stream);
+}
+int pddp_bnn_jvp_features_f64(const pddp_bnn_jvp_f64* s, void* stream) {
+  return pddp::bnn_jvp_features(reinterpret_cast<const pddp::BnnJvpV<double>*>(s), stream);
+}
+int pddp_bnn_jvp_moments_f64(const pddp_bnn_jvp_f64* s, void* stream) {
+  return pddp::bnn_jvp_moments(reinterpret_cast<const pddp::BnnJvpV<double>*>(s), stream);
 }
 
 }  // extern "C"

@@ -37,7 +37,52 @@ constexpr int kBnnGroup = 16;                  // lanes per candidate
 constexpr int kBnnPerWave = 64 / kBnnGroup;    // candidates per wavefront
 constexpr int kBnnMaxPPL = 128 / kBnnGroup;    // particles per lane (P <= 128)
 
-PDDP_DEV float group_sum(float v) {  // over the 16 lanes of a candidate
+PDDP_DEV float bnn_exp(float x) { return expf(x); }
+PDDP_DEV double bnn_exp(double x) { return exp(x); }
+PDDP_DEV float bnn_log(float x) { return logf(x); }
+PDDP_DEV double bnn_log(double x) { return log(x); }
+PDDP_DEV void bnn_sincos_core(float x, float& s, float& c) { sincos_core(x, s, c); }
+PDDP_DEV void bnn_sincos_core(double x, double& s, double& c) { sincos(x, &s, &c); }
+
+// pddp_bnn_step / pddp_bnn_step_f64 (include/pddp_hip.h) with the scalar type
+// as a parameter: the two structs differ in the pointee type only
+template <typename T>
+struct BnnStepV {
+  int32_t B, A, P, D, m, N, t;
+  int32_t n_ang, ang[2], n_non, non[8];
+  int32_t in_dim, out_dim;
+  const T* Z;
+  const T* U;
+  const T* gains;
+  const T* alphas;
+  const T* u_min;
+  const T* u_max;
+  const uint8_t* active;
+  const int32_t* bwd_status;
+  const T* Q;
+  const T* Q_term;
+  const T* R;
+  const T* x_goal;
+  const T* u_goal;
+  const T* X_mean;
+  const T* X_std_inv;
+  const T* dX_mean;
+  const T* dX_std;
+  const T* net_out;
+  T* Xp;
+  T* F;
+  T* Zc;
+  T* Uc;
+  T* J;
+  T* Jc;
+  const T* eps_out;
+  const int32_t* slot;
+};
+static_assert(sizeof(BnnStepV<float>) == sizeof(pddp_bnn_step) &&
+              sizeof(BnnStepV<double>) == sizeof(pddp_bnn_step_f64), "");
+
+template <typename T>
+PDDP_DEV T group_sum(T v) {  // over the 16 lanes of a candidate
 #pragma unroll
   for (int o = kBnnGroup / 2; o >= 1; o >>= 1) v += __shfl_xor(v, o);
   return v;
@@ -46,14 +91,15 @@ PDDP_DEV float group_sum(float v) {  // over the 16 lanes of a candidate
 // upper Cholesky of the d x d matrix C + jitter I (row-major, ld = kBnnMaxNa),
 // false when a pivot is not positive (encoding.py:536-564 tries jitter = 1e-12,
 // 1e-11, ... <= 10)
-PDDP_DEV bool chol_upper(const float* C, int d, float jitter, float* U) {
+template <typename T>
+PDDP_DEV bool chol_upper(const T* C, int d, T jitter, T* U) {
   for (int i = 0; i < d; ++i) {
     for (int j = i; j < d; ++j) {
-      float s = C[i * kBnnMaxNa + j] + (i == j ? jitter : 0.f);
+      T s = C[i * kBnnMaxNa + j] + (i == j ? jitter : 0.f);
       for (int k = 0; k < i; ++k) s -= U[k * kBnnMaxNa + i] * U[k * kBnnMaxNa + j];
       if (i == j) {
         if (!(s > 0.f)) return false;
-        U[i * kBnnMaxNa + i] = sqrtf(s);
+        U[i * kBnnMaxNa + i] = sqrt_(s);
       } else {
         U[i * kBnnMaxNa + j] = s / U[i * kBnnMaxNa + i];
       }
@@ -63,10 +109,11 @@ PDDP_DEV bool chol_upper(const float* C, int d, float jitter, float* U) {
   return true;
 }
 // with the escalation; returns the jitter used, -1 when none up to 10 works
-PDDP_DEV float chol_upper_jittered(const float* C, int d, float* U) {
-  double jit = 1e-12;  // python float in the reference
+template <typename T>
+PDDP_DEV T chol_upper_jittered(const T* C, int d, T* U) {
+  double jit = 1e-12;  // python T in the reference
   while (true) {
-    if (chol_upper(C, d, (float)jit, U)) return (float)jit;
+    if (chol_upper(C, d, (T)jit, U)) return (T)jit;
     jit *= 10.0;
     if (jit > 10.0) return -1.f;
   }
@@ -76,27 +123,27 @@ PDDP_DEV float chol_upper_jittered(const float* C, int d, float* U) {
 // argument).  With it the particle registers x[.][d] are indexed statically;
 // under a runtime D they lived in scratch memory (272 B per lane, 136 scratch
 // instructions) and the kernel waited for them.
-template <int DT>
-__global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
+template <typename T, int DT>
+__global__ __launch_bounds__(64) void bnn_moment_step_kernel(BnnStepV<T> s) {
   constexpr int DX = DT > 0 ? DT : kBnnMaxD;
   // per candidate: Ms, Cs, Us, zs, us, Ma, Ca, Ua; the stride is odd in banks
   constexpr int kM2 = kBnnMaxNa * kBnnMaxNa;
   constexpr int kStride = kBnnMaxD + 4 * kM2 + kBnnMaxN + kBnnMaxM + kBnnMaxNa + 1;
   static_assert(kStride % 2 == 1, "groups must start in different banks");
-  __shared__ float sm[kBnnPerWave][kStride];
+  __shared__ T sm[kBnnPerWave][kStride];
 
   const int lane = threadIdx.x & (kBnnGroup - 1);  // lane of the group
   const int grp = threadIdx.x / kBnnGroup;
   const int c = blockIdx.x * kBnnPerWave + grp;    // candidate = b * A + ai
   if (c >= s.B * s.A) return;
-  float* Ms = sm[grp];
-  float* Cs = Ms + kBnnMaxD;
-  float* Us = Cs + kM2;
-  float* zs = Us + kM2;
-  float* us = zs + kBnnMaxN;
-  float* Ma = us + kBnnMaxM;
-  float* Ca = Ma + kBnnMaxNa;
-  float* Ua = Ca + kM2;
+  T* Ms = sm[grp];
+  T* Cs = Ms + kBnnMaxD;
+  T* Us = Cs + kM2;
+  T* zs = Us + kM2;
+  T* us = zs + kBnnMaxN;
+  T* Ma = us + kBnnMaxM;
+  T* Ca = Ma + kBnnMaxNa;
+  T* Ua = Ca + kM2;
   const int b = c / s.A, ai = c - b * s.A;
   // (a group that leaves early takes no part in the barriers below: one
   // wavefront per workgroup, a barrier only orders its LDS traffic)
@@ -113,7 +160,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
   const bool terminal = (t == N);
 
   // ---- particles of this step (up to eight per lane: P <= 128)
-  float x[kBnnMaxPPL][DX];
+  T x[kBnnMaxPPL][DX];
   bool has[kBnnMaxPPL];
 #pragma unroll
   for (int q = 0; q < kBnnMaxPPL; ++q) {
@@ -124,23 +171,23 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     // rows of D (and out_dim = D or 2 D) floats: 8-byte vector accesses when D
     // is a compile-time even number (rows are then 8-byte aligned)
     constexpr bool kVec = DT > 0 && DT % 2 == 0;
-    float xin[DX], net[DX], nls[DX];
+    T xin[DX], net[DX], nls[DX];
     if constexpr (kVec) {
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      const f32x2* xr = reinterpret_cast<const f32x2*>(s.Xp + row * D);
-      const f32x2* nr = reinterpret_cast<const f32x2*>(
+      typedef T tx2 __attribute__((ext_vector_type(2)));
+      const tx2* xr = reinterpret_cast<const tx2*>(s.Xp + row * D);
+      const tx2* nr = reinterpret_cast<const tx2*>(
           s.net_out + nrow * s.out_dim);  // (dereferenced for t > 0 only)
 #pragma unroll
       for (int d2 = 0; d2 < DX / 2; ++d2) {
-        const f32x2 a = xr[d2];
+        const tx2 a = xr[d2];
         xin[2 * d2] = a[0];
         xin[2 * d2 + 1] = a[1];
         if (t > 0) {
-          const f32x2 b = nr[d2];
+          const tx2 b = nr[d2];
           net[2 * d2] = b[0];
           net[2 * d2 + 1] = b[1];
           if (s.eps_out != nullptr) {
-            const f32x2 e = nr[DX / 2 + d2];
+            const tx2 e = nr[DX / 2 + d2];
             nls[2 * d2] = e[0];
             nls[2 * d2 + 1] = e[1];
           }
@@ -160,11 +207,11 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
       if (d >= D) break;
-      float v = xin[d];
+      T v = xin[d];
       if (t > 0) {  // X + dx, dx = out[:D] * dX_std + dX_mean   (modules.py:262)
-        float dx = net[d] * s.dX_std[d] + s.dX_mean[d];
+        T dx = net[d] * s.dX_std[d] + s.dX_mean[d];
         if (s.eps_out != nullptr)  // + exp(log_std + log dX_std) eps (:242-260)
-          dx = dx + expf(nls[d] + logf(s.dX_std[d])) *
+          dx = dx + bnn_exp(nls[d] + bnn_log(s.dX_std[d])) *
                         s.eps_out[(has[q] ? p : 0) * D + d];
         v = v + dx;
       }
@@ -172,11 +219,11 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     }
     if (t > 0 && has[q]) {
       if constexpr (kVec) {
-        typedef float f32x2 __attribute__((ext_vector_type(2)));
-        f32x2* xw = reinterpret_cast<f32x2*>(s.Xp + row * D);
+        typedef T tx2 __attribute__((ext_vector_type(2)));
+        tx2* xw = reinterpret_cast<tx2*>(s.Xp + row * D);
 #pragma unroll
         for (int d2 = 0; d2 < DX / 2; ++d2)
-          xw[d2] = f32x2{x[q][2 * d2], x[q][2 * d2 + 1]};
+          xw[d2] = tx2{x[q][2 * d2], x[q][2 * d2 + 1]};
       } else {
 #pragma unroll
         for (int d = 0; d < DX; ++d) {
@@ -205,10 +252,10 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
 #pragma unroll
     for (int d = 0; d < DX; ++d) {
       if (d >= D) break;
-      float v = 0.f;
+      T v = 0.f;
 #pragma unroll
       for (int q = 0; q < kBnnMaxPPL; ++q) v += has[q] ? x[q][d] : 0.f;
-      v = group_sum(v) / (float)P;
+      v = group_sum(v) / (T)P;
       if (lane == 0) Ms[d] = v;
 #pragma unroll
       for (int q = 0; q < kBnnMaxPPL; ++q)
@@ -219,11 +266,11 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
 #pragma unroll
       for (int j = i; j < DX; ++j) {
         if (j >= D) break;
-        float v = 0.f;
+        T v = 0.f;
 #pragma unroll
         for (int q = 0; q < kBnnMaxPPL; ++q)
           v += has[q] ? x[q][i] * x[q][j] : 0.f;
-        v = group_sum(v) / (float)(P - 1);
+        v = group_sum(v) / (T)(P - 1);
         if (lane == 0) {
           Cs[i * kBnnMaxNa + j] = v;
           Cs[j * kBnnMaxNa + i] = v;
@@ -237,7 +284,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
         for (int i = 0; i < D; ++i)
           for (int j = 0; j < D; ++j)
             Us[i * kBnnMaxNa + j] =
-                i == j ? sqrtf(Cs[i * kBnnMaxNa + i]) : 0.f;
+                i == j ? sqrt_(Cs[i * kBnnMaxNa + i]) : 0.f;
       }
       for (int d = 0; d < D; ++d) zs[d] = Ms[d];
       int o = D;
@@ -260,14 +307,14 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
   if (lane == 0) {
     if (!terminal) {
       const int GS = m + m * n;
-      const float* g = s.gains + ((size_t)b * N + t) * GS;
-      const float* zn = s.Z + ((size_t)b * (N + 1) + t) * n;
+      const T* g = s.gains + ((size_t)b * N + t) * GS;
+      const T* zn = s.Z + ((size_t)b * (N + 1) + t) * n;
       for (int r = 0; r < m; ++r) {
-        float du = s.alphas[ai] * g[r];                     // ilqr.py:708
-        float acc = 0.f;
+        T du = s.alphas[ai] * g[r];                     // ilqr.py:708
+        T acc = 0.f;
         for (int k = 0; k < n; ++k) acc += (zs[k] - zn[k]) * g[m + r * n + k];
         du = du + acc;                                      // ilqr.py:710
-        float v = s.U[((size_t)b * N + t) * m + r] + du;
+        T v = s.U[((size_t)b * N + t) * m + r] + du;
         if (s.u_min != nullptr && s.u_max != nullptr)
           v = clamp1(v, s.u_min[r], s.u_max[r]);
         us[r] = v;
@@ -280,7 +327,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     // are exact zeros; the matrix is symmetric)
     for (int i = 0; i < D; ++i)
       for (int j = i; j < D; ++j) {
-        float v = 0.f;
+        T v = 0.f;
         for (int k = 0; k <= i; ++k) v += Us[k * kBnnMaxNa + i] * Us[k * kBnnMaxNa + j];
         Cs[i * kBnnMaxNa + j] = v;
         Cs[j * kBnnMaxNa + i] = v;
@@ -294,20 +341,20 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     }
     for (int a1 = 0; a1 < nang; ++a1) {
       const int i1 = s.ang[a1];
-      const float m1 = Ms[i1], v1 = Cs[i1 * kBnnMaxNa + i1];
-      const float damp = expf(-0.5f * v1);
-      float sin1, cos1;
+      const T m1 = Ms[i1], v1 = Cs[i1 * kBnnMaxNa + i1];
+      const T damp = bnn_exp(-0.5f * v1);
+      T sin1, cos1;
       sincos_(m1, sin1, cos1);
-      const float Es = damp * sin1, Ec = damp * cos1;
+      const T Es = damp * sin1, Ec = damp * cos1;
       Ma[nn + 2 * a1] = Es;
       Ma[nn + 2 * a1 + 1] = Ec;
       for (int a2 = 0; a2 < nang; ++a2) {
         const int i2 = s.ang[a2];
-        const float m2 = Ms[i2], v2 = Cs[i2 * kBnnMaxNa + i2];
-        const float cij = Cs[i1 * kBnnMaxNa + i2];
-        const float lq = -0.5f * (v1 + v2), q = expf(lq);
-        const float ep = expf(lq + cij) - q, em = expf(lq - cij) - q;
-        float sd, cd, ss, cs;
+        const T m2 = Ms[i2], v2 = Cs[i2 * kBnnMaxNa + i2];
+        const T cij = Cs[i1 * kBnnMaxNa + i2];
+        const T lq = -0.5f * (v1 + v2), q = bnn_exp(lq);
+        const T ep = bnn_exp(lq + cij) - q, em = bnn_exp(lq - cij) - q;
+        T sd, cd, ss, cs;
         sincos_(m1 - m2, sd, cd);
         sincos_(m1 + m2, ss, cs);
         const int r = nn + 2 * a1, cc = nn + 2 * a2;
@@ -318,7 +365,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
         Ca[(cc + 1) * kBnnMaxNa + r] = Ca[r * kBnnMaxNa + cc + 1];
       }
       for (int i = 0; i < nn; ++i) {
-        const float col = Cs[s.non[i] * kBnnMaxNa + i1];
+        const T col = Cs[s.non[i] * kBnnMaxNa + i1];
         const int r = nn + 2 * a1;
         Ca[i * kBnnMaxNa + r] = col * Ec;        // Cov(x, sin)
         Ca[i * kBnnMaxNa + r + 1] = -col * Es;   // Cov(x, cos)
@@ -328,22 +375,22 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     }
     // the cost re-encodes the augmented covariance (a jittered Cholesky) and
     // decodes it again: C'' = Ca + jitter I for the first jitter that works
-    float jit = chol_upper_jittered(Ca, na, Ua);
-    const float* Q = terminal ? s.Q_term : s.Q;
-    float cost = 0.f;
+    T jit = chol_upper_jittered(Ca, na, Ua);
+    const T* Q = terminal ? s.Q_term : s.Q;
+    T cost = 0.f;
     for (int i = 0; i < na; ++i) {
-      float row = 0.f;
+      T row = 0.f;
       for (int j = 0; j < na; ++j) row += (Ma[j] - s.x_goal[j]) * Q[j * na + i];
       cost += row * (Ma[i] - s.x_goal[i]);
     }
     if (!terminal) {
       for (int i = 0; i < m; ++i) {
-        float row = 0.f;
+        T row = 0.f;
         for (int j = 0; j < m; ++j) row += (us[j] - s.u_goal[j]) * s.R[j * m + i];
         cost += row * (us[i] - s.u_goal[i]);
       }
     }
-    float tr = 0.f;
+    T tr = 0.f;
     if (jit >= 0.f) {
       // tr(Q Ua^T Ua) with Ua^T Ua = Ca + jitter I: the factor only decides
       // which jitter the cost sees (as csrc/qr_cost_derivs.hip takes it);
@@ -357,7 +404,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
       for (int i = 0; i < na; ++i) tr += Ca[i * kBnnMaxNa + i] * Q[i * na + i];
     }
     cost += tr;
-    const float J = (t == 0 ? 0.f : s.J[c]) + cost;
+    const T J = (t == 0 ? 0.f : s.J[c]) + cost;
     s.J[c] = J;
     if (terminal) s.Jc[c] = J;
   }
@@ -368,7 +415,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
   // dimension (a static register index) to the feature slot the `non` / `ang`
   // lists give it - the other way round is a dynamic index into x, i.e.
   // scratch memory
-  float* frow = s.F + ((size_t)cc * P + lane) * s.in_dim;
+  T* frow = s.F + ((size_t)cc * P + lane) * s.in_dim;
   const size_t qstep = (size_t)kBnnGroup * s.in_dim;
 #pragma unroll
   for (int d = 0; d < DX; ++d) {
@@ -378,18 +425,18 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
     for (int a1 = 0; a1 < s.n_ang; ++a1)
       oa = s.ang[a1] == d ? s.n_non + 2 * a1 : oa;
     if (o >= 0) {
-      const float mu = s.X_mean[o], si = s.X_std_inv[o];
+      const T mu = s.X_mean[o], si = s.X_std_inv[o];
 #pragma unroll
       for (int q = 0; q < kBnnMaxPPL; ++q)
         if (has[q]) frow[q * qstep + o] = (x[q][d] - mu) * si;
     }
     if (oa >= 0) {
-      const float mu0 = s.X_mean[oa], si0 = s.X_std_inv[oa];
-      const float mu1 = s.X_mean[oa + 1], si1 = s.X_std_inv[oa + 1];
+      const T mu0 = s.X_mean[oa], si0 = s.X_std_inv[oa];
+      const T mu1 = s.X_mean[oa + 1], si1 = s.X_std_inv[oa + 1];
 #pragma unroll
       for (int q = 0; q < kBnnMaxPPL; ++q) {
-        float sn, cs;  // (a particle beyond 2^30 rad: see sincos_core)
-        sincos_core(x[q][d], sn, cs);
+        T sn, cs;  // (a particle beyond 2^30 rad: see sincos_core)
+        bnn_sincos_core(x[q][d], sn, cs);
         if (has[q]) {
           frow[q * qstep + oa] = (sn - mu0) * si0;
           frow[q * qstep + oa + 1] = (cs - mu1) * si1;
@@ -400,7 +447,7 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
   {
     const int o0 = s.n_non + 2 * s.n_ang;
     for (int r = 0; r < m; ++r) {
-      const float v = (us[r] - s.X_mean[o0 + r]) * s.X_std_inv[o0 + r];
+      const T v = (us[r] - s.X_mean[o0 + r]) * s.X_std_inv[o0 + r];
 #pragma unroll
       for (int q = 0; q < kBnnMaxPPL; ++q)
         if (has[q]) frow[q * qstep + o0 + r] = v;
@@ -410,7 +457,10 @@ __global__ __launch_bounds__(64) void bnn_moment_step_kernel(pddp_bnn_step s) {
 
 }  // namespace pddp
 
-extern "C" int pddp_bnn_moment_step_f32(const pddp_bnn_step* s, void* stream) {
+namespace pddp {
+
+template <typename T>
+static int bnn_moment_step(const BnnStepV<T>* s, void* stream) {
   if (s == nullptr) return PDDP_E_BADARG;
   if (s->B <= 0 || s->A <= 0 || s->P <= 1 || s->N <= 0 || s->t < 0 ||
       s->t > s->N || !s->Z || !s->U || !s->gains || !s->alphas || !s->Q ||
@@ -418,20 +468,31 @@ extern "C" int pddp_bnn_moment_step_f32(const pddp_bnn_step* s, void* stream) {
       !s->X_std_inv || !s->dX_mean || !s->dX_std || !s->Xp || !s->F || !s->Zc ||
       !s->Uc || !s->J || !s->Jc || (s->t > 0 && !s->net_out))
     return PDDP_E_BADARG;
-  if (s->D < 1 || s->D > pddp::kBnnMaxD || s->m < 1 || s->m > pddp::kBnnMaxM ||
-      s->P > 128 || s->n_ang < 0 || s->n_ang > pddp::kBnnMaxAng ||
+  if (s->D < 1 || s->D > kBnnMaxD || s->m < 1 || s->m > kBnnMaxM ||
+      s->P > 128 || s->n_ang < 0 || s->n_ang > kBnnMaxAng ||
       s->n_non < 0 || s->n_non + s->n_ang != s->D ||
       s->in_dim != s->n_non + 2 * s->n_ang + s->m || s->out_dim < s->D ||
       (s->eps_out != nullptr && s->out_dim < 2 * s->D))
     return PDDP_E_UNSUPPORTED;
   const int groups = s->B * s->A;
-  const dim3 grid((groups + pddp::kBnnPerWave - 1) / pddp::kBnnPerWave);
+  const dim3 grid((groups + kBnnPerWave - 1) / kBnnPerWave);
   hipStream_t st = (hipStream_t)stream;
   switch (s->D) {
-    case 2: PDDP_LAUNCH(pddp::bnn_moment_step_kernel<2>, grid, dim3(64), 0, st, *s); break;
-    case 4: PDDP_LAUNCH(pddp::bnn_moment_step_kernel<4>, grid, dim3(64), 0, st, *s); break;
-    case 6: PDDP_LAUNCH(pddp::bnn_moment_step_kernel<6>, grid, dim3(64), 0, st, *s); break;
-    default: PDDP_LAUNCH(pddp::bnn_moment_step_kernel<0>, grid, dim3(64), 0, st, *s); break;
+    case 2: PDDP_LAUNCH((bnn_moment_step_kernel<T, 2>), grid, dim3(64), 0, st, *s); break;
+    case 4: PDDP_LAUNCH((bnn_moment_step_kernel<T, 4>), grid, dim3(64), 0, st, *s); break;
+    case 6: PDDP_LAUNCH((bnn_moment_step_kernel<T, 6>), grid, dim3(64), 0, st, *s); break;
+    default: PDDP_LAUNCH((bnn_moment_step_kernel<T, 0>), grid, dim3(64), 0, st, *s); break;
   }
-  return pddp::launch_status();
+  return launch_status();
+}
+
+}  // namespace pddp
+
+extern "C" int pddp_bnn_moment_step_f32(const pddp_bnn_step* s, void* stream) {
+  return pddp::bnn_moment_step(
+      reinterpret_cast<const pddp::BnnStepV<float>*>(s), stream);
+}
+extern "C" int pddp_bnn_moment_step_f64(const pddp_bnn_step_f64* s, void* stream) {
+  return pddp::bnn_moment_step(
+      reinterpret_cast<const pddp::BnnStepV<double>*>(s), stream);
 }

@@ -18,59 +18,90 @@
 
 namespace pddp {
 
-struct HD {  // hyper-dual number
-  float v, a, b, ab;
+PDDP_DEV float qr_exp(float x) { return expf(x); }
+PDDP_DEV double qr_exp(double x) { return exp(x); }
+PDDP_DEV void qr_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
+PDDP_DEV void qr_sincos(double x, double& s, double& c) { sincos(x, &s, &c); }
+
+// pddp_qr_cost / pddp_qr_cost_f64 with the scalar type as a parameter
+template <typename T>
+struct QrCostV {
+  int32_t B, N, D, m;
+  int32_t n_ang, ang[2], n_non, non[8];
+  const T* Z;
+  const T* U;
+  const T* u_min;
+  const T* u_max;
+  const T* Q;
+  const T* Q_term;
+  const T* R;
+  const T* x_goal;
+  const T* u_goal;
+  T* L;
+  T* L_z;
+  T* L_u;
+  T* L_zz;
+  T* L_uz;
+  T* L_uu;
 };
-PDDP_DEV HD hd(float v) { return HD{v, 0.f, 0.f, 0.f}; }
-PDDP_DEV HD operator+(HD x, HD y) { return HD{x.v + y.v, x.a + y.a, x.b + y.b, x.ab + y.ab}; }
-PDDP_DEV HD operator-(HD x, HD y) { return HD{x.v - y.v, x.a - y.a, x.b - y.b, x.ab - y.ab}; }
-PDDP_DEV HD operator-(HD x) { return HD{-x.v, -x.a, -x.b, -x.ab}; }
-PDDP_DEV HD operator*(HD x, HD y) {
-  return HD{x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b,
+static_assert(sizeof(QrCostV<float>) == sizeof(pddp_qr_cost) &&
+              sizeof(QrCostV<double>) == sizeof(pddp_qr_cost_f64), "");
+
+template <typename T>
+struct HDT {  // hyper-dual number
+  typedef T S;
+  T v, a, b, ab;
+};
+template <typename T> PDDP_DEV HDT<T> hd_(typename HDT<T>::S v) { return HDT<T>{v, 0.f, 0.f, 0.f}; }
+template <typename T> PDDP_DEV HDT<T> operator+(HDT<T> x, HDT<T> y) { return HDT<T>{x.v + y.v, x.a + y.a, x.b + y.b, x.ab + y.ab}; }
+template <typename T> PDDP_DEV HDT<T> operator-(HDT<T> x, HDT<T> y) { return HDT<T>{x.v - y.v, x.a - y.a, x.b - y.b, x.ab - y.ab}; }
+template <typename T> PDDP_DEV HDT<T> operator-(HDT<T> x) { return HDT<T>{-x.v, -x.a, -x.b, -x.ab}; }
+template <typename T> PDDP_DEV HDT<T> operator*(HDT<T> x, HDT<T> y) {
+  return HDT<T>{x.v * y.v, x.a * y.v + x.v * y.a, x.b * y.v + x.v * y.b,
             x.ab * y.v + x.a * y.b + x.b * y.a + x.v * y.ab};
 }
-PDDP_DEV HD operator*(float s, HD x) { return HD{s * x.v, s * x.a, s * x.b, s * x.ab}; }
-PDDP_DEV HD operator+(HD x, float s) { return HD{x.v + s, x.a, x.b, x.ab}; }
-PDDP_DEV HD operator-(HD x, float s) { return HD{x.v - s, x.a, x.b, x.ab}; }
-PDDP_DEV HD exp_(HD x) {
-  const float e = expf(x.v);
-  return HD{e, e * x.a, e * x.b, e * (x.ab + x.a * x.b)};
+template <typename T> PDDP_DEV HDT<T> operator*(typename HDT<T>::S s, HDT<T> x) { return HDT<T>{s * x.v, s * x.a, s * x.b, s * x.ab}; }
+template <typename T> PDDP_DEV HDT<T> operator+(HDT<T> x, typename HDT<T>::S s) { return HDT<T>{x.v + s, x.a, x.b, x.ab}; }
+template <typename T> PDDP_DEV HDT<T> operator-(HDT<T> x, typename HDT<T>::S s) { return HDT<T>{x.v - s, x.a, x.b, x.ab}; }
+template <typename T> PDDP_DEV HDT<T> exp_(HDT<T> x) {
+  const T e = qr_exp(x.v);
+  return HDT<T>{e, e * x.a, e * x.b, e * (x.ab + x.a * x.b)};
 }
-PDDP_DEV void sincos_(HD x, HD& s, HD& c) {
-  float sv, cv;
-  sincosf(x.v, &sv, &cv);
-  s = HD{sv, cv * x.a, cv * x.b, cv * x.ab - sv * x.a * x.b};
-  c = HD{cv, -sv * x.a, -sv * x.b, -sv * x.ab - cv * x.a * x.b};
+template <typename T> PDDP_DEV void sincos_(HDT<T> x, HDT<T>& s, HDT<T>& c) {
+  T sv, cv;
+  qr_sincos(x.v, sv, cv);
+  s = HDT<T>{sv, cv * x.a, cv * x.b, cv * x.ab - sv * x.a * x.b};
+  c = HDT<T>{cv, -sv * x.a, -sv * x.b, -sv * x.ab - cv * x.a * x.b};
 }
 
 constexpr int kQrMaxAng = 2, kQrMaxM = 2;
 
 // the jittered upper Cholesky only decides which trace the cost sees
 // (encoding.py:536-564: jitter 1e-12, 1e-11, ... <= 10, else the diagonal)
-template <int NA>
-PDDP_DEV float chol_jitter_of(const float (&C)[NA][NA]) {
+template <typename T, int NA>
+PDDP_DEV T chol_jitter_of(const T (&C)[NA][NA]) {
   double jit = 1e-12;
   while (jit <= 10.0) {
-    float U[NA][NA];
+    T U[NA][NA];
     bool ok = true;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
 #pragma unroll
       for (int j = i; j < NA; ++j) {
-        float s = C[i][j] + (i == j ? (float)jit : 0.f);
+        T s = C[i][j] + (i == j ? (T)jit : 0.f);
 #pragma unroll
         for (int q = 0; q < i; ++q) s -= U[q][i] * U[q][j];
         if (i == j) {
           // (a failed pivot ends the reference's attempt; what follows here
           // is computed on garbage and discarded)
           if (!(s > 0.f)) ok = false;
-          U[i][i] = sqrtf(s);
+          U[i][i] = sqrt_(s);
         } else {
           U[i][j] = s / U[i][i];
         }
       }
     }
-    if (ok) return (float)jit;
+    if (ok) return (T)jit;
     jit *= 10.0;
   }
   return -1.f;
@@ -82,8 +113,10 @@ PDDP_DEV float chol_jitter_of(const float (&C)[NA][NA]) {
 // lives in registers.  (Indexed through the runtime `non` / `ang` lists it
 // lived in scratch memory: 149 GB of HBM traffic and 49 ms per launch for the
 // double cartpole, D = 6; 10 ms for cartpole.)
-template <int D, int NANG>
-__global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
+template <typename T, int D, int NANG>
+__global__ __launch_bounds__(64) void qr_cost_derivs_kernel(QrCostV<T> s) {
+  using HD = HDT<T>;
+  auto hd = [](T v) { return HD{v, 0.f, 0.f, 0.f}; };
   constexpr int n = D + D * (D + 1) / 2;
   constexpr int NN = D - NANG;       // non-angular dimensions
   constexpr int NA = NN + 2 * NANG;  // augmented dimensions
@@ -94,11 +127,11 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
   const bool terminal = (t == N);
   const int d = n + (terminal ? 0 : m);
   const int npairs = d * (d + 1) / 2;
-  const float* z = s.Z + ((size_t)b * (N + 1) + t) * n;
-  const float* Q = terminal ? s.Q_term : s.Q;
-  float u[kQrMaxM];
+  const T* z = s.Z + ((size_t)b * (N + 1) + t) * n;
+  const T* Q = terminal ? s.Q_term : s.Q;
+  T u[kQrMaxM];
   for (int r = 0; r < m; ++r) {
-    float v = terminal ? 0.f : s.U[((size_t)b * N + t) * m + r];
+    T v = terminal ? 0.f : s.U[((size_t)b * N + t) * m + r];
     if (!terminal && s.u_min != nullptr && s.u_max != nullptr)
       v = clamp1(v, s.u_min[r], s.u_max[r]);  // ilqr.py:461-462
     u[r] = v;
@@ -109,7 +142,7 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
   for (int a = 0; a < D; ++a) perm[a] = a < NN ? s.non[a] : s.ang[a - NN];
   // the inputs' values, permuted: mean, and row k of the Cholesky factor at
   // the permuted columns (zero below the diagonal) with its index in z
-  float zmu[D], zU[D][D];
+  T zmu[D], zU[D][D];
   int oU[D][D];
 #pragma unroll
   for (int a = 0; a < D; ++a) {
@@ -124,7 +157,7 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
       zU[k][a] = up ? z[up ? o : 0] : 0.f;
     }
   }
-  float Qr[NA][NA], goal[NA];
+  T Qr[NA][NA], goal[NA];
 #pragma unroll
   for (int r = 0; r < NA; ++r) {
     goal[r] = s.x_goal[r];
@@ -132,13 +165,13 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
     for (int c = 0; c < NA; ++c) Qr[r][c] = Q[r * NA + c];
   }
 
-  float jit = 0.f;
+  T jit = 0.f;
   bool have_jit = false;
   for (int q = lane; q < npairs; q += 64) {
     int i = 0, rem = q;  // pair q -> (i, j), i <= j, row-major upper triangle
     while (rem >= d - i) { rem -= d - i; ++i; }
     const int j = i + rem;
-    auto in = [&](int kx, float v) {
+    auto in = [&](int kx, T v) {
       return HD{v, kx == i ? 1.f : 0.f, kx == j ? 1.f : 0.f, 0.f};
     };
     HD mu[D];
@@ -164,7 +197,7 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
 #pragma unroll
       for (int c = 0; c < a; ++c) C[a][c] = C[c][a];
 
-    float Cav[NA][NA];
+    T Cav[NA][NA];
     HD Ma[NA];
     HD tr = hd(0.f), trd = hd(0.f);  // sum Ca_ij Q_ji; sum Ca_ii Q_ii
     auto put = [&](int r, int c, HD v) {  // every entry is written once
@@ -215,7 +248,7 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
       }
     }
     if (!have_jit) {  // values only: the same for every pair of this step
-      jit = chol_jitter_of<NA>(Cav);
+      jit = chol_jitter_of<T, NA>(Cav);
       have_jit = true;
     }
     HD cost = hd(0.f);
@@ -235,7 +268,7 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
       }
     }
     if (jit >= 0.f) {
-      float trq = 0.f;
+      T trq = 0.f;
 #pragma unroll
       for (int r = 0; r < NA; ++r) trq += Qr[r][r];
       cost = cost + tr + jit * trq;  // tr(Q (Ca + jitter I))
@@ -263,34 +296,43 @@ __global__ __launch_bounds__(64) void qr_cost_derivs_kernel(pddp_qr_cost s) {
   }
 }
 
-template <int D>
-static int launch_qr_cost(const pddp_qr_cost& s, hipStream_t st) {
+template <typename T, int D>
+static int launch_qr_cost(const QrCostV<T>& s, hipStream_t st) {
   const dim3 grid(s.B * (s.N + 1)), block(64);
   switch (s.n_ang) {
-    case 0: PDDP_LAUNCH((qr_cost_derivs_kernel<D, 0>), grid, block, 0, st, s); break;
-    case 1: PDDP_LAUNCH((qr_cost_derivs_kernel<D, 1>), grid, block, 0, st, s); break;
-    case 2: PDDP_LAUNCH((qr_cost_derivs_kernel<D, 2>), grid, block, 0, st, s); break;
+    case 0: PDDP_LAUNCH((qr_cost_derivs_kernel<T, D, 0>), grid, block, 0, st, s); break;
+    case 1: PDDP_LAUNCH((qr_cost_derivs_kernel<T, D, 1>), grid, block, 0, st, s); break;
+    case 2: PDDP_LAUNCH((qr_cost_derivs_kernel<T, D, 2>), grid, block, 0, st, s); break;
     default: return PDDP_E_UNSUPPORTED;
   }
   return launch_status();
 }
 
-}  // namespace pddp
 
-extern "C" int pddp_qr_cost_derivs_f32(const pddp_qr_cost* s, void* stream) {
+template <typename T>
+static int qr_cost_derivs(const QrCostV<T>* s, void* stream) {
   if (s == nullptr) return PDDP_E_BADARG;
   if (s->B <= 0 || s->N <= 0 || !s->Z || !s->U || !s->Q || !s->Q_term ||
       !s->R || !s->x_goal || !s->u_goal || !s->L || !s->L_z || !s->L_u ||
       !s->L_zz || !s->L_uz || !s->L_uu)
     return PDDP_E_BADARG;
-  if (s->m < 1 || s->m > pddp::kQrMaxM || s->n_ang < 0 ||
-      s->n_ang > pddp::kQrMaxAng || s->n_non < 0 || s->n_non + s->n_ang != s->D)
+  if (s->m < 1 || s->m > kQrMaxM || s->n_ang < 0 ||
+      s->n_ang > kQrMaxAng || s->n_non < 0 || s->n_non + s->n_ang != s->D)
     return PDDP_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   switch (s->D) {
-    case 2: return pddp::launch_qr_cost<2>(*s, st);
-    case 4: return pddp::launch_qr_cost<4>(*s, st);
-    case 6: return pddp::launch_qr_cost<6>(*s, st);
+    case 2: return launch_qr_cost<T, 2>(*s, st);
+    case 4: return launch_qr_cost<T, 4>(*s, st);
+    case 6: return launch_qr_cost<T, 6>(*s, st);
   }
   return PDDP_E_UNSUPPORTED;
+}
+
+}  // namespace pddp
+
+extern "C" int pddp_qr_cost_derivs_f32(const pddp_qr_cost* s, void* stream) {
+  return pddp::qr_cost_derivs(reinterpret_cast<const pddp::QrCostV<float>*>(s), stream);
+}
+extern "C" int pddp_qr_cost_derivs_f64(const pddp_qr_cost_f64* s, void* stream) {
+  return pddp::qr_cost_derivs(reinterpret_cast<const pddp::QrCostV<double>*>(s), stream);
 }

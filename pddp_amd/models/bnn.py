@@ -189,7 +189,10 @@ class BayesianMLP(torch.nn.Module):
     _NATIVE_H = (64, 128, 200)
 
     def _native_ok(self, x, resample):
-        if resample or not x.is_cuda or x.dtype != torch.float32:
+        if resample or not x.is_cuda or x.dtype not in (
+                torch.float32, torch.float64):
+            return False
+        if self.hidden[0].weight.dtype != x.dtype:
             return False
         if x.dim() < 2 or len(self.hidden) != 2:
             return False
@@ -212,11 +215,11 @@ class BayesianMLP(torch.nn.Module):
         if drop.noise is None or drop.noise.shape != (P, H):
             drop.noise = drop._draw(like.new_empty(P, H)).detach()
         key = (id(drop.noise), drop.noise._version, drop.logit_p._version,
-               drop.temperature._version)
+               drop.temperature._version, like.dtype)
         cache = self.__dict__.setdefault("_mask_cache", {})
         if cache.get(k, (None, None))[0] != key:
             m = drop._mask(drop.noise).detach()
-            cache[k] = (key, m.contiguous())
+            cache[k] = (key, m.to(like.dtype).contiguous())
         return cache[k][1]
 
     def _forward_native(self, x, out_rows=None, live_rows=None):
@@ -234,13 +237,15 @@ class BayesianMLP(torch.nn.Module):
         m1, m2 = self._mask_t(0, P, xc), self._mask_t(1, P, xc)
         c = lambda t: t.detach().contiguous()
         p = _native.ptr
-        rc = _native.lib().pddp_bnn_mlp_rows_f32(
+        fn = getattr(_native.lib(),
+                     "pddp_bnn_mlp_rows_" + _native.suffix(x.dtype))
+        rc = fn(
             R, P, in_dim, H, out_dim, p(xc), p(c(self.hidden[0].weight)),
             p(c(self.hidden[0].bias)), p(m1), p(c(self.hidden[1].weight)),
             p(c(self.hidden[1].bias)), p(m2), p(c(self.out.weight[:out_dim])),
             p(c(self.out.bias[:out_dim])), p(y), p(live_rows),
             _native.stream_handle(x.device))
-        _native.check(rc, "pddp_bnn_mlp_rows_f32")
+        _native.check(rc, "pddp_bnn_mlp_rows_" + _native.suffix(x.dtype))
         return y
 
     def _jvp_native(self, F, P, out_rows, group=16, live=None, live_rows=None):
@@ -258,7 +263,9 @@ class BayesianMLP(torch.nn.Module):
         c = lambda t: t.detach().contiguous()
         p = _native.ptr
         # (`live_rows`: an int32 device scalar - only that many leading rows)
-        rc = _native.lib().pddp_bnn_mlp_jvp_rows_f32(
+        fn = getattr(_native.lib(),
+                     "pddp_bnn_mlp_jvp_rows_" + _native.suffix(F.dtype))
+        rc = fn(
             R, P, int(group), int(group if live is None else live), in_dim, H,
             out_rows, p(F),
             p(c(self.hidden[0].weight)),
@@ -266,7 +273,7 @@ class BayesianMLP(torch.nn.Module):
             p(c(self.hidden[1].bias)), p(m2), p(c(self.out.weight[:out_rows])),
             p(c(self.out.bias[:out_rows])), p(Y), p(live_rows),
             _native.stream_handle(F.device))
-        _native.check(rc, "pddp_bnn_mlp_jvp_rows_f32")
+        _native.check(rc, "pddp_bnn_mlp_jvp_rows_" + _native.suffix(F.dtype))
         return Y
 
     def forward(self, x, resample=False):

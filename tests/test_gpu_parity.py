@@ -2757,7 +2757,7 @@ def test_boxqp_many_dimensions_on_the_gpu():
     assert torch.equal(f4.cpu(), ft.cpu())
 
 
-def _bnn_real_size_run():
+def _bnn_real_size_run(dtype=torch.float32, raw=None):
     """Runs the HIP BNN path (native nominal rollout, forward-mode Jacobians,
     hyper-dual cost derivatives, moment-step line search around the fused
     network kernel) on the inputs of tests/golden/bnn_cartpole_real_size.npz and
@@ -2778,17 +2778,18 @@ def _bnn_real_size_run():
             n_particles=P).float().eval()
     load_reference_state(model, {k[len("state/"):]: g[k] for k in g.files
                                  if k.startswith("state/")})
-    model = model.cuda()
-    model.eps_in = {k: v.cuda() for k, v in model.eps_in.items()}
+    # (float64: the same weights and noise cast up, as the fixture's f64 run)
+    model = model.to(dtype).cuda()
+    model.eps_in = {k: v.to(dtype).cuda() for k, v in model.eps_in.items()}
     for d in model.model.drops:
-        d.noise = d.noise.cuda()
-    cost = cartpole.CartpoleCost().cuda()
+        d.noise = d.noise.to(dtype).cuda()
+    cost = cartpole.CartpoleCost().to(dtype).cuda()
     enc = pddp_amd.StateEncoding.DEFAULT
     opts = {"use_predicted_std": False, "infer_noise_variables": True}
     plugin = TorchProblem(model, cost, enc, opts, {})
     R = g["z0"].shape[0]
-    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().cuda()
-    s = ILQRSolver(None, R, N, torch.float32, "cuda", cu(g["u_min"]),
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dtype).cuda()
+    s = ILQRSolver(None, R, N, dtype, "cuda", cu(g["u_min"]),
                    cu(g["u_max"]), cu(g["alphas"]), plugin=plugin, n=14, m=1)
     s.set_nominal(cu(g["z0"]), cu(g["U"]))  # native nominal rollout
     s.derivs()
@@ -2810,6 +2811,7 @@ def _bnn_real_size_run():
             np.abs(g["f64/%d/fwd/L_uz" % r]).max())
     # the line search on the reference's own gains
     for r in range(R):
+        # (the fixture feeds the float32 run's gains and nominal to both dtypes)
         s.gains[r, :, :1] = cu(g["f32/%d/k" % r])
         s.gains[r, :, 1:] = cu(g["f32/%d/K" % r]).reshape(N, 14)
         s.Z[r] = cu(g["f32/%d/fwd/Z" % r])
@@ -2817,6 +2819,8 @@ def _bnn_real_size_run():
     Zc = s.Zc.permute(0, 1, 2, 3).cpu().numpy()  # [R][N+1][A][n]
     Uc = s.Uc.cpu().numpy()
     Jc = s.Jc.cpu().numpy()
+    if raw is not None:  # (tools/dbg: the arrays themselves)
+        raw.update(Zc=Zc, Uc=Uc, Jc=Jc, g=g)
     for r in range(R):
         add("Z_new", r, Zc[r], "ls/Z_new")
         add("U_new", r, Uc[r], "ls/U_new")

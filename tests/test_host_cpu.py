@@ -363,9 +363,18 @@ def test_hot_kernels_keep_their_working_set_in_registers():
     assert len(rows) > 200
     allowed = (
         "accept_kernel<",                       # 36 B, one launch per round of the un-fused path
-        "bnn_jvp_features_kernel<6, false>",    # runtime-D fall-backs (D not 2 / 4 / 6)
-        "bnn_jvp_moments_kernel<16, 4, false>",
-        "bnn_jvp_moments_kernel<32, 6, false>",
+        # runtime-D fall-backs (D not 2 / 4 / 6), float and double
+        "bnn_jvp_features_kernel<float, 6, false>",
+        "bnn_jvp_features_kernel<double, 4, false>",
+        "bnn_jvp_features_kernel<double, 6, false>",
+        "bnn_jvp_moments_kernel<float, 16, 4, false>",
+        "bnn_jvp_moments_kernel<float, 32, 6, false>",
+        "bnn_jvp_moments_kernel<double, 16, 4, false>",
+        "bnn_jvp_moments_kernel<double, 32, 6, false>",
+        # the double cartpole's cost in hyper-dual DOUBLES (27 + 1 inputs, two
+        # angles): 96 registers spill at the 512-register file; one launch per
+        # round of a float64 BNN run
+        "qr_cost_derivs_kernel<double, 6, 2>",
         "derivs_default_kernel<double, 2, 1>",  # double cartpole, hyper-dual on 27 inputs
         "derivs_default_kernel<float, 2, 1>",
         # rendezvous, Cholesky encoding, fp64: the 36-entry re-factorisation in
@@ -409,7 +418,10 @@ def test_hot_kernels_keep_their_working_set_in_registers():
            "riccati_n4_elem_kernel<25u, true>", "riccati_n4_elem_kernel<25u, false>",
            "riccati_n4_defer_kernel<float",
            "bnn_mlp_kernel<200", "riccati_mfma16_kernel<", "riccati_mfma32_kernel<",
-           "bnn_moment_step_kernel<4>", "bnn_moment_step_kernel<6>",
-           "bnn_jvp_moments_kernel<16, 4, true>", "qr_cost_derivs_kernel<")
+           "bnn_mlp_f64_kernel<200", "bnn_moment_step_kernel<float, 4>",
+           "bnn_moment_step_kernel<float, 6>", "bnn_moment_step_kernel<double, 4>",
+           "bnn_jvp_moments_kernel<float, 16, 4, true>",
+           "bnn_jvp_moments_kernel<double, 16, 4, true>",
+           "qr_cost_derivs_kernel<float", "qr_cost_derivs_kernel<double, 4, 1>")
     for h in hot:
         assert any(h in r["kernel"] for r in rows), h
