@@ -2021,6 +2021,7 @@ def test_bnn_mlp_kernel_vs_torch(rows, P, in_dim, out_dim, H):
         net.use_native = False
         y32 = net(x)                     # library GEMMs, same masks
         net64 = BayesianMLP(in_dim, out_dim, [H, H]).cuda().double().eval()
+        net64.use_native = False         # the checker is torch's float64 ops
         net64.load_state_dict({k: v.double() for k, v in net.state_dict().items()})
         for d64, d in zip(net64.drops, net.drops):
             d64.noise = d.noise.double()
@@ -2057,6 +2058,7 @@ def test_bnn_mlp_bf16_split_twin_vs_torch(rows, P, in_dim, out_dim):
             net.use_native = False
             y32 = net(x)                     # library GEMMs, same masks
             net64 = BayesianMLP(in_dim, out_dim, [H, H]).cuda().double().eval()
+            net64.use_native = False     # the checker is torch's float64 ops
             net64.load_state_dict({k: v.double()
                                    for k, v in net.state_dict().items()})
             for d64, d in zip(net64.drops, net.drops):
@@ -3348,6 +3350,8 @@ def _bnn_problem(problem, B, N, seed=0):
 
     def solver(model_, cost_, rows, dtype):
         plugin = TorchProblem(model_, cost_, enc, opts, {})
+        if dtype == torch.float64:  # the float64 twin is the torch checker
+            plugin.use_native_cost = False
         return ILQRSolver(None, rows, N, dtype, "cuda", torch.tensor([-bound]),
                           torch.tensor([bound]), fit_alphas(dtype, "cuda"),
                           plugin=plugin, n=n, m=m)
@@ -3360,6 +3364,7 @@ def _float64_twin(model, cost):
     goldens at 1e-9: test_bnn.py, test_bnn_ilqr_fit_vs_reference_golden)."""
     import copy
     m64 = copy.deepcopy(model).double()
+    m64.model.use_native = False  # (float64 has HIP kernels too: tests/test_bnn_f64.py)
     m64.eps_in = {k: v.double() for k, v in model.eps_in.items()}
     m64.output = {}
     return m64, copy.deepcopy(cost).double()
