@@ -249,6 +249,7 @@ def cpu_baseline(problem_name, dt, N, bound, seconds=12.0):
                       % (trajs, attempts, el, workers, os.cpu_count())}
 
 
+MFMA_F64_PEAK_TFLOPS = 78.6  # dense f64 matrix rate (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.0  # MI355X_MICROARCH.md: dense f32 matrix peak
 _last_gp_solver = None
 
@@ -372,6 +373,11 @@ def bench_bnn(args, emit=True):
     world, rank, dev = init_ranks()
     seen = ranks_seen(world, dev)
     torch.manual_seed(0)  # the same network on every rank
+    # --dtype f64: the same rounds on the float64 kernels (csrc/bnn_mlp_f64.hip
+    # on v_mfma_f64_16x16x4; the reference runs in the dtype of its inputs)
+    f64 = args.dtype == "f64"
+    dt = torch.float64 if f64 else torch.float32
+    peak = MFMA_F64_PEAK_TFLOPS if f64 else MFMA_F32_PEAK_TFLOPS
     if args.workload == "cartpole_bnn":
         from pddp_amd.examples import cartpole as ex
         CM, cost_cls = ex.CartpoleDynamicsModel, ex.CartpoleCost
@@ -396,23 +402,23 @@ def bench_bnn(args, emit=True):
     W = args.warmup if args.warmup != 5 else 1
     model = bnn_dynamics_model_factory(D, m, [H, H], CM.angular_indices,
                                        CM.non_angular_indices)(
-        n_particles=P).to(dev).eval()
+        n_particles=P).to(dev).to(dt).eval()
     with torch.no_grad():  # untrained weights: keep the dynamics gentle
         model.model.out.weight.mul_(0.05)
         model.model.out.bias.mul_(0.05)
-    cost = cost_cls().to(dev)
+    cost = cost_cls().to(dev).to(dt)
     enc = pddp_amd.StateEncoding.DEFAULT
     plugin = TorchProblem(model, cost, enc, {"use_predicted_std": False,
                                              "infer_noise_variables": True}, {})
-    s = ILQRSolver(None, B, N, torch.float32, dev, torch.tensor([-bound]),
-                   torch.tensor([bound]), fit_alphas(torch.float32, dev),
+    s = ILQRSolver(None, B, N, dt, dev, torch.tensor([-bound], dtype=dt),
+                   torch.tensor([bound], dtype=dt), fit_alphas(dt, dev),
                    plugin=plugin, n=n, m=m)
     g = torch.Generator().manual_seed(rank)
     mean = torch.tensor(mean0)
     z0 = torch.stack([pddp_amd.GaussianVariable(
         mean + 1e-2 * torch.randn(D, generator=g),
-        var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).to(dev)
-    U0 = (0.1 * torch.randn(B, N, m, generator=g)).to(dev)
+        var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).to(dev).to(dt)
+    U0 = (0.1 * torch.randn(B, N, m, generator=g)).to(dev).to(dt)
     s.set_nominal(z0, U0)
     n_iter = 1 << 30
     for _ in range(W):
@@ -449,7 +455,7 @@ def bench_bnn(args, emit=True):
     # is launched on): one forward-mode network pass of a time step
     grp = 8  # rows per (state, particle) in memory
     live = 1 + D + m  # of which in use: the input and the D + m directions
-    F = torch.randn(B * P * grp, in_dim, device=dev)
+    F = torch.randn(B * P * grp, in_dim, device=dev, dtype=dt)
     model.model._jvp_native(F, P, D, grp, live=live)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 5
@@ -467,7 +473,7 @@ def bench_bnn(args, emit=True):
         "unit": "trajectory-iterations/s", "n_gpus": world, "steps": K,
         "warmup": W, "ms_per_step": elapsed / K * 1e3,
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic", "rccl_ranks_seen": seen,
+        "dtype": args.dtype, "data": "synthetic", "rccl_ranks_seen": seen,
         "config": {
             "workload": "BASELINE.json %s with BNN dynamics ([200,200] hidden, "
                         "%d particles, moment-matched rollouts, DEFAULT "
@@ -483,17 +489,20 @@ def bench_bnn(args, emit=True):
         },
         "roofline": {
             "bound": "mfma",
-            "kernel": "fused BNN network, forward-mode (bnn_mlp_kernel<%d, %d, %d, "
+            "kernel": ("fused BNN network, forward-mode (bnn_mlp_f64_kernel<%d, "
+                       "%d>: %d live rows per (state, particle); "
+                       "v_mfma_f64_16x16x4_f64)" % (H, grp, live)) if f64 else
+                      "fused BNN network, forward-mode (bnn_mlp_kernel<%d, %d, %d, "
                       "%d>: %d live rows per (state, particle))"
                       % (H, 8 if in_dim < 8 else 16, grp,
                          4 if live <= 4 else (6 if live <= 6 else 8), live),
-            "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
+            "achieved": flop / dur * 1e-12, "peak": peak,
+            "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / peak,
             "avg_launch_us": dur * 1e6,
             "algorithmic_flop_per_launch": flop,
             # (the network kernel is matrix-bound; its HBM traffic is reported
             # for completeness where a profiled run of this workload exists)
-            "traffic": profile_traffic(
+            "traffic": None if f64 else profile_traffic(
                 "bnn_mlp_kernel<%d, %d, %d, %d" % (
                     H, 8 if in_dim < 8 else 16, grp,
                     4 if live <= 4 else (6 if live <= 6 else 8)),
@@ -501,6 +510,10 @@ def bench_bnn(args, emit=True):
         },
         "cpu_baseline": None,
     }
+    if world == 1 and f64:
+        if rank == 0 and emit:
+            print(json.dumps(out))
+        return out
     if world == 1:
         from pddp_amd import _native
         out["roofline"]["other_kernels"] = [

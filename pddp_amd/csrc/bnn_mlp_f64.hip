@@ -8,20 +8,29 @@
 //
 // Weights-stationary, one workgroup of FOUR wavefronts per CU - one per SIMD,
 // so that each may hold 512 registers: wavefront w owns the 16-unit blocks w,
-// w + 4, w + 8, (w + 12) of both hidden layers and keeps ITS rows of W2 in
-// registers for the whole kernel (H = 200: 13 blocks, 4 / 3 / 3 / 3; 416
-// registers on the first wavefront).  Tiles of 16 rows:
-//   1  layer 1 of the own blocks: 4 matrix instructions per block (K = 16:
-//      inputs | zeros | bias slot; the A operand W1 | b1 from LDS), mask and
-//      ReLU on the accumulators, to LDS in the order layer 2 reads them;
-//      barrier
-//   2  layer 2 of the own blocks: 4 NB instructions per block, the B operand
-//      (one 32-byte LDS read per four instructions) shared by the wavefront's
-//      blocks; mask and ReLU on the accumulators - which, with the k-slots
-//      dealt as below, ARE the B operand of layer 3 for the block's 16 units:
-//      4 more instructions per block leave this wavefront's partial outputs;
-//      they go to LDS; barrier
-//   3  sum of the four partial outputs (fixed order), + b3, rows stored.
+// w + 4, w + 8 of both hidden layers and keeps ITS rows of W2 in registers for
+// the whole kernel (H = 200: 300 registers).  H = 200 is 12 such blocks and a
+// thirteenth with eight real units: that one is SHARED - its rows of W2 sit in
+// LDS and wavefront w takes the k-steps S = w, w + 4, .. of its contraction
+// (190 matrix instructions per SIMD and tile instead of 232 / 174 / 174 / 174
+// with the block owned by one wavefront).  Tiles of 16 rows, two barriers:
+//   1  layer 1 of the own blocks (wavefront 3: also the shared block's): 4
+//      matrix instructions per block (K = 16: inputs | zeros | bias slot; the
+//      A operand W1 | b1 from LDS), mask and ReLU on the accumulators, to LDS
+//      in the order layer 2 reads them; barrier
+//   2  layer 2 of the own blocks: 50 instructions per block, the B operand
+//      (one 32-byte LDS read per four instructions, requested a k-step ahead)
+//      shared by the wavefront's blocks; mask and ReLU on the accumulators -
+//      which, with the k-slots dealt as below, ARE the B operand of layer 3
+//      for the block's 16 units: 4 more instructions per block leave this
+//      wavefront's partial outputs; they and its partial sums of the shared
+//      block go to LDS; barrier
+//   3  the finisher, wavefront 0, while the others are in layer 1 of the next
+//      tile: the shared block's sum, mask, ReLU and layer 3, the sum of the
+//      partial outputs (fixed order), + b3, rows stored.
+// Inputs and layer-1 masks are requested a tile ahead, the layer-2 masks ahead
+// of the matrix instructions that cover them; W2 is loaded with nothing
+// between the load and the matrix instruction (see w2_of).
 // k-slots: instruction s of a group of four takes k = 16 S + kk + 4 s in slot
 // kk (kk = lane >> 4).  The f64 C/D layout holds row g + 4 r in register r of
 // lane group g (riccati_mfma16.hpp), so register q of lane (row j, g) of a
@@ -29,6 +38,10 @@
 // s = q, slot kk = g: the hidden activations of layer 2 never leave the
 // registers, and layer 1's go to LDS at position 4 g + q of their block - one
 // 32-byte write, and one 32-byte read per (S, lane) in layer 2.
+// Measured (MI355X, 4.1 M rows, H = 200): 8.6 ms = 40.8 TFLOP/s = 0.52 of the
+// f64 matrix peak (78.6; tools/probe/mfma_f64_rate_probe.hip reaches 69 - 73.5
+// with nothing but matrix instructions), 2.9x the library GEMMs; the matrix
+// pipe is busy 58 % of a wavefront's cycles (profiles/r04_mlp64_pmc.txt).
 //
 // JVP mode (the derivative rollout; see bnn_mlp.hip): rows in groups of 8 or
 // 16 = one input row and its tangent rows; tangents pass without biases and
@@ -74,7 +87,9 @@ struct Mlp64Shape {
       (size_t)kMlp64Tile * KP            // h1
       + (size_t)16 * NB * kMlp64W1Stride  // W1 | b1
       + (size_t)16 * KP                  // W3
-      + (size_t)4 * 64 * 4;              // partial outputs
+      + (size_t)8 * 64 * 4               // partial outputs | the shared block's partial sums
+      + (size_t)16 * KP                  // the shared block's rows of W2
+      + (size_t)16 * NB + 16;            // b2 (operand order), b3
 };
 
 PDDP_DEV f64x4 lds_read4(const double* p) {  // 16-byte aligned
@@ -96,9 +111,14 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
   static_assert(G == 0 || G == 8 || G == 16, "");
   extern __shared__ __attribute__((aligned(16))) double lds64[];
   double* h1 = lds64;                              // [16][KP]
-  double* w1s = h1 + kMlp64Tile * KP;              // [16 NB][18]
+  constexpr int kH1 = kMlp64Tile * KP;
+  double* w1s = h1 + kH1;                          // [16 NB][18]
   double* w3s = w1s + 16 * NB * kMlp64W1Stride;    // [16][KP]
-  double* part = w3s + 16 * KP;                    // [4][64][4]
+  double* part = w3s + 16 * KP;                    // [4 + 4][64][4]
+  constexpr int kPart = 8 * 64 * 4;
+  double* w2c = part + kPart;                      // [16][KP]: W2 rows of the last block
+  double* b2s = w2c + 16 * KP;                     // [16 NB] at position 4 g + q of its block
+  double* b3s = b2s + 16 * NB;                     // [16]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -135,6 +155,22 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
     w3s[o * KP + 16 * S + pos] = (o < OUT && k < H) ? a.W3[(size_t)o * H + k] : 0.0;
   }
 
+  for (int idx = tid; idx < 16 * 16 * NB; idx += kMlp64Threads) {
+    // the last block's rows of W2 as the A operand reads them: unit 16 (NB -
+    // 1) + i, k = 16 S + kk + 4 s at position 16 S + 4 kk + s
+    const int i = idx / (16 * NB), r = idx - i * (16 * NB);
+    const int S = r >> 4, pos = r & 15;
+    const int k = 16 * S + (pos >> 2) + 4 * (pos & 3);
+    const int u = 16 * (NB - 1) + i;
+    w2c[i * KP + 16 * S + pos] = (u < H && k < H) ? a.W2[(size_t)u * H + k] : 0.0;
+  }
+  for (int idx = tid; idx < 16 * NB; idx += kMlp64Threads) {
+    const int ub = idx >> 4, pos = idx & 15;
+    const int n = 16 * ub + (pos >> 2) + 4 * (pos & 3);  // unit g + 4 q at 4 g + q
+    b2s[idx] = n < H ? a.b2[n] : 0.0;
+  }
+  if (tid < 16) b3s[tid] = tid < OUT ? a.b3[tid] : 0.0;
+
   // rows of a tile as this lane sees them (lane j = tile row j)
   const int kin = G != 0 ? j % (G != 0 ? G : 1) : 0;  // row within its group
   const bool tangent = G != 0 && kin != 0;
@@ -142,7 +178,15 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
   // first lane of this lane's group within the 64-bit lane mask
   const int first_lane = G != 0 ? ((lane & 0x30) | (j - kin)) : lane;
 
-  const int nown = (NB - wave + 3) / 4;  // blocks of this wavefront (wave-uniform)
+  // COOP (H = 200: 13 blocks): the last block is dealt out by k - wavefront w
+  // takes the k-steps S = w, w + 4, .. of its contraction - instead of making
+  // one wavefront's fourth block: 190 matrix instructions per SIMD and tile,
+  // not 232 / 174 / 174 / 174.  The four partial accumulators meet in LDS and
+  // the finisher (wavefront 0, below) completes the block.
+  constexpr bool COOP = (NB % 4) == 1 && NB > 4;
+  constexpr int CB = NB - 1;                 // the shared block
+  constexpr int NOWN_MAX = COOP ? (NB - 1) / 4 : NBW;
+  const int nown = COOP ? NOWN_MAX : (NB - wave + 3) / 4;  // (wave-uniform)
 
   auto run = [&](auto NOWN_) {
     constexpr int NOWN = decltype(NOWN_)::value;
@@ -150,28 +194,37 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
       // ---- this wavefront's rows of W2: lane (i = j, kk = g) holds
       // W2[16 ub + i][16 S + kk + 4 s]
       double a2[NOWN][NB][4];
-      f64x4 binit[NOWN];
+
+      // Straight from memory, nothing in between: a value that a vector
+      // instruction touches (a select for padding) must live in an ordinary
+      // register, and of those there are 256 - the compiler then parks the
+      // weights in accumulation registers and copies each one back before its
+      // matrix instruction (two v_accvgpr_read per instruction, which on this
+      // chip take matrix time: 110 cycles per instruction instead of 64).  A
+      // loaded value that only matrix instructions read is allocated to an
+      // accumulation register directly.  No padding is needed: a block owned
+      // whole has 16 real units (a partial last block is the shared one, from
+      // LDS), and H % 4 == 0 keeps every k of a kept k-step below H.
+      static_assert(H % 16 == 0 || COOP, "a partial last block must be the shared one");
+      auto w2_of = [&](int ub, int S, int s) {
+        return a.W2[(size_t)(16 * ub + j) * H + 16 * S + g + 4 * s];
+      };
+      // b2 of a block's units as the accumulator holds them (zero on a
+      // tangent row: a property of the lane)
+      auto bias2_of = [&](int ub) {
+        const f64x4 v = lds_read4(b2s + 16 * ub + 4 * g);
+        return tangent ? f64x4{0.0, 0.0, 0.0, 0.0} : v;
+      };
 #pragma unroll
       for (int i = 0; i < NOWN; ++i) {
         const int ub = wave + 4 * i;
-        const int u = 16 * ub + j;
-        const bool uok = u < H;
-        const double* w2row = a.W2 + (size_t)(uok ? u : 0) * H;
 #pragma unroll
         for (int S = 0; S < NB; ++S)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             if (16 * S + 4 * s >= H) continue;  // (no lane has a k < H there)
-            const int k = 16 * S + g + 4 * s;
-            const double v = w2row[k < H ? k : 0];
-            a2[i][S][s] = (uok && k < H) ? v : 0.0;
+            a2[i][S][s] = w2_of(ub, S, s);
           }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = 16 * ub + g + 4 * q;
-          const double bb = a.b2[n < H ? n : 0];
-          binit[i][q] = (n < H && !tangent) ? bb : 0.0;
-        }
       }
       // mask, ReLU (or its linearisation at the group's first row)
       auto epilogue = [&](const f64x4& pre, const double (&m)[4]) {
@@ -195,43 +248,81 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
           m[q] = M[(size_t)p * H + (n < H ? n : 0)];
         }
       };
-      __syncthreads();  // W1, W3 staged
-
-      for (int it = 0; it < my; ++it) {
-        const int tile = blockIdx.x + it * gridDim.x;
-        const int mrow = tile * kMlp64Tile + j;
-        const bool live = mrow < R && in_use;
-        const int group = G != 0 ? mrow / (G != 0 ? G : 1) : mrow;
-        const int p = live ? group % P : 0;
-        // ---- layer 1
-        double xb[4];
+      // what a tile's rows are to this lane; the inputs and the layer-1 masks
+      // of a tile are requested a tile ahead
+      struct Row { int mrow, p, live; };  // (no padding: a copy stays in registers)
+      auto row_of = [&](int it) {
+        Row r;
+        r.mrow = (blockIdx.x + it * gridDim.x) * kMlp64Tile + j;
+        r.live = r.mrow < R && in_use;
+        const int group = G != 0 ? r.mrow / (G != 0 ? G : 1) : r.mrow;
+        r.p = r.live ? group % P : 0;
+        return r;
+      };
+      double xb[4], m1[NOWN][4], m1c[4];
+      auto request_inputs = [&](const Row& r) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int c = g + 4 * s;
-          const double v = a.X[(size_t)(live ? mrow : 0) * IN + (c < IN ? c : 0)];
-          xb[s] = c < IN ? (live ? v : 0.0)
+          const double v = a.X[(size_t)(r.live ? r.mrow : 0) * IN + (c < IN ? c : 0)];
+          xb[s] = c < IN ? (r.live ? v : 0.0)
                          : (c == 15 ? (tangent ? 0.0 : 1.0) : 0.0);
         }
 #pragma unroll
-        for (int i = 0; i < NOWN; ++i) {
-          const int ub = wave + 4 * i;
-          double m1[4];
-          masks_of(a.MT1, p, ub, m1);
-          const f64x4 wa = lds_read4(w1s + (16 * ub + j) * kMlp64W1Stride + 4 * g);
-          f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < NOWN; ++i) masks_of(a.MT1, r.p, wave + 4 * i, m1[i]);
+        if (COOP && wave == 3) masks_of(a.MT1, r.p, CB, m1c);
+      };
+      auto layer1_of = [&](double* dst, int ub, const double (&m)[4]) {
+        const f64x4 wa = lds_read4(w1s + (16 * ub + j) * kMlp64W1Stride + 4 * g);
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int s = 0; s < 4; ++s)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], xb[s], acc, 0, 0, 0);
-          lds_write4(h1 + j * KP + 16 * ub + 4 * g, epilogue(acc, m1));
-        }
-        __syncthreads();  // h1 complete
+        for (int s = 0; s < 4; ++s)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], xb[s], acc, 0, 0, 0);
+        lds_write4(dst + j * KP + 16 * ub + 4 * g, epilogue(acc, m));
+      };
+      auto layer1 = [&](int it) {  // of tile `it`, from xb / m1 (requested)
+        double* dst = h1;
+        (void)it;
+#pragma unroll
+        for (int i = 0; i < NOWN; ++i) layer1_of(dst, wave + 4 * i, m1[i]);
+        if (COOP && wave == 3) layer1_of(dst, CB, m1c);
+      };
+      // Two barriers per tile: layer 1 | barrier | layer 2, 3 | barrier | the
+      // finisher (wavefront 0) beside the others' layer 1 of the next tile.
+      // Inputs and layer-1 masks are requested a tile ahead, the layer-2 masks
+      // ahead of the matrix instructions that cover their latency.
+      Row row = row_of(0);     // tile `it`
+      request_inputs(row);
+      __syncthreads();         // W1, W3 staged
+      Row nxt = row;
+
+      for (int it = 0; it < my; ++it) {
+        layer1(it);
+        __syncthreads();
+        const double* h1r = h1;
+        double* partw = part;
+        // this tile's layer-2 masks: requested now, used after the matrix
+        // instructions
+        double m2[NOWN][4], m2c[4];
+#pragma unroll
+        for (int i = 0; i < NOWN; ++i) masks_of(a.MT2, row.p, wave + 4 * i, m2[i]);
+        if (COOP && wave == 0) masks_of(a.MT2, row.p, CB, m2c);
         // ---- layer 2
         f64x4 acc[NOWN];
+        f64x4 accc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < NOWN; ++i) acc[i] = binit[i];
+        for (int i = 0; i < NOWN; ++i) acc[i] = bias2_of(wave + 4 * i);
+        // (the B operand of k-step S + 1 and the shared block's A operand are
+        // requested before the matrix instructions of k-step S: issued where
+        // they are used, every k-step waited out an LDS round trip - the
+        // wavefront issues in order and has no other to hide behind)
+        f64x4 b = lds_read4(h1r + j * KP + 4 * g);
 #pragma unroll
         for (int S = 0; S < NB; ++S) {
-          const f64x4 b = lds_read4(h1 + j * KP + 16 * S + 4 * g);
+          f64x4 bn = b, wc = b;
+          if (S + 1 < NB) bn = lds_read4(h1r + j * KP + 16 * (S + 1) + 4 * g);
+          const bool mine = COOP && (S & 3) == wave;  // (wave-uniform)
+          if (mine) wc = lds_read4(w2c + j * KP + 16 * S + 4 * g);
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             if (16 * S + 4 * s >= H) continue;  // H = 200: 50 k-steps, not 52
@@ -240,46 +331,73 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
               acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i][S][s], b[s],
                                                             acc[i], 0, 0, 0);
           }
+          if (mine) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              if (16 * S + 4 * s >= H) continue;
+              accc = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s], b[s], accc, 0, 0, 0);
+            }
+          }
+          b = bn;
         }
         // ---- layer 3 of the own blocks' units
         f64x4 o = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < NOWN; ++i) {
           const int ub = wave + 4 * i;
-          double m2[4];
-          masks_of(a.MT2, p, ub, m2);
-          const f64x4 h2 = epilogue(acc[i], m2);
+          const f64x4 h2 = epilogue(acc[i], m2[i]);
           const f64x4 w3a = lds_read4(w3s + j * KP + 16 * ub + 4 * g);
 #pragma unroll
           for (int s = 0; s < 4; ++s)
             o = __builtin_amdgcn_mfma_f64_16x16x4f64(w3a[s], h2[s], o, 0, 0, 0);
         }
-        lds_write4(part + (wave * 64 + lane) * 4, o);
-        __syncthreads();  // partial outputs complete (and h1 free)
-        // ---- sum, bias, store: thread (row = tid & 15, output = tid >> 4);
-        // output oo of row r is register oo >> 2 of lane (r, oo & 3)
-        {
-          const int row = tid & 15, oo = tid >> 4;
-          const int src = (((oo & 3) << 4) | row) * 4 + (oo >> 2);
-          double y = part[src];
-          y += part[64 * 4 + src];
-          y += part[2 * 64 * 4 + src];
-          y += part[3 * 64 * 4 + src];
-          const int mr = tile * kMlp64Tile + row;
-          const int kr = G != 0 ? row % (G != 0 ? G : 1) : 0;
-          const bool lv = mr < R && (G == 0 || kr < a.live);
-          if (oo < OUT && lv) {
-            if (kr == 0) y += a.b3[oo];  // tangents: no bias
-            a.Y[(size_t)mr * OUT + oo] = y;
+        lds_write4(partw + (wave * 64 + lane) * 4, o);
+        if constexpr (COOP) lds_write4(partw + ((4 + wave) * 64 + lane) * 4, accc);
+        // ---- layer 1 of the next tile, requests for the one after
+        const Row cur = row;
+        if (it + 1 < my) {
+          nxt = row_of(it + 1);
+          row = nxt;
+          request_inputs(nxt);
+        }
+        __syncthreads();  // partial sums of tile it, h1 of tile it + 1
+        // ---- the finisher (wavefront 0): the shared block's sum, its mask,
+        // ReLU and layer 3; the sum of the partial outputs in a fixed order,
+        // + b3; rows stored from the accumulator layout - output g + 4 q of
+        // row j
+        if (wave == 0) {
+          f64x4 y = lds_read4(partw + lane * 4);
+#pragma unroll
+          for (int w = 1; w < 4; ++w) y += lds_read4(partw + (w * 64 + lane) * 4);
+          if constexpr (COOP) {
+            f64x4 pre = bias2_of(CB);
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+              pre += lds_read4(partw + ((4 + w) * 64 + lane) * 4);
+            const f64x4 h2 = epilogue(pre, m2c);
+            const f64x4 w3a = lds_read4(w3s + j * KP + 16 * CB + 4 * g);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              if (16 * CB + 4 * s >= H) continue;
+              y = __builtin_amdgcn_mfma_f64_16x16x4f64(w3a[s], h2[s], y, 0, 0, 0);
+            }
+          }
+          if (cur.live) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int oo = g + 4 * q;
+              if (oo < OUT)
+                a.Y[(size_t)cur.mrow * OUT + oo] = y[q] + (tangent ? 0.0 : b3s[oo]);
+            }
           }
         }
       }
     }
   };
-  if (nown == NBW) {
-    run(std::integral_constant<int, NBW>());
+  if (nown == NOWN_MAX) {
+    run(std::integral_constant<int, NOWN_MAX>());
   } else {
-    run(std::integral_constant<int, NBW - 1>());
+    run(std::integral_constant<int, NOWN_MAX - 1>());
   }
 }
 
