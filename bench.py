@@ -1352,12 +1352,14 @@ def main():
             del s
             torch.cuda.empty_cache()
             sec = []
-            for wl, k, w in (("cartpole_bnn", 5, 1),
-                             ("double_cartpole_bnn", 5, 1),
-                             ("double_cartpole_gp", 5, 1),
-                             ("mpc_bnn", 200, 2)):
+            # (configs[2] a second time on the float64 kernels: three rounds)
+            for wl, k, w, dt_ in (("cartpole_bnn", 5, 1, "f32"),
+                                  ("cartpole_bnn", 3, 1, "f64"),
+                                  ("double_cartpole_bnn", 5, 1, "f32"),
+                                  ("double_cartpole_gp", 5, 1, "f32"),
+                                  ("mpc_bnn", 200, 2, "f32")):
                 a2 = copy.copy(args)
-                a2.workload, a2.steps, a2.warmup = wl, k, w
+                a2.workload, a2.steps, a2.warmup, a2.dtype = wl, k, w, dt_
                 a2.batch = a2.horizon = None
                 try:
                     fn = {"mpc_bnn": bench_mpc_bnn,
