@@ -57,6 +57,19 @@ namespace pddp {
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
+// Debug build (-DPDDP_MLP64_MARKS, tools/mlp64_marks.py): the four wavefronts
+// of workgroup 0 leave s_memtime at the phase boundaries of their sixth tile
+#ifdef PDDP_MLP64_MARKS
+__device__ long long g_mlp64_marks[4 * 8];
+#define PDDP_MLP64_MARK(k)                                                   \
+  do {                                                                        \
+    if (blockIdx.x == 0 && it == 5 && lane == 0)                              \
+      g_mlp64_marks[wave * 8 + (k)] = __builtin_readcyclecounter();          \
+  } while (0)
+#else
+#define PDDP_MLP64_MARK(k) do { } while (0)
+#endif
+
 struct BnnMlpArgs64 {
   int R, P, in_dim, H, out_dim, live;
   const double* X;
@@ -136,39 +149,33 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
                      : 0;
   if (my == 0) return;
 
-  // position of k-slot (kk, s) inside its 16-block: k = kk + 4 s sits at 4 kk + s
-  // ---- W1 | b1 and W3 to LDS, in operand order
+  // ---- W1 | b1 and W3 to LDS as the A operand reads them: row i of a
+  // 16-row panel is unit (output) rowperm(i) of its block
+  auto rowperm = [](int i) { return 4 * (i & 3) + (i >> 2); };
   for (int idx = tid; idx < 16 * NB * 16; idx += kMlp64Threads) {
-    const int u = idx >> 4, pos = idx & 15;
-    const int c = (pos >> 2) + 4 * (pos & 3);  // input slot at position pos
+    const int r = idx >> 4, c = idx & 15;  // panel row, input slot
+    const int u = (r & ~15) + rowperm(r & 15);
     double v = 0.0;
     if (u < H) {
       if (c < IN) v = a.W1[(size_t)u * IN + c];
       else if (c == 15) v = a.b1[u];
     }
-    w1s[u * kMlp64W1Stride + pos] = v;
+    w1s[r * kMlp64W1Stride + c] = v;
   }
   for (int idx = tid; idx < 16 * 16 * NB; idx += kMlp64Threads) {
-    const int o = idx / (16 * NB), r = idx - o * (16 * NB);
-    const int S = r >> 4, pos = r & 15;
-    const int k = 16 * S + (pos >> 2) + 4 * (pos & 3);
-    w3s[o * KP + 16 * S + pos] = (o < OUT && k < H) ? a.W3[(size_t)o * H + k] : 0.0;
+    const int i = idx / (16 * NB), k = idx - i * (16 * NB);
+    const int o = rowperm(i);
+    w3s[i * KP + k] = (o < OUT && k < H) ? a.W3[(size_t)o * H + k] : 0.0;
   }
 
   for (int idx = tid; idx < 16 * 16 * NB; idx += kMlp64Threads) {
-    // the last block's rows of W2 as the A operand reads them: unit 16 (NB -
-    // 1) + i, k = 16 S + kk + 4 s at position 16 S + 4 kk + s
-    const int i = idx / (16 * NB), r = idx - i * (16 * NB);
-    const int S = r >> 4, pos = r & 15;
-    const int k = 16 * S + (pos >> 2) + 4 * (pos & 3);
-    const int u = 16 * (NB - 1) + i;
-    w2c[i * KP + 16 * S + pos] = (u < H && k < H) ? a.W2[(size_t)u * H + k] : 0.0;
+    // the last block's rows of W2 as the A operand reads them
+    const int i = idx / (16 * NB), k = idx - i * (16 * NB);
+    const int u = 16 * (NB - 1) + rowperm(i);
+    w2c[i * KP + k] = (u < H && k < H) ? a.W2[(size_t)u * H + k] : 0.0;
   }
-  for (int idx = tid; idx < 16 * NB; idx += kMlp64Threads) {
-    const int ub = idx >> 4, pos = idx & 15;
-    const int n = 16 * ub + (pos >> 2) + 4 * (pos & 3);  // unit g + 4 q at 4 g + q
-    b2s[idx] = n < H ? a.b2[n] : 0.0;
-  }
+  for (int idx = tid; idx < 16 * NB; idx += kMlp64Threads)
+    b2s[idx] = idx < H ? a.b2[idx] : 0.0;
   if (tid < 16) b3s[tid] = tid < OUT ? a.b3[tid] : 0.0;
 
   // rows of a tile as this lane sees them (lane j = tile row j)
@@ -183,6 +190,24 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
   // one wavefront's fourth block: 190 matrix instructions per SIMD and tile,
   // not 232 / 174 / 174 / 174.  The four partial accumulators meet in LDS and
   // the finisher (wavefront 0, below) completes the block.
+  // H % 16 == 8 (H = 200): the last k-step holds eight real k.  It alone deals
+  // its k-slots as k = 16 S + kk + 4 s, so that instructions s = 0, 1 cover
+  // them and s = 2, 3 are left out (50 k-steps a block, not 52); everywhere
+  // else k = 16 S + 4 kk + s - four consecutive k per lane, one 32-byte read.
+  static_assert(H % 16 == 0 || H % 16 == 8, "");
+  constexpr bool HALF = (H % 16) == 8;
+  auto half_step = [](int S) { return HALF && S == NB - 1; };
+  auto skipped = [&](int S, int s) { return half_step(S) && s >= 2; };
+  auto k_of = [&](int S, int s) {  // of this lane's slot kk = g
+    return half_step(S) ? 16 * S + g + 4 * s : 16 * S + 4 * g + s;
+  };
+  // the B operand of k-step S: the activations at this lane's k-slots
+  auto b_of = [&](const double* hrow, int S) {
+    if (half_step(S)) {
+      return f64x4{hrow[16 * S + g], hrow[16 * S + g + 4], 0.0, 0.0};
+    }
+    return lds_read4(hrow + 16 * S + 4 * g);
+  };
   constexpr bool COOP = (NB % 4) == 1 && NB > 4;
   constexpr int CB = NB - 1;                 // the shared block
   constexpr int NOWN_MAX = COOP ? (NB - 1) / 4 : NBW;
@@ -207,7 +232,7 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
       // LDS), and H % 4 == 0 keeps every k of a kept k-step below H.
       static_assert(H % 16 == 0 || COOP, "a partial last block must be the shared one");
       auto w2_of = [&](int ub, int S, int s) {
-        return a.W2[(size_t)(16 * ub + j) * H + 16 * S + g + 4 * s];
+        return a.W2[(size_t)(16 * ub + 4 * (j & 3) + (j >> 2)) * H + k_of(S, s)];
       };
       // b2 of a block's units as the accumulator holds them (zero on a
       // tangent row: a property of the lane)
@@ -222,7 +247,7 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         for (int S = 0; S < NB; ++S)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            if (16 * S + 4 * s >= H) continue;  // (no lane has a k < H there)
+            if (skipped(S, s)) continue;
             a2[i][S][s] = w2_of(ub, S, s);
           }
       }
@@ -241,12 +266,15 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         }
         return v;
       };
+      // (units 16 ub + 4 g .. + 3: one 32-byte load; H % 4 == 0 keeps it
+      // aligned and whole inside the row, the padding units' address is
+      // clamped - their weights are zero)
       auto masks_of = [&](const double* M, int p, int ub, double (&m)[4]) {
+        const int n0 = 16 * ub + 4 * g;
+        const f64x4 v = *reinterpret_cast<const f64x4*>(
+            M + (size_t)p * H + (n0 < H ? n0 : 0));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = 16 * ub + g + 4 * q;
-          m[q] = M[(size_t)p * H + (n < H ? n : 0)];
-        }
+        for (int q = 0; q < 4; ++q) m[q] = v[q];
       };
       // what a tile's rows are to this lane; the inputs and the layer-1 masks
       // of a tile are requested a tile ahead
@@ -259,15 +287,28 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         r.p = r.live ? group % P : 0;
         return r;
       };
-      double xb[4], m1[NOWN][4], m1c[4];
+      // The inputs are REQUESTED only: nothing looks at a loaded value before
+      // layer 1 of its tile.  (With the padding selects at the request the
+      // compiler put each load under its own exec mask with an s_waitcnt
+      // behind it: two round trips to HBM per tile, 3 - 4 k cycles.)  Slot c =
+      // g + 4 s of the lane takes x[c] for c < in_dim, the bias slot's one,
+      // zeros between: x_raw * xsel + xadd, lane constants.
+      double xraw[4], xsel[4], xadd[4], m1[NOWN][4], m1c[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int c = 4 * g + s;
+        xsel[s] = c < IN ? 1.0 : 0.0;
+        xadd[s] = (c == 15 && !tangent) ? 1.0 : 0.0;
+      }
+      int xlive = 0;
       auto request_inputs = [&](const Row& r) {
+        const double* xrow = a.X + (size_t)(r.live ? r.mrow : 0) * IN;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const int c = g + 4 * s;
-          const double v = a.X[(size_t)(r.live ? r.mrow : 0) * IN + (c < IN ? c : 0)];
-          xb[s] = c < IN ? (r.live ? v : 0.0)
-                         : (c == 15 ? (tangent ? 0.0 : 1.0) : 0.0);
+          const int c = 4 * g + s;
+          xraw[s] = xrow[c < IN ? c : 0];
         }
+        xlive = r.live;
 #pragma unroll
         for (int i = 0; i < NOWN; ++i) masks_of(a.MT1, r.p, wave + 4 * i, m1[i]);
         if (COOP && wave == 3) masks_of(a.MT1, r.p, CB, m1c);
@@ -276,8 +317,10 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         const f64x4 wa = lds_read4(w1s + (16 * ub + j) * kMlp64W1Stride + 4 * g);
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], xb[s], acc, 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+          const double xb = __builtin_fma(xraw[s], xlive ? xsel[s] : 0.0, xadd[s]);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], xb, acc, 0, 0, 0);
+        }
         lds_write4(dst + j * KP + 16 * ub + 4 * g, epilogue(acc, m));
       };
       auto layer1 = [&](int it) {  // of tile `it`, from xb / m1 (requested)
@@ -296,17 +339,23 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
       __syncthreads();         // W1, W3 staged
       Row nxt = row;
 
+      // the layer-2 masks, too, are requested a tile ahead - right after their
+      // last use: requested at the top of their own tile, ahead of the matrix
+      // instructions, the compiler moved the loads down to their use and the
+      // epilogue waited out a round trip to L2 per block (3.9 k of a tile's
+      // 20.7 k cycles, tools/mlp64_marks.py)
+      double m2[NOWN][4], m2c[4];
+#pragma unroll
+      for (int i = 0; i < NOWN; ++i) masks_of(a.MT2, row.p, wave + 4 * i, m2[i]);
+      if (COOP && wave == 0) masks_of(a.MT2, row.p, CB, m2c);
       for (int it = 0; it < my; ++it) {
+        PDDP_MLP64_MARK(0);
         layer1(it);
+        PDDP_MLP64_MARK(1);
         __syncthreads();
+        PDDP_MLP64_MARK(2);
         const double* h1r = h1;
         double* partw = part;
-        // this tile's layer-2 masks: requested now, used after the matrix
-        // instructions
-        double m2[NOWN][4], m2c[4];
-#pragma unroll
-        for (int i = 0; i < NOWN; ++i) masks_of(a.MT2, row.p, wave + 4 * i, m2[i]);
-        if (COOP && wave == 0) masks_of(a.MT2, row.p, CB, m2c);
         // ---- layer 2
         f64x4 acc[NOWN];
         f64x4 accc = {0.0, 0.0, 0.0, 0.0};
@@ -316,16 +365,16 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         // requested before the matrix instructions of k-step S: issued where
         // they are used, every k-step waited out an LDS round trip - the
         // wavefront issues in order and has no other to hide behind)
-        f64x4 b = lds_read4(h1r + j * KP + 4 * g);
+        f64x4 b = b_of(h1r + j * KP, 0);
 #pragma unroll
         for (int S = 0; S < NB; ++S) {
           f64x4 bn = b, wc = b;
-          if (S + 1 < NB) bn = lds_read4(h1r + j * KP + 16 * (S + 1) + 4 * g);
+          if (S + 1 < NB) bn = b_of(h1r + j * KP, S + 1);
           const bool mine = COOP && (S & 3) == wave;  // (wave-uniform)
-          if (mine) wc = lds_read4(w2c + j * KP + 16 * S + 4 * g);
+          if (mine) wc = b_of(w2c + j * KP, S);  // (same slots as the B operand)
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
-            if (16 * S + 4 * s >= H) continue;  // H = 200: 50 k-steps, not 52
+            if (skipped(S, s)) continue;  // H = 200: 50 k-steps, not 52
 #pragma unroll
             for (int i = 0; i < NOWN; ++i)
               acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[i][S][s], b[s],
@@ -334,12 +383,13 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
           if (mine) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-              if (16 * S + 4 * s >= H) continue;
+              if (skipped(S, s)) continue;
               accc = __builtin_amdgcn_mfma_f64_16x16x4f64(wc[s], b[s], accc, 0, 0, 0);
             }
           }
           b = bn;
         }
+        PDDP_MLP64_MARK(3);
         // ---- layer 3 of the own blocks' units
         f64x4 o = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -359,8 +409,13 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
           nxt = row_of(it + 1);
           row = nxt;
           request_inputs(nxt);
+#pragma unroll
+          for (int i = 0; i < NOWN; ++i)
+            masks_of(a.MT2, nxt.p, wave + 4 * i, m2[i]);
         }
+        PDDP_MLP64_MARK(4);
         __syncthreads();  // partial sums of tile it, h1 of tile it + 1
+        PDDP_MLP64_MARK(5);
         // ---- the finisher (wavefront 0): the shared block's sum, its mask,
         // ReLU and layer 3; the sum of the partial outputs in a fixed order,
         // + b3; rows stored from the accumulator layout - output g + 4 q of
@@ -377,20 +432,20 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
             const f64x4 h2 = epilogue(pre, m2c);
             const f64x4 w3a = lds_read4(w3s + j * KP + 16 * CB + 4 * g);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              if (16 * CB + 4 * s >= H) continue;
+            for (int s = 0; s < 4; ++s)
               y = __builtin_amdgcn_mfma_f64_16x16x4f64(w3a[s], h2[s], y, 0, 0, 0);
-            }
           }
           if (cur.live) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const int oo = g + 4 * q;
+              const int oo = 4 * g + q;
               if (oo < OUT)
                 a.Y[(size_t)cur.mrow * OUT + oo] = y[q] + (tangent ? 0.0 : b3s[oo]);
             }
           }
         }
+        if (COOP && wave == 0 && it + 1 < my) masks_of(a.MT2, row.p, CB, m2c);
+        PDDP_MLP64_MARK(6);
       }
     }
   };
@@ -470,6 +525,13 @@ static int bnn_mlp_f64_impl(int R, int P, int group, int live, int in_dim, int H
 }  // namespace pddp
 
 extern "C" {
+
+#ifdef PDDP_MLP64_MARKS
+int pddp_debug_mlp64_marks(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::g_mlp64_marks),
+                                  sizeof(long long) * 32);
+}
+#endif
 
 int pddp_bnn_mlp_f64(int R, int P, int in_dim, int H, int out_dim,
                      const double* X, const double* W1, const double* b1,
