@@ -370,6 +370,13 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         for (int S = 0; S < NB; ++S) {
           f64x4 bn = b, wc = b;
           if (S + 1 < NB) bn = b_of(h1r + j * KP, S + 1);
+          // (the next tile's inputs and layer-1 masks: requested here, where
+          // the instructions that form their addresses issue in the shadow of
+          // the matrix instructions; their registers are free since layer 1)
+          if (S == 1 && it + 1 < my) {
+            nxt = row_of(it + 1);
+            request_inputs(nxt);
+          }
           const bool mine = COOP && (S & 3) == wave;  // (wave-uniform)
           if (mine) wc = b_of(w2c + j * KP, S);  // (same slots as the B operand)
 #pragma unroll
@@ -406,9 +413,7 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         // ---- layer 1 of the next tile, requests for the one after
         const Row cur = row;
         if (it + 1 < my) {
-          nxt = row_of(it + 1);
           row = nxt;
-          request_inputs(nxt);
 #pragma unroll
           for (int i = 0; i < NOWN; ++i)
             masks_of(a.MT2, nxt.p, wave + 4 * i, m2[i]);
