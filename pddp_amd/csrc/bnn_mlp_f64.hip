@@ -28,20 +28,27 @@
 //   3  the finisher, wavefront 0, while the others are in layer 1 of the next
 //      tile: the shared block's sum, mask, ReLU and layer 3, the sum of the
 //      partial outputs (fixed order), + b3, rows stored.
-// Inputs and layer-1 masks are requested a tile ahead, the layer-2 masks ahead
-// of the matrix instructions that cover them; W2 is loaded with nothing
-// between the load and the matrix instruction (see w2_of).
-// k-slots: instruction s of a group of four takes k = 16 S + kk + 4 s in slot
-// kk (kk = lane >> 4).  The f64 C/D layout holds row g + 4 r in register r of
-// lane group g (riccati_mfma16.hpp), so register q of lane (row j, g) of a
-// block's accumulator is unit 16 ub + g + 4 q = the B operand of instruction
-// s = q, slot kk = g: the hidden activations of layer 2 never leave the
-// registers, and layer 1's go to LDS at position 4 g + q of their block - one
-// 32-byte write, and one 32-byte read per (S, lane) in layer 2.
-// Measured (MI355X, 4.1 M rows, H = 200): 8.6 ms = 40.8 TFLOP/s = 0.52 of the
+// Requests are pure loads made where they cost nothing: the inputs and layer-1
+// masks of tile i + 1 inside the layer-2 loop of tile i (their address
+// arithmetic issues in the shadow of the matrix instructions), the layer-2
+// masks of tile i + 1 right after their registers' last use; W2 is loaded
+// with nothing between the load and the matrix instruction (see w2_of).
+// Layout.  The f64 C/D layout holds row g + 4 r in register r of lane group g
+// (riccati_mfma16.hpp).  Row i of every A operand is therefore unit (output)
+// 4 (i mod 4) + i / 4 of its block, which makes register r of lane (row j, g)
+// unit 16 ub + 4 g + r: a lane's four units - and, with k = 16 S + 4 kk + s in
+// slot kk = lane >> 4 of instruction s, its four k, inputs and outputs - are
+// consecutive: one 32-byte access each for a mask segment, a weight
+// quadruple, an h1 segment, the outputs.  The accumulator of a block's layer 2
+// (after mask and ReLU) IS the B operand of layer 3 for its 16 units: the
+// hidden activations of layer 2 never leave the registers.  (The half k-step
+// of H = 200 alone takes k = 16 S + kk + 4 s: two of its four instructions
+// cover k = 192 .. 199, the other two are left out.)
+// Measured (MI355X, 4.1 M rows, H = 200): 7.1 ms = 49 TFLOP/s = 0.63 of the
 // f64 matrix peak (78.6; tools/probe/mfma_f64_rate_probe.hip reaches 69 - 73.5
-// with nothing but matrix instructions), 2.9x the library GEMMs; the matrix
-// pipe is busy 58 % of a wavefront's cycles (profiles/r04_mlp64_pmc.txt).
+// with nothing but matrix instructions), 3.6x the library GEMMs; the matrix
+// pipe is busy 72 % of a wavefront's cycles (profiles/r04_mlp64_pmc.txt,
+// phase by phase: tools/mlp64_marks.py).
 //
 // JVP mode (the derivative rollout; see bnn_mlp.hip): rows in groups of 8 or
 // 16 = one input row and its tangent rows; tangents pass without biases and
