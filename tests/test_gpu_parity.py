@@ -3419,9 +3419,23 @@ def test_smallest_preactivation_helper():
     assert rel_err(z.cpu().numpy(), s3.Z[2:3, 8].cpu().numpy()) < 1e-9
 
 
+@pytest.mark.parametrize("precision", [0, 3], ids=["exact", "bf16x3"])
 @pytest.mark.parametrize("problem,B,N", [("cartpole", 4096, 100),
                                          ("double_cartpole", 1024, 150)])
-def test_full_size_bnn_round(problem, B, N):
+def test_full_size_bnn_round(problem, B, N, precision):
+    """`precision` = 3: the same round with layer 2 of the network kernel on
+    its bf16-split twin (pddp_bnn_mlp_precision(3), opt-in) - held to the same
+    float64-torch records, costs and decisions as the exact kernel."""
+    from pddp_amd import _native
+    lib = _native.lib()
+    prev = lib.pddp_bnn_mlp_precision(precision)
+    try:
+        _full_size_bnn_round(problem, B, N, precision)
+    finally:
+        lib.pddp_bnn_mlp_precision(prev)
+
+
+def _full_size_bnn_round(problem, B, N, precision):
     """BASELINE.json configs[2] (cartpole BNN, B = 4096, N = 100) and one GPU's
     shard of configs[3] (double-cartpole BNN - the reference has no GP -
     B = 1024, N = 150, n = 27) at FULL size, one round of the fit loop on the
@@ -3531,7 +3545,7 @@ def test_full_size_bnn_round(problem, B, N):
     assert clear.sum() >= 16
     assert np.array_equal(J32.argmin(1)[clear], J64.argmin(1)[clear])
     STATS.append(dict(test="full_size_bnn_round", problem=problem, B=B, N=N,
-                      records_vs_float64=worst,
+                      precision=precision, records_vs_float64=worst,
                       J_vs_float64=rel_err(J32, J64),
                       clear_decisions=int(clear.sum())))
 
