@@ -426,7 +426,8 @@ int pddp_bnn_mlp_rows_f32(int R, int P, int in_dim, int H, int out_dim,
                           float* Y, const int32_t* live_rows, void* stream);
 /* The same network in double precision (modules.py runs in the dtype of its
  * inputs) on v_mfma_f64_16x16x4_f64, weights-stationary, four wavefronts per
- * CU (csrc/bnn_mlp_f64.hip); arguments as above with double data. */
+ * CU (csrc/bnn_mlp_f64.hip); arguments as above with double data.  M1, M2:
+ * 32-byte aligned (their rows then are: H is a multiple of 4). */
 int pddp_bnn_mlp_f64(int R, int P, int in_dim, int H, int out_dim,
                      const double* X, const double* W1, const double* b1,
                      const double* M1, const double* W2, const double* b2,

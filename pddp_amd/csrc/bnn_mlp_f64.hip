@@ -524,6 +524,8 @@ static int bnn_mlp_f64_impl(int R, int P, int group, int live, int in_dim, int H
     return PDDP_E_BADARG;
   if (in_dim >= kMlp64W1Max || out_dim > kMlp64MaxOut || group == 32)
     return PDDP_E_UNSUPPORTED;
+  // (the masks are read 32 bytes at a time)
+  if ((((uintptr_t)MT1 | (uintptr_t)MT2) & 31) != 0) return PDDP_E_BADARG;
   const BnnMlpArgs64 a{R, P, in_dim, H, out_dim, live, X, W1, b1, MT1,
                        W2, b2, MT2, W3, b3, Y, live_rows};
   hipStream_t st = (hipStream_t)stream;
