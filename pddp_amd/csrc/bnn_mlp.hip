@@ -57,6 +57,19 @@
 
 namespace pddp {
 
+// Debug build (-DPDDP_MLP_MARKS, tools/mlp_marks.py): the eight wavefronts of
+// workgroup 0 leave s_memtime at the phase boundaries of their sixth tile
+#ifdef PDDP_MLP_MARKS
+__device__ long long g_mlp_marks[8 * 8];
+#define PDDP_MLP_MARK(k)                                                       \
+  do {                                                                          \
+    if (blockIdx.x == 0 && i == 5 && lane == 0)                                 \
+      g_mlp_marks[wave * 8 + (k)] = __builtin_readcyclecounter();              \
+  } while (0)
+#else
+#define PDDP_MLP_MARK(k) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -336,10 +349,15 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       };
       tile_barrier();
       for (int i = 0; i < iters; ++i) {
+        PDDP_MLP_MARK(0);
         // h2 of tile i - 2 was completed by the owners in iteration i - 1
         if (i >= 2) layer3(i - 2);
+        PDDP_MLP_MARK(1);
         if (i < my) partials(i);
+        PDDP_MLP_MARK(2);
+        PDDP_MLP_MARK(3);
         tile_barrier();
+        PDDP_MLP_MARK(4);
       }
       return;
     }
@@ -567,6 +585,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     f32x16 acc = binit;
     f32x4 m2[4];
     for (int i = 0; i < iters; ++i) {
+      PDDP_MLP_MARK(0);
       if (i + 1 < my) l1_load(i + 1);
       if (i >= 1 && i <= my) {
         if (wave != 3) {
@@ -582,14 +601,18 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
         }
         epilogue(i - 1, acc, m2);
       }
+      PDDP_MLP_MARK(1);
       if (i < my) {
         // mask of layer 2, requested before the MFMAs so that its latency
         // is theirs (used by the epilogue, one iteration later)
         masks_of(a.MT2, row_of(blockIdx.x + i * gridDim.x, li), m2);
         acc = layer2(i);
       }
+      PDDP_MLP_MARK(2);
       if (i + 1 < my) layer1(i + 1);
+      PDDP_MLP_MARK(3);
       tile_barrier();
+      PDDP_MLP_MARK(4);
     }
     return;
   }
@@ -685,6 +708,13 @@ static int launch_bnn_mlp(const BnnMlpArgs& a, hipStream_t st) {
 }  // namespace pddp
 
 extern "C" {
+
+#ifdef PDDP_MLP_MARKS
+int pddp_debug_mlp_marks(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::g_mlp_marks),
+                                  sizeof(long long) * 64);
+}
+#endif
 
 int pddp_bnn_mlp_precision(int mode) {
   if (mode != 0 && mode != 3 && mode != -1) return PDDP_E_BADARG;
