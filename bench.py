@@ -502,7 +502,8 @@ def bench_bnn(args, emit=True):
             "algorithmic_flop_per_launch": flop,
             # (the network kernel is matrix-bound; its HBM traffic is reported
             # for completeness where a profiled run of this workload exists)
-            "traffic": None if f64 else profile_traffic(
+            "traffic": profile_traffic("bnn_mlp_f64_kernel<%d, %d>" % (H, grp),
+                                       "cpbnn_f64") if f64 else profile_traffic(
                 "bnn_mlp_kernel<%d, %d, %d, %d" % (
                     H, 8 if in_dim < 8 else 16, grp,
                     4 if live <= 4 else (6 if live <= 6 else 8)),

@@ -43,6 +43,17 @@ cd $R
 tail -c 600 gpurun_out/${TAG}_bench.json
 fi
 cd $R
+# configs[2] on the float64 kernels under the profiler
+if [ "${2:-}" = "bnn64" ]; then
+  cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_cpbnn_f64 -- \
+      python3 $R/bench.py --workload cartpole_bnn --dtype f64 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch_cpbnn_f64 -- \
+      python3 $R/bench.py --workload cartpole_bnn --dtype f64 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_cpbnn_f64 -- \
+      python3 $R/bench.py --workload cartpole_bnn --dtype f64 --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  cd $R
+fi
 # the BNN workloads (configs[2], configs[3]'s shard, configs[4]); bench lines only
 if [ "${2:-}" = "bnn" ]; then
   python3 bench.py --workload cartpole_bnn --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_cartpole_bnn.json

@@ -72,6 +72,10 @@ stats_and_traffic("_cpbnn", "cartpole BNN (configs[2]): n=14 m=1 N=100 B=4096 "
                   "fp32, [200,200] x 100 particles",
                   " --workload cartpole_bnn --steps 1 --warmup 1")
 
+stats_and_traffic("_cpbnn_f64", "cartpole BNN (configs[2]) in float64: n=14 m=1 "
+                  "N=100 B=4096, [200,200] x 100 particles",
+                  " --workload cartpole_bnn --dtype f64 --steps 1 --warmup 1")
+
 f = newest("gpurun_out/%s_pmc_sq/*/*counter_collection.csv" % tag)
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
