@@ -315,3 +315,85 @@ def test_bnn_f64_fit_runs_on_the_native_path():
                                        "cost": "autograd"}
     assert float((Ua - Ub).abs().max()) < 1e-6 * max(1.0, float(Ub.abs().max()))
     assert float((Za - Zb).abs().max()) < 1e-6 * max(1.0, float(Zb.abs().max()))
+
+
+@pytest.mark.parametrize("problem,B,N", [("cartpole", 4096, 100),
+                                         ("double_cartpole", 1024, 150)])
+def test_full_size_bnn_round_f64(problem, B, N):
+    """BASELINE.json configs[2] and one GPU's shard of configs[3]'s problem at
+    FULL size in float64, one round of the fit loop on the float64 HIP kernels
+    (test_full_size_bnn_round is the float32 one): duplicated trajectories are
+    bit-identical; a 64-trajectory sample re-run as its own batch is
+    bit-identical; the same sample against the float64 TORCH path (autograd
+    Jacobians, torch line search: the checker the float32 kernels are held to)
+    - nominal rollout 1e-12, derivative records 1e-8, candidate costs under the
+    HIP gains 1e-10, and the same best step size."""
+    import copy
+    from test_gpu_parity import _bnn_problem, rel_err
+    model, cost, z0, U, solver = _bnn_problem(problem, B, N)
+    dup = [(0, B - 1), (17, B // 2)]
+    for a, b in dup:
+        z0[b], U[b] = z0[a], U[a]
+    m64 = copy.deepcopy(model).double()
+    m64.eps_in = {k: v.double() for k, v in model.eps_in.items()}
+    m64.output = {}
+    c64 = copy.deepcopy(cost).double()
+    z0, U = z0.double(), U.double()
+    s = solver(m64, c64, B, torch.float64, native64=True)
+    s.set_nominal(z0, U)
+    with torch.no_grad():
+        assert s.plugin._bnn_native_ok(s)
+    s.round(n_iterations=50)
+    torch.cuda.synchronize()
+    assert s.plugin.last_derivs_path == {"dynamics": "hip", "cost": "hip"}
+    assert int((s.bwd_status != 0).sum()) == 0
+    for a, b in dup:
+        for t in (s.rec, s.gains, s.Jc, s.J_opt, s.U, s.state, s.mu):
+            assert torch.equal(t[a], t[b]), (a, b)
+    assert torch.isfinite(s.Jc).all()
+    sample = np.random.RandomState(2).choice(B, 64, replace=False)
+    sample[:2] = (0, B - 1)
+    idx = torch.from_numpy(sample).cuda()
+    gains_full, Jc_full, rec_full = s.gains[idx].clone(), s.Jc[idx].clone(), s.rec[idx].clone()
+    s2 = solver(m64, c64, 64, torch.float64, native64=True)
+    s2.set_nominal(z0[idx], U[idx])
+    Z_nom = s2.Z.clone()
+    s2.derivs(mask=s2.fresh)
+    rec_small = s2.rec.clone()
+    s2.backward(active=s2.active)
+    s2.line_search(active=s2.active)
+    assert torch.equal(rec_small, rec_full)
+    assert torch.equal(s2.gains, gains_full)
+    assert torch.equal(s2.Jc, Jc_full)
+    # ---- the float64 torch path on the sample
+    # (a copy of the float64 model AFTER its dropout and particle noise were
+    # drawn, with the HIP kernels switched off)
+    t64, tc64 = copy.deepcopy(m64), copy.deepcopy(c64)
+    t64.model.use_native = False
+    t64.output = {}
+    s3 = solver(t64, tc64, 64, torch.float64)
+    s3.set_nominal(z0[idx], U[idx])
+    assert rel_err(Z_nom.cpu().numpy(), s3.Z.cpu().numpy()) < 1e-12
+    s3.derivs(mask=s3.fresh)
+    assert s3.plugin.last_derivs_path == {"dynamics": "autograd",
+                                          "cost": "autograd"}
+    lay, n, m = s3.lay, s3.n, s3.m
+    for name, blocks in (
+            ("F_zu", ((lay.o_Fz, n * n), (lay.o_Fu, n * m))),
+            ("L_zu", ((lay.o_Lz, n), (lay.o_Lu, m))),
+            ("L_zuzu", ((lay.o_Lzz, n * n), (lay.o_Luz, m * n),
+                        (lay.o_Luu, m * m)))):
+        a = np.concatenate([rec_small[..., o:o + c].cpu().numpy()
+                            for o, c in blocks], -1)
+        b = np.concatenate([s3.rec[..., o:o + c].cpu().numpy()
+                            for o, c in blocks], -1)
+        assert rel_err(a, b) < 1e-8, (name, rel_err(a, b))
+    s3.gains.copy_(s2.gains)
+    s3.bwd_status.zero_()
+    s3.line_search(active=s3.active)
+    Ja, Jb = s2.Jc.cpu().numpy(), s3.Jc.cpu().numpy()
+    assert rel_err(Ja, Jb) < 1e-10, rel_err(Ja, Jb)
+    srt = np.sort(Jb, axis=1)
+    clear = (srt[:, 1] - srt[:, 0]) > 1e-8 * np.abs(srt[:, 0])
+    assert clear.sum() >= 16
+    assert np.array_equal(Ja.argmin(1)[clear], Jb.argmin(1)[clear])

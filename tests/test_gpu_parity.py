@@ -3348,10 +3348,10 @@ def _bnn_problem(problem, B, N, seed=0):
         var=1e-2 * torch.ones(D)).encode(enc) for _ in range(B)]).cuda()
     U = (0.1 * torch.randn(B, N, m, generator=g)).cuda()
 
-    def solver(model_, cost_, rows, dtype):
+    def solver(model_, cost_, rows, dtype, native64=False):
         plugin = TorchProblem(model_, cost_, enc, opts, {})
-        if dtype == torch.float64:  # the float64 twin is the torch checker
-            plugin.use_native_cost = False
+        if dtype == torch.float64 and not native64:
+            plugin.use_native_cost = False  # the float64 twin is the torch checker
         return ILQRSolver(None, rows, N, dtype, "cuda", torch.tensor([-bound]),
                           torch.tensor([bound]), fit_alphas(dtype, "cuda"),
                           plugin=plugin, n=n, m=m)
