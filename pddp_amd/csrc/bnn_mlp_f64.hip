@@ -14,7 +14,9 @@
 // LDS and wavefront w takes the k-steps S = w, w + 4, .. of its contraction
 // (190 matrix instructions per SIMD and tile instead of 232 / 174 / 174 / 174
 // with the block owned by one wavefront).  Tiles of 16 rows, two barriers:
-//   1  layer 1 of the own blocks (wavefront 3: also the shared block's): 4
+//   1  layer 1 of the own blocks (H = 200: wavefronts 1 - 3 also take one of
+//      wavefront 0's blocks each, 3 the shared block's - wavefront 0 is the
+//      finisher of the previous tile meanwhile): 4
 //      matrix instructions per block (K = 16: inputs | zeros | bias slot; the
 //      A operand W1 | b1 from LDS), mask and ReLU on the accumulators, to LDS
 //      in the order layer 2 reads them; barrier
@@ -44,7 +46,7 @@
 // hidden activations of layer 2 never leave the registers.  (The half k-step
 // of H = 200 alone takes k = 16 S + kk + 4 s: two of its four instructions
 // cover k = 192 .. 199, the other two are left out.)
-// Measured (MI355X, 4.1 M rows, H = 200): 7.1 ms = 49 TFLOP/s = 0.63 of the
+// Measured (MI355X, 4.1 M rows, H = 200): 6.9 ms = 51 TFLOP/s = 0.65 of the
 // f64 matrix peak (78.6; tools/probe/mfma_f64_rate_probe.hip reaches 69 - 73.5
 // with nothing but matrix instructions), 3.6x the library GEMMs; the matrix
 // pipe is busy 72 % of a wavefront's cycles (profiles/r04_mlp64_pmc.txt,
@@ -299,16 +301,18 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
       // compiler put each load under its own exec mask with an s_waitcnt
       // behind it: two round trips to HBM per tile, 3 - 4 k cycles.)  Slot c =
       // g + 4 s of the lane takes x[c] for c < in_dim, the bias slot's one,
-      // zeros between: x_raw * xsel + xadd, lane constants.
-      double xraw[4], xsel[4], xadd[4], m1[NOWN][4], m1c[4];
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int c = 4 * g + s;
-        xsel[s] = c < IN ? 1.0 : 0.0;
-        xadd[s] = (c == 15 && !tangent) ? 1.0 : 0.0;
-      }
+      // zeros between - selected at the use.
+      // COOP: wavefront 0 - the finisher - takes no part in layer 1; its blocks
+      // 0, 4, 8 go to wavefronts 1, 2, 3 (and the shared block to 3): between
+      // the two barriers of a tile the finisher's 1.6 k cycles and the others'
+      // layer 1 then run side by side instead of one after the other
+      static_assert(!COOP || NOWN_MAX == 3, "wavefront 0's blocks go to 1, 2, 3");
+      const bool l1_own = !COOP || wave != 0;   // (wave-uniform)
+      const bool l1_extra = COOP && wave != 0;
+      double xraw[4], m1[NOWN][4], m1c[4], m1x[4];
       int xlive = 0;
       auto request_inputs = [&](const Row& r) {
+        if (!l1_own) return;
         const double* xrow = a.X + (size_t)(r.live ? r.mrow : 0) * IN;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         xlive = r.live;
 #pragma unroll
         for (int i = 0; i < NOWN; ++i) masks_of(a.MT1, r.p, wave + 4 * i, m1[i]);
+        if (l1_extra) masks_of(a.MT1, r.p, 4 * (wave - 1), m1x);
         if (COOP && wave == 3) masks_of(a.MT1, r.p, CB, m1c);
       };
       auto layer1_of = [&](double* dst, int ub, const double (&m)[4]) {
@@ -325,7 +330,9 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const double xb = __builtin_fma(xraw[s], xlive ? xsel[s] : 0.0, xadd[s]);
+          const int c = 4 * g + s;
+          const double xb = c < IN ? (xlive ? xraw[s] : 0.0)
+                                   : ((c == 15 && !tangent) ? 1.0 : 0.0);
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], xb, acc, 0, 0, 0);
         }
         lds_write4(dst + j * KP + 16 * ub + 4 * g, epilogue(acc, m));
@@ -333,8 +340,10 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
       auto layer1 = [&](int it) {  // of tile `it`, from xb / m1 (requested)
         double* dst = h1;
         (void)it;
+        if (!l1_own) return;
 #pragma unroll
         for (int i = 0; i < NOWN; ++i) layer1_of(dst, wave + 4 * i, m1[i]);
+        if (l1_extra) layer1_of(dst, 4 * (wave - 1), m1x);
         if (COOP && wave == 3) layer1_of(dst, CB, m1c);
       };
       // Two barriers per tile: layer 1 | barrier | layer 2, 3 | barrier | the
