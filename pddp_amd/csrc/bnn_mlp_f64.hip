@@ -309,7 +309,10 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
       static_assert(!COOP || NOWN_MAX == 3, "wavefront 0's blocks go to 1, 2, 3");
       const bool l1_own = !COOP || wave != 0;   // (wave-uniform)
       const bool l1_extra = COOP && wave != 0;
-      double xraw[4], m1[NOWN][4], m1c[4], m1x[4];
+      // (mx: the layer-1 mask of the extra block on wavefronts 1 - 3, the
+      // layer-2 mask of the shared block on wavefront 0 - one array, so that
+      // the allocator sees one set of registers)
+      double xraw[4], m1[NOWN][4], m1c[4], mx[4];
       int xlive = 0;
       auto request_inputs = [&](const Row& r) {
         if (!l1_own) return;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         xlive = r.live;
 #pragma unroll
         for (int i = 0; i < NOWN; ++i) masks_of(a.MT1, r.p, wave + 4 * i, m1[i]);
-        if (l1_extra) masks_of(a.MT1, r.p, 4 * (wave - 1), m1x);
+        if (l1_extra) masks_of(a.MT1, r.p, 4 * (wave - 1), mx);
         if (COOP && wave == 3) masks_of(a.MT1, r.p, CB, m1c);
       };
       auto layer1_of = [&](double* dst, int ub, const double (&m)[4]) {
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         if (!l1_own) return;
 #pragma unroll
         for (int i = 0; i < NOWN; ++i) layer1_of(dst, wave + 4 * i, m1[i]);
-        if (l1_extra) layer1_of(dst, 4 * (wave - 1), m1x);
+        if (l1_extra) layer1_of(dst, 4 * (wave - 1), mx);
         if (COOP && wave == 3) layer1_of(dst, CB, m1c);
       };
       // Two barriers per tile: layer 1 | barrier | layer 2, 3 | barrier | the
@@ -360,10 +363,10 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
       // instructions, the compiler moved the loads down to their use and the
       // epilogue waited out a round trip to L2 per block (3.9 k of a tile's
       // 20.7 k cycles, tools/mlp64_marks.py)
-      double m2[NOWN][4], m2c[4];
+      double m2[NOWN][4];
 #pragma unroll
       for (int i = 0; i < NOWN; ++i) masks_of(a.MT2, row.p, wave + 4 * i, m2[i]);
-      if (COOP && wave == 0) masks_of(a.MT2, row.p, CB, m2c);
+      if (COOP && wave == 0) masks_of(a.MT2, row.p, CB, mx);
       for (int it = 0; it < my; ++it) {
         PDDP_MLP64_MARK(0);
         layer1(it);
@@ -450,7 +453,7 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
 #pragma unroll
             for (int w = 0; w < 4; ++w)
               pre += lds_read4(partw + ((4 + w) * 64 + lane) * 4);
-            const f64x4 h2 = epilogue(pre, m2c);
+            const f64x4 h2 = epilogue(pre, mx);
             const f64x4 w3a = lds_read4(w3s + j * KP + 16 * CB + 4 * g);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -465,7 +468,7 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
             }
           }
         }
-        if (COOP && wave == 0 && it + 1 < my) masks_of(a.MT2, row.p, CB, m2c);
+        if (COOP && wave == 0 && it + 1 < my) masks_of(a.MT2, row.p, CB, mx);
         PDDP_MLP64_MARK(6);
       }
     }
