@@ -2890,7 +2890,7 @@ def test_bnn_hip_kernels_vs_reference_real_size():
 
 
 def _bnn_mpc_controller(B, N, graph, P=100, H=200, seed=0,
-                        use_predicted_std=False):
+                        use_predicted_std=False, dtype=torch.float32):
     import pddp_amd
     from pddp_amd.examples import cartpole
     from pddp_amd.models.bnn import bnn_dynamics_model_factory
@@ -2898,24 +2898,34 @@ def _bnn_mpc_controller(B, N, graph, P=100, H=200, seed=0,
     CM = cartpole.CartpoleDynamicsModel
     model = bnn_dynamics_model_factory(
         4, 1, [H, H], CM.angular_indices, CM.non_angular_indices)(
-            n_particles=P).cuda().eval()
+            n_particles=P).cuda().to(dtype).eval()
     with torch.no_grad():  # untrained network: keep its dynamics gentle
         model.model.out.weight.mul_(0.05)
         model.model.out.bias.mul_(0.05)
-    cost = cartpole.CartpoleCost().cuda()
+    cost = cartpole.CartpoleCost().cuda().to(dtype)
     ctrl = pddp_amd.controllers.iLQRController(
         None, model, cost, graph=graph,
         model_opts={"use_predicted_std": use_predicted_std,
                     "infer_noise_variables": True})
     g = torch.Generator().manual_seed(seed + 1)
-    ctrl._U_nominal = (0.1 * torch.randn(B, N, 1, generator=g)).cuda()
+    ctrl._U_nominal = (0.1 * torch.randn(B, N, 1, generator=g)).cuda().to(dtype)
     x = (torch.tensor([0.0, 0.0, 3.14159, 0.0]) +
-         1e-2 * torch.randn(B, 4, generator=g)).cuda()
-    return ctrl, CM(0.1).cuda(), x
+         1e-2 * torch.randn(B, 4, generator=g)).cuda().to(dtype)
+    return ctrl, CM(0.1).cuda().to(dtype), x
 
 
 @pytest.mark.parametrize("use_predicted_std", [False, True])
 def test_bnn_mpc_graph_replay_equals_eager(use_predicted_std):
+    _mpc_graph_replay_equals_eager(use_predicted_std, torch.float32)
+
+
+def test_bnn_mpc_graph_replay_equals_eager_f64():
+    """The same loop on the float64 kernels (tests/test_bnn_f64.py): the
+    float64 rounds capture into hipGraphs like the float32 ones."""
+    _mpc_graph_replay_equals_eager(False, torch.float64)
+
+
+def _mpc_graph_replay_equals_eager(use_predicted_std, dtype):
     """BASELINE.json configs[4] (shortened): the receding-horizon loop of
     examples/mpc_animation.py:29-39 on the cartpole BNN ([200, 200], 100
     particles, DEFAULT encoding), horizon 50, 256 restarts x 5 control steps,
@@ -2929,12 +2939,13 @@ def test_bnn_mpc_graph_replay_equals_eager(use_predicted_std):
     enc = pddp_amd.StateEncoding.DEFAULT
     ienc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
     iu = torch.triu_indices(4, 4)
-    tri = (0.1 * torch.eye(4))[iu[0], iu[1]].cuda()
-    u_min, u_max = torch.tensor([-10.0]), torch.tensor([10.0])
+    tri = (0.1 * torch.eye(4))[iu[0], iu[1]].cuda().to(dtype)
+    u_min = torch.tensor([-10.0], dtype=dtype)
+    u_max = torch.tensor([10.0], dtype=dtype)
     runs = {}
     for graph in (False, True):
         ctrl, plant, x = _bnn_mpc_controller(
-            B, N, graph, use_predicted_std=use_predicted_std)
+            B, N, graph, use_predicted_std=use_predicted_std, dtype=dtype)
         x[255], x[100] = x[0], x[7]          # duplicated restarts
         ctrl._U_nominal[255] = ctrl._U_nominal[0]
         ctrl._U_nominal[100] = ctrl._U_nominal[7]
