@@ -3271,7 +3271,16 @@ def test_bnn_graphs_follow_model_resample_and_refit():
         s = ctrl._solver
         assert (s._graph is not None) == graph
     assert torch.isfinite(runs[True]).all()
-    assert torch.equal(runs[False], runs[True])
+    assert torch.equal(runs[False][:2], runs[True][:2])
+    # After the refit: bit for bit as a rule - but the two runs TRAIN the model
+    # separately (eight Adam steps through the framework's backward kernels),
+    # and once in ~10 runs of the whole suite those differ in the last bits
+    # (seen: 3e-4 on the plan).  A graph replaying the old model's buffers is
+    # off by the whole effect of the refit, 5e-2 here: held to 2e-3, with the
+    # refit's effect checked to be far above that.
+    tol = 2e-3
+    assert float((runs[False][2] - runs[True][2]).abs().max()) < tol
+    assert float((runs[True][2] - runs[True][1]).abs().max()) > 10 * tol
     # the three plans differ (the model did change under the controller)
     assert not torch.equal(runs[True][0], runs[True][1])
     assert not torch.equal(runs[True][1], runs[True][2])
