@@ -14,7 +14,8 @@
 // LDS and wavefront w takes the k-steps S = w, w + 4, .. of its contraction
 // (190 matrix instructions per SIMD and tile instead of 232 / 174 / 174 / 174
 // with the block owned by one wavefront).  Tiles of 16 rows, two barriers:
-//   1  layer 1 of the own blocks (H = 200: wavefronts 1 - 3 also take one of
+//   1  layer 1 of the own blocks (two instructions per block for up to seven
+//      inputs; H = 200: wavefronts 1 - 3 also take one of
 //      wavefront 0's blocks each, 3 the shared block's - wavefront 0 is the
 //      finisher of the previous tile meanwhile): 4
 //      matrix instructions per block (K = 16: inputs | zeros | bias slot; the
@@ -46,7 +47,7 @@
 // hidden activations of layer 2 never leave the registers.  (The half k-step
 // of H = 200 alone takes k = 16 S + kk + 4 s: two of its four instructions
 // cover k = 192 .. 199, the other two are left out.)
-// Measured (MI355X, 4.1 M rows, H = 200): 6.9 ms = 51 TFLOP/s = 0.65 of the
+// Measured (MI355X, 4.1 M rows, H = 200): 6.6 ms = 53 TFLOP/s = 0.67 of the
 // f64 matrix peak (78.6; tools/probe/mfma_f64_rate_probe.hip reaches 69 - 73.5
 // with nothing but matrix instructions), 3.6x the library GEMMs; the matrix
 // pipe is busy 72 % of a wavefront's cycles (profiles/r04_mlp64_pmc.txt,
@@ -125,7 +126,12 @@ PDDP_DEV void lds_write4(double* p, const f64x4& v) {
 }
 
 // G: rows per (state, particle) in JVP mode (8 or 16; 0: plain inference)
-template <int H, int G>
+// SMALL: in_dim <= 7 (cartpole 6, pendulum 4) - layer 1 is K = 8, inputs |
+// bias in slot 7, on TWO instructions per block, their slots dealt as c = kk +
+// 4 s (as the half k-step's), two input loads per lane instead of four.  (A
+// template parameter: as a run-time branch the second code path cost 16
+// spilled registers and 0.8 ms.)
+template <int H, int G, bool SMALL>
 __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64 a) {
   using S_ = Mlp64Shape<H>;
   constexpr int NB = S_::NB, NBW = S_::NBW, KP = S_::KP;
@@ -312,15 +318,20 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
       // (mx: the layer-1 mask of the extra block on wavefronts 1 - 3, the
       // layer-2 mask of the shared block on wavefront 0 - one array, so that
       // the allocator sees one set of registers)
-      double xraw[4], m1[NOWN][4], m1c[4], mx[4];
+      double xraw[SMALL ? 2 : 4], m1[NOWN][4], m1c[4], mx[4];
       int xlive = 0;
       auto request_inputs = [&](const Row& r) {
         if (!l1_own) return;
         const double* xrow = a.X + (size_t)(r.live ? r.mrow : 0) * IN;
+        if constexpr (SMALL) {
+          xraw[0] = xrow[g < IN ? g : 0];
+          xraw[1] = xrow[g + 4 < IN ? g + 4 : 0];
+        } else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int c = 4 * g + s;
-          xraw[s] = xrow[c < IN ? c : 0];
+          for (int s = 0; s < 4; ++s) {
+            const int c = 4 * g + s;
+            xraw[s] = xrow[c < IN ? c : 0];
+          }
         }
         xlive = r.live;
 #pragma unroll
@@ -329,14 +340,25 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
         if (COOP && wave == 3) masks_of(a.MT1, r.p, CB, m1c);
       };
       auto layer1_of = [&](double* dst, int ub, const double (&m)[4]) {
-        const f64x4 wa = lds_read4(w1s + (16 * ub + j) * kMlp64W1Stride + 4 * g);
+        const double* wrow = w1s + (16 * ub + j) * kMlp64W1Stride;
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (SMALL) {
+          // (the staged row holds zeros from in_dim to 14 and b1 at 15)
+          const double w0 = wrow[g], w1 = wrow[g == 3 ? 15 : g + 4];
+          const double x0 = (g < IN && xlive) ? xraw[0] : 0.0;
+          const double x1 = g == 3 ? (tangent ? 0.0 : 1.0)
+                                   : ((g + 4 < IN && xlive) ? xraw[1] : 0.0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w0, x0, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(w1, x1, acc, 0, 0, 0);
+        } else {
+          const f64x4 wa = lds_read4(wrow + 4 * g);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const int c = 4 * g + s;
-          const double xb = c < IN ? (xlive ? xraw[s] : 0.0)
-                                   : ((c == 15 && !tangent) ? 1.0 : 0.0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], xb, acc, 0, 0, 0);
+          for (int s = 0; s < 4; ++s) {
+            const int c = 4 * g + s;
+            const double xb = c < IN ? (xlive ? xraw[s] : 0.0)
+                                     : ((c == 15 && !tangent) ? 1.0 : 0.0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[s], xb, acc, 0, 0, 0);
+          }
         }
         lds_write4(dst + j * KP + 16 * ub + 4 * g, epilogue(acc, m));
       };
@@ -480,8 +502,8 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
   }
 }
 
-template <int H, int G>
-static int launch_bnn_mlp_f64(const BnnMlpArgs64& a, hipStream_t st) {
+template <int H, int G, bool SMALL>
+static int launch_bnn_mlp_f64_s(const BnnMlpArgs64& a, hipStream_t st) {
   constexpr int kMaxDev = 16;
   static int cus_of[kMaxDev] = {};
   static bool attr_set[kMaxDev] = {};
@@ -501,14 +523,20 @@ static int launch_bnn_mlp_f64(const BnnMlpArgs64& a, hipStream_t st) {
   static_assert(lds <= 160 * 1024, "a workgroup's LDS");
   if (!attr_set[dev]) {  // more than 64 KB of dynamic LDS needs the opt-in
     const hipError_t e = hipFuncSetAttribute(
-        (const void*)bnn_mlp_f64_kernel<H, G>,
+        (const void*)bnn_mlp_f64_kernel<H, G, SMALL>,
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set[dev] = true;
   }
-  PDDP_LAUNCH((bnn_mlp_f64_kernel<H, G>), dim3(grid), dim3(kMlp64Threads), lds,
+  PDDP_LAUNCH((bnn_mlp_f64_kernel<H, G, SMALL>), dim3(grid), dim3(kMlp64Threads), lds,
               st, a);
   return launch_status();
+}
+
+template <int H, int G>
+static int launch_bnn_mlp_f64(const BnnMlpArgs64& a, hipStream_t st) {
+  return a.in_dim <= 7 ? launch_bnn_mlp_f64_s<H, G, true>(a, st)
+                       : launch_bnn_mlp_f64_s<H, G, false>(a, st);
 }
 
 template <int G>

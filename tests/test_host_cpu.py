@@ -378,7 +378,7 @@ def test_hot_kernels_keep_their_working_set_in_registers():
         # the float64 network kernel in JVP mode at the 512-register file
         # (300 of them W2): ten values spill in the prologue, none in the
         # tile loop
-        "bnn_mlp_f64_kernel<200, 8>", "bnn_mlp_f64_kernel<200, 16>",
+        "bnn_mlp_f64_kernel<200, 8,", "bnn_mlp_f64_kernel<200, 16,",
         "derivs_default_kernel<double, 2, 1>",  # double cartpole, hyper-dual on 27 inputs
         "derivs_default_kernel<float, 2, 1>",
         # rendezvous, Cholesky encoding, fp64: the 36-entry re-factorisation in
