@@ -50,7 +50,7 @@
 // Measured (MI355X, 4.1 M rows, H = 200): 6.6 ms = 53 TFLOP/s = 0.67 of the
 // f64 matrix peak (78.6; tools/probe/mfma_f64_rate_probe.hip reaches 69 - 73.5
 // with nothing but matrix instructions), 3.6x the library GEMMs; the matrix
-// pipe is busy 72 % of a wavefront's cycles (profiles/r04_mlp64_pmc.txt,
+// pipe is busy 74 % of a wavefront's cycles (profiles/r04_mlp64_pmc.txt,
 // phase by phase: tools/mlp64_marks.py).
 //
 // JVP mode (the derivative rollout; see bnn_mlp.hip): rows in groups of 8 or
