@@ -159,6 +159,10 @@ class iLQRController(Controller):
                 on_iteration(s.iter.cpu() - 1, s.state.cpu(), s.Z.clone(),
                              s.U.clone(), s.J_opt.clone())
             else:
+                # (a callback reads the regularisation of the attempt it is
+                # told about, as in the reference: ilqr.py:166-181 update
+                # _mu / _delta before on_iteration fires, :232-233)
+                self._mu, self._delta = float(s.mu[0]), float(s.delta[0])
                 it = int(s.iter[0]) - 1
                 st = iLQRState(int(s.state[0]))
                 if st == iLQRState.ACCEPTED and int(s.active[0]):
@@ -231,6 +235,7 @@ class iLQRController(Controller):
                 on_iteration(i, s.state.cpu(), s.Z.clone(), s.U.clone(),
                              s.J_opt.clone())
             else:
+                self._mu, self._delta = float(s.mu[0]), float(s.delta[0])
                 on_iteration(i, iLQRState(int(s.state[0])), s.Z[0].clone(),
                              s.U[0].clone(), s.J_opt[0].clone())
         self._last_rounds = s.fit(1, kwargs.get("tol", 5e-6),

@@ -18,6 +18,19 @@ def load(problem, encoding="ignore", dtype="f64"):
     return np.load(path)
 
 
+def load_dc150():
+    """BASELINE configs[3]'s horizon: the double cartpole under
+    IGNORE_UNCERTAINTY at N = 5 and N = 150, fp64, with a three-iteration
+    bounded fit at N = 150 (tools/make_golden.py --dc-default; at N = 150
+    only the bounded forward pass, the backward branches and the fit
+    schedule's line search are stored)."""
+    return np.load(os.path.join(GOLDEN_DIR,
+                                "double_cartpole_ignore150_f64.npz"))
+
+
+TAGS_DC150 = ["N5_cos", "N5_seeded", "N150_cos"]
+
+
 def tags(problem):
     N0, N1 = HORIZONS[problem]
     return ["N%d_cos" % N0, "N%d_seeded" % N0, "N%d_cos" % N1]

@@ -8,8 +8,8 @@ import pytest
 import torch
 
 import oracle as orc
-from golden_util import (DT, FWD_NAMES, elementwise_err, load, np_dtype,
-                         rel_err, tags)
+from golden_util import (DT, FWD_NAMES, TAGS_DC150, elementwise_err, load,
+                         load_dc150, np_dtype, rel_err, tags)
 
 pytestmark = pytest.mark.gpu
 
@@ -647,7 +647,7 @@ def test_plugin_path_equals_native_path():
     ("cartpole", "variance"), ("pendulum", "variance"),
     ("cartpole", "std"), ("pendulum", "std"), ("cartpole", "fullcov"),
     ("pendulum", "fullcov"), ("double_cartpole", "fullcov"),
-    ("rendezvous", "default"), ("rendezvous", "variance"),
+    ("double_cartpole", "default"), ("rendezvous", "default"), ("rendezvous", "variance"),
     ("rendezvous", "std"), ("rendezvous", "fullcov")])
 def test_default_encoding_vs_reference_golden(problem, enc_key):
     """The Gaussian state encodings - DEFAULT (upper-triangular Cholesky, n =
@@ -661,7 +661,14 @@ def test_default_encoding_vs_reference_golden(problem, enc_key):
     derivatives, line-search kernel) - asserted below.  Round 4: rendezvous
     (8 states, 4 actions; it carries the FULL covariance through its dynamics,
     rendezvous/model.py:94,110): n = 44 / 16 / 16 / 72, horizons 5 and 12
-    (tools/make_golden.py --rendezvous-gaussian)."""
+    (tools/make_golden.py --rendezvous-gaussian).  Round 5: the double cartpole
+    under DEFAULT - n = 27, BASELINE configs[3]'s encoded size - at horizons 5
+    and 150 (configs[3]'s; tools/make_golden.py --dc-default).  From that
+    start the reference's `fit` RAISES (mu = 0: candidates leave the basin and
+    hand the cost a covariance that is not positive definite, outside `_step`'s
+    try block), so the controller leg there is three calls of `step()` from
+    mu = 1000, and the line search is also held at the reg = 100 gains, whose
+    ten candidates all stay finite."""
     import pddp_amd
     from pddp_amd import StateEncoding
     from pddp_amd.controllers.ilqr import _control_law, backward, forward
@@ -713,10 +720,45 @@ def test_default_encoding_vs_reference_golden(problem, enc_key):
         Jr = g[tag + "/ls_fit/J"]
         fin = np.isfinite(Jr)
         assert np.allclose(J.cpu().numpy()[fin], Jr[fin], rtol=1e-6)
+        if tag + "/ls_fit100/J" in g.files:
+            # every candidate finite: the whole rollouts, all ten costs
+            k, K = cu(g[tag + "/bwd/B/100/k"]), cu(g[tag + "/bwd/B/100/K"])
+            Zn, Un, J = _control_law(model, out[0], U, k, K,
+                                     cu(g[tag + "/ls_fit100/alphas"]), enc,
+                                     u_min=u_min, u_max=u_max, cost=cost,
+                                     return_cost=True)
+            assert np.isfinite(g[tag + "/ls_fit100/J"]).all()
+            assert rel_err(Zn.cpu().numpy(), g[tag + "/ls_fit100/Z_new"]) < 1e-8
+            assert rel_err(Un.cpu().numpy(), g[tag + "/ls_fit100/U_new"]) < 1e-8
+            assert np.allclose(J.cpu().numpy(), g[tag + "/ls_fit100/J"],
+                               rtol=1e-9)
     # whole controller
     env = env_cls(dt=DT[problem])
     ctrl = pddp_amd.controllers.iLQRController(env, model, cost)
     trace = []
+    if "steps/trace" in g.files:
+        assert int(g["steps/fit_raises"]) == 1 and int(g["steps/N"]) == 150
+        ctrl._U_nominal = cu(g["steps/U0"])
+        ctrl._mu, ctrl._delta = float(g["steps/mu0"]), 2.0
+        for it in range(int(g["steps/n_steps"])):
+            state = ctrl.step(
+                cu(g["z0"]), U=None, i=it, encoding=enc,
+                alphas=cu(g["steps/alphas"]), u_min=u_min, u_max=u_max,
+                on_iteration=lambda i, st, Z, U, J: trace.append(
+                    (i, int(st), float(J), ctrl._mu, ctrl._delta)))
+        ref = g["steps/trace"]
+        got = np.array(trace)
+        assert got.shape == ref.shape
+        assert np.array_equal(got[:, :2], ref[:, :2])
+        assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-9)
+        assert np.array_equal(got[:, 3:], ref[:, 3:])
+        assert int(state) == int(g["steps/state"])
+        assert rel_err(ctrl._U_nominal.cpu().numpy(), g["steps/U"]) < 1e-7
+        assert rel_err(ctrl._Z_nominal.cpu().numpy(), g["steps/Z"]) < 1e-7
+        assert rel_err(ctrl._K.cpu().numpy(), g["steps/K"]) < 1e-6
+        assert ctrl._solver.plugin is None and ctrl._solver.problem is not None
+        assert ctrl._solver.problem.encoding == int(enc)
+        return
     Z, U, state = ctrl.fit(
         cu(g["fit_bounded/U0"]), encoding=enc,
         n_iterations=int(g["fit_bounded/n_iterations"]), u_min=u_min,
@@ -734,6 +776,81 @@ def test_default_encoding_vs_reference_golden(problem, enc_key):
     # no plugin: problem kernels only
     assert ctrl._solver.plugin is None and ctrl._solver.problem is not None
     assert ctrl._solver.problem.encoding == int(enc)
+
+
+def test_double_cartpole_at_configs3_horizon_vs_reference_golden():
+    """BASELINE configs[3]'s horizon under IGNORE_UNCERTAINTY: the double
+    cartpole at N = 150 (and 5) through the reference-signature API against the
+    reference's own outputs (double_cartpole/model.py:100-195 through
+    ilqr.py:393-674; tools/make_golden.py --dc-default): bounded forward pass,
+    the four backward branches x four regularisations (expected failures
+    included), the fit schedule's line search and a three-iteration bounded fit
+    at N = 150 (11 attempts: state, cost, mu, delta)."""
+    import pddp_amd
+    from pddp_amd import StateEncoding
+    from pddp_amd.controllers.ilqr import _control_law, backward, forward
+    mod = pddp_amd.examples.double_cartpole
+    dt = DT["double_cartpole"]
+    model = mod.DoubleCartpoleDynamicsModel(dt).double().cuda()
+    cost = mod.DoubleCartpoleCost().double().cuda()
+    enc = StateEncoding.IGNORE_UNCERTAINTY
+    g = load_dc150()
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    u_min, u_max = cu(g["u_min"]), cu(g["u_max"])
+    n_ok = 0
+    for tag in TAGS_DC150:
+        U = cu(g[tag + "/U"])
+        out = forward(cu(g["z0"]), U, model, cost, enc, u_min=u_min,
+                      u_max=u_max)
+        for nm, t in zip(FWD_NAMES, out):
+            ref = g["%s/fwd_bounded/%s" % (tag, nm)]
+            assert rel_err(t.cpu().numpy(), ref) < 1e-10, (tag, nm)
+        for branch in "ABCD":
+            for reg in (0.0, 1e-6, 1.0, 100.0):
+                key = "%s/bwd/%s/%g" % (tag, branch, reg)
+                kw = dict(reg=reg, V_zz_reg=branch in "CD")
+                if branch in "BD":
+                    kw.update(u_min=u_min, u_max=u_max, U=U)
+                k, K, st = backward(*out, return_status=True, **kw)
+                assert (st == 0) == bool(int(g[key + "/ok"])), key
+                if st == 0:
+                    n_ok += 1
+                    kb, Kb = k.cpu().numpy(), K.cpu().numpy()
+                    assert rel_err(kb, g[key + "/k"]) < 1e-8, key
+                    assert rel_err(Kb, g[key + "/K"]) < 1e-8, key
+                    assert elementwise_err(Kb, g[key + "/K"]) < 1e-6, key
+        k, K = cu(g[tag + "/bwd/B/1/k"]), cu(g[tag + "/bwd/B/1/K"])
+        Zn, Un, J = _control_law(model, out[0], U, k, K,
+                                 cu(g[tag + "/ls_fit/alphas"]), enc,
+                                 u_min=u_min, u_max=u_max, cost=cost,
+                                 return_cost=True)
+        T = 12  # stable prefix of diverging candidates
+        assert rel_err(Zn[:T].cpu().numpy(), g[tag + "/ls_fit/Z_new"][:T]) < 1e-9
+        assert rel_err(Un[:T].cpu().numpy(), g[tag + "/ls_fit/U_new"][:T]) < 1e-9
+        Jr = g[tag + "/ls_fit/J"]
+        fin = np.isfinite(Jr)
+        assert np.allclose(J.cpu().numpy()[fin], Jr[fin], rtol=1e-6)
+    assert n_ok >= 20
+    env = mod.DoubleCartpoleEnv(dt=dt)
+    ctrl = pddp_amd.controllers.iLQRController(env, model, cost)
+    trace = []
+    assert int(g["fit_bounded/N"]) == 150
+    Z, U, state = ctrl.fit(
+        cu(g["fit_bounded/U0"]), encoding=enc,
+        n_iterations=int(g["fit_bounded/n_iterations"]), u_min=u_min,
+        u_max=u_max, z0=cu(g["z0"]),
+        on_iteration=lambda i, st, Z, U, J: trace.append(
+            (i, int(st), float(J), ctrl._mu, ctrl._delta)))
+    ref = g["fit_bounded/trace"]
+    got = np.array(trace)
+    assert got.shape == ref.shape
+    assert np.array_equal(got[:, :2], ref[:, :2])
+    assert np.allclose(got[:, 2], ref[:, 2], rtol=1e-8)
+    assert np.array_equal(got[:, 3:], ref[:, 3:])
+    assert int(state) == int(g["fit_bounded/state"])
+    assert rel_err(U.cpu().numpy(), g["fit_bounded/U"]) < 1e-6
+    assert rel_err(ctrl._K.cpu().numpy(), g["fit_bounded/K"]) < 1e-5
+    assert ctrl._solver.plugin is None
 
 
 def test_double_cartpole_full_covariance_fit_native_vs_plugin():

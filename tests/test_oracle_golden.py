@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 import oracle as orc
-from golden_util import (DT, FWD_NAMES, load, np_dtype, rel_err, tags)
+from golden_util import (DT, FWD_NAMES, TAGS_DC150, load, load_dc150, np_dtype,
+                         rel_err, tags)
 
 PROBLEMS = ["cartpole", "pendulum", "double_cartpole", "rendezvous"]
 # fp64: restatement vs reference differ only by summation order / LAPACK
@@ -215,6 +216,66 @@ def test_fit_trace_matches_reference(problem, mode):
     assert state == int(g[ft + "/state"])
     assert rel_err(U, g[ft + "/U"]) < 1e-5
     assert rel_err(Z, g[ft + "/Z"]) < 1e-5
+    assert rel_err(K, g[ft + "/K"]) < 1e-5
+
+
+def test_oracle_at_configs3_horizon_matches_reference():
+    """BASELINE configs[3]'s horizon (double cartpole, N = 150) against the
+    reference's own outputs (tools/make_golden.py --dc-default): bounded
+    forward pass, the four backward branches x four regularisations, the fit
+    schedule's line search, and the three-iteration bounded fit (11 attempts)."""
+    g = load_dc150()
+    o = orc.load(np.float64)
+    p = orc.make_problem("double_cartpole", DT["double_cartpole"])
+    kwb = dict(u_min=g["u_min"], u_max=g["u_max"])
+    n_ok = 0
+    for tag in TAGS_DC150:
+        U = g[tag + "/U"]
+        out = o.forward(p, g["z0"], U, **kwb)
+        for nm in FWD_NAMES:
+            err = rel_err(out[nm], g["%s/fwd_bounded/%s" % (tag, nm)])
+            assert err < 1e-11, (tag, nm, err)
+        f = {nm: g["%s/fwd_bounded/%s" % (tag, nm)] for nm in FWD_NAMES}
+        for branch in "ABCD":
+            for reg in (0.0, 1e-6, 1.0, 100.0):
+                key = "%s/bwd/%s/%g" % (tag, branch, reg)
+                kw = dict(reg=reg, V_zz_reg=branch in "CD")
+                if branch in "BD":
+                    kw.update(U=U, **kwb)
+                k, K, status = o.backward(f["F_z"], f["F_u"], f["L_z"],
+                                          f["L_u"], f["L_zz"], f["L_uz"],
+                                          f["L_uu"], **kw)
+                assert int(g[key + "/ok"]) == (status == 0), (key, status)
+                if status == 0:
+                    n_ok += 1
+                    assert rel_err(k, g[key + "/k"]) < 1e-9, key
+                    assert rel_err(K, g[key + "/K"]) < 1e-9, key
+        alphas = g[tag + "/ls_fit/alphas"]
+        Zn, Un = o.control_law(p, f["Z"], U, g[tag + "/bwd/B/1/k"],
+                               g[tag + "/bwd/B/1/K"], alphas, g["u_min"],
+                               g["u_max"])
+        J = o.trajectory_cost(p, Zn, Un)
+        Zr, Ur, Jr = (g["%s/ls_fit/%s" % (tag, nm)] for nm in
+                      ("Z_new", "U_new", "J"))
+        T = 12  # (candidates of reg = 1 gains diverge on long horizons)
+        assert rel_err(Zn[:T], Zr[:T]) < 1e-9 and rel_err(Un[:T], Ur[:T]) < 1e-9
+        assert np.array_equal(np.isfinite(J), np.isfinite(Jr))
+        fin = np.isfinite(Jr)
+        assert np.allclose(J[fin], Jr[fin], rtol=1e-6)
+    assert n_ok >= 20
+    ft = "fit_bounded"
+    assert int(g[ft + "/N"]) == 150
+    Z, U, K, state, trace = o.fit(p, g["z0"], g[ft + "/U0"],
+                                  1.025 ** (-np.arange(10.0) ** 2),
+                                  n_iterations=int(g[ft + "/n_iterations"]),
+                                  **kwb)
+    ref = g[ft + "/trace"]
+    assert trace.shape == ref.shape
+    assert np.array_equal(trace[:, :2], ref[:, :2])
+    assert np.allclose(trace[:, 3:], ref[:, 3:], rtol=1e-12)
+    assert np.allclose(trace[:, 2], ref[:, 2], rtol=1e-7)
+    assert state == int(g[ft + "/state"])
+    assert rel_err(U, g[ft + "/U"]) < 1e-5
     assert rel_err(K, g[ft + "/K"]) < 1e-5
 
 

@@ -111,7 +111,19 @@ def capture_backward(store, prefix, Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu,
                 store[key + "/err"] = np.array(str(e)[:60])
 
 
-def capture_problem(name, enc_name, dtype, Ns, with_fit):
+def capture_problem(name, enc_name, dtype, Ns, with_fit, fit_iters=None,
+                    suffix="", lean_long=False, steps_from_mu=None):
+    """`lean_long`: at the horizons after the first keep only what the tests
+    read - the bounded forward pass, the four backward branches and the fit
+    schedule's line search (a record of n = 27, N = 150 is 0.9 MB per tensor).
+    `fit_iters`: iteration counts of the bounded fit trace; `suffix`: appended
+    to the file's encoding key.  `steps_from_mu`: instead of `fit` (which
+    starts at mu = 0, ilqr.py:277, 364-367) `fit_iters` calls of the
+    controller's own `step` (ilqr.py:183-235) with the regularisation state
+    preset to (mu, delta_0) - for starts from which `fit` RAISES in the
+    reference: under a Gaussian encoding a line-search candidate that leaves
+    the basin hands the cost a covariance that is not positive definite, and
+    `_trajectory_cost` (ilqr.py:159) is outside `_step`'s try block."""
     model_cls, cost_cls, env_cls, dt, bound, mean0 = PROBLEMS[name]
     encoding = ENCODINGS[enc_name]
     store = {}
@@ -143,7 +155,8 @@ def capture_problem(name, enc_name, dtype, Ns, with_fit):
             if kind == "seeded":
                 U = 30 * U  # exercises the clamp in forward() on pendulum
             store[tag + "/U"] = np_(U)
-            for bounded in (False, True):
+            lean = lean_long and N != Ns[0]
+            for bounded in ((True,) if lean else (False, True)):
                 bt = tag + ("/fwd_bounded" if bounded else "/fwd")
                 kw = dict(u_min=u_min, u_max=u_max) if bounded else {}
                 out = forward(z0, U.clone(), model, cost, encoding, **kw)
@@ -162,15 +175,39 @@ def capture_problem(name, enc_name, dtype, Ns, with_fit):
             capture_backward(store, tag + "/bwd", Z, F_z, F_u, L, L_z, L_u,
                              L_zz, L_uz, L_uu, U, u_min, u_max, regs)
 
-            # Line search from the branch-B (controller default) gains, reg=1.
-            k, K = backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu,
-                            reg=1.0, u_min=u_min, u_max=u_max, U=U)
-            for aname, alphas in (("fit", ALPHAS_FIT(dtype)),
-                                  ("mpc", ALPHAS_MPC())):
+            # Line search from the branch-B (controller default) gains, reg=1
+            # (at the long horizons of --dc-default also from the reg = 100
+            # gains, whose candidates all stay in the basin).
+            for aname, alphas, ls_reg in (
+                    ("fit", ALPHAS_FIT(dtype), 1.0),
+                    ("mpc", ALPHAS_MPC(), 1.0),
+                    ("fit100", ALPHAS_FIT(dtype), 100.0)):
+                if (lean and aname == "mpc") or (not lean and
+                                                 aname == "fit100"):
+                    continue
+                k, K = backward(Z, F_z, F_u, L, L_z, L_u, L_zz, L_uz, L_uu,
+                                reg=ls_reg, u_min=u_min, u_max=u_max, U=U)
                 alphas = alphas.to(dtype)
                 Zb, Ub = _control_law(model, Z, U, k, K, alphas, encoding, {},
                                       u_min=u_min, u_max=u_max)
-                J = _trajectory_cost(cost, Zb, Ub, encoding, {})
+                try:
+                    J = _trajectory_cost(cost, Zb, Ub, encoding, {})
+                except RuntimeError:
+                    # a candidate that left the basin (a covariance that is no
+                    # longer positive definite, encoding.py:552-563): the
+                    # reference raises for the whole batch; step size by step
+                    # size, NaN where it raises
+                    Js = []
+                    for a in range(alphas.shape[0]):
+                        try:
+                            Js.append(_trajectory_cost(
+                                cost, Zb[:, a:a + 1], Ub[:, a:a + 1],
+                                encoding, {})[0])
+                        except RuntimeError:
+                            Js.append(torch.tensor(float("nan"), dtype=dtype))
+                    J = torch.stack(Js)
+                    print("  ", tag, aname, "candidates the reference raises "
+                          "on:", int(torch.isnan(J).sum()))
                 store["%s/ls_%s/alphas" % (tag, aname)] = np_(alphas)
                 store["%s/ls_%s/Z_new" % (tag, aname)] = np_(Zb)
                 store["%s/ls_%s/U_new" % (tag, aname)] = np_(Ub)
@@ -178,7 +215,8 @@ def capture_problem(name, enc_name, dtype, Ns, with_fit):
 
     if with_fit:
         N = with_fit
-        for n_iter, bounded in (((25, True), (8, False))
+        for n_iter, bounded in (((fit_iters, True),) if fit_iters else
+                                ((25, True), (8, False))
                                 if enc_name == "ignore" else ((6, True),)):
             env = env_cls(dt=dt, model=model_cls(dt))
             env._state = mean.clone()
@@ -190,6 +228,43 @@ def capture_problem(name, enc_name, dtype, Ns, with_fit):
                 trace.append((i, int(state), float(J), ctrl._mu, ctrl._delta))
 
             kw = dict(u_min=u_min, u_max=u_max) if bounded else {}
+            if steps_from_mu is not None:
+                # what `fit` itself does from here
+                try:
+                    ctrl.fit(U.clone(), encoding=encoding, n_iterations=1,
+                             quiet=True, **kw)
+                    store["steps/fit_raises"] = np.array(0)
+                except RuntimeError as e:
+                    store["steps/fit_raises"] = np.array(1)
+                    store["steps/fit_error"] = np.array(str(e)[:60])
+                del trace[:]
+                ctrl._U_nominal = U.clone()
+                ctrl._mu, ctrl._delta = float(steps_from_mu), ctrl._delta_0
+                z0s = env.get_state().encode(encoding).detach().to(dtype)
+                assert torch.equal(z0s, z0)
+                alphas = ALPHAS_FIT(dtype).to(dtype)
+                done = 0
+                for it in range(n_iter):
+                    try:
+                        state = ctrl.step(z0s, U=None, i=it, encoding=encoding,
+                                          alphas=alphas, quiet=True,
+                                          on_iteration=on_iteration, **kw)
+                    except RuntimeError as e:
+                        print("   step", it, "raises:", str(e)[:60])
+                        break
+                    done += 1
+                store["steps/mu0"] = np.array(float(steps_from_mu))
+                store["steps/N"] = np.array(N)
+                store["steps/n_steps"] = np.array(done)
+                store["steps/alphas"] = np_(alphas)
+                store["steps/U0"] = np_(U)
+                store["steps/trace"] = np.array(trace, dtype=np.float64)
+                store["steps/Z"] = np_(ctrl._Z_nominal)
+                store["steps/U"] = np_(ctrl._U_nominal)
+                store["steps/K"] = np_(ctrl._K)
+                store["steps/state"] = np.array(int(state))
+                print("   steps from mu = %g:" % steps_from_mu, trace)
+                continue
             Zf, Uf, state = ctrl.fit(U.clone(), encoding=encoding,
                                      n_iterations=n_iter, quiet=True,
                                      on_iteration=on_iteration, **kw)
@@ -204,7 +279,8 @@ def capture_problem(name, enc_name, dtype, Ns, with_fit):
             store[ft + "/state"] = np.array(int(state))
 
     dname = "f64" if dtype == torch.float64 else "f32"
-    path = os.path.join(OUT, "%s_%s_%s.npz" % (name, enc_name, dname))
+    path = os.path.join(OUT, "%s_%s%s_%s.npz" % (name, enc_name, suffix,
+                                                  dname))
     np.savez_compressed(path, **store)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024.0))
 
@@ -706,6 +782,18 @@ def main():
         for enc in ("default", "fullcov", "variance", "std"):
             capture_problem("rendezvous", enc, torch.float64, [5, 12],
                             with_fit=6)
+        return
+    if "--dc-default" in sys.argv:
+        # round 5: BASELINE configs[3]'s own shape - the double cartpole under
+        # DEFAULT (n = 27) at horizons 5 and 150, and under IGNORE_UNCERTAINTY
+        # at horizon 150, each with a three-iteration fit at N = 150
+        # (double_cartpole/model.py:100-195 through ilqr.py:393-674)
+        capture_problem("double_cartpole", "default", torch.float64, [5, 150],
+                        with_fit=150, fit_iters=3, lean_long=True,
+                        steps_from_mu=1000.0)
+        capture_problem("double_cartpole", "ignore", torch.float64, [5, 150],
+                        with_fit=150, fit_iters=3, suffix="150",
+                        lean_long=True)
         return
     if "--default-only" in sys.argv:
         capture_problem("cartpole", "default", torch.float64, [5, 25],
