@@ -372,6 +372,29 @@ int pddp_search_accept_f64(const pddp_problem* problem, int B, int N, int A,
                            int32_t* iter, uint8_t* fresh, int32_t* n_live,
                            double* rec, double* L, void* stream);
 
+/* ---- a whole round in ONE launch: pddp_sweep_nominal_f32 followed by
+ * pddp_search_accept_f32(L = NULL) for the same arguments, the workgroups
+ * going straight from their sweep to their line search (csrc/round_n4.hip:
+ * the gains, the nominal's rows, its cost and the sweep's status stay in LDS /
+ * registers between the phases; no second launch, no second prologue).  Results
+ * are the two calls' bit for bit (replaces ilqr.py:125-181 of one attempt:
+ * backward, _control_law, _trajectory_cost, accept / reject, mu schedule).
+ * `mu` is both the sweep's `reg` and the schedule's state; `scratch` as `rec`
+ * of pddp_search_accept_* with L == NULL (B (N+1) n scalars).  Cartpole under
+ * IGNORE_UNCERTAINTY, f32, bounded, PDDP_BRANCH_EIG, A <= 16, N <= 127 and at
+ * most 4096 trajectories (one workgroup of 16 per CU); PDDP_E_UNSUPPORTED
+ * otherwise (make the two calls then). */
+int pddp_round_nominal_f32(const pddp_problem* problem, int B, int N, int A,
+                           float* Z, float* U, const float* alphas,
+                           const float* u_min, const float* u_max, int branch,
+                           uint8_t* active, uint8_t* fresh, float* gains,
+                           int32_t* bwd_status, float* L, float* J_opt,
+                           float* Zc, float* Uc, float* Jc, double tol,
+                           double max_reg, int n_iterations, float* gains_acc,
+                           double* mu, double* delta, int32_t* state,
+                           int32_t* iter, int32_t* n_live, float* scratch,
+                           void* stream);
+
 /* The variant entry with two HIP events (pddp_event_create) attached to the
  * sweep's own dispatch: elapsed(start, stop) is the kernel's duration as
  * rocprofv3 --kernel-trace reports it (bench.py's roofline leg). */

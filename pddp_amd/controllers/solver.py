@@ -120,6 +120,9 @@ class ILQRSolver(object):
         self._model_gen = None  # model generation the plugin graphs captured
         self.graph_rollout = False  # nominal rollout of a plugin as a hipGraph
         self._fused = None  # None: untried, True / False: fused kernel applies
+        # the whole round in one launch (round_nominal): None untried, True /
+        # False applies / does not (set False to force the two launches)
+        self._one_launch = None
         self._derivs_due = True
         # The sweep that evaluates the derivative records itself, from the
         # nominal (pddp_sweep_nominal_f32): None untried, then True / False.
@@ -345,6 +348,41 @@ class ILQRSolver(object):
         return True
 
     @_on_device
+    def round_nominal(self, tol, max_reg, n_iterations, events=None):
+        """A whole round in ONE launch (pddp_round_nominal_f32,
+        csrc/round_n4.hip): the sweep from the nominal, then line search,
+        accept and regularisation schedule in the same workgroups - the two
+        launches' results bit for bit.  False when it does not apply (the
+        caller then makes the two calls)."""
+        if self.dtype != torch.float32 or self.plugin is not None or \
+                self.u_min is None or self.u_max is None:
+            self._one_launch = False
+            return False
+        p = _native.ptr
+        if events is not None:
+            _native.lib().pddp_attach_events(*events)
+        rc = _native.lib().pddp_round_nominal_f32(
+            self._pp, self.B, self.N, self.A, p(self.Z), p(self.U),
+            p(self.alphas), p(self.u_min), p(self.u_max), int(self.branch),
+            p(self.active), p(self.fresh), p(self.gains), p(self.bwd_status),
+            p(self.L), p(self.J_opt), p(self.Zc), p(self.Uc), p(self.Jc),
+            float(tol), float(max_reg), int(n_iterations), p(self.gains_acc),
+            p(self.mu), p(self.delta), p(self.state), p(self.iter),
+            p(self.n_live), p(self._rec), self._s())
+        if rc == _native.E_UNSUPPORTED:
+            if events is not None:
+                _native.lib().pddp_attach_events(None, None)
+            self._one_launch = False
+            return False
+        _native.check(rc, "pddp_round_nominal_f32")
+        self._one_launch = True
+        self._nominal_sweep = True
+        self._fused = True
+        self._rec_stale = True
+        self._derivs_due = False
+        return True
+
+    @_on_device
     def line_search(self, active=None, use_status=True):
         if self.plugin is not None:
             return self.plugin.line_search(self, active, use_status)
@@ -406,6 +444,12 @@ class ILQRSolver(object):
         nominals (so the first call is a no-op from the second round on)."""
         if variant is None:
             variant = self.kernel_variant
+        if self._one_launch is not False and variant == 0 and \
+                self._nominal_sweep is not False and \
+                self._fused is not False and search_events is None and \
+                self.round_nominal(tol, max_reg, n_iterations,
+                                   events=backward_events):
+            return
         if self._nominal_sweep is not False and variant == 0 and \
                 self._fused is not False and \
                 self.sweep_nominal(events=backward_events):

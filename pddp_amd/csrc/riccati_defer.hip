@@ -137,3 +137,11 @@ extern "C" int pddp_debug_elem_marks(long long* out) {
   return 0;
 }
 #endif
+#ifdef PDDP_WG_TIMELINE
+extern "C" int pddp_debug_elem_timeline(long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4e::g_elem_timeline),
+                      sizeof(long long) * 1024 * 12);
+  return 0;
+}
+#endif

@@ -219,6 +219,33 @@ __device__ long long g_elem_marks[8];
 #define PDDP_EM_NOW() 0
 #endif
 
+#ifdef PDDP_WG_TIMELINE
+// when every workgroup starts, reaches its first step, ends (wall clock, 100
+// MHz, the same counter for the whole chip) and where it ran: wavefront 0
+// (sweep) in slots 0-3, wavefront 4 (its generator) in 4-7, 8 HW_ID, 9 XCC_ID,
+// 10 / 11 the shader clock at begin / end (tools/wg_timeline.py)
+__device__ long long g_elem_timeline[1024][12];
+#define PDDP_TL(I)                                                            \
+  do {                                                                        \
+    if ((threadIdx.x & 255) == 0 && blockIdx.x < 1024)                        \
+      g_elem_timeline[blockIdx.x][(I) + 4 * (threadIdx.x >> 8)] =             \
+          wall_clock64();                                                     \
+  } while (0)
+#define PDDP_TL_HW(I)                                                         \
+  do {                                                                        \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                              \
+      g_elem_timeline[blockIdx.x][8] =                                        \
+          __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));               \
+      g_elem_timeline[blockIdx.x][9] =                                        \
+          __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));               \
+      g_elem_timeline[blockIdx.x][I] = clock64();                             \
+    }                                                                         \
+  } while (0)
+#else
+#define PDDP_TL(I)
+#define PDDP_TL_HW(I)
+#endif
+
 // OVL = false: four independent wavefronts per workgroup, each evaluates its
 // own records between its blocks of steps (LDS: 17.6 KB per wavefront - up to
 // two workgroups per CU).
@@ -229,15 +256,36 @@ __device__ long long g_elem_marks[8];
 // its SIMD to itself uses a fifth of its issue slots, the partner's 250
 // instructions per block fit into the rest).  LDS: 31 KB per pair - one
 // workgroup per CU, for batches of up to 16 trajectories per CU.
-template <unsigned QM, bool OVL>
-__global__ __launch_bounds__((OVL ? 2 : 1) * kWaves * kWave) void
-riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
-                       ProblemT<float> prob) {
+//
+// ROUND (round_n4.hip; implies OVL): the sweep is the first phase of a launch
+// that goes on with the line search of the same four trajectories in the same
+// wavefronts (line_search_lds.hpp).  The gains then ALSO land in a region of
+// LDS in the layout the search reads ([t][k, K0..K3] per trajectory), the
+// generator stages the nominal's states and actions into the image buffer the
+// last block does not use, the nominal's cost is handed over in LDS, and both
+// wavefronts of a pair leave through one more barrier instead of returning.
+// Returns false when the pair has nothing to do (both wavefronts alike).
+struct RoundOut {       // (ROUND) what the search phase needs, per lane
+  const float* Zs;      // this lane's trajectory: states [N + 1][4] in LDS
+  const float* Us;      //   actions [N]
+  const float* Gs;      //   gains [N][5]
+  int status;           // sweep wavefront: PDDP_BWD_* of the trajectory
+  float J_opt;          // cost of the nominal (summed here when it was new)
+};
+constexpr int round_zu_stride(int N) { return (5 * N + 4 + 3) & ~3; }
+constexpr int round_gains_floats(int N) { return (kTrajW * N * kGain + 3) & ~3; }
+
+template <unsigned QM, bool OVL, bool ROUND>
+PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
+                              const GenArgs<float>& gen,
+                              const ProblemT<float>& prob,
+                              unsigned char* smem_raw, RoundOut& ro) {
+  static_assert(OVL || !ROUND, "");
   using T = float;
   constexpr int MODEL = PDDP_MODEL_CARTPOLE;
   constexpr RecLayout lay(4, 1);
-  constexpr int kPairLds = OVL ? kPairLdsOvl : kPairLdsInl;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int kPairLds = OVL ? kPairLdsOvl + (ROUND ? round_gains_floats(a.N) : 0)
+                           : kPairLdsInl;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int pair = OVL ? (wave & (kWaves - 1)) : wave;
@@ -257,10 +305,12 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
   const int nblk = (N + kBlk - 1) / kBlk;
   // (both wavefronts of a pair decide alike: they own the same trajectories;
   // s_barrier does not wait for wavefronts that have ended)
-  if (b0 >= a.B) return;
+  if (b0 >= a.B) return false;
   const bool counted = exists && (a.active == nullptr || a.active[bc] != 0);
-  if (!__any(counted)) return;
+  if (!__any(counted)) return false;
   PDDP_EM_MARK(0);
+  PDDP_TL(0);
+  PDDP_TL_HW(10);
   const T umin = a.u_min[0], umax = a.u_max[0];
   const int rbase = row * kRowStride;
 
@@ -339,10 +389,44 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
     const bool sums = counted && (gen.fresh == nullptr || gen.fresh[bc] != 0);
     // (OVL: the terminal cost is the sweep wavefront's; inline: our own)
     const T Jrow = group_sum(Jacc) + (OVL ? term_w[row * kTermRow + 20] : l_term);
+    if constexpr (ROUND) {
+      // the cost the accept test compares with (ilqr.py:166): the new sum, or
+      // what the nominal already had
+      const T Jold = gen.J_opt[bc];
+      if (l == 0) term_w[row * kTermRow + 21] = sums ? Jrow : Jold;
+    }
     if (sums && l == 0) {
       gen.J_opt[bc] = Jrow;
       if (gen.fresh != nullptr) gen.fresh[bc] = 0;
     }
+  };
+  // the gains of a block's first `cnt` steps (t_top, t_top - 1, ...) from the
+  // dead image words they were left in (see `step`) to HBM - lane (row, l)
+  // stores step l's five words - and, ROUND, to the search's rows in LDS
+  [[maybe_unused]] T* const gains_w = img0 + kPairLdsOvl;  // (ROUND) [row][N][5]
+  auto flush_gains = [&](const T* ib, int t_top, int cnt) {
+    const T* sg = ib + l * kImg + rbase;
+    const f32x4 Kv = *reinterpret_cast<const f32x4*>(sg);
+    const T kv = sg[4];
+    if (exists && l < cnt) {
+      T* g = a.gains + ((size_t)bc * (size_t)N + (size_t)(t_top - l)) * kGain;
+      g[0] = kv; g[1] = Kv[0]; g[2] = Kv[1]; g[3] = Kv[2]; g[4] = Kv[3];
+      if constexpr (ROUND) {
+        T* gl = gains_w + (row * N + (t_top - l)) * kGain;
+        gl[0] = kv; gl[1] = Kv[0]; gl[2] = Kv[1]; gl[3] = Kv[2]; gl[4] = Kv[3];
+      }
+    }
+  };
+  [[maybe_unused]] T* const zu_w =
+      img0 + (nblk & 1) * kImgBuf + row * round_zu_stride(N);
+  // (ROUND) what the search reads, and the way out of the sweep phase
+  [[maybe_unused]] auto round_out = [&](int status_) {
+    ro.Zs = zu_w;
+    ro.Us = zu_w + (N + 1) * 4;
+    ro.Gs = gains_w + row * N * kGain;
+    ro.status = status_;
+    n4::lds_publish_barrier();  // the last barrier: gains, nominal, J_opt
+    ro.J_opt = term_w[row * kTermRow + 21];
   };
   if constexpr (OVL) {
     if (is_gen) {
@@ -350,13 +434,44 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
       // to do before its first block)
       request(0);
       pass(0, img0);
+      PDDP_TL(1);
       n4::lds_publish_barrier();  // barrier 0: block 0, the terminal state
       for (int jb = 1; jb < nblk; ++jb) {
+        // the gains of block jb - 2 leave from the buffer block jb is about
+        // to be written to (the sweep wavefront only flushes its last block:
+        // ~700 cycles a block off its chain)
+        if (jb >= 2)
+          flush_gains(img0 + (jb & 1) * kImgBuf, N - 1 - kBlk * (jb - 2), kBlk);
         pass(jb, img0 + (jb & 1) * kImgBuf);
         n4::lds_publish_barrier();  // barrier jb (LDS only: no vmcnt)
       }
+      if (nblk >= 2)
+        flush_gains(img0 + (nblk & 1) * kImgBuf, N - 1 - kBlk * (nblk - 2), kBlk);
+      if constexpr (ROUND) {
+        // the nominal's rows for the search, into the image buffer the last
+        // block does not use (its gains were flushed just above); every load
+        // requested before the first write: one memory latency
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        constexpr int kCh = 8;  // N + 1 <= 128 (checked by the launcher)
+        f32x4 zc[kCh];
+        T uc[kCh];
+#pragma unroll
+        for (int c = 0; c < kCh; ++c) {
+          const int tz = l + 16 * c;
+          zc[c] = *reinterpret_cast<const f32x4*>(Zg + 4 * (tz <= N ? tz : N));
+          uc[c] = Ug[tz < N ? tz : 0];
+        }
+#pragma unroll
+        for (int c = 0; c < kCh; ++c) {
+          const int tz = l + 16 * c;
+          if (tz <= N) *reinterpret_cast<f32x4*>(zu_w + 4 * tz) = zc[c];
+          if (tz < N) zu_w[(N + 1) * 4 + tz] = uc[c];
+        }
+      }
       finish_costs();
-      return;
+      PDDP_TL(3);
+      if constexpr (ROUND) round_out(PDDP_BWD_OK);
+      return true;
     }
   }
 
@@ -476,19 +591,9 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
              mul_nc(c, mul_nc(q.Quzr, Quzc)));
     vc = fma_(wv, Quzc, q.Qzc);
   };
-  // the gains of the block's first `cnt` steps (t_top, t_top - 1, ...) to
-  // HBM: lane (row, l) stores step l's five words
-  auto flush_gains = [&](const T* ib, int t_top, int cnt) {
-    const T* sg = ib + l * kImg + rbase;
-    const f32x4 Kv = *reinterpret_cast<const f32x4*>(sg);
-    const T kv = sg[4];
-    if (exists && l < cnt) {
-      T* g = a.gains + ((size_t)bc * (size_t)N + (size_t)(t_top - l)) * kGain;
-      g[0] = kv; g[1] = Kv[0]; g[2] = Kv[1]; g[3] = Kv[2]; g[4] = Kv[3];
-    }
-  };
 
   PDDP_EM_MARK(1);
+  PDDP_TL(1);
   int t = N - 1;
   for (int jb = 0; jb < nblk; ++jb) {
     T* ib = img0;
@@ -512,7 +617,8 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
         step(wb, ib, s + 1);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      flush_gains(ib, t, kBlk);
+      // (OVL: the generator flushes every block but the last)
+      if (!OVL || jb + 1 == nblk) flush_gains(ib, t, kBlk);
       t -= kBlk;
     } else {
       // the last, partial block
@@ -539,9 +645,23 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
     }
   }
   PDDP_EM_MARK(2);
+  PDDP_TL(2);
   if (counted && l == 0) a.status[bc] = status;
   if constexpr (!OVL) finish_costs();
   PDDP_EM_MARK(3);
+  PDDP_TL(3);
+  PDDP_TL_HW(11);
+  if constexpr (ROUND) round_out(status);
+  return true;
+}
+
+template <unsigned QM, bool OVL>
+__global__ __launch_bounds__((OVL ? 2 : 1) * kWaves * kWave) void
+riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
+                       ProblemT<float> prob) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  RoundOut ro;
+  elem_sweep_body<QM, OVL, false>(a, gen, prob, smem_raw, ro);
 }
 
 }  // namespace n4e

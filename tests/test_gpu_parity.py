@@ -1726,8 +1726,44 @@ def _sweep_from_nominal_case(B, N, same_arithmetic):
     if same_arithmetic:
         assert float(per.max()) < 3e-4, float(per.max())
     else:
-        assert float(per.median()) < 3e-5 and float(per.max()) < 2e-2, (
-            float(per.median()), float(per.max()))
+        assert float(per.median()) < 3e-5, float(per.median())
+        # ... and each of the two against the fp64 oracle on the same records
+        # (the fp32 oracle's, cast up): trajectory by trajectory the sweep
+        # from the nominal is no further from it than F32_RATIO x the recorded
+        # sweep (or 3e-4 of the trajectory's largest gain: two draws from the
+        # same heavy-tailed error distribution - measured ratios reach 6 at the
+        # 1e-4 level), never further than 1e-3 unless the recorded sweep is off
+        # by a quarter of that itself, and no worse in the median
+        o32 = orc.load(np.float32)
+        names = ("F_z", "F_u", "L_z", "L_u", "L_zz", "L_uz", "L_uu")
+        idx = np.where(live.numpy())[0]
+        ok = (ref["bwd_status"].cpu().numpy() == 0)
+        e_new, e_rec = [], []
+        gains_new, gains_rec = s.gains.cpu().numpy(), ref["gains"].cpu().numpy()
+        for b in idx[:48]:
+            if not ok[b]:
+                continue
+            f = o32.forward(op, z0[b], U[b], u_min, u_max)
+            kw = dict(reg=1.0, u_min=u_min, u_max=u_max, U=U[b])
+            k64, K64, st64 = _backward64([f[nm] for nm in names], kw)
+            if st64 != 0:
+                continue
+            g64 = np.concatenate([k64.reshape(N, -1), K64.reshape(N, -1)], 1)
+            scale = np.abs(g64).max()
+            e_new.append(np.abs(gains_new[b] - g64).max() / scale)
+            e_rec.append(np.abs(gains_rec[b] - g64).max() / scale)
+        e_new, e_rec = np.array(e_new), np.array(e_rec)
+        STATS.append(dict(test="sweep_from_nominal_vs_recorded", B=B, N=N,
+                          new_med_max=[float(np.median(e_new)),
+                                       float(e_new.max())],
+                          rec_med_max=[float(np.median(e_rec)),
+                                       float(e_rec.max())]))
+        assert len(e_new) >= min(len(idx), 48) // 2
+        assert np.all(e_new <= np.maximum(F32_RATIO * e_rec, 3e-4)), (
+            e_new.tolist(), e_rec.tolist())
+        assert np.all(e_new <= np.maximum(4.0 * e_rec, 1e-3)), (
+            e_new.tolist(), e_rec.tolist())
+        assert np.median(e_new) <= 2.0 * np.median(e_rec) + 1e-6
     assert torch.equal(s.bwd_status.cpu()[live], ref["bwd_status"].cpu()[live])
     assert (s.bwd_status.cpu()[~live] == -7).all()
     # (stage costs: rows of active trajectories; an inactive row is left alone)
@@ -1761,6 +1797,69 @@ def test_round_from_nominal_equals_round_with_records(kernel):
     the plain recursion: values to 2e-2 after 14 rounds.)"""
     with _nominal_kernel(kernel):
         _rounds_side_by_side(2e-2)
+
+
+@pytest.mark.parametrize("B,N", [(64, 40), (37, 33), (130, 100), (21, 16),
+                                 (9, 5), (16, 127), (3, 1), (70, 17)])
+def test_one_launch_round_equals_two_launches(B, N):
+    """pddp_round_nominal_f32 (csrc/round_n4.hip: the sweep from the nominal
+    and then line search + accept in the SAME workgroups, one launch) against
+    pddp_sweep_nominal_f32 followed by pddp_search_accept_f32(L = NULL), round
+    by round through a fit: the same device functions, so decisions, masks,
+    regularisation and status are identical and the sweep's outputs (gains,
+    stage costs, J_opt) bit for bit; the search's outputs to rounding (the same
+    closed forms inlined into another kernel are contracted into FMAs
+    differently, Makefile)."""
+    s, op, z0, U, u_min, u_max = _setup("cartpole", "f32", B, N, seed=5)
+    s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    names = ("Z", "U", "L", "J_opt", "mu", "delta", "state", "iter", "active",
+             "fresh", "gains", "gains_acc", "Jc", "bwd_status", "n_live")
+    exact = ("mu", "delta", "state", "iter", "active", "fresh", "bwd_status",
+             "n_live")
+    tol_roll = 2e-3  # (diverging candidates amplify a rounding difference)
+    accepted = 0
+    for r in range(14):
+        pre = {k: getattr(s, k).clone() for k in names}
+        s._one_launch = None
+        s.round(n_iterations=10)
+        assert s._one_launch is True
+        one = {k: getattr(s, k).clone() for k in names}
+        for k in names:  # rewind, run the two launches
+            getattr(s, k).copy_(pre[k])
+        s._one_launch = False
+        s.round(n_iterations=10)
+        assert s._nominal_sweep is True and s._fused is True
+        for k in exact:
+            assert torch.equal(one[k], getattr(s, k)), (r, k)
+        swept = pre["active"].bool()
+        ok = swept & (s.bwd_status == 0)
+        assert torch.equal(one["gains"][ok], s.gains[ok]), r
+        assert torch.equal(one["L"][swept], s.L[swept]), r
+        acc = (s.state == 1) | (s.state == 5)
+        assert torch.equal(one["gains_acc"][acc & swept],
+                           s.gains_acc[acc & swept]), r
+        for k in ("Z", "U", "J_opt"):
+            x, y = one[k].double(), getattr(s, k).double()
+            assert float((x - y).abs().max()) <= tol_roll * float(
+                y.abs().max().clamp_min(1.0)), (r, k)
+        x, y = one["Jc"][ok].double(), s.Jc[ok].double()
+        if x.numel():
+            assert torch.equal(torch.isfinite(x), torch.isfinite(y)), (r, "Jc")
+            fin = torch.isfinite(y) & (y.abs() < 1e6)
+            rel = ((x - y).abs() / y.abs().clamp_min(1.0))[fin]
+            # (from a random nominal most step sizes roll out chaotically:
+            # half of the candidates agree to rounding, nine in ten to 2e-3,
+            # and so does every trajectory's best)
+            assert float(rel.median()) <= 2e-6, (r, "Jc")
+            assert float(rel.quantile(0.9)) <= tol_roll, (r, "Jc")
+            bx = torch.nan_to_num(x, nan=1e30).amin(1)
+            by = torch.nan_to_num(y, nan=1e30).amin(1)
+            assert float(((bx - by).abs() / by.abs().clamp_min(1.0)).max()) \
+                <= tol_roll, (r, "Jc min")
+        accepted += int(acc.sum())
+        for k in names:  # go on from the one-launch state
+            getattr(s, k).copy_(one[k])
+    assert accepted > B // 2
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
@@ -2114,9 +2213,13 @@ def test_fit_through_the_record_free_round_vs_oracle():
     STATS.append(dict(test="fit_record_free", attempts=total, hip=hip_len,
                       o32=o32_len, identical_trajectories=full,
                       J_err_max=max(e_J)))
-    assert hip_len >= 0.9 * o32_len and hip_len >= 0.5 * total, (
+    # measured (profiles/r04_timed_kernels_parity_rows.json): 1003 of 1003
+    # attempts identical to the fp64 oracle's for the kernels AND for the fp32
+    # oracle, costs to 1.4e-5.  Held to: no more than 1 % of the attempts
+    # short of the fp32 oracle's agreement, 95 % of all attempts, costs 3e-5
+    assert hip_len >= 0.99 * o32_len and hip_len >= 0.95 * total, (
         hip_len, o32_len, total)
-    assert max(e_J) < 1e-4, max(e_J)
+    assert max(e_J) < 3e-5, max(e_J)
 
 
 @pytest.mark.parametrize("H", [64, 128, 200])
