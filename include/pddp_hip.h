@@ -383,7 +383,11 @@ int pddp_search_accept_f64(const pddp_problem* problem, int B, int N, int A,
  * of pddp_search_accept_* with L == NULL (B (N+1) n scalars).  Cartpole under
  * IGNORE_UNCERTAINTY, f32, bounded, PDDP_BRANCH_EIG, A <= 16, N <= 127 and at
  * most 4096 trajectories (one workgroup of 16 per CU); PDDP_E_UNSUPPORTED
- * otherwise (make the two calls then). */
+ * otherwise (make the two calls then).
+ * `rounds` >= 1: that many attempts of every trajectory in the one launch,
+ * exactly as `rounds` calls with rounds = 1 (trajectories are independent and
+ * a workgroup owns its sixteen for the whole launch; one that has left the fit
+ * - active[b] == 0 - is skipped, as by a later call). */
 int pddp_round_nominal_f32(const pddp_problem* problem, int B, int N, int A,
                            float* Z, float* U, const float* alphas,
                            const float* u_min, const float* u_max, int branch,
@@ -393,7 +397,7 @@ int pddp_round_nominal_f32(const pddp_problem* problem, int B, int N, int A,
                            double max_reg, int n_iterations, float* gains_acc,
                            double* mu, double* delta, int32_t* state,
                            int32_t* iter, int32_t* n_live, float* scratch,
-                           void* stream);
+                           int rounds, void* stream);
 
 /* The variant entry with two HIP events (pddp_event_create) attached to the
  * sweep's own dispatch: elapsed(start, stop) is the kernel's duration as

@@ -348,12 +348,16 @@ class ILQRSolver(object):
         return True
 
     @_on_device
-    def round_nominal(self, tol, max_reg, n_iterations, events=None):
+    def round_nominal(self, tol, max_reg, n_iterations, events=None,
+                      rounds=1):
         """A whole round in ONE launch (pddp_round_nominal_f32,
         csrc/round_n4.hip): the sweep from the nominal, then line search,
         accept and regularisation schedule in the same workgroups - the two
-        launches' results bit for bit.  False when it does not apply (the
-        caller then makes the two calls)."""
+        launches' results (the sweep's bit for bit, the search's to rounding).
+        `rounds` > 1: that many rounds back to back in the one launch (a
+        workgroup owns its trajectories; no launch boundary between their
+        attempts).  False when it does not apply (the caller then makes the two
+        calls)."""
         if self.dtype != torch.float32 or self.plugin is not None or \
                 self.u_min is None or self.u_max is None:
             self._one_launch = False
@@ -368,7 +372,7 @@ class ILQRSolver(object):
             p(self.L), p(self.J_opt), p(self.Zc), p(self.Uc), p(self.Jc),
             float(tol), float(max_reg), int(n_iterations), p(self.gains_acc),
             p(self.mu), p(self.delta), p(self.state), p(self.iter),
-            p(self.n_live), p(self._rec), self._s())
+            p(self.n_live), p(self._rec), int(rounds), self._s())
         if rc == _native.E_UNSUPPORTED:
             if events is not None:
                 _native.lib().pddp_attach_events(None, None)
@@ -434,6 +438,21 @@ class ILQRSolver(object):
             _native.lib().pddp_attach_events(None, None)  # nothing launched
             self.last_search_timed = None
         return self._fused
+
+    def rounds(self, count, tol=5e-6, max_reg=1e10, n_iterations=50,
+               events=None):
+        """`count` rounds; in one launch where pddp_round_nominal_f32 applies
+        (`events` are then attached to that launch), `count` calls of round()
+        otherwise."""
+        if count > 1 and self._one_launch is not False and \
+                self.kernel_variant == 0 and \
+                self._nominal_sweep is not False and \
+                self._fused is not False and \
+                self.round_nominal(tol, max_reg, n_iterations, events=events,
+                                   rounds=count):
+            return
+        for _ in range(count):
+            self.round(tol, max_reg, n_iterations)
 
     def round(self, tol=5e-6, max_reg=1e10, n_iterations=50, variant=None,
               backward_events=None, always_derivs=False, search_events=None):

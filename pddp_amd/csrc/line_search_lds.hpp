@@ -292,7 +292,13 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
     // of Zc[b][.][0][.]: the tail's copy of the winner into the nominal then
     // reads whole sectors instead of 16 bytes out of every 160-byte step of Zc
     // (a per-lane stride in the address update: no instruction more)
-    const bool compact0 = FUSED && Lout == nullptr && rec != nullptr && ai == 0;
+    // (only where the tail's short form - the reader of those rows - applies:
+    // the long form gathers every winner from Zc.  Round 5: it was taken for
+    // N + 1 > 64 H as well, and an accepted full step then copied rows of Zc
+    // nobody had written into the nominal - cartpole f32 horizons beyond
+    // ~101, found by test_one_launch_round_equals_two_launches[16-127])
+    const bool compact0 = FUSED && Lout == nullptr && rec != nullptr &&
+                          ai == 0 && n <= 6 && N + 1 <= 16 * H * kTailRows;
     T* Zci = compact0 ? rec + (size_t)b * (N + 1) * n
                       : a.Zc + ((size_t)b * (N + 1) * a.A + ai) * n;
     T* Uci = a.Uc + ((size_t)b * N * a.A + ai) * m;

@@ -29,30 +29,59 @@
 
 namespace pddp {
 
-template <unsigned QM>
+template <unsigned QM, bool MULTI>
 __global__ __launch_bounds__(2 * n4e::kWaves * kWave) void round_n4_kernel(
     RiccatiArgs<float> a, n4d::GenArgs<float> gen, ProblemT<float> prob,
-    LineSearchArgs<float> ls, AcceptArgs<float> ac, float* scratch) {
+    LineSearchArgs<float> ls, AcceptArgs<float> ac, float* scratch,
+    int rounds) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  n4e::RoundOut ro;
-  // (a pair without a live trajectory leaves here, both wavefronts alike;
-  // s_barrier does not wait for wavefronts that have ended)
-  if (!n4e::elem_sweep_body<QM, true, true>(a, gen, prob, smem_raw, ro)) return;
-  const PreStaged<float> pre{ro.Zs, ro.Us, ro.Gs, ro.status, ro.J_opt};
-  line_search_lds_body<float, PDDP_MODEL_CARTPOLE, true, n4e::kWaves, 2, QM,
-                       false, true>(prob, ls, ac, scratch, nullptr, smem_raw,
-                                    pre);
+  // `rounds` attempts of every trajectory, back to back: trajectories are
+  // independent (ilqr.py:298-314 is a loop over ONE trajectory's attempts), a
+  // workgroup owns its sixteen for the whole launch, and everything a round
+  // hands to the next - nominal, regularisation state, masks, costs - was
+  // written by this workgroup: a workgroup-scope fence and a barrier, no
+  // launch boundary.  (A trajectory that has left the fit is skipped, as by
+  // the next launch.)
+  for (int r = 0;; ++r) {
+    // (a zero the compiler cannot see through, added to the horizon: address
+    // arithmetic and everything else that depends on it stays INSIDE the
+    // round - hoisted out of this loop, both phases' invariants live across
+    // both phases: 255 VGPRs and 53 spilled against 102)
+    int z = 0;
+    if constexpr (MULTI) asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    RiccatiArgs<float> a_r = a;
+    a_r.N += z;
+    LineSearchArgs<float> ls_r = ls;
+    ls_r.N += z;
+    AcceptArgs<float> ac_r = ac;
+    ac_r.N += z;
+    n4e::RoundOut ro;
+    // (a pair without a live trajectory leaves here, both wavefronts alike -
+    // it has none in any later round either; s_barrier does not wait for
+    // wavefronts that have ended)
+    if (!n4e::elem_sweep_body<QM, true, true>(a_r, gen, prob, smem_raw, ro))
+      return;
+    const PreStaged<float> pre{ro.Zs, ro.Us, ro.Gs, ro.status, ro.J_opt};
+    line_search_lds_body<float, PDDP_MODEL_CARTPOLE, true, n4e::kWaves, 2, QM,
+                         false, true>(prob, ls_r, ac_r, scratch, nullptr,
+                                      smem_raw, pre);
+    if (!MULTI || r + 1 >= rounds) break;
+    // the round's writes (global: nominal, mu, delta, J_opt, masks; LDS: read
+    // to the end by the tail) before the next round's reads and LDS writes
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __syncthreads();
+  }
 }
 
 static int launch_round_n4(const pddp_problem& p, const RiccatiArgs<float>& a,
                            const n4d::GenArgs<float>& gen,
                            const LineSearchArgs<float>& ls,
                            const AcceptArgs<float>& ac, float* scratch,
-                           hipStream_t st) {
+                           int rounds, hipStream_t st) {
   if (p.model != PDDP_MODEL_CARTPOLE ||
       p.encoding != PDDP_ENC_IGNORE_UNCERTAINTY || a.u_min == nullptr ||
       a.u_max == nullptr || a.branch != PDDP_BRANCH_EIG || a.N < 1 ||
-      a.N + 1 > 128 || ls.A > 16)
+      a.N + 1 > 128 || ls.A > 16 || rounds < 1)
     return PDDP_E_UNSUPPORTED;
   constexpr int kPer = n4e::kWaves * n4e::kTrajW;  // trajectories / workgroup
   const dim3 grid((a.B + kPer - 1) / kPer);
@@ -70,13 +99,14 @@ static int launch_round_n4(const pddp_problem& p, const RiccatiArgs<float>& a,
       (live_mask(p.Q, ModelDims<PDDP_MODEL_CARTPOLE>::na) & ~kSparse) == 0;
 #define PDDP_ROUND_GO(QMV)                                                    \
   do {                                                                        \
-    auto kern = round_n4_kernel<QMV>;                                         \
+    auto kern = rounds > 1 ? round_n4_kernel<QMV, true>                       \
+                           : round_n4_kernel<QMV, false>;                     \
     const hipError_t e = hipFuncSetAttribute(                                 \
         (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
         (int)lds);                                                            \
     if (e != hipSuccess) return (int)e;                                       \
     PDDP_LAUNCH(kern, grid, dim3(2 * n4e::kWaves * kWave), lds, st, a, gen,   \
-                P, ls, ac, scratch);                                          \
+                P, ls, ac, scratch, rounds);                                  \
   } while (0)
   if (sparse) PDDP_ROUND_GO(kSparse); else PDDP_ROUND_GO(kFull);
 #undef PDDP_ROUND_GO
@@ -92,7 +122,7 @@ extern "C" int pddp_round_nominal_f32(
     float* L, float* J_opt, float* Zc, float* Uc, float* Jc, double tol,
     double max_reg, int n_iterations, float* gains_acc, double* mu,
     double* delta, int32_t* state, int32_t* iter, int32_t* n_live,
-    float* scratch, void* stream) {
+    float* scratch, int rounds, void* stream) {
   if (problem == nullptr || B <= 0 || N <= 0 || A <= 0 || !Z || !U || !alphas ||
       !active || !fresh || !gains || !bwd_status || !L || !J_opt || !Zc ||
       !Uc || !Jc || !gains_acc || !mu || !delta || !state || !iter || !scratch)
@@ -114,7 +144,7 @@ extern "C" int pddp_round_nominal_f32(
   const pddp::AcceptArgs<float> ac{
       B, N, 4, 1, A, Zc, Uc, Jc, gains, bwd_status, tol, max_reg, n_iterations,
       Z, U, gains_acc, J_opt, mu, delta, state, iter, active, fresh, n_live};
-  return pddp::launch_round_n4(*problem, a, gen, ls, ac, scratch,
+  return pddp::launch_round_n4(*problem, a, gen, ls, ac, scratch, rounds,
                                (hipStream_t)stream);
 }
 

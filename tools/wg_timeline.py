@@ -57,9 +57,26 @@ def rounds_us(solver, one_launch, n=200):
     return (time.perf_counter() - t_) / n * 1e6
 
 
+def multi_us(solver, R, n=200):
+    import time
+    solver._one_launch = None
+    solver.set_nominal(z0, U)
+    for _ in range(5):
+        solver.round(5e-6, 1e10, 1 << 30)
+    torch.cuda.synchronize()
+    t_ = time.perf_counter()
+    for _ in range(n // R):
+        solver.rounds(R, 5e-6, 1e10, 1 << 30)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t_) / (n // R * R) * 1e6
+
+
 for rep in range(2):
     print("round, mean of 200 (fresh nominal): one launch %.2f us, two "
-          "launches %.2f us" % (rounds_us(s, True), rounds_us(s, False)))
+          "launches %.2f us; 2 / 5 / 10 / 20 rounds per launch: %.2f / %.2f / "
+          "%.2f / %.2f us" % (rounds_us(s, True), rounds_us(s, False),
+                            multi_us(s, 2), multi_us(s, 5), multi_us(s, 10),
+                            multi_us(s, 20)))
 s._one_launch = False if "--two" in sys.argv else None
 s.set_nominal(z0, U)
 rounds = 12
