@@ -996,6 +996,7 @@ def sweep_point(lib, B, N, dtype, device, variant, rounds=12, cold=False,
         s, z0, U, _ = make_cartpole_solver(B, N, dtype, device, 0, variant)
     else:
         s, z0, U = solver
+    s._one_launch = False  # (the sweep as a launch of its own)
     s.set_nominal(z0, U)
     for _ in range(3):
         s.round(5e-6, 1e10, 1 << 30)
@@ -1011,6 +1012,7 @@ def sweep_point(lib, B, N, dtype, device, variant, rounds=12, cold=False,
         for _ in range(rounds):
             s.round(5e-6, 1e10, 1 << 30, backward_events=pool.pair())
     torch.cuda.synchronize(device)
+    s._one_launch = None
     live = int(s.active.sum().item())
     d = np.array(pool.durations())
     itemsize = 4 if dtype == torch.float32 else 8
@@ -1079,6 +1081,14 @@ def main():
                          "[4] appended to the default line")
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="backward kernel (include/pddp_hip.h): 0 auto")
+    ap.add_argument("--rounds-per-launch", type=int, default=10,
+                    help="cartpole f32: rounds per pddp_round_nominal_f32 "
+                         "launch (csrc/round_n4.hip: a workgroup owns its "
+                         "trajectories, their attempts follow one another "
+                         "without a launch boundary); 1: one launch per round; "
+                         "0: the two launches per round of rounds 3-4.  With "
+                         "more than one rank the exchange needs the round "
+                         "boundary: at most --exchange-every rounds per launch")
     args = ap.parse_args()
     launch_ranks_if_asked(args)
     if args.workload == "mpc_bnn":
@@ -1117,35 +1127,78 @@ def main():
     # ms per round at B = 4096 - and are not part of the product's step)
     R_EV = 2
     pool_sweep, pool_search = EventPool(lib), EventPool(lib)
+    pool_round = EventPool(lib)
     reps, reps_ev = [], []
     accepted_acc = torch.zeros((), dtype=torch.int64, device=device)
+    # rounds per launch of the timed region (the exchange of the multi-GPU
+    # path sits between launches)
+    rpl = max(args.rounds_per_launch, 0)
+    if world > 1 and args.exchange_every > 0:
+        rpl = min(rpl, args.exchange_every)
+    chunks_timed = []
+    phase_us = None
+    # (torch loads an operator's code object at its first use - 0.2 s once)
+    accepted_acc += ((s.state == 1) | (s.state == 5)).sum()
+    accepted_acc.zero_()
+    # (does the one-launch round apply here?  cartpole f32, B <= 4096)
+    s.set_nominal(z0, U)
+    s.round(5e-6, 1e10, n_iter)
+    round_kernel_ok = s._one_launch is True
     for rep in range(R + R_EV):
         with_events = rep >= R
+        # the repetitions with events: first the timed region's own launches
+        # with events on them, then the same rounds as TWO launches (sweep,
+        # search + accept - the same device code) with events on each: the
+        # sweep's own duration for the roofline of SURVEY 8(d)
+        two_launch = rpl == 0 or not round_kernel_ok or rep == R + R_EV - 1
+        s._one_launch = False if two_launch else None
         # every repetition times the same K rounds from the same nominal
         s.set_nominal(z0, U)
         for _ in range(W):
             s.round(5e-6, 1e10, n_iter)
         s.n_live.zero_()
         live0 = int(s.active.sum().item())
-        ev = [(pool_sweep.pair(), pool_search.pair()) if with_events
-              else (None, None) for _ in range(K)]
+        one_launch = not two_launch
+        chunk = max(rpl, 1) if one_launch else 1
+        ev = [(pool_sweep.pair(), pool_search.pair())
+              if with_events and two_launch else (None, None)
+              for _ in range(K)]
+        ev_round = [pool_round.pair() if with_events and one_launch else None
+                    for _ in range((K + chunk - 1) // chunk)]
+        if with_events and one_launch:
+            # the workgroups' own clocks around their two phases (not in the
+            # timed repetitions)
+            s.phase_ticks = torch.zeros((B + 15) // 16, 2, dtype=torch.int64,
+                                        device=device)
         torch.cuda.synchronize(device)
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
-        for i in range(K):
-            # the product's round (ILQRSolver.round): records of fresh
-            # nominals, sweep, fused line search + accept + records of the
-            # accepted nominals
-            s.round(5e-6, 1e10, n_iter, backward_events=ev[i][0],
-                    search_events=ev[i][1])
+        i = 0
+        while i < K:
+            c = min(chunk, K - i)
+            if one_launch:
+                # the product's round(s) in one launch (ILQRSolver.rounds):
+                # sweep from the nominal, line search, accept, c times
+                if with_events:
+                    chunks_timed.append(c)
+                s.rounds(c, 5e-6, 1e10, n_iter, events=ev_round[i // chunk]) \
+                    if c > 1 else s.round(5e-6, 1e10, n_iter,
+                                          backward_events=ev_round[i // chunk])
+            else:
+                # the product's round as separate launches (ILQRSolver.round):
+                # records of fresh nominals, sweep, fused line search + accept
+                # + records of the accepted nominals
+                s.round(5e-6, 1e10, n_iter, backward_events=ev[i][0],
+                        search_events=ev[i][1])
+            i += c
             if world > 1 and args.exchange_every > 0 and \
-                    (i + 1) % args.exchange_every == 0:
+                    i % args.exchange_every == 0:
                 # the exchange of the path: best rollout over RCCL - one pack
                 # launch on this stream, the all-gather on a side stream
                 # behind an event, no host synchronisation
                 last_exchange = post_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
-            if with_events:  # (no host sync: a device-side sum)
+            if with_events and two_launch:  # (no host sync: a device-side sum)
                 # attempts of this round that were accepted (state 1 ACCEPTED,
                 # 5 CONVERGED; every trajectory is live throughout the region)
                 accepted_acc += ((s.state == 1) | (s.state == 5)).sum()
@@ -1169,20 +1222,28 @@ def main():
             t = torch.tensor([attempted], dtype=torch.float64, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             total_attempted = int(t.item())
+        if s.phase_ticks is not None:
+            phase_us = (s.phase_ticks.double().cpu().numpy() / 100.0) / K
+            s.phase_ticks = None
         (reps_ev if with_events else reps).append(
             {"elapsed": elapsed, "attempted": attempted,
-             "total_attempted": total_attempted, "live": [live0, liveK]})
+             "total_attempted": total_attempted, "live": [live0, liveK],
+             "form": "two launches" if two_launch else
+                     "%d rounds per launch" % chunk})
+    s._one_launch = None
 
     order = sorted(range(R), key=lambda i: reps[i]["elapsed"])
     med = reps[order[R // 2]]
     elapsed, total_attempted = med["elapsed"], med["total_attempted"]
-    attempted_all = sum(r["attempted"] for r in reps_ev)
+    # (the repetition with events on the separate sweep / search launches)
+    attempted_all = reps_ev[-1]["attempted"]
+    timed_form = reps[0]["form"]
 
     itemsize = 4 if dtype == torch.float32 else 8
     per_traj = algorithmic_bytes_per_trajectory(N, n, m, itemsize, True)
     d_sweep = np.array(pool_sweep.durations())
     d_search = np.array(pool_search.durations())
-    launches = R_EV * K
+    launches = K
     # every timed launch swept `attempted_all / launches` trajectories on average
     sweep_bytes = attempted_all / launches * per_traj
     achieved = sweep_bytes / float(d_sweep.mean()) / 1e9
@@ -1196,6 +1257,51 @@ def main():
                                        accepted_share,
                                        records=not from_nominal)
     search_timed = getattr(s, "last_search_timed", None)
+    # the timed region's own launches (pddp_round_nominal_f32: `c` rounds each)
+    d_round = np.array(pool_round.durations())
+    round_obj = None
+    if len(d_round):
+        per_round = d_round / np.array(chunks_timed[:len(d_round)], np.float64)
+        round_bytes = sweep_bytes + search_bytes
+        round_obj = {
+            "kernel": "round_n4_kernel (csrc/round_n4.hip): sweep from the "
+                      "nominal, then line search + accept, in the same "
+                      "workgroups; %s" % timed_form,
+            "rounds_per_launch": chunks_timed[:len(d_round)],
+            "avg_launch_us": float(d_round.mean()) * 1e6,
+            "avg_round_us": float(per_round.mean()) * 1e6,
+            "min_round_us": float(per_round.min()) * 1e6,
+            "algorithmic_bytes_per_round": round_bytes,
+            "what_the_bytes_are": "the backward sweep's SURVEY 8(d) figure "
+                                  "(%.1f MB: the records it would read) + the "
+                                  "search's (%.1f MB: nominal in, candidates, "
+                                  "costs and the accepted nominals out)" % (
+                                      sweep_bytes / 1e6, search_bytes / 1e6),
+            "achieved": round_bytes / float(per_round.mean()) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round_bytes / float(per_round.mean()) / 1e9 / HBM_PEAK_GBS,
+        }
+        if phase_us is not None:
+            # rocprofv3 sees one kernel: the split is the workgroups' own
+            # 100 MHz clock around their phases (pddp_round_nominal_f32
+            # `phase_ticks`), per round, over the 256 workgroups.  Every
+            # workgroup sweeps its 16 trajectories in `sweep_us` while all the
+            # others do the same: the batch's sweep bandwidth is the agreed
+            # bytes over the MEAN workgroup's sweep time
+            sw_, se_ = phase_us[:, 0], phase_us[:, 1]
+            round_obj["phases"] = {
+                "source": "device clock (s_memrealtime) around the phases, "
+                          "wavefront 0 of every workgroup, mean per round",
+                "sweep_us": {"mean": float(sw_.mean()), "min": float(sw_.min()),
+                             "max": float(sw_.max())},
+                "search_accept_us": {"mean": float(se_.mean()),
+                                     "min": float(se_.min()),
+                                     "max": float(se_.max())},
+                "sweep_achieved_GBs": sweep_bytes / (float(sw_.mean()) * 1e-6)
+                                      / 1e9,
+                "sweep_frac": sweep_bytes / (float(sw_.mean()) * 1e-6) / 1e9 /
+                              HBM_PEAK_GBS,
+            }
 
     # HBM traffic of the same kernels from rocprofv3 PMC passes (FETCH_SIZE and
     # WRITE_SIZE cannot share a pass, and counters cannot be read from inside
@@ -1241,8 +1347,9 @@ def main():
             "repeats": R,
             "ms_per_step_min": reps[order[0]]["elapsed"] / K * 1e3,
             "ms_per_step_all": [r["elapsed"] / K * 1e3 for r in reps],
-            "ms_per_step_with_kernel_events": [r["elapsed"] / K * 1e3
-                                               for r in reps_ev],
+            "ms_per_step_with_kernel_events": [
+                {"form": r["form"], "ms": r["elapsed"] / K * 1e3}
+                for r in reps_ev],
             "config": {
                 "workload": "BASELINE.json configs[1]: cartpole n=4 m=1, "
                             "known-dynamics iLQR, horizon=%d, batch=%d "
@@ -1256,6 +1363,9 @@ def main():
                 "value_definition": "median of %d repetitions of the timed "
                                     "region (each: set_nominal, %d warm-up "
                                     "rounds, %d timed rounds)" % (R, W, K),
+                # how the K timed rounds were issued
+                "launch_form": timed_form,
+                "rounds_per_launch": args.rounds_per_launch,
                 "batched_iterations_per_s": K / elapsed,
                 "trajectory_timesteps_per_s": total_attempted * N / elapsed,
                 "live_trajectories_start_end": med["live"],
@@ -1292,10 +1402,19 @@ def main():
                 # generator, no stores: tools/probe/riccati_floor_probe.hip,
                 # profiles/r04_riccati_floor.txt (447 cycles per step: 22.75
                 # us per 100 steps, launch included)
-                "floor_us": 22.75 * N / 100.0 if from_nominal else None,
-                "frac_of_floor": (22.75 * N / 100.0) /
-                                 (float(d_sweep.mean()) * 1e6)
-                                 if from_nominal else None,
+                # (a MODEL: round 4's probe of round 4's step on one box, not
+                # re-measured by this run)
+                "floor_model_us": 22.75 * N / 100.0 if from_nominal else None,
+                "floor_model_source": "profiles/r04_riccati_floor.txt",
+                "frac_of_floor_model": (22.75 * N / 100.0) /
+                                       (float(d_sweep.mean()) * 1e6)
+                                       if from_nominal else None,
+                # the sweep is timed as a launch of its own (the last
+                # repetition runs the rounds as two launches, events on each);
+                # the timed region itself runs `timed_region_kernel`
+                "measured_in": "two-launch repetition (same device code as "
+                               "the round kernel's first phase)",
+                "timed_region_kernel": round_obj,
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "avg_launch_us": float(d_sweep.mean()) * 1e6,

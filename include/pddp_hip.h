@@ -387,7 +387,11 @@ int pddp_search_accept_f64(const pddp_problem* problem, int B, int N, int A,
  * `rounds` >= 1: that many attempts of every trajectory in the one launch,
  * exactly as `rounds` calls with rounds = 1 (trajectories are independent and
  * a workgroup owns its sixteen for the whole launch; one that has left the fit
- * - active[b] == 0 - is skipped, as by a later call). */
+ * - active[b] == 0 - is skipped, as by a later call).
+ * `phase_ticks`, nullable: [ceil(B / 16)][2] counters to which every workgroup
+ * ADDS the ticks of the chip's 100 MHz clock it spent in its sweeps and in its
+ * searches (rocprofv3 sees one kernel; bench.py's roofline leg wants the
+ * sweep's share). */
 int pddp_round_nominal_f32(const pddp_problem* problem, int B, int N, int A,
                            float* Z, float* U, const float* alphas,
                            const float* u_min, const float* u_max, int branch,
@@ -397,7 +401,7 @@ int pddp_round_nominal_f32(const pddp_problem* problem, int B, int N, int A,
                            double max_reg, int n_iterations, float* gains_acc,
                            double* mu, double* delta, int32_t* state,
                            int32_t* iter, int32_t* n_live, float* scratch,
-                           int rounds, void* stream);
+                           int rounds, long long* phase_ticks, void* stream);
 
 /* The variant entry with two HIP events (pddp_event_create) attached to the
  * sweep's own dispatch: elapsed(start, stop) is the kernel's duration as

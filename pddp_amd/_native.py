@@ -84,7 +84,7 @@ _SIGS = {
     "pddp_sweep_nominal_kernel": [c_int],
     "pddp_round_nominal_f32": [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int] +
                               [_P] * 9 + [c_double, c_double, c_int] +
-                              [_P] * 7 + [c_int, _P],
+                              [_P] * 7 + [c_int, _P, _P],
     "pddp_search_candidates": [c_int],
     "pddp_search_form": [c_int],
     "pddp_bnn_mlp_precision": [c_int],

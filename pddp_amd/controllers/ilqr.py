@@ -169,8 +169,13 @@ class iLQRController(Controller):
                     it -= 1  # the counter already points at the next step()
                 on_iteration(it, st, s.Z[0].clone(), s.U[0].clone(),
                              s.J_opt[0].clone())
-        self._last_rounds = s.fit(n_iterations, tol, max_reg, on_round,
-                                  graph=self._graph and s.graph_ok())
+        # (nobody watches the attempts: several rounds per launch where the
+        # one-launch round applies - cartpole f32 - and one look at the live
+        # count per launch)
+        self._last_rounds = s.fit(
+            n_iterations, tol, max_reg,
+            on_round if on_iteration is not None else None,
+            graph=self._graph and s.graph_ok(), rounds_per_launch=8)
 
     # -- reference API ----------------------------------------------------------
     def fit(self, U, encoding=StateEncoding.DEFAULT, n_iterations=50, tol=5e-6,

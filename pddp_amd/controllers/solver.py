@@ -123,6 +123,9 @@ class ILQRSolver(object):
         # the whole round in one launch (round_nominal): None untried, True /
         # False applies / does not (set False to force the two launches)
         self._one_launch = None
+        self._round_args = None
+        # int64 [ceil(B / 16)][2] or None: pddp_round_nominal_f32's phase clock
+        self.phase_ticks = None
         self._derivs_due = True
         # The sweep that evaluates the derivative records itself, from the
         # nominal (pddp_sweep_nominal_f32): None untried, then True / False.
@@ -362,17 +365,27 @@ class ILQRSolver(object):
                 self.u_min is None or self.u_max is None:
             self._one_launch = False
             return False
-        p = _native.ptr
         if events is not None:
             _native.lib().pddp_attach_events(*events)
+        # (the buffers are the solver's own for its lifetime: their addresses
+        # are looked up once - a launch of this entry point is the whole host
+        # side of a round, and 27 data_ptr() calls were a third of it)
+        key = (self._rec.data_ptr(), self.Z.data_ptr(), self.U.data_ptr(),
+               self.gains.data_ptr(), int(self.branch))
+        if self._round_args is None or self._round_args[0] != key:
+            p = _native.ptr
+            self._round_args = (key, (
+                self._pp, self.B, self.N, self.A, p(self.Z), p(self.U),
+                p(self.alphas), p(self.u_min), p(self.u_max), int(self.branch),
+                p(self.active), p(self.fresh), p(self.gains),
+                p(self.bwd_status), p(self.L), p(self.J_opt), p(self.Zc),
+                p(self.Uc), p(self.Jc)), (
+                p(self.gains_acc), p(self.mu), p(self.delta), p(self.state),
+                p(self.iter), p(self.n_live), p(self._rec)))
+        _, head, tail = self._round_args
         rc = _native.lib().pddp_round_nominal_f32(
-            self._pp, self.B, self.N, self.A, p(self.Z), p(self.U),
-            p(self.alphas), p(self.u_min), p(self.u_max), int(self.branch),
-            p(self.active), p(self.fresh), p(self.gains), p(self.bwd_status),
-            p(self.L), p(self.J_opt), p(self.Zc), p(self.Uc), p(self.Jc),
-            float(tol), float(max_reg), int(n_iterations), p(self.gains_acc),
-            p(self.mu), p(self.delta), p(self.state), p(self.iter),
-            p(self.n_live), p(self._rec), int(rounds), self._s())
+            *head, float(tol), float(max_reg), int(n_iterations), *tail,
+            int(rounds), _native.ptr(self.phase_ticks), self._s())
         if rc == _native.E_UNSUPPORTED:
             if events is not None:
                 _native.lib().pddp_attach_events(None, None)
@@ -576,21 +589,31 @@ class ILQRSolver(object):
         g.replay()
 
     def fit(self, n_iterations=50, tol=5e-6, max_reg=1e10, on_round=None,
-            max_rounds=None, graph=False, rounds_per_sync=1):
+            max_rounds=None, graph=False, rounds_per_sync=1,
+            rounds_per_launch=1):
         """Runs rounds until every trajectory left the fit loop
         (ilqr.py:298-314). Returns the number of rounds.  With `graph=True`
         rounds are hipGraph replays and the host looks at the live count only
         every `rounds_per_sync` rounds (a round with nothing live is a no-op
-        on the device, so the result does not depend on it)."""
+        on the device, so the result does not depend on it).
+        `rounds_per_launch` > 1 (no `on_round`, no graph): that many rounds per
+        launch where pddp_round_nominal_f32 applies (`rounds()`), the live
+        count read after each launch - the same results, up to
+        rounds_per_launch - 1 no-op rounds more."""
         if graph:
             self.capture_round(tol, max_reg, n_iterations)
             if self.plugin is not None:
                 rounds_per_sync = 1  # which graph comes next is read back
+        rpl = 1 if (graph or on_round is not None) else max(1, rounds_per_launch)
         rounds = 0
         need_derivs = True
         while True:
             if graph:
                 self.replay_round(need_derivs)
+            elif rpl > 1:
+                c = rpl if max_rounds is None else min(rpl, max_rounds - rounds)
+                self.rounds(c, tol, max_reg, n_iterations)
+                rounds += c - 1
             else:
                 self.round(tol, max_reg, n_iterations)
             rounds += 1
@@ -598,7 +621,7 @@ class ILQRSolver(object):
                 on_round(rounds, self)
             if max_rounds is not None and rounds >= max_rounds:
                 break
-            if rounds % rounds_per_sync:
+            if rpl == 1 and rounds % rounds_per_sync:
                 continue
             # the one host sync: live trajectories, and (plugin graphs) whether
             # any nominal changed

@@ -33,8 +33,13 @@ template <unsigned QM, bool MULTI>
 __global__ __launch_bounds__(2 * n4e::kWaves * kWave) void round_n4_kernel(
     RiccatiArgs<float> a, n4d::GenArgs<float> gen, ProblemT<float> prob,
     LineSearchArgs<float> ls, AcceptArgs<float> ac, float* scratch,
-    int rounds) {
+    int rounds, long long* phase_ticks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // (bench.py's roofline leg: what share of the launch is sweep - rocprofv3
+  // sees one kernel.  Wavefront 0 of the workgroup reads the chip's 100 MHz
+  // clock around its phases and adds the differences up; NULL: nothing)
+  const bool timed = phase_ticks != nullptr && threadIdx.x == 0;
+  long long t_sweep = 0, t_search = 0;
   // `rounds` attempts of every trajectory, back to back: trajectories are
   // independent (ilqr.py:298-314 is a loop over ONE trajectory's attempts), a
   // workgroup owns its sixteen for the whole launch, and everything a round
@@ -56,20 +61,30 @@ __global__ __launch_bounds__(2 * n4e::kWaves * kWave) void round_n4_kernel(
     AcceptArgs<float> ac_r = ac;
     ac_r.N += z;
     n4e::RoundOut ro;
+    const long long t0 = timed ? wall_clock64() : 0;
     // (a pair without a live trajectory leaves here, both wavefronts alike -
     // it has none in any later round either; s_barrier does not wait for
     // wavefronts that have ended)
     if (!n4e::elem_sweep_body<QM, true, true>(a_r, gen, prob, smem_raw, ro))
-      return;
+      break;
+    const long long t1 = timed ? wall_clock64() : 0;
     const PreStaged<float> pre{ro.Zs, ro.Us, ro.Gs, ro.status, ro.J_opt};
     line_search_lds_body<float, PDDP_MODEL_CARTPOLE, true, n4e::kWaves, 2, QM,
                          false, true>(prob, ls_r, ac_r, scratch, nullptr,
                                       smem_raw, pre);
+    if (timed) {
+      t_sweep += t1 - t0;
+      t_search += wall_clock64() - t1;
+    }
     if (!MULTI || r + 1 >= rounds) break;
     // the round's writes (global: nominal, mu, delta, J_opt, masks; LDS: read
     // to the end by the tail) before the next round's reads and LDS writes
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __syncthreads();
+  }
+  if (timed) {
+    phase_ticks[2 * blockIdx.x] += t_sweep;
+    phase_ticks[2 * blockIdx.x + 1] += t_search;
   }
 }
 
@@ -77,7 +92,8 @@ static int launch_round_n4(const pddp_problem& p, const RiccatiArgs<float>& a,
                            const n4d::GenArgs<float>& gen,
                            const LineSearchArgs<float>& ls,
                            const AcceptArgs<float>& ac, float* scratch,
-                           int rounds, hipStream_t st) {
+                           int rounds, long long* phase_ticks,
+                           hipStream_t st) {
   if (p.model != PDDP_MODEL_CARTPOLE ||
       p.encoding != PDDP_ENC_IGNORE_UNCERTAINTY || a.u_min == nullptr ||
       a.u_max == nullptr || a.branch != PDDP_BRANCH_EIG || a.N < 1 ||
@@ -106,7 +122,7 @@ static int launch_round_n4(const pddp_problem& p, const RiccatiArgs<float>& a,
         (int)lds);                                                            \
     if (e != hipSuccess) return (int)e;                                       \
     PDDP_LAUNCH(kern, grid, dim3(2 * n4e::kWaves * kWave), lds, st, a, gen,   \
-                P, ls, ac, scratch, rounds);                                  \
+                P, ls, ac, scratch, rounds, phase_ticks);                     \
   } while (0)
   if (sparse) PDDP_ROUND_GO(kSparse); else PDDP_ROUND_GO(kFull);
 #undef PDDP_ROUND_GO
@@ -122,7 +138,7 @@ extern "C" int pddp_round_nominal_f32(
     float* L, float* J_opt, float* Zc, float* Uc, float* Jc, double tol,
     double max_reg, int n_iterations, float* gains_acc, double* mu,
     double* delta, int32_t* state, int32_t* iter, int32_t* n_live,
-    float* scratch, int rounds, void* stream) {
+    float* scratch, int rounds, long long* phase_ticks, void* stream) {
   if (problem == nullptr || B <= 0 || N <= 0 || A <= 0 || !Z || !U || !alphas ||
       !active || !fresh || !gains || !bwd_status || !L || !J_opt || !Zc ||
       !Uc || !Jc || !gains_acc || !mu || !delta || !state || !iter || !scratch)
@@ -145,7 +161,7 @@ extern "C" int pddp_round_nominal_f32(
       B, N, 4, 1, A, Zc, Uc, Jc, gains, bwd_status, tol, max_reg, n_iterations,
       Z, U, gains_acc, J_opt, mu, delta, state, iter, active, fresh, n_live};
   return pddp::launch_round_n4(*problem, a, gen, ls, ac, scratch, rounds,
-                               (hipStream_t)stream);
+                               phase_ticks, (hipStream_t)stream);
 }
 
 #ifdef PDDP_WG_TIMELINE
