@@ -331,7 +331,7 @@ def profile_traffic(kernel_substr, workload_tag=None):
     cannot be read from inside this process: the summaries are of profiled
     runs of the same bench command (tools/collect_profiles.sh)."""
     import glob
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         pat = os.path.join(ROOT, "profiles", "%s_%spmc_traffic.json" % (
             rnd, (workload_tag + "_") if workload_tag else "*"))
         for path in sorted(glob.glob(pat)):
@@ -919,10 +919,11 @@ def bench_mpc_bnn(args, emit=True):
             "achieved": flop / dur * 1e-12, "peak": MFMA_F32_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": flop / dur * 1e-12 / MFMA_F32_PEAK_TFLOPS,
             "avg_launch_us": dur * 1e6, "algorithmic_flop_per_launch": flop,
-            "traffic": profile_traffic("bnn_mlp_kernel<200, 8, 8", "mpc") or
-                       profile_traffic("bnn_mlp_kernel<200, 8, 8", "cpbnn"),
+            # (this workload's own counters, profiles/<round>_mpc_pmc_traffic
+            # .json, or null: never another batch's launch)
+            "traffic": profile_traffic("bnn_mlp_kernel<200, 8, 8", "mpc"),
             "other_kernels": [sweep_roofline_of(sv, _native.lib(),
-                                                traffic_tag="cpbnn")]}
+                                                traffic_tag="mpc")]}
         if not args.no_cpu_baseline:
             cb = bnn_cpu_baseline(model, enc, N, 14, 1, 11,
                                   {"use_predicted_std": False,
@@ -1308,7 +1309,8 @@ def main():
     # this process): taken from the committed summary of the profiled run of
     # this very command, see profiles/.
     traffic, traffic_search = None, None
-    for tname in ("r04_pmc_traffic.json", "r03_pmc_traffic.json",
+    for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json",
+                  "r03_pmc_traffic.json",
                   "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if not (os.path.exists(tpath) and B == 4096 and N == 100

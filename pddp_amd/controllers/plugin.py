@@ -305,6 +305,18 @@ class TorchProblem(object):
 
     use_gp_rollout = True  # pddp_gp_rollout_* (False: the per-step torch form)
 
+    def cost_generation(self):
+        """Identity and version of the cost's tensors whose converted copies
+        captured launches read (`_line_search_gp`): a captured round is stale
+        when this changes (ILQRSolver._graphs_fresh)."""
+        co = self.cost
+        ts = [getattr(co, k, None) for k in ("Q", "Q_term", "R", "x_goal",
+                                             "u_goal")]
+        if not hasattr(self, "_gp_cost_cache") or any(
+                not torch.is_tensor(t) for t in ts):
+            return None
+        return tuple((t.data_ptr(), t._version) for t in ts)
+
     @torch.no_grad()
     def _line_search_gp(self, s, active=None, use_status=True):
         """ilqr.py:677-723 + :764-791 for every (trajectory, step size) as a
@@ -325,11 +337,20 @@ class TorchProblem(object):
             (t.data_ptr(), t._version)
             for t in (co.Q, co.Q_term, co.R, co.x_goal, co.u_goal))
         cc = getattr(self, "_gp_cost_cache", None)
-        if cc is None or cc[0] != key:
-            conv = lambda t: t.detach().to(dtype=s.dtype,
-                                           device=s.device).contiguous()
-            cc = self._gp_cost_cache = (key, tuple(
-                conv(t) for t in (co.Q, co.Q_term, co.R, co.x_goal, co.u_goal)))
+        src = (co.Q, co.Q_term, co.R, co.x_goal, co.u_goal)
+        if cc is not None and cc[0] != key and cc[0][:2] == key[:2] and all(
+                d.shape == t.shape for d, t in zip(cc[1], src)):
+            # new values INTO the converted copies: launches baked into a
+            # hipGraph hold their addresses (a replaced tuple would free them
+            # under the graph); the graphs themselves are dropped by
+            # ILQRSolver._graphs_fresh through cost_generation()
+            for d, t in zip(cc[1], src):
+                d.copy_(t.detach())
+            cc = self._gp_cost_cache = (key, cc[1])
+        elif cc is None or cc[0] != key:
+            conv = lambda t: t.detach().to(dtype=s.dtype, device=s.device,
+                                           copy=True).contiguous()
+            cc = self._gp_cost_cache = (key, tuple(conv(t) for t in src))
         Q, Qt, R, xg, ug = cc[1]
         p = _native.ptr
         r = _native.GpRollout()

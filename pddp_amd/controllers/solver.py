@@ -126,6 +126,10 @@ class ILQRSolver(object):
         self._round_args = None
         # int64 [ceil(B / 16)][2] or None: pddp_round_nominal_f32's phase clock
         self.phase_ticks = None
+        # False after a search launch that dropped the candidates (large
+        # batches without records, pddp_search_candidates): `Zc`, `Uc` are then
+        # scratch - only `Jc` and the nominal are results of that round
+        self.candidates_kept = True
         self._derivs_due = True
         # The sweep that evaluates the derivative records itself, from the
         # nominal (pddp_sweep_nominal_f32): None untried, then True / False.
@@ -265,10 +269,14 @@ class ILQRSolver(object):
             return
         from ..models.bnn import generation
         gen = generation(self.plugin.model)
-        if gen != self._model_gen:
+        # (and the cost's tensors where launches read converted copies of
+        # them: the GP line search, plugin.cost_generation)
+        cg = getattr(self.plugin, "cost_generation", lambda: None)()
+        if gen != self._model_gen or cg != getattr(self, "_cost_gen", cg):
             self._graph = None
             self._rollout_graph = None
             self._model_gen = gen
+        self._cost_gen = cg
 
     @_on_device
     def nominal_rollout(self, mask=None):
@@ -447,6 +455,16 @@ class ILQRSolver(object):
             p(self.n_live), p(self._rec), p(self.L) if records else None,
             self._s())
         self._fused = rc == 0
+        if self._fused:
+            # (pddp_search_candidates: without records the candidates are
+            # dropped beyond 200 MB - Zc / Uc are scratch after such a launch,
+            # only Jc and the nominal are results)
+            mode = _native.lib().pddp_search_candidates(-1)
+            nbytes = float(self.B) * self.A * (
+                (self.N + 1) * self.n + self.N * self.m) * \
+                self.Z.element_size()
+            self.candidates_kept = records or self._rec is None or not (
+                mode == 2 or (mode == 0 and nbytes > 200e6))
         if not self._fused and events is not None:
             _native.lib().pddp_attach_events(None, None)  # nothing launched
             self.last_search_timed = None

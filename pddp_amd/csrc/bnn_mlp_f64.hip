@@ -58,6 +58,7 @@
 // through the ReLUs linearised at the group's first row.  Groups are whole
 // inside a 16-row tile; rows k >= live of a group are neither read nor
 // written.
+#include <atomic>
 #include <type_traits>
 
 #include "pddp_common.hpp"
@@ -505,8 +506,11 @@ __global__ __launch_bounds__(kMlp64Threads) void bnn_mlp_f64_kernel(BnnMlpArgs64
 template <int H, int G, bool SMALL>
 static int launch_bnn_mlp_f64_s(const BnnMlpArgs64& a, hipStream_t st) {
   constexpr int kMaxDev = 16;
-  static int cus_of[kMaxDev] = {};
-  static bool attr_set[kMaxDev] = {};
+  // (first use from several host threads: both caches are idempotent - every
+  // writer stores the same value - and atomic, so a racing reader sees either
+  // "unset" and repeats the query / the opt-in, or the value)
+  static std::atomic<int> cus_of[kMaxDev] = {};
+  static std::atomic<bool> attr_set[kMaxDev] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev)
     return PDDP_E_UNSUPPORTED;

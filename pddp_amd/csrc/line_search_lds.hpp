@@ -141,7 +141,8 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
                                    const LineSearchArgs<T> a,
                                    const AcceptArgs<T> c, T* rec, T* Lout,
                                    unsigned char* smem_raw,
-                                   const PreStaged<T> pre) {
+                                   const PreStaged<T> pre,
+                                   const unsigned tid = threadIdx.x) {
   using D = ModelDims<MODEL>;
   constexpr int n = D::n, m = D::m;
   constexpr int GS = m + m * n;
@@ -150,8 +151,8 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
   static_assert(!PRE || (FUSED && H == 2 && !DENSE), "");
   constexpr int kTailRows = DENSE ? 8 : 4;  // rows per lane of the short tail
   __shared__ int sh_dec[WPB][4][2];  // H = 2: {amin_out, fresh} per trajectory
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave_all = threadIdx.x >> 6;
+  const int lane = tid & (kWave - 1);
+  const int wave_all = tid >> 6;
   const int wave = H == 1 ? wave_all : wave_all % WPB;
   const int hid = H == 1 ? 0 : wave_all / WPB;  // 0 rollout wave, 1 helper
   const int grp = lane >> 4, ai = lane & 15;

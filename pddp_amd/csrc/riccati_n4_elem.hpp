@@ -279,15 +279,18 @@ template <unsigned QM, bool OVL, bool ROUND>
 PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
                               const GenArgs<float>& gen,
                               const ProblemT<float>& prob,
-                              unsigned char* smem_raw, RoundOut& ro) {
+                              unsigned char* smem_raw, RoundOut& ro,
+                              const unsigned tid = threadIdx.x) {
   static_assert(OVL || !ROUND, "");
   using T = float;
   constexpr int MODEL = PDDP_MODEL_CARTPOLE;
   constexpr RecLayout lay(4, 1);
   const int kPairLds = OVL ? kPairLdsOvl + (ROUND ? round_gains_floats(a.N) : 0)
                            : kPairLdsInl;
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // (`tid`: threadIdx.x - through an opaque move in the loop over rounds of
+  // round_n4.hip, so that nothing derived from it is hoisted out of a round)
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((int)tid >> 6);
   const int pair = OVL ? (wave & (kWaves - 1)) : wave;
   const bool is_gen = OVL && wave >= kWaves;
   T* const img0 = reinterpret_cast<T*>(smem_raw) + pair * kPairLds;

@@ -53,7 +53,11 @@ __global__ __launch_bounds__(2 * n4e::kWaves * kWave) void round_n4_kernel(
     // round - hoisted out of this loop, both phases' invariants live across
     // both phases: 255 VGPRs and 53 spilled against 102)
     int z = 0;
-    if constexpr (MULTI) asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    unsigned tid = threadIdx.x;
+    if constexpr (MULTI) {
+      asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+      asm volatile("" : "+v"(tid));  // (likewise: what the lane id feeds)
+    }
     RiccatiArgs<float> a_r = a;
     a_r.N += z;
     LineSearchArgs<float> ls_r = ls;
@@ -65,13 +69,14 @@ __global__ __launch_bounds__(2 * n4e::kWaves * kWave) void round_n4_kernel(
     // (a pair without a live trajectory leaves here, both wavefronts alike -
     // it has none in any later round either; s_barrier does not wait for
     // wavefronts that have ended)
-    if (!n4e::elem_sweep_body<QM, true, true>(a_r, gen, prob, smem_raw, ro))
+    if (!n4e::elem_sweep_body<QM, true, true>(a_r, gen, prob, smem_raw, ro,
+                                              tid))
       break;
     const long long t1 = timed ? wall_clock64() : 0;
     const PreStaged<float> pre{ro.Zs, ro.Us, ro.Gs, ro.status, ro.J_opt};
     line_search_lds_body<float, PDDP_MODEL_CARTPOLE, true, n4e::kWaves, 2, QM,
                          false, true>(prob, ls_r, ac_r, scratch, nullptr,
-                                      smem_raw, pre);
+                                      smem_raw, pre, tid);
     if (timed) {
       t_sweep += t1 - t0;
       t_search += wall_clock64() - t1;

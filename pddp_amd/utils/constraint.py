@@ -54,9 +54,13 @@ def constrain_model(min_bounds, max_bounds):
 
         def __init__(self, *args, **kwargs):
             init(self, *args, **kwargs)
+            # (tensor bounds keep their dtype, like the reference's
+            # torch.tensor(bounds), constraint.py:100-102; Python scalars take
+            # the default dtype)
             P = lambda b: torch.nn.Parameter(
-                torch.as_tensor(b, dtype=torch.get_default_dtype()).expand(
-                    cls.action_size).clone(), requires_grad=False)
+                (b.detach() if torch.is_tensor(b) else torch.as_tensor(
+                    b, dtype=torch.get_default_dtype())).expand(
+                        cls.action_size).clone(), requires_grad=False)
             self.max_bounds, self.min_bounds = P(max_bounds), P(min_bounds)
 
         def forward(self, z, u, i, encoding=None, **kwargs):

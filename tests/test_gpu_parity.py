@@ -3180,7 +3180,13 @@ def test_bnn_mpc_graph_replay_equals_eager_f64():
     _mpc_graph_replay_equals_eager(False, torch.float64)
 
 
-def _mpc_graph_replay_equals_eager(use_predicted_std, dtype):
+def test_bnn_mpc_graph_replay_equals_eager_at_full_length():
+    """BASELINE.json configs[4] at its stated length: 256 restarts x 200
+    control steps (9 s per run on the MI355X, eager and replayed)."""
+    _mpc_graph_replay_equals_eager(False, torch.float32, steps=200)
+
+
+def _mpc_graph_replay_equals_eager(use_predicted_std, dtype, steps=5):
     """BASELINE.json configs[4] (shortened): the receding-horizon loop of
     examples/mpc_animation.py:29-39 on the cartpole BNN ([200, 200], 100
     particles, DEFAULT encoding), horizon 50, 256 restarts x 5 control steps,
@@ -3190,7 +3196,7 @@ def _mpc_graph_replay_equals_eager(use_predicted_std, dtype):
     the eager run bit for bit (same kernels, same order, same buffers);
     duplicated restarts stay bit-identical; states stay finite."""
     import pddp_amd
-    B, N, steps = 256, 50, 5
+    B, N = 256, 50
     enc = pddp_amd.StateEncoding.DEFAULT
     ienc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
     iu = torch.triu_indices(4, 4)

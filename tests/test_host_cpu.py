@@ -221,6 +221,50 @@ def test_best_rollout_all_gather_two_ranks(tmp_path):
     assert out.stdout.count("ok") == 2
 
 
+_WORKER8 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from pddp_amd.parallel import gather_best_rollout, shard_bounds
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+# a ragged batch: 8 ranks over 29 trajectories (shards of 4 and 3), the rounds
+# of a fit one after another with the winner moving between ranks
+B, N, n, m = 29, 5, 4, 1
+lo, hi = shard_bounds(B, rank, world)
+assert 3 <= hi - lo <= 4
+g = torch.Generator().manual_seed(11)
+for it in range(6):
+    J = torch.rand(B, generator=g, dtype=torch.float64) + 1.0
+    J[(5 * it + 2) %% B] = float("nan")      # diverged: never wins
+    best = (7 * it + 3) %% B
+    J[best] = 0.125 + 0.0625 * it
+    Z = torch.rand(B, N + 1, n, generator=g, dtype=torch.float64)
+    U = torch.rand(B, N, m, generator=g, dtype=torch.float64)
+    Jb, idx, Zb, Ub = gather_best_rollout(J[lo:hi], Z[lo:hi], U[lo:hi],
+                                          offset=lo)
+    assert idx == best and float(Jb) == 0.125 + 0.0625 * it, (it, idx)
+    assert torch.equal(Zb, Z[best]) and torch.equal(Ub, U[best])
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_best_rollout_all_gather_eight_ranks_ragged(tmp_path):
+    """BASELINE configs[3]'s world size on the CPU: eight gloo ranks, a batch
+    that does not divide by eight, six exchanges with the winner on a
+    different rank each time."""
+    script = tmp_path / "worker8.py"
+    script.write_text(_WORKER8 % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+         "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port",
+         "29571", str(script)], capture_output=True, text=True, env=env,
+        timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 8
+
+
 def test_oracle_under_address_and_ub_sanitizers():
     """SURVEY 5 (sanitizers run on the CPU side): the oracle's golden suite
     re-run in a child interpreter against the -fsanitize=address,undefined
