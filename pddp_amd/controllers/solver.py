@@ -152,7 +152,8 @@ class ILQRSolver(object):
                 self.kernel_variant == 0):
             return False
         if self.problem.model == 1:  # cartpole: csrc/riccati_n4_elem.hpp
-            return (self.dtype == torch.float32 and self.n == 4 and
+            # (f32, and - round 5 - the same mapping in f64)
+            return (self.n == 4 and
                     self.u_min is not None and self.u_max is not None and
                     self.branch == BRANCH_EIG)
         # pendulum (3), double cartpole (2): csrc/riccati_mfma16_nominal.hpp -

@@ -79,6 +79,11 @@ extern "C" int pddp_sweep_nominal_f64(const pddp_problem* problem, int B, int N,
   a.gains = gains;
   a.status = status;
   const pddp::n4d::GenArgs<double> gen = {Z, U, L, J_opt, fresh};
+  if (problem->model == PDDP_MODEL_CARTPOLE) {
+    // riccati_n4_elem.hpp in float64 (round 5): the inline form
+    a.n = 4;
+    return pddp::launch_n4_elem_f64(*problem, a, gen, (hipStream_t)stream);
+  }
   return pddp::launch_m16_nominal<double>(*problem, a, gen,
                                           (hipStream_t)stream);
 }

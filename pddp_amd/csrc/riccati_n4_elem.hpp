@@ -36,6 +36,7 @@
 // results agree to rounding.
 #pragma once
 
+#include <type_traits>
 #include "models.hpp"
 #include "riccati_n4_defer.hpp"
 
@@ -97,6 +98,17 @@ struct LsTableF {
   }
 };
 __device__ constexpr LsTableF kLsF{};
+template <typename T>
+PDDP_DEV const T* ls_table();
+template <>
+PDDP_DEV const float* ls_table<float>() { return kLsF.v; }
+template <>
+PDDP_DEV const double* ls_table<double>() { return n4::kLs.v; }
+template <typename T>
+struct Vec {
+  typedef T v4 __attribute__((ext_vector_type(4)));
+  typedef T v2 __attribute__((ext_vector_type(2)));
+};
 
 // QpLean (riccati_n4_defer.hpp) without the third iterate: where the
 // reference's loop takes one more full Newton step from a live interior x1
@@ -158,9 +170,40 @@ struct QpLean1 {
 //   Quzr = Luz[i] + sum_j A[i][j] f[j]                      (row form)
 // The reductions are butterflies of ROUNDED products (separate v_mul), whose
 // results are bit-identical in every lane that holds a copy (a + b == b + a).
-struct StepCore {
-  float Quu, Qu, Qzz, Qzc, Quzr;
+template <typename T>
+struct StepCoreT {
+  T Quu, Qu, Qzz, Qzc, Quzr;
 };
+typedef StepCoreT<float> StepCore;
+// The same products for any scalar type, statement by statement (the DPP
+// helpers of riccati_n4.hpp; a 64-bit DPP move is two 32-bit ones): the
+// float64 instantiation of the sweep (pddp_sweep_nominal_f64, cartpole).
+template <typename T>
+PDDP_DEV StepCoreT<T> step_core(T V, T vc, T fr, T fc,
+                                typename Vec<T>::v4 Fs, typename Vec<T>::v4 Fq,
+                                T Lzz, T Lzc, T Luzr, T Luu, T Lu) {
+  using n4::dot_cols;
+  using n4::dot_rows;
+  using n4::from_col_plus;
+  using n4::from_row_plus;
+  StepCoreT<T> o;
+  o.Quu = Luu + dot_cols(dot_rows(fr, V), fc);
+  o.Qu = Lu + dot_cols(fc, vc);
+  T A = V * Fs[0];
+  A = fma_(from_row_plus<1>(V), Fs[1], A);
+  A = fma_(from_row_plus<2>(V), Fs[2], A);
+  A = fma_(from_row_plus<3>(V), Fs[3], A);
+  T Qzz = fma_(A, Fq[0], Lzz);
+  Qzz = fma_(from_col_plus<1>(A), Fq[1], Qzz);
+  Qzz = fma_(from_col_plus<2>(A), Fq[2], Qzz);
+  o.Qzz = fma_(from_col_plus<3>(A), Fq[3], Qzz);
+  T Qzc = fma_(vc, Fq[0], Lzc);
+  Qzc = fma_(from_col_plus<1>(vc), Fq[1], Qzc);
+  Qzc = fma_(from_col_plus<2>(vc), Fq[2], Qzc);
+  o.Qzc = fma_(from_col_plus<3>(vc), Fq[3], Qzc);
+  o.Quzr = Luzr + dot_cols(A, fc);
+  return o;
+}
 PDDP_DEV StepCore step_core(float V, float vc, float fr, float fc, f32x4 Fs,
                             f32x4 Fq, float Lzz, float Lzc, float Luzr,
                             float Luu, float Lu) {
@@ -275,14 +318,19 @@ struct RoundOut {       // (ROUND) what the search phase needs, per lane
 constexpr int round_zu_stride(int N) { return (5 * N + 4 + 3) & ~3; }
 constexpr int round_gains_floats(int N) { return (kTrajW * N * kGain + 3) & ~3; }
 
-template <unsigned QM, bool OVL, bool ROUND>
-PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
-                              const GenArgs<float>& gen,
-                              const ProblemT<float>& prob,
-                              unsigned char* smem_raw, RoundOut& ro,
+template <typename T, unsigned QM, bool OVL, bool ROUND>
+PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
+                              const ProblemT<T>& prob, unsigned char* smem_raw,
+                              RoundOut& ro,
                               const unsigned tid = threadIdx.x) {
   static_assert(OVL || !ROUND, "");
-  using T = float;
+  // (float64: the inline form only - two image buffers of doubles for four
+  // pairs are 220 KB - with the closed-form BoxQP of riccati_n4.hpp and IEEE
+  // division: the design held to the oracle at 1e-9, tests/test_gpu_parity.py)
+  constexpr bool F32 = std::is_same<T, float>::value;
+  static_assert(F32 || (!OVL && !ROUND), "");
+  using V4 = typename Vec<T>::v4;
+  using V2 = typename Vec<T>::v2;
   constexpr int MODEL = PDDP_MODEL_CARTPOLE;
   constexpr RecLayout lay(4, 1);
   const int kPairLds = OVL ? kPairLdsOvl + (ROUND ? round_gains_floats(a.N) : 0)
@@ -325,7 +373,7 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
   auto request = [&](int jb) {
     int tau = N - 1 - kBlk * jb - l;
     tau = tau < 0 ? 0 : tau;
-    const f32x4 v = *reinterpret_cast<const f32x4*>(Zg + 4 * tau);
+    const V4 v = *reinterpret_cast<const V4*>(Zg + 4 * tau);
     zq[0] = v[0]; zq[1] = v[1]; zq[2] = v[2]; zq[3] = v[3];
     uq = Ug[tau];
   };
@@ -333,7 +381,7 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
   // of the row (the wavefront pays the instructions once either way), handed
   // over through LDS
   auto terminal = [&]() {
-    const f32x4 zNv = *reinterpret_cast<const f32x4*>(Zg + 4 * N);
+    const V4 zNv = *reinterpret_cast<const V4*>(Zg + 4 * N);
     const T zN[4] = {zNv[0], zNv[1], zNv[2], zNv[3]};
     T lz[4], lzz[16], lu[1], luu[1];
     l_term = cost_derivs<T, MODEL>(prob, zN, nullptr, trig_of<T, MODEL>(zN),
@@ -342,9 +390,9 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
     if (l == 0) {
 #pragma unroll
       for (int k = 0; k < 16; k += 4)
-        *reinterpret_cast<f32x4*>(scr + k) =
-            f32x4{lzz[k], lzz[k + 1], lzz[k + 2], lzz[k + 3]};
-      *reinterpret_cast<f32x4*>(scr + 16) = f32x4{lz[0], lz[1], lz[2], lz[3]};
+        *reinterpret_cast<V4*>(scr + k) =
+            V4{lzz[k], lzz[k + 1], lzz[k + 2], lzz[k + 3]};
+      *reinterpret_cast<V4*>(scr + 16) = V4{lz[0], lz[1], lz[2], lz[3]};
       scr[20] = l_term;
       if (counted) gen.L[(size_t)bc * (size_t)(N + 1) + N] = l_term;
     }
@@ -360,27 +408,27 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
     T* dst = buf + rbase + l * kImg;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<f32x4*>(dst + 4 * r) =
-          f32x4{w[lay.oFz + ((r + 0) & 3) * 4 + r],
+      *reinterpret_cast<V4*>(dst + 4 * r) =
+          V4{w[lay.oFz + ((r + 0) & 3) * 4 + r],
                 w[lay.oFz + ((r + 1) & 3) * 4 + r],
                 w[lay.oFz + ((r + 2) & 3) * 4 + r],
                 w[lay.oFz + ((r + 3) & 3) * 4 + r]};
 #pragma unroll
     for (int x = 0; x < 4; x += 2) {
-      *reinterpret_cast<f32x4*>(dst + 16 + 2 * x) =
-          f32x4{w[lay.oFu + x], w[lay.oLuz + x], w[lay.oFu + x + 1],
+      *reinterpret_cast<V4*>(dst + 16 + 2 * x) =
+          V4{w[lay.oFu + x], w[lay.oLuz + x], w[lay.oFu + x + 1],
                 w[lay.oLuz + x + 1]};
-      *reinterpret_cast<f32x4*>(dst + 24 + 2 * x) =
-          f32x4{w[lay.oFu + x], w[lay.oLz + x], w[lay.oFu + x + 1],
+      *reinterpret_cast<V4*>(dst + 24 + 2 * x) =
+          V4{w[lay.oFu + x], w[lay.oLz + x], w[lay.oFu + x + 1],
                 w[lay.oLz + x + 1]};
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      *reinterpret_cast<f32x4*>(dst + 32 + 4 * r) =
-          f32x4{w[lay.oLzz + 4 * r], w[lay.oLzz + 4 * r + 1],
+      *reinterpret_cast<V4*>(dst + 32 + 4 * r) =
+          V4{w[lay.oLzz + 4 * r], w[lay.oLzz + 4 * r + 1],
                 w[lay.oLzz + 4 * r + 2], w[lay.oLzz + 4 * r + 3]};
-    *reinterpret_cast<f32x4*>(dst + 48) =
-        f32x4{w[lay.oLuu], w[lay.oLu], umin - w[lay.oU], umax - w[lay.oU]};
+    *reinterpret_cast<V4*>(dst + 48) =
+        V4{w[lay.oLuu], w[lay.oLu], umin - w[lay.oU], umax - w[lay.oU]};
     if (tau >= 0) {
       if (counted) gen.L[(size_t)bc * (size_t)(N + 1) + tau] = lc;
       Jacc += lc;
@@ -409,7 +457,7 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
   [[maybe_unused]] T* const gains_w = img0 + kPairLdsOvl;  // (ROUND) [row][N][5]
   auto flush_gains = [&](const T* ib, int t_top, int cnt) {
     const T* sg = ib + l * kImg + rbase;
-    const f32x4 Kv = *reinterpret_cast<const f32x4*>(sg);
+    const V4 Kv = *reinterpret_cast<const V4*>(sg);
     const T kv = sg[4];
     if (exists && l < cnt) {
       T* g = a.gains + ((size_t)bc * (size_t)N + (size_t)(t_top - l)) * kGain;
@@ -424,12 +472,14 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
       img0 + (nblk & 1) * kImgBuf + row * round_zu_stride(N);
   // (ROUND) what the search reads, and the way out of the sweep phase
   [[maybe_unused]] auto round_out = [&](int status_) {
-    ro.Zs = zu_w;
-    ro.Us = zu_w + (N + 1) * 4;
-    ro.Gs = gains_w + row * N * kGain;
-    ro.status = status_;
-    n4::lds_publish_barrier();  // the last barrier: gains, nominal, J_opt
-    ro.J_opt = term_w[row * kTermRow + 21];
+    if constexpr (ROUND) {
+      ro.Zs = zu_w;
+      ro.Us = zu_w + (N + 1) * 4;
+      ro.Gs = gains_w + row * N * kGain;
+      ro.status = status_;
+      n4::lds_publish_barrier();  // the last barrier: gains, nominal, J_opt
+      ro.J_opt = term_w[row * kTermRow + 21];
+    }
   };
   if constexpr (OVL) {
     if (is_gen) {
@@ -456,18 +506,18 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
         // requested before the first write: one memory latency
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         constexpr int kCh = 8;  // N + 1 <= 128 (checked by the launcher)
-        f32x4 zc[kCh];
+        V4 zc[kCh];
         T uc[kCh];
 #pragma unroll
         for (int c = 0; c < kCh; ++c) {
           const int tz = l + 16 * c;
-          zc[c] = *reinterpret_cast<const f32x4*>(Zg + 4 * (tz <= N ? tz : N));
+          zc[c] = *reinterpret_cast<const V4*>(Zg + 4 * (tz <= N ? tz : N));
           uc[c] = Ug[tz < N ? tz : 0];
         }
 #pragma unroll
         for (int c = 0; c < kCh; ++c) {
           const int tz = l + 16 * c;
-          if (tz <= N) *reinterpret_cast<f32x4*>(zu_w + 4 * tz) = zc[c];
+          if (tz <= N) *reinterpret_cast<V4*>(zu_w + 4 * tz) = zc[c];
           if (tz < N) zu_w[(N + 1) * 4 + tz] = uc[c];
         }
       }
@@ -498,20 +548,20 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
   T vc = term_w[row * kTermRow + 16 + j];
 
   struct Words {
-    f32x4 Fs, Fq;
-    f32x2 Ti, Tj;  // {f[i], Luz[i]}, {f[j], Lz[j]}
-    f32x4 Sc;      // Luu, Lu, lo, hi
+    V4 Fs, Fq;
+    V2 Ti, Tj;  // {f[i], Luz[i]}, {f[j], Lz[j]}
+    V4 Sc;      // Luu, Lu, lo, hi
     T Lzz;
   };
   auto gather = [&](const T* ib, const int s) {
     const T* p = ib + s * kImg;
     Words w;
-    w.Fs = *reinterpret_cast<const f32x4*>(p + oA);       // F_z[(i+d)%4][i]
-    w.Fq = *reinterpret_cast<const f32x4*>(p + oB);       // F_z[(j+d)%4][j]
-    w.Ti = *reinterpret_cast<const f32x2*>(p + oTi);
-    w.Tj = *reinterpret_cast<const f32x2*>(p + oTj);
+    w.Fs = *reinterpret_cast<const V4*>(p + oA);       // F_z[(i+d)%4][i]
+    w.Fq = *reinterpret_cast<const V4*>(p + oB);       // F_z[(j+d)%4][j]
+    w.Ti = *reinterpret_cast<const V2*>(p + oTi);
+    w.Tj = *reinterpret_cast<const V2*>(p + oTj);
     w.Lzz = p[oL];
-    w.Sc = *reinterpret_cast<const f32x4*>(p + 48 + rbase);
+    w.Sc = *reinterpret_cast<const V4*>(p + 48 + rbase);
     return w;
   };
   T kprev = T(0);
@@ -523,8 +573,8 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
   const int ostage = rbase + l;
 
   auto step = [&](const Words& w, T* ib, const int s) {
-    const StepCore q = step_core(V, vc, w.Ti[0], w.Tj[0], w.Fs, w.Fq, w.Lzz,
-                                 w.Tj[1], w.Ti[1], w.Sc[0], w.Sc[1]);
+    const StepCoreT<T> q = step_core(V, vc, w.Ti[0], w.Tj[0], w.Fs, w.Fq,
+                                     w.Lzz, w.Tj[1], w.Ti[1], w.Sc[0], w.Sc[1]);
     const T Quu = q.Quu, Qu = q.Qu;
     // transposes (lane (i, j) <- lane (j, i)) issued HERE: their latency under
     // the BoxQP (left to itself the scheduler sinks them to their use)
@@ -532,24 +582,32 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
     const T Quzc = bperm(tr_addr, q.Quzr);
     __builtin_amdgcn_sched_barrier(0);
     // ---- gains: e = Quu < 0 ? 1e-12 : Quu (ilqr.py:633), + reg (:634)
-    const T qp_Q = bsel(splat(sgn(Quu)), 1e-12f, Quu) + reg;
     const T lo_b = w.Sc[2], hi_b = w.Sc[3];
-    QpLean1 ql;
-    ql.solve(kprev, qp_Q, Qu, lo_b, hi_b);
-    T kt = ql.x;
-    T sK = __int_as_float(splat(ql.free_w) & __float_as_int(ql.inv));
-    T c, wv;
-    n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, wv);
-    // anything the lean form does not cover - a non-finite Quu (0 Quu is NaN
-    // then), a Q that is not positive and finite, `slow` (all ones: a NaN) -
-    // in ONE class test: QpClosed, the reference's loop behind it, for those
-    // rows only
-    const T chk = __int_as_float(__float_as_int(fma_(Quu, T(0), qp_Q)) |
-                                 splat(ql.slow_w));
-    unsigned long long regular;  // (the mask straight into a scalar pair)
-    asm("v_cmp_class_f32 %0, %1, %2" : "=s"(regular) : "v"(chk), "v"(0x180));
-    const unsigned long long oddm = ~regular & alive_m;
-    if (__builtin_expect(oddm != 0, 0)) {
+    T qp_Q, kt = T(0), sK = T(0), c = T(0), wv = T(0);
+    unsigned long long oddm;
+    if constexpr (F32) {
+      qp_Q = bsel(splat(sgn(Quu)), 1e-12f, Quu) + reg;
+      QpLean1 ql;
+      ql.solve(kprev, qp_Q, Qu, lo_b, hi_b);
+      kt = ql.x;
+      sK = __int_as_float(splat(ql.free_w) & __float_as_int(ql.inv));
+      n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, wv);
+      // anything the lean form does not cover - a non-finite Quu (0 Quu is
+      // NaN then), a Q that is not positive and finite, `slow` (all ones: a
+      // NaN) - in ONE class test: QpClosed, the reference's loop behind it,
+      // for those rows only
+      const T chk = __int_as_float(__float_as_int(fma_(Quu, T(0), qp_Q)) |
+                                   splat(ql.slow_w));
+      unsigned long long regular;  // (the mask straight into a scalar pair)
+      asm("v_cmp_class_f32 %0, %1, %2" : "=s"(regular) : "v"(chk), "v"(0x180));
+      oddm = ~regular & alive_m;
+    } else {
+      // float64: every live row through the closed form of riccati_n4.hpp
+      // (IEEE division; the reference's loop behind it) - the block below
+      qp_Q = (Quu < T(0) ? T(1e-12) : Quu) + reg;
+      oddm = alive_m;
+    }
+    if (__builtin_expect(oddm != 0, F32 ? 0 : 1)) {
       const bool take = (oddm & lane_bit) != 0;
       int st = PDDP_BWD_OK;
       if (!is_finite(Quu)) st = PDDP_BWD_NAN;      // eig raises (ilqr.py:631)
@@ -567,7 +625,7 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<float>& a,
           todo &= todo - 1;
           const n4::SlowQpOut<T> o = n4q::boxqp1_wave<T, true>(
               __shfl(kprev, src), __shfl(qp_Q, src), __shfl(Qu, src),
-              __shfl(lo_b, src), __shfl(hi_b, src), kLsF.v, lane);
+              __shfl(lo_b, src), __shfl(hi_b, src), ls_table<T>(), lane);
           const bool mine = (lane >> 4) == (src >> 4);
           kx = mine ? o.x : kx;
           Kzero = mine ? ((o.result_free & 1) == 0) : Kzero;
@@ -664,7 +722,15 @@ riccati_n4_elem_kernel(RiccatiArgs<float> a, GenArgs<float> gen,
                        ProblemT<float> prob) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   RoundOut ro;
-  elem_sweep_body<QM, OVL, false>(a, gen, prob, smem_raw, ro);
+  elem_sweep_body<float, QM, OVL, false>(a, gen, prob, smem_raw, ro);
+}
+// float64 (cartpole, bounded eig-clamp branch): the inline form
+template <unsigned QM>
+__global__ __launch_bounds__(kWaves * kWave) void riccati_n4_elem_f64_kernel(
+    RiccatiArgs<double> a, GenArgs<double> gen, ProblemT<double> prob) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  RoundOut ro;
+  elem_sweep_body<double, QM, false, false>(a, gen, prob, smem_raw, ro);
 }
 
 }  // namespace n4e
@@ -710,6 +776,36 @@ static int launch_n4_elem(const pddp_problem& p, const RiccatiArgs<float>& a,
   if (sparse) { if (ovl) PDDP_ELEM_GO(kSparse, true); else PDDP_ELEM_GO(kSparse, false); }
   else { if (ovl) PDDP_ELEM_GO(kFull, true); else PDDP_ELEM_GO(kFull, false); }
 #undef PDDP_ELEM_GO
+  return launch_status();
+}
+
+static int launch_n4_elem_f64(const pddp_problem& p,
+                              const RiccatiArgs<double>& a,
+                              const n4d::GenArgs<double>& gen, hipStream_t st) {
+  if (p.model != PDDP_MODEL_CARTPOLE ||
+      p.encoding != PDDP_ENC_IGNORE_UNCERTAINTY || a.u_min == nullptr ||
+      a.u_max == nullptr || a.branch != PDDP_BRANCH_EIG || a.N < 1)
+    return PDDP_E_UNSUPPORTED;
+  const ProblemT<double> P = convert_problem<double>(p);
+  constexpr int kPer = n4e::kWaves * n4e::kTrajW;
+  const dim3 grid((a.B + kPer - 1) / kPer);
+  constexpr unsigned kSparse = 0b11001u;
+  constexpr unsigned kFull = kFullMask<PDDP_MODEL_CARTPOLE>;
+  const bool sparse =
+      (live_mask(p.Q, ModelDims<PDDP_MODEL_CARTPOLE>::na) & ~kSparse) == 0;
+  const size_t lds =
+      (size_t)n4e::kWaves * sizeof(double) * n4e::kPairLdsInl;  // 106 KB
+#define PDDP_ELEM64_GO(QMV)                                                   \
+  do {                                                                        \
+    auto kern = n4e::riccati_n4_elem_f64_kernel<QMV>;                         \
+    const hipError_t e = hipFuncSetAttribute(                                 \
+        (const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+        (int)lds);                                                            \
+    if (e != hipSuccess) return (int)e;                                       \
+    PDDP_LAUNCH(kern, grid, dim3(n4e::kWaves * kWave), lds, st, a, gen, P);   \
+  } while (0)
+  if (sparse) PDDP_ELEM64_GO(kSparse); else PDDP_ELEM64_GO(kFull);
+#undef PDDP_ELEM64_GO
   return launch_status();
 }
 

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(2 * n4e::kWaves * kWave) void round_n4_kernel(
     // (a pair without a live trajectory leaves here, both wavefronts alike -
     // it has none in any later round either; s_barrier does not wait for
     // wavefronts that have ended)
-    if (!n4e::elem_sweep_body<QM, true, true>(a_r, gen, prob, smem_raw, ro,
+    if (!n4e::elem_sweep_body<float, QM, true, true>(a_r, gen, prob, smem_raw, ro,
                                               tid))
       break;
     const long long t1 = timed ? wall_clock64() : 0;

@@ -1584,6 +1584,72 @@ class _nominal_kernel(object):
         _native.lib().pddp_sweep_nominal_kernel(self.prev)
 
 
+@pytest.mark.parametrize("B,N", [(37, 33), (16, 100), (5, 10), (130, 47),
+                                 (3, 8), (300, 201), (2, 1), (70, 16),
+                                 (33, 32), (6, 17)])
+def test_sweep_from_nominal_f64_vs_oracle_and_records(B, N):
+    """pddp_sweep_nominal_f64 for the cartpole (round 5: the mapping of the
+    benched f32 sweep - riccati_n4_elem.hpp, 16 lanes per trajectory, records
+    generated in the workgroup into LDS images, gains out through dead image
+    words - instantiated in float64, with the closed-form BoxQP and IEEE
+    division): against the fp64 ORACLE on the same nominal - gains and status
+    to 1e-9, stage costs and J_opt to 1e-12 (ilqr.py:393-486, :529-674) - and
+    against pddp_derivs_f64 followed by the recorded sweep; ragged batches,
+    horizons shorter than / not a multiple of a block, masked trajectories."""
+    s, op, z0, U, u_min, u_max = _setup("cartpole", "f64", B, N, seed=11)
+    assert s._nominal_sweep is None  # in its domain, untried
+    s.set_nominal(torch.from_numpy(z0).cuda(), torch.from_numpy(U).cuda())
+    s.mu.fill_(1.0)
+    s.active[::5] = 0
+    s.derivs()
+    s.backward(active=s.active, variant=0)
+    ref = {k: getattr(s, k).clone() for k in ("gains", "bwd_status", "L",
+                                              "J_opt")}
+    s.gains.zero_()
+    s.bwd_status.fill_(-7)
+    s.L.zero_()
+    s.J_opt.fill_(123.0)
+    s.fresh.fill_(1)
+    s.fresh[1::7] = 0
+    assert s.sweep_nominal()
+    torch.cuda.synchronize()
+    live = s.active.bool().cpu()
+    assert torch.equal(s.bwd_status.cpu()[live], ref["bwd_status"].cpu()[live])
+    assert (s.bwd_status.cpu()[~live] == -7).all()
+    g, gr = s.gains.cpu()[live], ref["gains"].cpu()[live]
+    assert float((g - gr).abs().max()) <= 1e-9 * float(gr.abs().max())
+    assert bool((s.gains.cpu()[~live] == 0).all())
+    Lg, Lr = s.L.cpu(), ref["L"].cpu()
+    assert float((Lg[live] - Lr[live]).abs().max()) <= 1e-12 * float(
+        Lr.abs().max())
+    fr = torch.ones(B, dtype=torch.bool)
+    fr[1::7] = False
+    take = live & fr
+    J, Jr = s.J_opt.cpu(), ref["J_opt"].cpu()
+    if take.any():
+        assert float((J[take] - Jr[take]).abs().max()) <= 1e-12 * float(
+            Jr.abs().max())
+    assert (J[~take] == 123.0).all()
+    assert int(s.fresh.cpu()[take].sum()) == 0
+    # ... and the oracle itself, trajectory by trajectory
+    o64 = orc.load(np.float64)
+    names = ("F_z", "F_u", "L_z", "L_u", "L_zz", "L_uz", "L_uu")
+    gains = s.gains.cpu().numpy()
+    st = s.bwd_status.cpu().numpy()
+    n_ok = 0
+    for b in np.where(live.numpy())[0][:40]:
+        f = o64.forward(op, z0[b], U[b], u_min, u_max)
+        kr, Kr, sr = o64.backward(*[f[nm] for nm in names], reg=1.0,
+                                  u_min=u_min, u_max=u_max, U=U[b])
+        assert (sr == 0) == (st[b] == 0), (b, sr, st[b])
+        assert rel_err(Lg[b].numpy(), f["L"]) < 1e-12, b
+        if sr == 0:
+            n_ok += 1
+            g64 = np.concatenate([kr.reshape(N, -1), Kr.reshape(N, -1)], 1)
+            assert rel_err(gains[b], g64) < 1e-9, b
+    assert n_ok >= 1
+
+
 @pytest.mark.parametrize("kernel", [3, 4])
 @pytest.mark.parametrize("B,N", [(37, 33), (16, 100), (5, 10), (130, 47),
                                  (3, 8), (21, 9), (17, 12), (300, 201),
@@ -1905,6 +1971,14 @@ def test_rounds_from_nominal_of_the_other_problems(problem, N, dtype):
     it is the faster round) against the rounds on records: the same decisions
     and regularisation round by round; nominals equal to rounding in fp64."""
     _rounds_side_by_side(1e-8 if dtype == "f64" else 2e-2, problem, dtype, N)
+
+
+def test_rounds_from_nominal_cartpole_f64():
+    """The cartpole's fit in float64 through pddp_sweep_nominal_f64 (the
+    benched sweep's mapping, riccati_n4_elem.hpp) against the rounds on
+    records: the same decisions and regularisation round by round, nominals
+    to 1e-8."""
+    _rounds_side_by_side(1e-8, "cartpole", "f64", 40)
 
 
 def _rounds_side_by_side(vtol, problem="cartpole", dtype="f32", N=40):
