@@ -143,6 +143,22 @@ int pddp_boxqp_m1_f64(int count, const double* x0, const double* Q,
                       const double* upper, double* x, int32_t* result,
                       uint8_t* free_mask, void* stream);
 
+/* The scalar BoxQP AS THE BENCHED SWEEP RUNS IT (csrc/riccati_n4_elem.hpp
+ * elem_gains: ilqr.py:633-634 e = (Quu < 0 ? 1e-12 : Quu) + reg, then
+ * constraint.py:150-266 on (x0, e, Qu, lower, upper) in the lean closed form
+ * with v_rcp_f32 - the closed form of pddp_boxqp_m1_* and the reference's loop
+ * behind it for the rows it does not cover): x = the feed-forward gain,
+ * free_mask = 1 where the feedback row is not zeroed (the reference's possibly
+ * stale `free`), status = PDDP_BWD_OK / _NAN / _BOXQP_FAILED; coeffs, nullable,
+ * [count][3] = {s, c, w}: 1 / e or 0, and the two coefficients of the rank-one
+ * value update V' = sym(Qzz) + c Quz Quz^T, V_z' = Qz + w Quz (ilqr.py:664-672
+ * with K = -s Quz).  The unit-test entry of that routine. */
+int pddp_boxqp_m1_lean_f32(int count, const float* x0, const float* Quu,
+                           const float* Qu, const float* reg,
+                           const float* lower, const float* upper, float* x,
+                           uint8_t* free_mask, int32_t* status, float* coeffs,
+                           void* stream);
+
 /* ---- utils/constraint.py:150-266 boxqp() for m <= 4 action dimensions ------ */
 /* `count` independent QPs  min 0.5 x^T Q x + c^T x  s.t. lower <= x <= upper,
  * warm-started at x0; the routine the generic sweep calls (csrc/gains.hpp),

@@ -82,6 +82,7 @@ _SIGS = {
     "pddp_sweep_nominal": [_P, c_int, c_int] + [_P] * 5 + [c_int] +
                           [_P] * 7,
     "pddp_sweep_nominal_kernel": [c_int],
+    "pddp_boxqp_m1_lean_f32": [c_int] + [_P] * 11,
     "pddp_round_nominal_f32": [_P, c_int, c_int, c_int] + [_P] * 5 + [c_int] +
                               [_P] * 9 + [c_double, c_double, c_int] +
                               [_P] * 7 + [c_int, _P, _P],

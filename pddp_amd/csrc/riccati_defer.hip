@@ -88,6 +88,54 @@ extern "C" int pddp_sweep_nominal_f64(const pddp_problem* problem, int B, int N,
                                           (hipStream_t)stream);
 }
 
+namespace pddp {
+namespace n4e {
+// elem_gains on `count` independent scalar problems, four per wavefront as in
+// the sweep (pddp_boxqp_m1_lean_f32: the unit-test entry of the benched
+// sweep's BoxQP).  x = k, free_mask = (K is not zeroed), status = PDDP_BWD_*.
+__global__ __launch_bounds__(kWave) void elem_gains_kernel(
+    int count, const float* x0, const float* Quu, const float* Qu,
+    const float* reg, const float* lo, const float* hi, float* x,
+    uint8_t* free_mask, int32_t* status_out, float* coeffs) {
+  const int lane = threadIdx.x;
+  const int p = blockIdx.x * kTrajW + (lane >> 4);
+  const bool exists = p < count;
+  const int pc = exists ? p : count - 1;
+  int status = PDDP_BWD_OK;
+  unsigned long long alive_m = __ballot(exists);
+  const ElemGains<float> g = elem_gains<float>(
+      x0[pc], Quu[pc], Qu[pc], reg[pc], lo[pc], hi[pc], lane, status, alive_m);
+  if (exists && (lane & 15) == 0) {
+    x[p] = g.kt;
+    free_mask[p] = g.sK != 0.0f ? 1 : 0;
+    status_out[p] = status;
+    if (coeffs != nullptr) {
+      coeffs[3 * p] = g.sK;
+      coeffs[3 * p + 1] = g.c;
+      coeffs[3 * p + 2] = g.wv;
+    }
+  }
+}
+
+}  // namespace n4e
+}  // namespace pddp
+
+extern "C" int pddp_boxqp_m1_lean_f32(int count, const float* x0,
+                                      const float* Quu, const float* Qu,
+                                      const float* reg, const float* lower,
+                                      const float* upper, float* x,
+                                      uint8_t* free_mask, int32_t* status,
+                                      float* coeffs, void* stream) {
+  if (count <= 0 || !x0 || !Quu || !Qu || !reg || !lower || !upper || !x ||
+      !free_mask || !status)
+    return PDDP_E_BADARG;
+  PDDP_LAUNCH(pddp::n4e::elem_gains_kernel,
+              dim3((count + pddp::n4e::kTrajW - 1) / pddp::n4e::kTrajW),
+              dim3(pddp::kWave), 0, (hipStream_t)stream, count, x0, Quu, Qu,
+              reg, lower, upper, x, free_mask, status, coeffs);
+  return pddp::launch_status();
+}
+
 extern "C" int pddp_sweep_nominal_kernel(int which) {
   const int prev = pddp::nominal_kernel_choice();
   if (which == 0 || which == 3 || which == 4)

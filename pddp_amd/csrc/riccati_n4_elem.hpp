@@ -248,6 +248,89 @@ PDDP_DEV StepCore step_core(float V, float vc, float fr, float fc, f32x4 Fs,
   return o;
 }
 
+// The gains of one step for the four trajectories of a wavefront (row = lane
+// >> 4, the same values in the 16 lanes of a row): the scalar BoxQP of
+// ilqr.py:645-656 / constraint.py:150-266 on e = (Quu < 0 ? 1e-12 : Quu) + reg
+// (ilqr.py:633-634) warm-started at the previous step's k, then c and w of the
+// rank-one value update.  float: QpLean1, and - behind ONE class test - the
+// closed form of riccati_n4.hpp and the reference's loop for the rows the lean
+// form does not cover; float64: the closed form (IEEE division) and the loop.
+// `status` / `alive_m`: a row that fails gets its PDDP_BWD_* code and leaves
+// the mask of live rows.  Shared by the sweep (elem_sweep_body) and by
+// pddp_boxqp_m1_lean_f32, the unit-test entry of exactly this routine.
+template <typename T>
+struct ElemGains {
+  T kt, sK, c, wv;
+};
+template <typename T>
+PDDP_DEV ElemGains<T> elem_gains(T kprev, T Quu, T Qu, T reg, T lo_b, T hi_b,
+                                 int lane, int& status,
+                                 unsigned long long& alive_m) {
+  constexpr bool F32 = std::is_same<T, float>::value;
+  const int l = lane & 15;
+  const unsigned long long lane_bit = 1ull << lane;
+  T qp_Q, kt = T(0), sK = T(0), c = T(0), wv = T(0);
+  unsigned long long oddm;
+  if constexpr (F32) {
+    qp_Q = bsel(splat(sgn(Quu)), 1e-12f, Quu) + reg;
+    QpLean1 ql;
+    ql.solve(kprev, qp_Q, Qu, lo_b, hi_b);
+    kt = ql.x;
+    sK = __int_as_float(splat(ql.free_w) & __float_as_int(ql.inv));
+    n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, wv);
+    // anything the lean form does not cover - a non-finite Quu (0 Quu is
+    // NaN then), a Q that is not positive and finite, `slow` (all ones: a
+    // NaN) - in ONE class test: QpClosed, the reference's loop behind it,
+    // for those rows only
+    const T chk = __int_as_float(__float_as_int(fma_(Quu, T(0), qp_Q)) |
+                                 splat(ql.slow_w));
+    unsigned long long regular;  // (the mask straight into a scalar pair)
+    asm("v_cmp_class_f32 %0, %1, %2" : "=s"(regular) : "v"(chk), "v"(0x180));
+    oddm = ~regular & alive_m;
+  } else {
+    // float64: every live row through the closed form of riccati_n4.hpp
+    // (IEEE division; the reference's loop behind it) - the block below
+    qp_Q = (Quu < T(0) ? T(1e-12) : Quu) + reg;
+    oddm = alive_m;
+  }
+  if (__builtin_expect(oddm != 0, F32 ? 0 : 1)) {
+    const bool take = (oddm & lane_bit) != 0;
+    int st = PDDP_BWD_OK;
+    if (!is_finite(Quu)) st = PDDP_BWD_NAN;      // eig raises (ilqr.py:631)
+    n4::QpClosed<T, true> qc;
+    qc.solve(kprev, qp_Q, Qu, lo_b, hi_b);
+    T kx = qc.x;
+    bool Kzero = !qc.free_, fail = qc.fail;
+    const bool slow = qc.slow & take;
+    if (__any(slow)) {
+      // rare: the reference's loop, one slow trajectory at a time on the
+      // whole wavefront
+      unsigned long long todo = __ballot(slow && l == 0);
+      while (todo != 0) {
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const n4::SlowQpOut<T> o = n4q::boxqp1_wave<T, true>(
+            __shfl(kprev, src), __shfl(qp_Q, src), __shfl(Qu, src),
+            __shfl(lo_b, src), __shfl(hi_b, src), ls_table<T>(), lane);
+        const bool mine = (lane >> 4) == (src >> 4);
+        kx = mine ? o.x : kx;
+        Kzero = mine ? ((o.result_free & 1) == 0) : Kzero;
+        fail = mine ? (o.result_free < 2) : fail;
+      }
+    }
+    const T sx = Kzero ? T(0) : qc.inv;
+    const int stt = st != PDDP_BWD_OK ? st : (fail ? (int)PDDP_BWD_BOXQP_FAILED : (int)PDDP_BWD_OK);
+    T cx, wx;
+    n4q::rank_one_coeffs(kx, sx, Quu, Qu, cx, wx);
+    kt = take ? kx : kt; sK = take ? sx : sK;
+    c = take ? cx : c; wv = take ? wx : wv;
+    const bool bad = take & (stt != PDDP_BWD_OK);
+    status = bad ? stt : status;
+    alive_m &= ~__ballot(bad);
+  }
+  return ElemGains<T>{kt, sK, c, wv};
+}
+
 #ifdef PDDP_ELEM_MARKS
 // time marks of wavefront 0 of workgroup 0: begin, first step, last step done,
 // end (tools/elem_sweep_marks.py)
@@ -581,67 +664,10 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
     const T QzzT = bperm(tr_addr, q.Qzz);
     const T Quzc = bperm(tr_addr, q.Quzr);
     __builtin_amdgcn_sched_barrier(0);
-    // ---- gains: e = Quu < 0 ? 1e-12 : Quu (ilqr.py:633), + reg (:634)
-    const T lo_b = w.Sc[2], hi_b = w.Sc[3];
-    T qp_Q, kt = T(0), sK = T(0), c = T(0), wv = T(0);
-    unsigned long long oddm;
-    if constexpr (F32) {
-      qp_Q = bsel(splat(sgn(Quu)), 1e-12f, Quu) + reg;
-      QpLean1 ql;
-      ql.solve(kprev, qp_Q, Qu, lo_b, hi_b);
-      kt = ql.x;
-      sK = __int_as_float(splat(ql.free_w) & __float_as_int(ql.inv));
-      n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, wv);
-      // anything the lean form does not cover - a non-finite Quu (0 Quu is
-      // NaN then), a Q that is not positive and finite, `slow` (all ones: a
-      // NaN) - in ONE class test: QpClosed, the reference's loop behind it,
-      // for those rows only
-      const T chk = __int_as_float(__float_as_int(fma_(Quu, T(0), qp_Q)) |
-                                   splat(ql.slow_w));
-      unsigned long long regular;  // (the mask straight into a scalar pair)
-      asm("v_cmp_class_f32 %0, %1, %2" : "=s"(regular) : "v"(chk), "v"(0x180));
-      oddm = ~regular & alive_m;
-    } else {
-      // float64: every live row through the closed form of riccati_n4.hpp
-      // (IEEE division; the reference's loop behind it) - the block below
-      qp_Q = (Quu < T(0) ? T(1e-12) : Quu) + reg;
-      oddm = alive_m;
-    }
-    if (__builtin_expect(oddm != 0, F32 ? 0 : 1)) {
-      const bool take = (oddm & lane_bit) != 0;
-      int st = PDDP_BWD_OK;
-      if (!is_finite(Quu)) st = PDDP_BWD_NAN;      // eig raises (ilqr.py:631)
-      n4::QpClosed<T, true> qc;
-      qc.solve(kprev, qp_Q, Qu, lo_b, hi_b);
-      T kx = qc.x;
-      bool Kzero = !qc.free_, fail = qc.fail;
-      const bool slow = qc.slow & take;
-      if (__any(slow)) {
-        // rare: the reference's loop, one slow trajectory at a time on the
-        // whole wavefront
-        unsigned long long todo = __ballot(slow && l == 0);
-        while (todo != 0) {
-          const int src = __builtin_ctzll(todo);
-          todo &= todo - 1;
-          const n4::SlowQpOut<T> o = n4q::boxqp1_wave<T, true>(
-              __shfl(kprev, src), __shfl(qp_Q, src), __shfl(Qu, src),
-              __shfl(lo_b, src), __shfl(hi_b, src), ls_table<T>(), lane);
-          const bool mine = (lane >> 4) == (src >> 4);
-          kx = mine ? o.x : kx;
-          Kzero = mine ? ((o.result_free & 1) == 0) : Kzero;
-          fail = mine ? (o.result_free < 2) : fail;
-        }
-      }
-      const T sx = Kzero ? T(0) : qc.inv;
-      const int stt = st != PDDP_BWD_OK ? st : (fail ? (int)PDDP_BWD_BOXQP_FAILED : (int)PDDP_BWD_OK);
-      T cx, wx;
-      n4q::rank_one_coeffs(kx, sx, Quu, Qu, cx, wx);
-      kt = take ? kx : kt; sK = take ? sx : sK;
-      c = take ? cx : c; wv = take ? wx : wv;
-      const bool bad = take & (stt != PDDP_BWD_OK);
-      status = bad ? stt : status;
-      alive_m &= ~__ballot(bad);
-    }
+    // ---- gains: the scalar BoxQP of the step (elem_gains above)
+    const ElemGains<T> g_ = elem_gains<T>(kprev, Quu, Qu, reg, w.Sc[2], w.Sc[3],
+                                          lane, status, alive_m);
+    const T kt = g_.kt, sK = g_.sK, c = g_.c, wv = g_.wv;
     // ---- gains out: K = -s Quz (column form in lanes (0, j)), k elsewhere
     ib[s * kImg + ostage] = (l < 4) ? -(sK * Quzc) : kt;
     kprev = kt;

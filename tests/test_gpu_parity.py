@@ -496,6 +496,117 @@ def test_boxqp_m1_vs_oracle(dtype):
     assert n_exact >= (n - 50 if dtype == "f64" else int(0.97 * n))
 
 
+def test_lean_boxqp_of_the_benched_sweep_vs_oracle():
+    """The scalar BoxQP exactly as the benched f32 sweep runs it
+    (pddp_boxqp_m1_lean_f32 = riccati_n4_elem.hpp elem_gains: the eig-clamp of
+    ilqr.py:633-634, QpLean1 with v_rcp_f32, the closed form and the
+    reference's loop behind ONE class test) against the oracle's restatement
+    of constraint.py:150-266 on 60 000 problems: the distribution the sweep
+    meets (warm starts inside the box, ON a bound, a few ulps off it, outside;
+    Newton points inside / beyond / on the bounds) and the corners (vanishing
+    gradients, negative and zero curvature with and without regularisation,
+    NaN / inf curvature).  Held to the fp64 oracle on the same inputs, and
+    measured against what the IEEE fp32 oracle - the reference's own
+    arithmetic - does on them: status identical wherever the two oracles
+    agree with each other; x to 2e-6 and the `free` flag (which zeroes the
+    feedback row) identical except on knife edges, counted - no more than
+    twice the fp32 oracle's own count plus 0.05 %; and the value-update
+    coefficients s, c, w against their definitions."""
+    from pddp_amd import _native
+    rng = np.random.RandomState(17)
+    n = 60000
+    Quu = np.exp(rng.uniform(-2, 4, n))
+    reg = rng.choice([0.0, 1e-6, 1e-3, 1.0, 100.0], n)
+    Qu = rng.randn(n) * np.exp(rng.uniform(-4, 4, n))
+    Un = 3.0 * rng.randn(n)
+    lo, hi = -10.0 - Un, 10.0 - Un
+    x0 = lo + (hi - lo) * rng.rand(n)
+    k = n // 12
+    x0[0 * k:1 * k] = lo[0 * k:1 * k]                      # on the lower bound
+    x0[1 * k:2 * k] = hi[1 * k:2 * k]                      # on the upper bound
+    x0[2 * k:3 * k] = lo[2 * k:3 * k] + 30 * rng.randn(k)  # anywhere
+    # a few ulps off a bound
+    x0[3 * k:4 * k] = np.nextafter(hi[3 * k:4 * k].astype(np.float32),
+                                   np.float32(0)).astype(np.float64)
+    # Newton point ON / next to a bound: Qu = -e * bound (1 +- few 1e-7)
+    e_ = Quu + reg
+    sl = slice(4 * k, 5 * k)
+    Qu[sl] = -e_[sl] * hi[sl] * (1.0 + 3e-7 * rng.randn(k))
+    sl = slice(5 * k, 6 * k)
+    Qu[sl] = -e_[sl] * lo[sl] * (1.0 + 3e-7 * rng.randn(k))
+    # warm start next to the Newton point (tiny decrease: the `conv` exit)
+    sl = slice(6 * k, 7 * k)
+    x0[sl] = np.clip(-Qu[sl] / e_[sl] * (1.0 + 1e-6 * rng.randn(k)), lo[sl],
+                     hi[sl])
+    # vanishing gradient at the warm start
+    sl = slice(7 * k, 8 * k)
+    Qu[sl] = -e_[sl] * x0[sl] + 1e-8 * rng.randn(k)
+    # negative / zero curvature (ilqr.py:633: replaced by 1e-12, + reg)
+    Quu[8 * k:9 * k] *= -1.0
+    Quu[9 * k:9 * k + 50] = 0.0
+    a32 = [v.astype(np.float32) for v in (x0, Quu, Qu, reg, lo, hi)]
+    # non-finite curvature
+    a32[1][9 * k + 50:9 * k + 60] = np.nan
+    a32[1][9 * k + 60:9 * k + 70] = np.inf
+    dev = [torch.from_numpy(v).cuda() for v in a32]
+    x = torch.empty(n, device="cuda")
+    free = torch.empty(n, dtype=torch.uint8, device="cuda")
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    co = torch.empty(n, 3, device="cuda")
+    p = _native.ptr
+    _native.check(_native.lib().pddp_boxqp_m1_lean_f32(
+        n, *[p(t) for t in dev], p(x), p(free), p(st), p(co),
+        _native.stream_handle()), "pddp_boxqp_m1_lean_f32")
+    x, free, st, co = (t.cpu().numpy() for t in (x, free, st, co))
+    x0_, Quu_, Qu_, reg_, lo_, hi_ = a32
+    # ilqr.py:633-634 in the run's dtype
+    e32 = (np.where(Quu_ < 0, np.float32(1e-12), Quu_) + reg_).astype(np.float32)
+    o32, o64 = orc.load(np.float32), orc.load(np.float64)
+    cnt = dict(status=0, status_o32=0, x=0, x_o32=0, free=0, free_o32=0,
+               compared=0, oracles_differ=0)
+    worst = 0.0
+    for i in range(n):
+        if not np.isfinite(Quu_[i]):
+            assert st[i] == 1, (i, st[i])  # PDDP_BWD_NAN: eig raises
+            continue
+        a = [np.array([v[i]]) for v in (x0_, e32, Qu_, lo_, hi_)]
+        x3, r3, _, f3 = o32.boxqp(*a)
+        x6, r6, _, f6 = o64.boxqp(*[v.astype(np.float64) for v in a])
+        ok3, ok6 = r3 >= 1, r6 >= 1
+        cnt["compared"] += 1
+        if ok3 != ok6:
+            cnt["oracles_differ"] += 1
+        else:
+            assert (st[i] == 0) == ok6, (i, st[i], r3, r6)
+        cnt["status"] += int((st[i] == 0) != ok6)
+        cnt["status_o32"] += int(ok3 != ok6)
+        if not (ok6 and st[i] == 0):
+            continue
+        tol = lambda u, v: abs(u - v) <= 2e-6 * max(1.0, abs(v))
+        cnt["x"] += int(not tol(x[i], x6[0]))
+        cnt["x_o32"] += int(ok3 and not tol(x3[0], x6[0]))
+        cnt["free"] += int(free[i] != f6[0])
+        cnt["free_o32"] += int(ok3 and f3[0] != f6[0])
+        if tol(x[i], x6[0]):
+            worst = max(worst, abs(x[i] - x6[0]) / max(1.0, abs(x6[0])))
+        # s = 1 / e where the row is free, c = s (s Quu - 2), w = k - s (Quu k
+        # + Qu): ilqr.py:664-672 with K = -s Quz
+        s_ = float(co[i, 0])
+        if free[i]:
+            assert abs(s_ * float(e32[i]) - 1.0) < 1e-6, i
+        else:
+            assert s_ == 0.0, i
+        q_, k_ = float(Quu_[i]), float(x[i])
+        c_ref = s_ * (s_ * q_ - 2.0)
+        w_ref = k_ - s_ * (q_ * k_ + float(Qu_[i]))
+        assert abs(co[i, 1] - c_ref) <= 1e-5 * max(abs(c_ref), s_, 1e-30), i
+        assert abs(co[i, 2] - w_ref) <= 1e-4 * max(abs(k_), abs(w_ref), 1e-6), i
+    STATS.append(dict(test="lean_boxqp", worst_x=worst, **cnt))
+    m = cnt["compared"]
+    for key in ("status", "x", "free"):
+        assert cnt[key] <= 2 * cnt[key + "_o32"] + m // 2000, cnt
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_boxqp_vs_reference_golden_and_oracle(dtype):
     """`pddp_amd.utils.constraint.boxqp` (constraint.py:150-266) as a callable
