@@ -595,7 +595,10 @@ def bench_gp(args, emit=True):
     N = args.horizon or 150
     K = args.steps if args.steps != 30 else 2
     W = args.warmup if args.warmup != 5 else 1
-    M = 60
+    # training points: 60 (rounds 3-4), or what the outer loop of
+    # PDDPController.fit hands a model after its first two trials -
+    # n_initial_sample_trajectories = 2 x N = 150 rows (pddp.py:67-71,121-150)
+    M = getattr(args, "gp_points", None) or 60
     D, m, A = 6, 1, 10
     n = D + D * (D + 1) // 2
     g = torch.Generator().manual_seed(0)
@@ -1082,6 +1085,9 @@ def main():
                          "[4] appended to the default line")
     ap.add_argument("--kernel-variant", type=int, default=0,
                     help="backward kernel (include/pddp_hip.h): 0 auto")
+    ap.add_argument("--gp-points", type=int, default=None,
+                    help="double_cartpole_gp: training points of the GP "
+                         "(default 60; 300 = two trials of 150 steps)")
     ap.add_argument("--rounds-per-launch", type=int, default=10,
                     help="cartpole f32: rounds per pddp_round_nominal_f32 "
                          "launch (csrc/round_n4.hip: a workgroup owns its "
@@ -1475,13 +1481,22 @@ def main():
             torch.cuda.empty_cache()
             sec = []
             # (configs[2] a second time on the float64 kernels: three rounds)
-            for wl, k, w, dt_ in (("cartpole_bnn", 5, 1, "f32"),
-                                  ("cartpole_bnn", 3, 1, "f64"),
-                                  ("double_cartpole_bnn", 5, 1, "f32"),
-                                  ("double_cartpole_gp", 5, 1, "f32"),
-                                  ("mpc_bnn", 200, 2, "f32")):
+            # (the GP a second time at the data-set size the reference's
+            # outer loop produces - 300 rows: one round, 25 x the pair loop)
+            for wl, k, w, dt_, gp_m in (("cartpole_bnn", 5, 1, "f32", None),
+                                        ("cartpole_bnn", 3, 1, "f64", None),
+                                        ("double_cartpole_bnn", 5, 1, "f32",
+                                         None),
+                                        ("double_cartpole_gp", 5, 1, "f32",
+                                         None),
+                                        ("double_cartpole_gp", 1, 1, "f32",
+                                         300),
+                                        ("mpc_bnn", 200, 2, "f32", None)):
                 a2 = copy.copy(args)
                 a2.workload, a2.steps, a2.warmup, a2.dtype = wl, k, w, dt_
+                a2.gp_points = gp_m
+                if gp_m:
+                    a2.no_graph_replay = True
                 a2.batch = a2.horizon = None
                 try:
                     fn = {"mpc_bnn": bench_mpc_bnn,

@@ -145,11 +145,21 @@ def gp_dynamics_model_factory(state_size, action_size, angular_indices=(),
             K = self._kernel(Xt, Xt)
             K = K + ((2.0 * self.log_sn).exp() + self.jitter)[:, None, None] * \
                 torch.eye(M, dtype=Xt.dtype, device=Xt.device)
-            L = torch.linalg.cholesky(K)
-            eye = torch.eye(M, dtype=Xt.dtype, device=Xt.device).expand(
-                state_size, M, M)
-            self.Kinv = cholesky_solve(eye, L)
-            self.beta = cholesky_solve(Y.t().unsqueeze(-1), L).squeeze(-1)
+            # The factorisation of the E kernel matrices on the HOST, in
+            # float64 (once per fit; M <= 1000: milliseconds): on this image's
+            # PyTorch 2.10 / ROCm 7.0 build the batched device potrf fails
+            # outright on a [6, 300, 300] float batch ("unspecified launch
+            # failure", bench.py --gp-points 300) - after the batched potrs
+            # that writes outside its outputs (utils/linalg.py), the second
+            # defect of that library path.  The weights go back in the model's
+            # dtype; nothing on the controller's path runs here.
+            Kh, Yh = K.double().cpu(), Y.double().cpu()
+            L = torch.linalg.cholesky(Kh)
+            eye = torch.eye(M, dtype=torch.float64).expand(state_size, M, M)
+            self.Kinv = cholesky_solve(eye, L).to(dtype=Xt.dtype,
+                                                  device=Xt.device)
+            self.beta = cholesky_solve(Yh.t().unsqueeze(-1), L).squeeze(-1).to(
+                dtype=Xt.dtype, device=Xt.device)
             self.Xt = Xt.clone()
             self.fitted = True
             self._drop_native_view()

@@ -656,6 +656,36 @@ def test_gp_step_kernel_training_set_sizes(M):
 
 
 @pytest.mark.gpu
+def test_gp_step_kernel_at_the_outer_loops_dataset_size():
+    """BASELINE configs[3]'s shape at the training-set size the outer loop of
+    PDDPController.fit produces after its two initial trials (pddp.py:67-71,
+    121-150: 2 x N = 300 rows): double cartpole, DEFAULT encoding (n = 27),
+    M = 300 - the float kernel's step and Jacobian (what the bench's second GP
+    line runs; M <= 318 fits a workgroup's LDS with the Jacobian) against the
+    fp64 torch module and autograd on the same inputs with the float module's
+    own distance as the yardstick, and the fp64 kernel's step (its Jacobian
+    form stops at M = 74: the derivative rollout then goes through autograd)
+    to 1e-10."""
+    import copy
+    enc = StateEncoding.DEFAULT
+    model, _ = _system_model("double_cartpole", 300, torch.float32, seed=3)
+    z, u = _system_rows("double_cartpole", 5, enc, torch.float32, seed=4)
+    assert model.native_ok(z, enc, jacobian=True)
+    ref, Fz_r, Fu_r = _torch_step(model, z, u, enc, True)
+    out, Fz, Fu = model.native_step(z, u, enc, jacobian=True)
+    m64 = copy.deepcopy(model).double()
+    m64._native_cache = {}
+    r64, Fz64, Fu64 = _torch_step(m64, z.double(), u.double(), enc, True)
+    for got, tor, exact, tol in ((out, ref, r64, 2e-5), (Fz, Fz_r, Fz64, 5e-4),
+                                 (Fu, Fu_r, Fu64, 5e-4)):
+        assert _rel(got.double(), exact) < max(
+            tol, 4.0 * _rel(tor.double(), exact))
+    assert not m64.native_ok(z.double(), enc, jacobian=True)
+    assert m64.native_ok(z.double(), enc)
+    assert _rel(m64.native_step(z.double(), u.double(), enc), r64) < 1e-10
+
+
+@pytest.mark.gpu
 def test_gp_kernel_view_follows_a_loaded_state():
     """The kernel's cached view of the model is keyed by the tensors it was
     made from: after `load_state_dict` (or a parameter changed in place) the
