@@ -344,3 +344,22 @@ int pddp_attach_events(void* start, void* stop) {
 }
 
 }  // extern "C"
+
+// ---- a clock probe for tools/dbg/clock_after_kernels.py: shader cycles and
+// ticks of the chip's constant 100 MHz clock over ~15 us of one sleeping
+// wavefront - the shader clock the NEXT launch on the stream starts at
+namespace pddp {
+__global__ void clock_probe_kernel(long long* out) {
+  if (threadIdx.x != 0) return;
+  const long long t0 = wall_clock64(), c0 = clock64();
+  for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(127);
+  const long long c1 = clock64(), t1 = wall_clock64();
+  out[0] = c1 - c0;
+  out[1] = t1 - t0;
+}
+}  // namespace pddp
+extern "C" int pddp_debug_clock_probe(long long* out, void* stream) {
+  hipLaunchKernelGGL(pddp::clock_probe_kernel, dim3(1), dim3(64), 0,
+                     (hipStream_t)stream, out);
+  return pddp::launch_status();
+}

@@ -388,3 +388,12 @@ int pddp_boxqp_m1_f64(int count, const double* x0, const double* Q,
 }
 
 }  // extern "C"
+
+#ifdef PDDP_WG_TIMELINE
+extern "C" int pddp_debug_mfma32s_clock(long long* out) {
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::m32s::g_mfma32s_clock),
+                            sizeof(long long) * 2);
+  return 0;
+}
+#endif

@@ -58,6 +58,9 @@ constexpr int kTraj = 1;                 // trajectories per workgroup
 constexpr int kSweep = 2 * kTraj;        // sweeping wavefronts
 constexpr int kThreads = kWave * 3 * kTraj;  // + a producer per trajectory
 
+#ifdef PDDP_WG_TIMELINE
+__device__ long long g_mfma32s_clock[2];
+#endif
 template <bool BOUNDED, bool FAST, int NDMA>
 __global__ __launch_bounds__(kThreads) void riccati_mfma32s_kernel(
     RiccatiArgs<float> a) {
@@ -382,9 +385,21 @@ __global__ __launch_bounds__(kThreads) void riccati_mfma32s_kernel(
       if (t >= 1) step(half, std::integral_constant<int, 1>{}, t - 1);
     }
   };
+#ifdef PDDP_WG_TIMELINE
+  // (tools/dbg/clock_after_kernels.py: the shader clock DURING the sweep -
+  // cycles and 100 MHz ticks of workgroup 0's first sweeping wavefront)
+  const bool tl_ = blockIdx.x == 0 && tw == 0 && w == 0 && lane == 0;
+  const long long tl_c0 = clock64(), tl_t0 = wall_clock64();
+#endif
   if (w == 0) sweep(std::integral_constant<int, 0>{});
   else sweep(std::integral_constant<int, 1>{});
   n4::wait_vmcnt<0>();
+#ifdef PDDP_WG_TIMELINE
+  if (tl_) {
+    g_mfma32s_clock[0] = clock64() - tl_c0;
+    g_mfma32s_clock[1] = wall_clock64() - tl_t0;
+  }
+#endif
   // both halves hold the same status except for the unbounded branch's NaN
   // test of K, which each makes on its own columns: the first non-zero wins,
   // column half 0 first (one writer per trajectory: wave 0 after the exchange)
