@@ -95,15 +95,9 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  *   6 / 7   sixteen lanes per trajectory, BoxQP in closed form with the
  *           reference's loop as fall-back (IEEE division / v_rcp + v_sqrt,
  *           f32 only for the odd numbers throughout);
- *   8 / 9   the same step split over two wavefronts (bounded problems only);
  *   16 / 17 four lanes per trajectory, sixteen trajectories per wavefront
  *           (all four branches); 18 = 16 with every BoxQP through the
  *           reference's loop (bounded branches);
- *   20 / 21 the quad mapping over three wavefronts of a workgroup - record
- *           producer, matrices, scalars (bounded eig-clamp branch only);
- *   24 / 25 the rank-one value update deferred by two steps, four wavefronts
- *           - producer, matrices on the 4x4x1 matrix instruction, carried
- *           vectors, scalars (bounded eig-clamp branch only);
  * 14 / 15: the matrix-core kernels for n <= 30, m = 1 (IEEE / approximate
  * division; auto for those shapes other than n = 4); f64: n <= 14 on the f64
  * matrix cores, variant 14 only (15 and n > 14: PDDP_E_UNSUPPORTED; auto then
@@ -111,11 +105,11 @@ int pddp_riccati_backward_f64(int B, int N, int n, int m, const double* rec,
  * 26 / 27 (IEEE / approximate division): 15 <= n <= 30, m = 1, f32, eig-clamp
  * branches with one trajectory's step split over two wavefronts; auto for
  * those shapes and branches: 27.
- * Auto for n = 4, m = 1: bounded eig-clamp branch: f32 below 12288
- * trajectories -> 25, up to 16383 -> 21, f64 up to 8192 -> 20; f32 from 12288
- * trajectories on -> 17; bounded Cholesky branch f32 below that -> 9; otherwise
- * 7 (f32) / 6 (f64).  Any other number: PDDP_E_BADARG (rounds 1-2 carried
- * 2 / 3, 10 - 13, 22 / 23: superseded A/B twins, removed). */
+ * Auto for n = 4, m = 1: f32 from 12288 trajectories on -> 17, otherwise 7
+ * (f32) / 6 (f64).  Any other number: PDDP_E_BADARG (rounds 1-4 carried 2 / 3,
+ * 8 - 13, 20 - 25: other formulations of the n = 4 sweep ON RECORDS, retired
+ * once the cartpole's rounds took their sweep from the nominal,
+ * pddp_sweep_nominal_* / pddp_round_nominal_f32). */
 int pddp_riccati_backward_variant_f32(int B, int N, int n, int m,
                                       const float* rec, const float* u_min,
                                       const float* u_max, const double* reg,

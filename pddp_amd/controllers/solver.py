@@ -225,15 +225,7 @@ class ILQRSolver(object):
         if self.dtype != torch.float32:
             return 0  # the f64 kernels are IEEE throughout
         if self.n == 4 and self.m == 1:
-            if bounded and branch == BRANCH_EIG and self.B < 12288:
-                return 24
-            if bounded and branch == BRANCH_EIG and self.B < 16384:
-                return 20
-            if self.B >= 12288:
-                return 16
-            if bounded:
-                return 8
-            return 6
+            return 16 if self.B >= 12288 else 6
         if self.m == 1 and self.n <= 30:
             return 14
         return 0  # generic kernel: IEEE throughout
@@ -629,7 +621,10 @@ class ILQRSolver(object):
         while True:
             if graph:
                 self.replay_round(need_derivs)
-            elif rpl > 1:
+            elif rpl > 1 and self._one_launch is True:
+                # (only where the one-launch round has applied: elsewhere
+                # rounds() is a loop of round() calls that would run past the
+                # last live trajectory)
                 c = rpl if max_rounds is None else min(rpl, max_rounds - rounds)
                 self.rounds(c, tol, max_reg, n_iterations)
                 rounds += c - 1
@@ -640,7 +635,8 @@ class ILQRSolver(object):
                 on_round(rounds, self)
             if max_rounds is not None and rounds >= max_rounds:
                 break
-            if rpl == 1 and rounds % rounds_per_sync:
+            if not (rpl > 1 and self._one_launch is True) and \
+                    rounds % rounds_per_sync:
                 continue
             # the one host sync: live trajectories, and (plugin graphs) whether
             # any nominal changed

@@ -2,7 +2,6 @@
 // (pddp/controllers/ilqr.py:529-674) and their dispatch.
 #include "riccati_generic.hpp"
 #include "riccati_n4.hpp"
-#include "riccati_n4_split.hpp"
 #include "riccati_mfma16.hpp"
 #include "riccati_mfma32.hpp"
 #include "riccati_mfma32s.hpp"
@@ -21,25 +20,6 @@ static int launch_n4_quad(const RiccatiArgs<float>& a, hipStream_t st, bool f,
 static int launch_n4_quad(const RiccatiArgs<double>& a, hipStream_t st, bool f,
                           bool loop_always = false) {
   return launch_n4_quad_f64(a, st, f, loop_always);
-}
-
-int launch_n4_qpipe_f32(const RiccatiArgs<float>& a, hipStream_t st, bool fast);
-int launch_n4_qpipe_f64(const RiccatiArgs<double>& a, hipStream_t st, bool fast);
-static int launch_n4_qpipe(const RiccatiArgs<float>& a, hipStream_t st, bool f) {
-  return launch_n4_qpipe_f32(a, st, f);
-}
-static int launch_n4_qpipe(const RiccatiArgs<double>& a, hipStream_t st, bool f) {
-  return launch_n4_qpipe_f64(a, st, f);
-}
-
-// riccati_defer.hip
-int launch_n4_defer_f32(const RiccatiArgs<float>& a, hipStream_t st, bool fast);
-int launch_n4_defer_f64(const RiccatiArgs<double>& a, hipStream_t st, bool fast);
-static int launch_n4_defer(const RiccatiArgs<float>& a, hipStream_t st, bool f) {
-  return launch_n4_defer_f32(a, st, f);
-}
-static int launch_n4_defer(const RiccatiArgs<double>& a, hipStream_t st, bool f) {
-  return launch_n4_defer_f64(a, st, f);
 }
 
 template <typename T, int NMAX, int M>
@@ -83,29 +63,20 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
                    status};
   hipStream_t st = (hipStream_t)stream;
   // variant: 0 auto; 1 generic kernel (any n, m <= 4, IEEE throughout);
-  //          6 / 7 the n = 4, m = 1 kernel on sixteen lanes per trajectory
+  //          n = 4, m = 1: 6 / 7 sixteen lanes per trajectory
   //          (riccati_n4.hpp; IEEE division / v_rcp + v_sqrt, f32), BoxQP in
-  //          closed form with the reference's loop as fall-back; 8 / 9 the
-  //          same step split over two wavefronts (riccati_n4_split.hpp;
-  //          bounded branches); 14 / 15 the matrix-core kernels for n <= 30,
-  //          m = 1 (riccati_mfma16.hpp / riccati_mfma32.hpp; fp64: the 16x16
-  //          form for n <= 14, variant 14); 16 / 17 four lanes per trajectory
-  //          (riccati_n4_quad.hpp), 18 = 16 with every BoxQP through the
-  //          reference's loop; 20 / 21 the quad mapping over three wavefronts
-  //          (riccati_n4_qpipe.hpp); 24 / 25 the deferred rank-one form on four
-  //          wavefronts (riccati_n4_defer.hpp).  (Rounds 1-2 also carried 2 / 3
-  //          - BoxQP always through the loop -, 10 / 11 - four-wave workgroups
-  //          -, 12 / 13 - the two-wavefront pipelined form - and 22 / 23 - the
-  //          three-wavefront form without Qzz's mirror: superseded A/B
-  //          history, removed in round 3.)
-  //          auto: n = 4, m = 1, bounded eig-clamp branch: f32 below 12288
-  //          trajectories -> 25, up to 16383 -> 21, f64 up to 8192 -> 20;
-  //          f32 from 12288 trajectories on (other branches; all from 16384)
-  //          -> 17; bounded Cholesky branch f32 below that -> 9; otherwise 7
-  //          (f32) / 6 (f64); other shapes with m = 1, n <= 30 (f64: n <= 14)
-  //          -> 15 / 14 (f32, 15 <= n <= 30, eig-clamp branches: 27); everything else -> 1
-  //          26 / 27: 15 <= n <= 30, m = 1, f32, eig-clamp branches with one
-  //          trajectory's step split over two wavefronts (riccati_mfma32s.hpp)
+  //          closed form with the reference's loop as fall-back; 16 / 17 four
+  //          lanes per trajectory (riccati_n4_quad.hpp), 18 = 16 with every
+  //          BoxQP through the reference's loop;
+  //          14 / 15 the matrix-core kernels for n <= 30, m = 1
+  //          (riccati_mfma16.hpp / riccati_mfma32.hpp; fp64: the 16x16 form
+  //          for n <= 14, variant 14); 26 / 27: 15 <= n <= 30, m = 1, f32,
+  //          eig-clamp branches with one trajectory's step split over two
+  //          wavefronts (riccati_mfma32s.hpp).
+  //          auto: n = 4, m = 1: f32 from 12288 trajectories on -> 17,
+  //          otherwise 7 (f32) / 6 (f64); other shapes with m = 1, n <= 30
+  //          (f64: n <= 14) -> 15 / 14 (f32, 15 <= n <= 30, eig-clamp
+  //          branches: 27); everything else -> 1
   if (variant == 26 || variant == 27) {
     if constexpr (sizeof(T) == 4) {
       if (m != 1) return PDDP_E_UNSUPPORTED;
@@ -140,55 +111,27 @@ static int riccati_backward_impl(int B, int N, int n, int m, const T* rec,
   if (variant == 16 || variant == 17)
     return launch_n4_quad(a, st, variant == 17);
   if (variant == 18) return launch_n4_quad(a, st, false, true);
-  //          20 / 21: the quad mapping over three wavefronts - producer,
-  //          matrices, scalars (riccati_n4_qpipe.hpp; IEEE / approximate
-  //          division; bounded eig-clamp branch only)
-  if (variant == 20 || variant == 21)
-    return launch_n4_qpipe(a, st, variant == 21);
-  //          24 / 25: the rank-one value update deferred by two steps, four
-  //          wavefronts (riccati_n4_defer.hpp; IEEE / approximate division;
-  //          bounded eig-clamp branch only)
-  if (variant == 24 || variant == 25)
-    return launch_n4_defer(a, st, variant == 25);
-  if (variant != 0 && variant != 1 && (variant < 6 || variant > 9))
+  if (variant != 0 && variant != 1 && variant != 6 && variant != 7)
     return PDDP_E_BADARG;
 
-  if (variant == 0 && n == 4 && m == 1 && u_min != nullptr &&
-      branch == PDDP_BRANCH_EIG && B < (sizeof(T) == 4 ? 16384 : 8193)) {
-    // the controller's default branch (bounds, eig-clamp).  fp32 below 12288
-    // trajectories: the deferred rank-one form on four wavefronts
-    // (riccati_n4_defer.hpp) - the sweep alone on the bench's records
-    // (tools/sweep_variants_time.py): 35.3 / 36.3 / 37.6 / 43.8 us at B =
-    // 1024 / 2048 / 4096 / 8192 against 37.6 / 38.8 / 39.8 / 46.8 for the
-    // three-wavefront quad kernel (riccati_n4_qpipe.hpp), which stays for
-    // 12288 .. 16383 (50.3 against 52.8 us) and for fp64 (65.4 against 66.6 us
-    // at B = 4096).  Same error distribution against the fp64 kernel on the
-    // same records (tools/sweep_accuracy.py: median 3.1e-5 / p99 1.6e-4 against
-    // 2.9e-5 / 1.3e-4).
-    if (sizeof(T) == 4 && B < 12288) return launch_n4_defer(a, st, true);
-    return launch_n4_qpipe(a, st, sizeof(T) == 4);
-  }
   if (variant == 0 && n == 4 && m == 1 && sizeof(T) == 4 && B >= 12288) {
     // large batches: four lanes per trajectory (riccati_n4_quad.hpp) - a
-    // third of the issue slots per trajectory-step of the kernels below.
+    // third of the issue slots per trajectory-step of the kernel below.
     // Measured inside the fit loop (bench.py --batch B): 66 / 90 / 98 us at
-    // B = 8192 / 12288 / 16384 against 67 / 92 / 128 for the kernels below
+    // B = 8192 / 12288 / 16384 against 67 / 92 / 128 for the kernel below
     // (alone on records that sit in the Infinity Cache: 64 / 66 / 86 against
     // 69 / 90 / 131)
     return launch_n4_quad(a, st, true);
   }
-  if (variant == 0 && n == 4 && m == 1 && u_min != nullptr && B <= 16384 &&
-      branch == PDDP_BRANCH_CHOLESKY && sizeof(T) == 4) {
-    // latency-bound batches of the bounded Cholesky branch: the two-wavefront
-    // kernel.  (f32 only: with f64 the one-wave line search
-    // that follows is placed badly after a kernel of two-wave workgroups, and
-    // its LDS slice does not leave room for four-wave workgroups)
-    variant = 9;
-  }
-  if (variant == 8 || variant == 9) {
-    if (u_min == nullptr) return PDDP_E_UNSUPPORTED;
-    return launch_n4_split<T>(a, st, variant == 9 && sizeof(T) == 4);
-  }
+  // (Rounds 2-4 carried three more formulations of this 4 x 4 recursion ON
+  // RECORDS - the step split over two wavefronts, 8 / 9; the quad mapping on
+  // three wavefronts, 20 / 21; the deferred rank-one form on four, 24 / 25:
+  // 40 against 56 us at B = 4096 - each the default of some branch / batch.
+  // Since the cartpole's rounds take their sweep from the nominal
+  // (riccati_n4_elem.hpp, f32 and f64, 26 us inside round_n4.hip) the sweep
+  // on records serves the reference-signature `backward()`, the Cholesky /
+  // unbounded branches and plugin models of this shape; the three were
+  // retired in round 5, docs/history.)
   if (variant != 1 && n == 4 && m == 1) {
     const bool fast = (variant == 0 || variant == 7) && sizeof(T) == 4;
     return launch_n4<T>(a, st, fast);

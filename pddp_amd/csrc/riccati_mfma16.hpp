@@ -32,7 +32,7 @@
 // everything above holds unchanged (`Tile<T>::row`).
 #pragma once
 
-#include "riccati_n4_split.hpp"
+#include "riccati_n4.hpp"
 
 namespace pddp {
 namespace m16 {

@@ -22,7 +22,7 @@
 
 #include "models.hpp"
 #include "riccati_mfma16.hpp"
-#include "riccati_n4_defer.hpp"  // GenArgs
+#include "riccati_n4_elem.hpp"  // GenArgs
 
 namespace pddp {
 namespace m16n {

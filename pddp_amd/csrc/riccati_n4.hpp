@@ -189,6 +189,14 @@ struct LsTable {
 };
 __device__ constexpr LsTable kLs{};
 
+// all LDS traffic of this wave done (its words are visible), then meet the
+// other wavefronts of the workgroup.  No vmcnt wait: global traffic stays in
+// flight.
+PDDP_DEV void lds_publish_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+PDDP_DEV void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // clamp for the hot loop: v_med3 when the operands are known finite
 template <bool FAST>
 PDDP_DEV float clampq(float v, float lo, float hi) {

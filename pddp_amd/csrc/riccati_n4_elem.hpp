@@ -38,9 +38,41 @@
 
 #include <type_traits>
 #include "models.hpp"
-#include "riccati_n4_defer.hpp"
+#include "riccati_n4_quad.hpp"  // boxqp1_wave, rank_one_coeffs
 
 namespace pddp {
+
+namespace n4d {
+// ---- flags carried in the SIGN BIT of a 32-bit word (the lean BoxQP).
+// A compare that goes through an SGPR pair (v_cmp -> v_cndmask) costs a
+// dependent chain ~40 cycles per trip; a subtraction leaves the same
+// predicate in the sign bit of a VGPR, where v_and / v_or / v_bfi combine it
+// at 4 cycles each.  The two instructions the optimiser would turn back into
+// compare + select are issued by hand.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+PDDP_DEV int sgn(float x) { return __float_as_int(x); }
+PDDP_DEV int splat(int w) {  // 0 / -1 from the sign bit
+  int r;
+  asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(w));
+  return r;
+}
+PDDP_DEV float bsel(int mask, float a, float b) {  // mask ? a : b, bitwise
+  float r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+  return r;
+}
+
+// What a sweep needs to evaluate its records itself: the nominal trajectory
+// instead of `a.rec`, and where the stage costs and their sum go.
+template <typename T>
+struct GenArgs {
+  const T* Z;      // [B][N + 1][n]
+  const T* U;      // [B][N]  (un-clamped nominal actions)
+  T* L;            // [B][N + 1] stage / terminal cost of the nominal
+  T* J_opt;        // [B]: sum of L in t order, where `fresh` is set
+  uint8_t* fresh;  // [B] nullable: "the nominal changed"; cleared
+};
+}  // namespace n4d
 
 namespace n4e {
 
@@ -651,7 +683,6 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
   int status = PDDP_BWD_OK;
   // counted and status still OK (changes in the odd path only), as a lane mask
   unsigned long long alive_m = __ballot(counted);
-  const unsigned long long lane_bit = 1ull << lane;
   // gains of a block: word l of the (dead) image of (row, step)
   const int ostage = rbase + l;
 

@@ -587,6 +587,14 @@ __global__ __launch_bounds__(kWave * WPB) void riccati_n4_quad_kernel(
   if (counted && q == 0) a.status[bc] = status;
 }
 
+// c and w of the rank-one form of the value update (ilqr.py:664-672 with
+// K = -s Quz):  V' = sym(Qzz) + c Quz Quz^T,  V_z' = Qz + w Quz
+template <typename T>
+PDDP_DEV void rank_one_coeffs(T k, T s, T Quu, T Qu, T& c, T& w) {
+  c = n4::mul_nc(s, n4::fma_(s, Quu, T(-2)));
+  w = n4::fma_(-s, n4::fma_(Quu, k, Qu), k);
+}
+
 }  // namespace n4q
 
 // 16 trajectories per wavefront; WPB wavefronts per workgroup (independent

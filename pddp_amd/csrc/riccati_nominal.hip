@@ -1,23 +1,12 @@
-// riccati_defer.hip - the deferred rank-one n = 4 sweep (riccati_n4_defer.hpp)
-// in its own translation unit: no SLP pairing (its FMAs take DPP operands,
-// riccati_quad.hip) and matrix-instruction results in ordinary VGPRs
-// (-amdgpu-mfma-vgpr-form: the 4x4x1 products feed vector code directly).
-#include "riccati_n4_defer.hpp"
+// riccati_nominal.hip - the sweeps that evaluate their derivative records
+// themselves, from the nominal trajectory (pddp_sweep_nominal_*): the n = 4
+// sweep of riccati_n4_elem.hpp (cartpole; f32 with the generator on partner
+// wavefronts, f64 inline) and the 16 x 16 matrix-core sweep of
+// riccati_mfma16_nominal.hpp (pendulum, double cartpole).  A translation unit
+// of its own: no SLP pairing (the FMAs take DPP operands, riccati_quad.hip)
+// and matrix-instruction results in ordinary VGPRs.
 #include "riccati_n4_elem.hpp"
 #include "riccati_mfma16_nominal.hpp"
-
-namespace pddp {
-
-int launch_n4_defer_f32(const RiccatiArgs<float>& a, hipStream_t st,
-                        bool fast_math) {
-  return launch_n4_defer<float>(a, st, fast_math);
-}
-int launch_n4_defer_f64(const RiccatiArgs<double>& a, hipStream_t st,
-                        bool fast_math) {
-  return launch_n4_defer<double>(a, st, fast_math);
-}
-
-}  // namespace pddp
 
 extern "C" int pddp_sweep_nominal_f32(const pddp_problem* problem, int B, int N,
                                       const float* Z, const float* U,
@@ -143,44 +132,6 @@ extern "C" int pddp_sweep_nominal_kernel(int which) {
   return prev;
 }
 
-#ifdef PDDP_QP_STATS
-extern "C" int pddp_debug_defer_stats(unsigned long long* out, int reset) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_stats), 64);
-  if (reset) {
-    unsigned long long z[8] = {};
-    hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4d::g_defer_stats), z, 64);
-  }
-  return 0;
-}
-extern "C" int pddp_debug_defer_seg(unsigned long long* out, int reset) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_seg), 256);
-  if (reset) {
-    unsigned long long z[32] = {};
-    hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4d::g_defer_seg), z, 256);
-  }
-  return 0;
-}
-#endif
-#ifdef PDDP_QP_MARKS
-extern "C" int pddp_debug_defer_odd(unsigned long long* out, int reset) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_odd), 16);
-  if (reset) {
-    unsigned long long z[2] = {};
-    hipMemcpyToSymbol(HIP_SYMBOL(pddp::n4d::g_defer_odd), z, 16);
-  }
-  return 0;
-}
-#endif
-#if defined(PDDP_QP_STATS) || defined(PDDP_QP_MARKS)
-extern "C" int pddp_debug_defer_marks(long long* out) {
-  hipDeviceSynchronize();
-  hipMemcpyFromSymbol(out, HIP_SYMBOL(pddp::n4d::g_defer_marks), 64);
-  return 0;
-}
-#endif
 #ifdef PDDP_ELEM_MARKS
 extern "C" int pddp_debug_elem_marks(long long* out) {
   hipDeviceSynchronize();

@@ -4,7 +4,6 @@
 // DPP operand; every quad broadcast then costs a v_mov_b32_dpp of its own (58
 // per step).  Unpaired, the broadcast folds into v_fmac_f32_dpp.
 #include "riccati_n4_quad.hpp"
-#include "riccati_n4_qpipe.hpp"
 
 namespace pddp {
 
@@ -17,17 +16,6 @@ int launch_n4_quad_f64(const RiccatiArgs<double>& a, hipStream_t st,
   return launch_n4_quad<double>(a, st, fast_math, loop_always);
 }
 
-}  // namespace pddp
-
-namespace pddp {
-int launch_n4_qpipe_f32(const RiccatiArgs<float>& a, hipStream_t st,
-                        bool fast_math) {
-  return launch_n4_qpipe<float>(a, st, fast_math);
-}
-int launch_n4_qpipe_f64(const RiccatiArgs<double>& a, hipStream_t st,
-                        bool fast_math) {
-  return launch_n4_qpipe<double>(a, st, fast_math);
-}
 }  // namespace pddp
 
 #ifdef PDDP_QP_STATS

@@ -160,24 +160,24 @@ def test_derivative_records_vs_oracle(problem, dtype):
         assert np.array_equal(got_U, U[b])
 
 
-@pytest.mark.parametrize("variant", [0, 1, 6, 7, 8, 9, 14, 15, 16, 17, 18,
-                                     20, 21, 24, 25])
+@pytest.mark.parametrize("variant", [0, 1, 6, 7, 14, 15, 16, 17, 18])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", PROBLEMS)
 def test_backward_vs_oracle(problem, dtype, variant):
     """All four gain branches x regularisations, native record path.
-    Variants (include/pddp_hip.h): 0 auto (closed-form BoxQP), 1 generic
-    kernel, 2 / 3 n=4 kernel with the BoxQP loop (IEEE / approximate division),
-    6 / 7 n=4 kernel with the closed-form BoxQP, 8 / 9 the same with the step
-    split over two wavefronts (bounded branches only)."""
+    Variants (include/pddp_hip.h): 0 auto, 1 generic kernel, 6 / 7 the n = 4
+    kernel on sixteen lanes per trajectory (closed-form BoxQP, IEEE /
+    approximate division), 16 / 17 / 18 four lanes per trajectory, 14 / 15 the
+    matrix-core kernels.  (Rounds 2-4 also carried 8 / 9, 20 / 21, 24 / 25 -
+    three more formulations of the n = 4 sweep on records, retired in round 5:
+    the cartpole's rounds take their sweep from the nominal.)"""
     if variant in (14, 15):
         if dtype != "f32" or problem == "rendezvous":
             pytest.skip("variants 14 / 15 = fp32 matrix-core kernel, m = 1")
     elif variant >= 2 and problem != "cartpole":
         pytest.skip("variants >= 2 are the n=4/m=1 kernel")
-    if variant in (7, 9, 17, 21, 25) and dtype != "f32":
-        pytest.skip("variants 7 / 9 / 17 / 21 / 25 = f32 kernels with "
-                    "approximate division")
+    if variant in (7, 17) and dtype != "f32":
+        pytest.skip("variants 7 / 17 = f32 kernels with approximate division")
     B, N = 5, 40
     s, op, z0, U, u_min, u_max = _setup(problem, dtype, B, N)
     s.nominal_rollout()
@@ -191,8 +191,6 @@ def test_backward_vs_oracle(problem, dtype, variant):
             pass  # all four branches
         elif variant >= 8 and not bounded:
             continue  # (18: the quad kernel with the BoxQP loop on every step)
-        if variant in (20, 21, 24, 25) and branch != 0:
-            continue  # the decoupled kernels are the eig-clamp + BoxQP branch
         for reg in (0.0, 1e-6, 1.0, 100.0):
             regv = torch.full((B,), reg, dtype=torch.float64, device="cuda")
             s.gains.zero_()
@@ -1204,13 +1202,8 @@ def test_backward_ragged_shapes(B, N, dtype, problem):
     active = torch.ones(B, dtype=torch.uint8, device="cuda")
     if B > 2:
         active[1] = 0
-    for variant in ((0, 1, 6, 8, 16, 20, 24) if problem == "cartpole"
-                    else (0, 1)):
+    for variant in ((0, 1, 6, 16) if problem == "cartpole" else (0, 1)):
         for branch, bounded in ((0, True), (0, False), (1, True), (1, False)):
-            if variant in (8, 20, 24) and not bounded:
-                continue
-            if variant in (20, 24) and branch != 0:
-                continue
             regv = torch.full((B,), 1.0, dtype=torch.float64, device="cuda")
             s.gains.fill_(float("nan"))
             s.bwd_status.fill_(-7)
@@ -1493,11 +1486,8 @@ def test_matrix_core_sweeps_report_failures_like_the_generic_kernel(n):
                 elif n == 14:
                     variants = (0, 15)
                 else:
-                    # n = 4: every specialised sweep (7 sixteen lanes, 17 quad;
-                    # bounded: 9 split; bounded eig-clamp only: 21 three
-                    # wavefronts, 25 deferred)
-                    variants = (0, 7, 17) + ((9,) if bounded else ()) + (
-                        (21, 25) if bounded and branch == 0 else ())
+                    # n = 4: every specialised sweep (7 sixteen lanes, 17 quad)
+                    variants = (0, 7, 17)
                 for variant in variants:
                     g_bad, s_bad = run(rec_bad, variant, bounded, branch)
                     g_ok, _ = run(rec_ok, variant, bounded, branch)
@@ -1879,7 +1869,7 @@ def _sweep_from_nominal_case(B, N, same_arithmetic):
     s.mu.fill_(1.0)
     s.active[::5] = 0
     s.derivs()
-    s.backward(active=s.active, variant=25)
+    s.backward(active=s.active, variant=7)
     ref = {k: getattr(s, k).clone() for k in ("gains", "bwd_status", "L",
                                               "J_opt")}
     s.gains.zero_()
@@ -1895,10 +1885,11 @@ def _sweep_from_nominal_case(B, N, same_arithmetic):
     assert torch.isfinite(g).all()
     # (the records of the two paths agree to rounding - the same code inlined
     # into two kernels - and a hundred steps of an f32 sweep carry that on.
-    # Variant 25 is the deferred rank-one form; the one-wavefront kernel sums
-    # in another order and runs the plain recursion - two f32 sweeps then part
-    # by what f32 loses over N steps, which the oracle tests measure: here
-    # only that nothing is wild)
+    # Variant 7 is the recorded sweep on the same lane mapping with the
+    # mirrored K-trees and the closed-form BoxQP; the sweep from the nominal
+    # sums in another order and updates the value function in its rank-one
+    # form - two f32 sweeps then part by what f32 loses over N steps, which
+    # the oracle tests measure: here only that nothing is wild)
     per = (g - gr).abs().amax(dim=(1, 2)) / gr.abs().max()
     if same_arithmetic:
         assert float(per.max()) < 3e-4, float(per.max())
@@ -3002,13 +2993,15 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
     +-10), all four gain branches, two regularisations, trajectory by
     trajectory against the oracle: status and gains.
 
-    fp64: 1e-9 on every trajectory, statuses identical.
+    fp64: 1e-9 on every trajectory, statuses identical - including "nominal3"
+    = pddp_sweep_nominal_f64, the benched sweep's mapping in float64.
 
     fp32 (what bench.py times: "nominal4" = pddp_sweep_nominal_f32, the sweep
     that evaluates the derivative records itself - riccati_n4_elem_kernel with
     its generator wavefronts, v_rcp and the sign-bit BoxQP; "nominal3" the same
-    with the generator inline; 25 = the deferred four-role sweep on records in
-    HBM; 9, 7, 17 for the other branches): the sweep is a 100-step recursion through a discontinuous BoxQP, so the yardstick is the
+    with the generator inline; 7, 17 = the sweeps on records in HBM, for
+    every branch): the sweep is a 100-step recursion through a discontinuous
+    BoxQP, so the yardstick is the
     fp64 oracle and the reference point is what IEEE fp32 arithmetic in the
     reference's operation order (the fp32 oracle) loses against it.  Asserted
     per (variant, branch, reg): status flips and clamp-pattern flips against
@@ -3027,9 +3020,9 @@ def test_sweep_variants_vs_oracle_many_trajectories(dtype):
     fwd = [o.forward(op, z0[b], U[b], u_min, u_max) for b in range(B)]
     f64 = dtype == "f64"
     plan = (  # branch, bounded, variants (f64 | f32)
-        (0, True, (6, 8, 16, 18, 20, 24) if f64 else
-         (7, 9, 15, 16, 17, 18, 20, 21, 24, 25, "nominal3", "nominal4")),
-        (1, True, (6, 8, 16, 18) if f64 else (7, 8, 9, 15, 16, 17, 18)),
+        (0, True, (6, 16, 18, "nominal3") if f64 else
+         (7, 15, 16, 17, 18, "nominal3", "nominal4")),
+        (1, True, (6, 16, 18) if f64 else (7, 15, 16, 17, 18)),
         (0, False, (6, 16) if f64 else (6, 7, 15, 16, 17)),
         (1, False, (6, 16) if f64 else (6, 7, 15, 16, 17)))
     compared = 0

@@ -461,10 +461,11 @@ def test_hot_kernels_keep_their_working_set_in_registers():
                or r.get("vgpr_spill_count", 0) > 0)
            and not any(a in r["kernel"] for a in allowed)]
     assert not bad, bad
-    hot = ("riccati_n4_qpipe_kernel<float", "riccati_n4_quad_kernel<float",
+    hot = ("round_n4_kernel<25u, true>", "round_n4_kernel<25u, false>",
+           "riccati_n4_quad_kernel<float",
            "line_search_lds_kernel<float, 1, true, 4, 2, 25u, false>",
            "riccati_n4_elem_kernel<25u, true>", "riccati_n4_elem_kernel<25u, false>",
-           "riccati_n4_defer_kernel<float",
+           "riccati_n4_elem_f64_kernel<25u>",
            "bnn_mlp_kernel<200", "riccati_mfma16_kernel<", "riccati_mfma32_kernel<",
            "bnn_mlp_f64_kernel<200", "bnn_moment_step_kernel<float, 4>",
            "bnn_moment_step_kernel<float, 6>", "bnn_moment_step_kernel<double, 4>",

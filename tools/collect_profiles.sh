@@ -28,7 +28,7 @@ for B in 1024 8192 12288 16384 65536; do
   python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-points --no-secondary --batch $B 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_B$B.json
 done
 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-points --no-secondary --dtype f64 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_f64.json
-for v in 1 7 9 16 17 20 21 24 25; do
+for v in 1 7 16 17; do
   python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-points --no-secondary --kernel-variant $v 2>/dev/null | tail -1 > gpurun_out/${TAG}_bench_variant$v.json
 done
 # the B = 16384 sweep (quad kernel) under the counters

@@ -1,6 +1,6 @@
 """Times the backward sweep alone (events on the dispatch) for several kernel
 variants on the bench workload's records, after a few fit rounds:
-    python tools/sweep_variants_time.py --variants 21,25 --batch 4096
+    python tools/sweep_variants_time.py --variants 7,17 --batch 4096
 Prints microseconds (median / min) and the HBM-roofline fraction."""
 import argparse
 import os
@@ -15,7 +15,7 @@ from pddp_amd import _native  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="21,25")
+    ap.add_argument("--variants", default="7,17")
     ap.add_argument("--batch", default="4096")
     ap.add_argument("--horizon", type=int, default=100)
     ap.add_argument("--dtype", default="f32")
