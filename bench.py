@@ -1314,7 +1314,7 @@ def main():
     # WRITE_SIZE cannot share a pass, and counters cannot be read from inside
     # this process): taken from the committed summary of the profiled run of
     # this very command, see profiles/.
-    traffic, traffic_search = None, None
+    traffic, traffic_search, traffic_round = None, None, None
     for tname in ("r05_pmc_traffic.json", "r04_pmc_traffic.json",
                   "r03_pmc_traffic.json",
                   "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
@@ -1332,9 +1332,17 @@ def main():
                         traffic = t
                     elif "line_search" in kname:
                         traffic_search = t
+                    elif "round_n4_kernel<25u, true>" in kname:
+                        # (the profiled command: --steps 10, one launch of ten
+                        # rounds per repetition)
+                        traffic_round = dict(t, rounds_per_launch=10,
+                                             hbm_bytes_per_round=v[
+                                                 "hbm_bytes_per_launch"] / 10)
             break
         except (OSError, KeyError, ValueError):
-            traffic = traffic_search = None
+            traffic = traffic_search = traffic_round = None
+    if round_obj is not None:
+        round_obj["traffic"] = traffic_round
 
     out = None
     if rank == 0:

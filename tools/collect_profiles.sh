@@ -4,7 +4,7 @@
 # Writes raw output under gpurun_out/<tag>_* ; tools/summarise_profiles.py then
 # condenses it into profiles/ (tracked).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 if [ "${2:-}" != "bnn" ]; then
@@ -40,6 +40,15 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_B16384 -- \
     python3 $R/bench.py --steps 10 --warmup 2 --repeats 1 --no-points --no-secondary --no-cpu-baseline --batch 16384 > /dev/null 2>&1
 cd $R
+# where a round goes, workgroup by workgroup (a -DPDDP_WG_TIMELINE build:
+# tools/build_variant.sh tl -DPDDP_WG_TIMELINE)
+if [ -f pddp_amd/lib_tl/libpddp_hip.so ]; then
+  PDDP_HIP_LIB=pddp_amd/lib_tl/libpddp_hip.so python3 tools/wg_timeline.py 4096 --two 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_wg_timeline_two_launches.txt
+  PDDP_HIP_LIB=pddp_amd/lib_tl/libpddp_hip.so python3 tools/wg_timeline.py 4096 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_wg_timeline_one_launch.txt
+  PDDP_HIP_LIB=pddp_amd/lib_tl/libpddp_hip.so python3 tools/wg_timeline.py 64 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_wg_timeline_B64.txt
+  PDDP_HIP_LIB=pddp_amd/lib_tl/libpddp_hip.so python3 tools/wg_timeline.py 512 2>&1 | grep -v amdgpu.ids > gpurun_out/${TAG}_wg_timeline_B512.txt
+fi
+python3 tools/wg_timeline.py 4096 2>&1 | grep "mean of" > gpurun_out/${TAG}_rounds_per_launch.txt
 tail -c 600 gpurun_out/${TAG}_bench.json
 fi
 cd $R
@@ -67,6 +76,13 @@ if [ "${2:-}" = "bnn" ]; then
       python3 $R/bench.py --workload double_cartpole_gp --no-cpu-baseline --no-graph-replay > /dev/null 2>&1 )
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_dcgp -- \
       python3 $R/bench.py --workload double_cartpole_gp --no-cpu-baseline --no-graph-replay > /dev/null 2>&1 )
+  # configs[4]'s own launches under the counters (20 control steps)
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_stats_mpc -- \
+      python3 $R/bench.py --workload mpc_bnn --steps 20 --no-cpu-baseline > /dev/null 2>&1 )
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_fetch_mpc -- \
+      python3 $R/bench.py --workload mpc_bnn --steps 20 --no-cpu-baseline > /dev/null 2>&1 )
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_pmc_write_mpc -- \
+      python3 $R/bench.py --workload mpc_bnn --steps 20 --no-cpu-baseline > /dev/null 2>&1 )
   tail -c 400 gpurun_out/${TAG}_bench_mpc_bnn.json
   # configs[3]'s shard under the profiler: per-kernel time and HBM traffic of
   # the n = 27 sweep (riccati_mfma32_kernel) and the BNN kernels

@@ -72,6 +72,10 @@ stats_and_traffic("_cpbnn", "cartpole BNN (configs[2]): n=14 m=1 N=100 B=4096 "
                   "fp32, [200,200] x 100 particles",
                   " --workload cartpole_bnn --steps 1 --warmup 1")
 
+stats_and_traffic("_mpc", "MPC loop (configs[4]): cartpole BNN, 256 restarts, "
+                  "horizon 50, 20 control steps",
+                  " --workload mpc_bnn --steps 20")
+
 stats_and_traffic("_cpbnn_f64", "cartpole BNN (configs[2]) in float64: n=14 m=1 "
                   "N=100 B=4096, [200,200] x 100 particles",
                   " --workload cartpole_bnn --dtype f64 --steps 1 --warmup 1")
