@@ -310,7 +310,37 @@ def sweep_roofline_of(s, lib, reps=6, traffic_tag=None):
     nbytes = s.B * algorithmic_bytes_per_trajectory(
         s.N, s.n, s.m, s.rec.element_size(), True)
     ach = nbytes / float(d.mean()) / 1e9
+    # the same kernel INSIDE the workload's rounds, from the committed
+    # rocprofv3 summary of this workload (profiles/<round>_<tag>_kernel_stats
+    # .csv): behind the derivative rollout's launches the sweep runs at 0.6-0.8
+    # of its back-to-back speed for a few launches - the
+    # figure above is the back-to-back one
+    in_round = None
+    if traffic_tag is not None:
+        import csv
+        import glob
+        for path in sorted(glob.glob(os.path.join(
+                ROOT, "profiles", "r0*_%s_kernel_stats.csv" % traffic_tag)),
+                reverse=True):
+            try:
+                for row in csv.DictReader(open(path)):
+                    if "riccati" in row["Name"]:
+                        avg = float(row["AverageNs"]) * 1e-3
+                        in_round = {
+                            "avg_launch_us": avg,
+                            "min_launch_us": float(row["MinNs"]) * 1e-3,
+                            "max_launch_us": float(row["MaxNs"]) * 1e-3,
+                            "calls": int(row["Calls"]),
+                            "frac": nbytes / (avg * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                            "source": "profiles/" + os.path.basename(path)}
+                        break
+            except (OSError, KeyError, ValueError):
+                in_round = None
+            if in_round:
+                break
     return {"bound": "hbm", "kernel": "backward Riccati sweep (n = %d)" % s.n,
+            "measured": "launched back to back, events on the dispatch",
+            "in_the_workloads_rounds": in_round,
             "avg_launch_us": float(d.mean()) * 1e6,
             "min_launch_us": float(d.min()) * 1e6,
             "algorithmic_bytes_per_launch": nbytes, "achieved": ach,
