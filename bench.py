@@ -20,8 +20,9 @@ child, before this process has touched the GPU) and relays its line; under the
 driver's own torchrun launch it simply is one of the ranks.  Ranks own disjoint
 shards (--scaling weak: --batch trajectories per GPU; strong: --batch in total;
 no data-path collective) and exchange their best rollout through RCCL after
-every round (--exchange-every E: every E rounds; 0: once per timed region) -
-one `all_gather_into_tensor` of a fixed-size record, no host synchronisation.
+every launch of a round (--exchange-every E: every E rounds; 0: once per timed
+region; the cartpole's rounds come ten to a launch: every ten) - one
+`all_gather_into_tensor` of a fixed-size record, no host synchronisation.
 
 The timed region (W warm-up rounds, then exactly K rounds between barrier +
 synchronize pairs) is repeated --repeats times from the same nominal; the line
@@ -1112,10 +1113,17 @@ def main():
     ap.add_argument("--no-points", action="store_true",
                     help="skip the extra roofline points (B = 16384, fp64, "
                          "cold cache)")
-    ap.add_argument("--exchange-every", type=int, default=1,
+    ap.add_argument("--exchange-every", type=int, default=None,
                     help="multi-GPU: all-gather the best rollout every E "
-                         "rounds inside the timed region (SURVEY 8(e): one "
-                         "exchange per iteration; 0: once, after the rounds)")
+                         "rounds inside the timed region; 0: once, after the "
+                         "rounds.  Default: after every LAUNCH - every round "
+                         "for the workloads whose round is several launches "
+                         "(SURVEY 8(e): one exchange per iteration), every "
+                         "--rounds-per-launch rounds for the cartpole's "
+                         "one-launch rounds (the exchange reports the best "
+                         "rollout, nothing on a rank's path reads it; "
+                         "--exchange-every 1 = per iteration, one round per "
+                         "launch)")
     ap.add_argument("--no-graph-replay", action="store_true",
                     help="double_cartpole_gp: skip the informational hipGraph "
                          "replay (rocprofv3 --pmc and stream capture do not "
@@ -1137,6 +1145,9 @@ def main():
                          "more than one rank the exchange needs the round "
                          "boundary: at most --exchange-every rounds per launch")
     args = ap.parse_args()
+    exchange_default = args.exchange_every is None
+    if exchange_default:
+        args.exchange_every = 1
     launch_ranks_if_asked(args)
     if args.workload == "mpc_bnn":
         return bench_mpc_bnn(args)
@@ -1180,6 +1191,8 @@ def main():
     # rounds per launch of the timed region (the exchange of the multi-GPU
     # path sits between launches)
     rpl = max(args.rounds_per_launch, 0)
+    if world > 1 and exchange_default and rpl > 1:
+        args.exchange_every = rpl  # (one exchange per launch)
     if world > 1 and args.exchange_every > 0:
         rpl = min(rpl, args.exchange_every)
     chunks_timed = []
@@ -1422,6 +1435,10 @@ def main():
                 # how the K timed rounds were issued
                 "launch_form": timed_form,
                 "rounds_per_launch": args.rounds_per_launch,
+                # (ranks > 1) the best rollout is all-gathered every so many
+                # rounds, between launches
+                "exchange_every_rounds": args.exchange_every if world > 1
+                else None,
                 "batched_iterations_per_s": K / elapsed,
                 "trajectory_timesteps_per_s": total_attempted * N / elapsed,
                 "live_trajectories_start_end": med["live"],

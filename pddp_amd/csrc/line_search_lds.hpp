@@ -420,7 +420,21 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
           for (int j = 0; j < n; ++j) zz[k][j] = cz[(size_t)tz * czs + j];
         }
         const T* Gl = Gs;  // (the staged gains)
-        for (int o = ai + 16 * hid; o < N * GS; o += 16 * H) Ga[o] = Gl[o];
+        {
+          // eight words per lane requested from LDS before the first is
+          // stored (a plain loop waits out an LDS latency per word: 16 trips
+          // at N = 100)
+          constexpr int kDeep = 8;
+          int o = ai + 16 * hid;
+          for (; o + 16 * H * (kDeep - 1) < N * GS; o += 16 * H * kDeep) {
+            T tmp[kDeep];
+#pragma unroll
+            for (int r = 0; r < kDeep; ++r) tmp[r] = Gl[o + 16 * H * r];
+#pragma unroll
+            for (int r = 0; r < kDeep; ++r) Ga[o + 16 * H * r] = tmp[r];
+          }
+          for (; o < N * GS; o += 16 * H) Ga[o] = Gl[o];
+        }
         PDDP_TLS_AT(10);
         const T alpha_w = a.alphas[amin_out];
 #pragma unroll
