@@ -1262,7 +1262,9 @@ def main():
                 # attempts of this round that were accepted (state 1 ACCEPTED,
                 # 5 CONVERGED; every trajectory is live throughout the region)
                 accepted_acc += ((s.state == 1) | (s.state == 5)).sum()
-        if world > 1 and args.exchange_every <= 0:  # one exchange per region
+        if world > 1 and (args.exchange_every <= 0 or
+                          K % args.exchange_every != 0):
+            # one exchange per region / behind the last, shorter launch
             last_exchange = post_best_rollout(s.J_opt, s.Z, s.U, offset=lo)
         if world > 1:
             last_exchange.result()  # (this stream waits for the last gather)
