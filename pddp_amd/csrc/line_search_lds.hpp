@@ -163,7 +163,12 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
   const int b0 = (blockIdx.x * WPB + wave) * 4;
   PDDP_TLS(0);
 
-  // cooperative, coalesced staging of up to four trajectories
+  // cooperative, coalesced staging of up to four trajectories.  (5.4 us of the
+  // launch at B = 4096, tools/wg_timeline.py - and not the loop's doing:
+  // eight or sixteen requests in flight per lane change nothing, round 5; all
+  // 256 workgroups ask for their 64 KB in the launch's first microsecond, 16
+  // MB at what the memory system delivers in a burst.  round_n4.hip stages
+  // the same words during the sweep's last block instead.)
   for (int g = 0; g < (PRE ? 0 : 4); ++g) {
     const int bg = b0 + g;
     if (bg >= a.B) break;
