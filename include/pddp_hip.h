@@ -389,6 +389,8 @@ int pddp_search_accept_f64(const pddp_problem* problem, int B, int N, int A,
  * registers between the phases; no second launch, no second prologue).  Results
  * are the two calls' bit for bit (replaces ilqr.py:125-181 of one attempt:
  * backward, _control_law, _trajectory_cost, accept / reject, mu schedule).
+ * (of the candidates, `Zc` and the costs `Jc` are written, `Uc` is NOT: the
+ * winner's actions are its control law at its states, re-evaluated.)
  * `mu` is both the sweep's `reg` and the schedule's state; `scratch` as `rec`
  * of pddp_search_accept_* with L == NULL (B (N+1) n scalars).  Cartpole under
  * IGNORE_UNCERTAINTY, f32, bounded, PDDP_BRANCH_EIG, A <= 16, N <= 127 and at
