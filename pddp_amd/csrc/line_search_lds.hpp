@@ -149,6 +149,11 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
   static_assert(H == 1 || (H == 2 && FUSED), "");
   static_assert(!DENSE || (FUSED && H == 1), "");
   static_assert(!PRE || (FUSED && H == 2 && !DENSE), "");
+  // rows of the staged gains / actions: [k, K] of a step next to one another
+  // and the actions in a table of their own - or, PRE (round_n4.hip), one row
+  // [k, K, u] per step (riccati_n4_elem.hpp lays it out: 8-byte reads)
+  constexpr int GST = PRE ? GS + m : GS;
+  constexpr int UST = PRE ? GS + m : m;
   constexpr int kTailRows = DENSE ? 8 : 4;  // rows per lane of the short tail
   __shared__ int sh_dec[WPB][4][2];  // H = 2: {amin_out, fresh} per trajectory
   const int lane = tid & (kWave - 1);
@@ -250,12 +255,30 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
       // cosines of the state need none of it and run while it arrives (the
       // compiler, left alone, starts with the control law and stalls on it)
       T zr[n], gr[GS], us[m];
+      if constexpr (PRE && n == 4) {
+        // (the round kernel's staged rows are 16-byte aligned: one read)
+        typedef T V4_ __attribute__((ext_vector_type(4)));
+        const V4_ v = *reinterpret_cast<const V4_*>(
+            __builtin_assume_aligned(Zs + t * 4, 16));
+        zr[0] = v[0]; zr[1] = v[1]; zr[2] = v[2]; zr[3] = v[3];
+      } else {
 #pragma unroll
-      for (int j = 0; j < n; ++j) zr[j] = Zs[t * n + j];
+        for (int j = 0; j < n; ++j) zr[j] = Zs[t * n + j];
+      }
+      if constexpr (PRE && GST == 6) {
+        // (k K0 | K1 K2 | K3 u: three 8-byte reads)
+        typedef T V2_ __attribute__((ext_vector_type(2)));
+        const V2_* g2 = reinterpret_cast<const V2_*>(
+            __builtin_assume_aligned(Gs + t * 6, 8));
+        const V2_ a0 = g2[0], a1 = g2[1], a2 = g2[2];
+        gr[0] = a0[0]; gr[1] = a0[1]; gr[2] = a1[0]; gr[3] = a1[1];
+        gr[4] = a2[0]; us[0] = a2[1];
+      } else {
 #pragma unroll
-      for (int j = 0; j < GS; ++j) gr[j] = Gs[t * GS + j];
+        for (int j = 0; j < GS; ++j) gr[j] = Gs[t * GST + j];
 #pragma unroll
-      for (int j = 0; j < m; ++j) us[j] = Us[t * m + j];
+        for (int j = 0; j < m; ++j) us[j] = Us[t * UST + j];
+      }
       const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
       __builtin_amdgcn_sched_barrier(0);
       control_law<T, n, m>(z, zr, gr, us, alpha, umin, umax, un);
@@ -432,7 +455,13 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
           for (int j = 0; j < n; ++j) zz[k][j] = cz[(size_t)tz * czs + j];
         }
         const T* Gl = Gs;  // (the staged gains)
-        {
+        if constexpr (PRE) {
+          // (rows of GST words in LDS, of GS in gains_acc)
+          for (int t = ai + 16 * hid; t < N; t += 16 * H) {
+#pragma unroll
+            for (int j = 0; j < GS; ++j) Ga[t * GS + j] = Gl[t * GST + j];
+          }
+        } else {
           // eight words per lane requested from LDS before the first is
           // stored (a plain loop waits out an LDS latency per word: 16 trips
           // at N = 100)
@@ -457,9 +486,9 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
 #pragma unroll
           for (int j = 0; j < n; ++j) zr[j] = Zs[tu * n + j];
 #pragma unroll
-          for (int j = 0; j < GS; ++j) gr[j] = Gs[tu * GS + j];
+          for (int j = 0; j < GS; ++j) gr[j] = Gs[tu * GST + j];
 #pragma unroll
-          for (int j = 0; j < m; ++j) us[j] = Us[tu * m + j];
+          for (int j = 0; j < m; ++j) us[j] = Us[tu * UST + j];
           control_law<T, n, m>(zz[k], zr, gr, us, alpha_w, umin, umax, uu[k]);
         }
 #pragma unroll

@@ -425,13 +425,16 @@ __device__ long long g_elem_timeline[1024][12];
 // Returns false when the pair has nothing to do (both wavefronts alike).
 struct RoundOut {       // (ROUND) what the search phase needs, per lane
   const float* Zs;      // this lane's trajectory: states [N + 1][4] in LDS
-  const float* Us;      //   actions [N]
-  const float* Gs;      //   gains [N][5]
+  const float* Gs;      //   [N][6]: k, K[0..3], the nominal action
+  const float* Us;      //   = Gs + 5 (stride 6)
   int status;           // sweep wavefront: PDDP_BWD_* of the trajectory
   float J_opt;          // cost of the nominal (summed here when it was new)
 };
-constexpr int round_zu_stride(int N) { return (5 * N + 4 + 3) & ~3; }
-constexpr int round_gains_floats(int N) { return (kTrajW * N * kGain + 3) & ~3; }
+constexpr int round_zu_stride(int N) { return 4 * (N + 1); }
+// (ROUND) a step's row in the search's LDS table: k, K[0..3] and the nominal
+// action - 24 bytes, three 8-byte reads per rollout step
+constexpr int kGainL = kGain + 1;
+constexpr int round_gains_floats(int N) { return (kTrajW * N * kGainL + 3) & ~3; }
 
 template <typename T, unsigned QM, bool OVL, bool ROUND>
 PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
@@ -578,7 +581,7 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
       T* g = a.gains + ((size_t)bc * (size_t)N + (size_t)(t_top - l)) * kGain;
       g[0] = kv; g[1] = Kv[0]; g[2] = Kv[1]; g[3] = Kv[2]; g[4] = Kv[3];
       if constexpr (ROUND) {
-        T* gl = gains_w + (row * N + (t_top - l)) * kGain;
+        T* gl = gains_w + (row * N + (t_top - l)) * kGainL;
         gl[0] = kv; gl[1] = Kv[0]; gl[2] = Kv[1]; gl[3] = Kv[2]; gl[4] = Kv[3];
       }
     }
@@ -589,8 +592,8 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
   [[maybe_unused]] auto round_out = [&](int status_) {
     if constexpr (ROUND) {
       ro.Zs = zu_w;
-      ro.Us = zu_w + (N + 1) * 4;
-      ro.Gs = gains_w + row * N * kGain;
+      ro.Gs = gains_w + row * N * kGainL;
+      ro.Us = ro.Gs + kGain;  // (the sixth word of a step's row)
       ro.status = status_;
       n4::lds_publish_barrier();  // the last barrier: gains, nominal, J_opt
       ro.J_opt = term_w[row * kTermRow + 21];
@@ -633,7 +636,7 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
         for (int c = 0; c < kCh; ++c) {
           const int tz = l + 16 * c;
           if (tz <= N) *reinterpret_cast<V4*>(zu_w + 4 * tz) = zc[c];
-          if (tz < N) zu_w[(N + 1) * 4 + tz] = uc[c];
+          if (tz < N) gains_w[(row * N + tz) * kGainL + kGain] = uc[c];
         }
       }
       finish_costs();

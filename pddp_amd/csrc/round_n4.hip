@@ -112,7 +112,7 @@ static int launch_round_n4(const pddp_problem& p, const RiccatiArgs<float>& a,
   if (grid.x > 256u) return PDDP_E_UNSUPPORTED;
   const size_t lds = (size_t)n4e::kWaves * sizeof(float) *
                      (n4e::kPairLdsOvl + n4e::round_gains_floats(a.N));
-  if (lds > 150 * 1024) return PDDP_E_UNSUPPORTED;
+  if (lds > 159 * 1024) return PDDP_E_UNSUPPORTED;
   const ProblemT<float> P = convert_problem<float>(p);
   constexpr unsigned kSparse = 0b11001u;  // CartpoleCost: {x, sin, cos}
   constexpr unsigned kFull = kFullMask<PDDP_MODEL_CARTPOLE>;
