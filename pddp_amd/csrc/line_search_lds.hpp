@@ -281,6 +281,10 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
       }
       const Trig<T, MODEL> tr = trig_of<T, MODEL>(z);
       __builtin_amdgcn_sched_barrier(0);
+      // (PRE: the row was requested a sincos ago - ONE s_waitcnt lgkmcnt(0)
+      // for all of it instead of one per operand of the control law: 51.0 ->
+      // 50.7 us per round, tools/dbg/ab_round.py)
+      if constexpr (PRE) __builtin_amdgcn_s_waitcnt(0xC07F);
       control_law<T, n, m>(z, zr, gr, us, alpha, umin, umax, un);
 #pragma unroll
       for (int j = 0; j < n; ++j) Zci[(size_t)t * zstep + j] = z[j];
