@@ -311,18 +311,13 @@ PDDP_DEV ElemGains<T> elem_gains(T kprev, T Quu, T Qu, T reg, T lo_b, T hi_b,
     sK = __int_as_float(splat(ql.free_w) & __float_as_int(ql.inv));
     n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, wv);
     // anything the lean form does not cover - a non-finite Quu (0 Quu is
-    // NaN then), a Q that is not positive and finite, `slow` (all ones: a
-    // NaN) - in ONE class test: QpClosed, the reference's loop behind it,
-    // for those rows only
-#if defined(PDDP_CHK_ANDOR)
-    // (`slow` as the SIGN of the word the class test looks at - v_and_or_b32 -
-    // instead of a splat and an or: a negative value is not "regular")
+    // NaN then), a Q that is not positive and finite, `slow` - in ONE class
+    // test: QpClosed, the reference's loop behind it, for those rows only
+    // (`slow` rides as the SIGN of the word the class test looks at - one
+    // v_and_or_b32 - a negative value is not "regular": an instruction less
+    // than a splat and an or, 50.9 -> 50.7 us per round, tools/dbg/ab_round.py)
     const T chk = __int_as_float((ql.slow_w & (int)0x80000000) |
                                  __float_as_int(fma_(Quu, T(0), qp_Q)));
-#else
-    const T chk = __int_as_float(__float_as_int(fma_(Quu, T(0), qp_Q)) |
-                                 splat(ql.slow_w));
-#endif
     unsigned long long regular;  // (the mask straight into a scalar pair)
     asm("v_cmp_class_f32 %0, %1, %2" : "=s"(regular) : "v"(chk), "v"(0x180));
     oddm = ~regular & alive_m;
