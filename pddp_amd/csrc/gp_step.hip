@@ -197,7 +197,15 @@ struct Lds {
   int m, S, Sx, Cxf, G, ld, nu, lk, be, mu, W, h, c, F, Sig, ub, sj;  // always
   int g, Y1, Y2, dm, dS, dSx, dCxf, gmu, GSmu, gmS, GSS, dW, dO;  // JAC
   int total;
-  PDDP_HD Lds(int M, int K, bool jac) {
+  // `gstore`: the per-point g_i = G_a nu_i of the Jacobian form (E M D words,
+  // 216 of the 336 bytes a training point costs it in float) are kept from
+  // A2 for C's tangents of W_a.  False - the launcher's choice when the
+  // layout would not fit 160 KB otherwise (round 5) - they are formed again
+  // where C needs them (81 FMAs per point and task: C costs twice as much, the
+  // double cartpole's limit goes from 318 to 890 training points, f64 74 to
+  // 208)
+  bool gstore;
+  PDDP_HD Lds(int M, int K, bool jac, bool gstore_ = true) : gstore(gstore_) {
     int o = 0;
     auto take = [&](int k) { const int r = o; o += (k + 3) & ~3; return r; };
     m = take(D); S = take(DD); Sx = take(E * E); Cxf = take(E * D);
@@ -206,7 +214,7 @@ struct Lds {
     F = take(NP); Sig = take(NP); ub = take(4 * 2 * (((M + 3) >> 2) << 1)); sj = take(4 * 2 * (((M + 3) >> 2) << 1));
     g = Y1 = Y2 = dm = dS = dSx = dCxf = gmu = GSmu = gmS = GSS = dW = dO = 0;
     if (jac) {
-      g = take(E * M * D); Y1 = take(NP * D); Y2 = take(NP * DD);
+      g = gstore ? take(E * M * D) : 0; Y1 = take(NP * D); Y2 = take(NP * DD);
       dm = take(K * D); dS = take(K * DD); dSx = take(K * E * E); dCxf = take(K * E * D);
       gmu = take(E * D); GSmu = take(E * DD); gmS = take(NP * D); GSS = take(NP * DD);
       dW = take(K * E * D); dO = take(K * NS);
@@ -214,6 +222,15 @@ struct Lds {
     total = o;
   }
 };
+
+// the Jacobian form's layout: with g_i kept when that fits a workgroup's LDS
+constexpr long long kGpLdsMax = 160 * 1024;
+template <int E, int D>
+PDDP_HD Lds<E, D> lds_of(int M, int K, bool jac, int element_size) {
+  const Lds<E, D> full(M, K, jac, true);
+  if (!jac || (long long)full.total * element_size <= kGpLdsMax) return full;
+  return Lds<E, D>(M, K, jac, false);
+}
 
 PDDP_DEV void pair_of(int item, int E, int& a, int& b) {
   a = 0;
@@ -308,7 +325,7 @@ PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
   extern __shared__ __align__(32) unsigned char smem_raw[];
   T* sm = reinterpret_cast<T*>(smem_raw);
   const int M = A.M, n = A.n, K = n + A.m_act;
-  const Lds<E, D> o(M, K, JAC);
+  const Lds<E, D> o = lds_of<E, D>(M, K, JAC, (int)sizeof(T));
   auto nu_at = [&](int i, int p) -> T& { return sm[o.nu + (i >> 1) * PS + 2 * p + (i & 1)]; };
   const int row = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   if constexpr (!ROLL) {
@@ -568,7 +585,7 @@ PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
       if (JAC) {
 #pragma unroll
         for (int p = 0; p < D; ++p) {
-          sm[o.g + (a * M + i) * D + p] = g[p];
+          if (o.gstore) sm[o.g + (a * M + i) * D + p] = g[p];
 #pragma unroll
           for (int q = 0; q <= p; ++q) gg[p * (p + 1) / 2 + q] += be * g[p] * g[q];
         }
@@ -867,10 +884,25 @@ PDDP_DEV void gp_step_body(const Args<T>& A, const Roll<T>& RL = Roll<T>()) {
         }
       }
       for (int i = 0; i < M; ++i) {
-        const T* g = sm + o.g + (a * M + i) * D;
         T gv[D], q2 = 0, gd = 0;
+        if (o.gstore) {
+          const T* g = sm + o.g + (a * M + i) * D;
 #pragma unroll
-        for (int p = 0; p < D; ++p) gv[p] = g[p], gd += g[p] * dmv[p];
+          for (int p = 0; p < D; ++p) gv[p] = g[p];
+        } else {  // g_i = G_a nu_i, formed again (the same sums as in A2)
+          T nu[D];
+#pragma unroll
+          for (int p = 0; p < D; ++p) nu[p] = nu_at(i, p);
+#pragma unroll
+          for (int p = 0; p < D; ++p) {
+            T s_ = 0;
+#pragma unroll
+            for (int q = 0; q < D; ++q) s_ += Ga[p * D + q] * nu[q];
+            gv[p] = s_;
+          }
+        }
+#pragma unroll
+        for (int p = 0; p < D; ++p) gd += gv[p] * dmv[p];
 #pragma unroll
         for (int p = 0; p < D; ++p) {
           T s = (T)0.5 * ds[p * (p + 1) / 2 + p] * gv[p];
@@ -1048,7 +1080,7 @@ template <typename T, int E, int D>
 int launch(const Args<T>& a, bool jac, hipStream_t st) {
   const int K = a.n + a.m_act;
   if (K > 64) return PDDP_E_UNSUPPORTED;
-  const Lds<E, D> o(a.M, K, jac);
+  const Lds<E, D> o = lds_of<E, D>(a.M, K, jac, (int)sizeof(T));
   const size_t bytes = (size_t)o.total * sizeof(T);
   if (bytes > 160 * 1024) return PDDP_E_UNSUPPORTED;
   auto kern = Kernels<T, E, D>::pick(jac);
@@ -1217,9 +1249,9 @@ long long pddp_gp_step_lds_bytes(int state_size, int d, int M, int inputs, int j
                                  int element_size) {
   using namespace pddp::gp;
   long long words = -1;
-  if (state_size == 2 && d == 4) words = Lds<2, 4>(M, inputs, jacobian != 0).total;
-  if (state_size == 4 && d == 6) words = Lds<4, 6>(M, inputs, jacobian != 0).total;
-  if (state_size == 6 && d == 9) words = Lds<6, 9>(M, inputs, jacobian != 0).total;
+  if (state_size == 2 && d == 4) words = lds_of<2, 4>(M, inputs, jacobian != 0, element_size).total;
+  if (state_size == 4 && d == 6) words = lds_of<4, 6>(M, inputs, jacobian != 0, element_size).total;
+  if (state_size == 6 && d == 9) words = lds_of<6, 9>(M, inputs, jacobian != 0, element_size).total;
   return words < 0 ? -1 : words * element_size;
 }
 int pddp_gp_step_f32(const pddp_gp_model* g, int R, const float* z, const float* u, float* z_next,

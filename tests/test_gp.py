@@ -550,8 +550,14 @@ def test_gp_step_lds_bytes_query():
     assert fn(6, 9, 60, 28, 1, 8) == 2 * fn(6, 9, 60, 28, 1, 4)
     limit = 160 * 1024
     assert fn(6, 9, 1278, 28, 0, 4) <= limit < fn(6, 9, 1282, 28, 0, 4)
-    assert fn(6, 9, 318, 28, 1, 4) <= limit < fn(6, 9, 322, 28, 1, 4)
-    assert fn(6, 9, 74, 28, 1, 8) <= limit < fn(6, 9, 78, 28, 1, 8)
+    # with the Jacobian: the per-point g_i table is kept up to 318 (f32) / 74
+    # (f64) training points and formed again in phase C beyond (round 5) -
+    # the query steps DOWN there, and the form holds up to 890 / 208
+    assert fn(6, 9, 318, 28, 1, 4) <= limit
+    assert fn(6, 9, 322, 28, 1, 4) < fn(6, 9, 318, 28, 1, 4)
+    assert fn(6, 9, 890, 28, 1, 4) <= limit < fn(6, 9, 894, 28, 1, 4)
+    assert fn(6, 9, 74, 28, 1, 8) <= limit
+    assert fn(6, 9, 208, 28, 1, 8) <= limit < fn(6, 9, 212, 28, 1, 8)
 
 
 @pytest.mark.gpu
@@ -683,6 +689,40 @@ def test_gp_step_kernel_at_the_outer_loops_dataset_size():
     assert not m64.native_ok(z.double(), enc, jacobian=True)
     assert m64.native_ok(z.double(), enc)
     assert _rel(m64.native_step(z.double(), u.double(), enc), r64) < 1e-10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,dtype", [(319, torch.float32), (640, torch.float32),
+                                     (890, torch.float32), (75, torch.float64),
+                                     (208, torch.float64)])
+def test_gp_jacobian_beyond_the_g_table(M, dtype):
+    """The Jacobian form beyond the training-set size whose per-point g_i =
+    G_a nu_i table fits a workgroup's LDS (double cartpole: 318 points in f32,
+    74 in f64): the launcher drops the table and phase C forms g_i again
+    (csrc/gp_step.hip `Lds::gstore`; round 5) - up to 890 / 208 points, the
+    sizes PDDPController.fit's data set grows to (pddp.py:67-71: up to 1000
+    rows).  Step and Jacobian against the fp64 torch module and autograd on
+    the same inputs (f32: with the float module's own distance as the
+    yardstick), the first size past the table and the last that fits."""
+    import copy
+    enc = StateEncoding.DEFAULT
+    model, _ = _system_model("double_cartpole", M, dtype, seed=M)
+    z, u = _system_rows("double_cartpole", 2, enc, dtype, seed=M + 1)
+    assert model.native_ok(z, enc, jacobian=True)
+    out, Fz, Fu = model.native_step(z, u, enc, jacobian=True)
+    if dtype == torch.float64:
+        ref, Fz_r, Fu_r = _torch_step(model, z, u, enc, True)
+        assert _rel(out, ref) < 1e-10
+        assert _rel(Fz, Fz_r) < 1e-9 and _rel(Fu, Fu_r) < 1e-9
+        return
+    ref, Fz_r, Fu_r = _torch_step(model, z, u, enc, True)
+    m64 = copy.deepcopy(model).double()
+    m64._native_cache = {}
+    r64, Fz64, Fu64 = _torch_step(m64, z.double(), u.double(), enc, True)
+    for got, tor, exact, tol in ((out, ref, r64, 2e-5), (Fz, Fz_r, Fz64, 5e-4),
+                                 (Fu, Fu_r, Fu64, 5e-4)):
+        assert _rel(got.double(), exact) < max(
+            tol, 4.0 * _rel(tor.double(), exact))
 
 
 @pytest.mark.gpu
