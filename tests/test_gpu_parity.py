@@ -2038,6 +2038,61 @@ def test_one_launch_round_equals_two_launches(B, N):
     assert accepted > B // 2
 
 
+def test_one_launch_round_single_trajectory_and_mpc_schedule():
+    """The one-launch round at the reference's own batch - ONE trajectory - and
+    with the eleven step sizes of the receding-horizon schedule (ilqr.py:116):
+    a fit through `iLQRController.fit` (several rounds per launch, the live
+    count read once per launch) against the same fit through the two-launch
+    rounds: the same states, costs to 1e-6, plans to 1e-4."""
+    import pddp_amd
+    from pddp_amd.controllers.solver import mpc_alphas
+    from pddp_amd.examples import cartpole
+    enc = pddp_amd.StateEncoding.IGNORE_UNCERTAINTY
+    model, cost = cartpole.CartpoleDynamicsModel(0.1), cartpole.CartpoleCost()
+    u_min, u_max = torch.tensor([-10.0]), torch.tensor([10.0])
+    g = torch.Generator().manual_seed(3)
+    U0 = (0.1 * torch.randn(30, 1, generator=g)).cuda()
+    z0 = (1e-2 * torch.randn(4, generator=g)).cuda()
+    out = {}
+    for one in (True, False):
+        ctrl = pddp_amd.controllers.iLQRController(None, model, cost)
+        if not one:
+            import pddp_amd.controllers.solver as sv
+            orig = sv.ILQRSolver.round_nominal
+            sv.ILQRSolver.round_nominal = lambda self, *a, **k: False
+        try:
+            Z, U, st = ctrl.fit(U0.clone(), encoding=enc, n_iterations=12,
+                                u_min=u_min, u_max=u_max, z0=z0, quiet=True)
+        finally:
+            if not one:
+                sv.ILQRSolver.round_nominal = orig
+        assert (ctrl._solver._one_launch is True) == one
+        out[one] = (Z.clone(), U.clone(), int(st), float(ctrl._solver.J_opt[0]))
+    assert out[True][2] == out[False][2]
+    assert abs(out[True][3] - out[False][3]) <= 1e-6 * abs(out[False][3])
+    assert float((out[True][1] - out[False][1]).abs().max()) <= 1e-4 * float(
+        out[False][1].abs().max().clamp_min(1.0))
+    # eleven step sizes, a small batch: rounds in one launch == single rounds
+    a, op, z0n, Un, _, _ = _setup("cartpole", "f32", 3, 20, seed=2)
+    from pddp_amd.controllers.solver import ILQRSolver
+    prob = a.problem
+    mk = lambda: ILQRSolver(prob, 3, 20, torch.float32, "cuda",
+                            torch.tensor([-10.0]), torch.tensor([10.0]),
+                            mpc_alphas(torch.float32, "cuda"))
+    a, b = mk(), mk()
+    assert a.A == 11
+    for s_ in (a, b):
+        s_.set_nominal(torch.from_numpy(z0n).cuda(), torch.from_numpy(Un).cuda())
+    a.rounds(6, n_iterations=5)
+    for _ in range(6):
+        b.round(n_iterations=5)
+    assert a._one_launch is True and b._one_launch is True
+    for k in ("Z", "U", "J_opt", "mu", "delta", "state", "iter", "active",
+              "gains", "gains_acc", "Jc"):
+        assert torch.equal(torch.nan_to_num(getattr(a, k).double(), nan=1.5),
+                           torch.nan_to_num(getattr(b, k).double(), nan=1.5)), k
+
+
 @pytest.mark.parametrize("B,N,R", [(64, 40, 5), (37, 33, 3), (130, 100, 4),
                                    (21, 16, 7), (16, 127, 2)])
 def test_rounds_in_one_launch_equal_single_rounds(B, N, R):
