@@ -134,6 +134,10 @@ struct PreStaged {
   const T* Gs;
   int status;
   T J_opt;
+  // nullable: [17][n + m] in LDS, the nominal's rows t = N - 16 .. N at index
+  // N - t - the winner's go there too (round_n4.hip, several rounds per
+  // launch: the next round's first records are made from them)
+  T* carry_rows = nullptr;
 };
 template <typename T, int MODEL, bool FUSED, int WPB, int H, unsigned QM,
           bool DENSE, bool PRE = false>
@@ -505,6 +509,17 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
           if (t < N) {
 #pragma unroll
             for (int j = 0; j < m; ++j) Ub[t * m + j] = uu[k][j];
+          }
+          if constexpr (PRE) {
+            if (pre.carry_rows != nullptr && t <= N && N - t <= 16) {
+              T* cr = pre.carry_rows + (N - t) * (n + m);
+#pragma unroll
+              for (int j = 0; j < n; ++j) cr[j] = zz[k][j];
+              if (t < N) {
+#pragma unroll
+                for (int j = 0; j < m; ++j) cr[n + j] = uu[k][j];
+              }
+            }
           }
         }
       } else {

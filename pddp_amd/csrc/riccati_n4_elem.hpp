@@ -431,8 +431,17 @@ struct RoundOut {       // (ROUND) what the search phase needs, per lane
   const float* Us;      //   = Gs + 5 (stride 6)
   int status;           // sweep wavefront: PDDP_BWD_* of the trajectory
   float J_opt;          // cost of the nominal (summed here when it was new)
+  float* carry_rows;    // [17][5] rows carried between rounds, or NULL
 };
 constexpr int round_zu_stride(int N) { return 4 * (N + 1); }
+// (ROUND, several rounds per launch) the nominal's last seventeen rows {z, u}
+// of the pair's four trajectories, kept in LDS from round to round: what the
+// next round's first block of records and its terminal value are made from
+// (index N - t: 0 the terminal state) - the winner's rows go there from the
+// search's tail as well as to global memory, and the next round does not wait
+// out a trip to L2 for rows its own workgroup has just produced
+constexpr int kCarryRows = kBlk + 1, kCarryW = 5;
+constexpr int kCarryF = kTrajW * kCarryRows * kCarryW;  // 340 floats
 // (ROUND) a step's row in the search's LDS table: k, K[0..3] and the nominal
 // action - 24 bytes, three 8-byte reads per rollout step
 constexpr int kGainL = kGain + 1;
@@ -442,7 +451,10 @@ template <typename T, unsigned QM, bool OVL, bool ROUND>
 PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
                               const ProblemT<T>& prob, unsigned char* smem_raw,
                               RoundOut& ro,
-                              const unsigned tid = threadIdx.x) {
+                              const unsigned tid = threadIdx.x,
+                              const int carry = -1) {
+  // carry (ROUND): -1 none; 1 this is the launch's first round - the rows
+  // above are filled from global memory; 0 a later round - they are read
   static_assert(OVL || !ROUND, "");
   // (float64: the inline form only - two image buffers of doubles for four
   // pairs are 220 KB - with the closed-form BoxQP of riccati_n4.hpp and IEEE
@@ -453,7 +465,9 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
   using V2 = typename Vec<T>::v2;
   constexpr int MODEL = PDDP_MODEL_CARTPOLE;
   constexpr RecLayout lay(4, 1);
-  const int kPairLds = OVL ? kPairLdsOvl + (ROUND ? round_gains_floats(a.N) : 0)
+  const int kPairLds = OVL ? kPairLdsOvl + (ROUND ? round_gains_floats(a.N) +
+                                                        (carry >= 0 ? kCarryF : 0)
+                                                  : 0)
                            : kPairLdsInl;
   // (`tid`: threadIdx.x - through an opaque move in the loop over rounds of
   // round_n4.hip, so that nothing derived from it is hoisted out of a round)
@@ -490,19 +504,49 @@ PDDP_DEV bool elem_sweep_body(const RiccatiArgs<T>& a, const GenArgs<T>& gen,
   // trajectory `row` (models.hpp record_of: the code of derivs_kernel) and
   // writes its image; the operands of a block are requested one block ahead
   T zq[4], uq, Jacc = T(0), l_term = T(0);
+  // (ROUND) rows carried from round to round, this lane's trajectory's
+  [[maybe_unused]] T* const carry_w =
+      img0 + kPairLdsOvl + (ROUND ? round_gains_floats(N) : 0) +
+      row * kCarryRows * kCarryW;
+  if constexpr (ROUND) ro.carry_rows = carry >= 0 ? carry_w : nullptr;
   auto request = [&](int jb) {
     int tau = N - 1 - kBlk * jb - l;
     tau = tau < 0 ? 0 : tau;
+    if constexpr (ROUND) {
+      if (jb == 0 && carry == 0) {  // from the rows the last round left
+        const T* cr = carry_w + (N - tau) * kCarryW;
+        zq[0] = cr[0]; zq[1] = cr[1]; zq[2] = cr[2]; zq[3] = cr[3];
+        uq = cr[4];
+        return;
+      }
+    }
     const V4 v = *reinterpret_cast<const V4*>(Zg + 4 * tau);
     zq[0] = v[0]; zq[1] = v[1]; zq[2] = v[2]; zq[3] = v[3];
     uq = Ug[tau];
+    if constexpr (ROUND) {
+      if (jb == 0 && carry == 1 && N - tau <= kBlk) {
+        T* cr = carry_w + (N - tau) * kCarryW;
+        cr[0] = zq[0]; cr[1] = zq[1]; cr[2] = zq[2]; cr[3] = zq[3];
+        cr[4] = uq;
+      }
+    }
   };
   // terminal value function V = L_zz[N], V_z = L_z[N]: evaluated by every lane
   // of the row (the wavefront pays the instructions once either way), handed
   // over through LDS
   auto terminal = [&]() {
-    const V4 zNv = *reinterpret_cast<const V4*>(Zg + 4 * N);
-    const T zN[4] = {zNv[0], zNv[1], zNv[2], zNv[3]};
+    T zN[4];
+    if (ROUND && carry == 0) {
+      zN[0] = carry_w[0]; zN[1] = carry_w[1]; zN[2] = carry_w[2];
+      zN[3] = carry_w[3];
+    } else {
+      const V4 zNv = *reinterpret_cast<const V4*>(Zg + 4 * N);
+      zN[0] = zNv[0]; zN[1] = zNv[1]; zN[2] = zNv[2]; zN[3] = zNv[3];
+      if (ROUND && carry == 1 && l == 0) {
+        carry_w[0] = zN[0]; carry_w[1] = zN[1]; carry_w[2] = zN[2];
+        carry_w[3] = zN[3];
+      }
+    }
     T lz[4], lzz[16], lu[1], luu[1];
     l_term = cost_derivs<T, MODEL>(prob, zN, nullptr, trig_of<T, MODEL>(zN),
                                    true, lz, lzz, lu, luu);

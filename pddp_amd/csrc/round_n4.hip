@@ -33,7 +33,7 @@ template <unsigned QM, bool MULTI>
 __global__ __launch_bounds__(2 * n4e::kWaves * kWave) void round_n4_kernel(
     RiccatiArgs<float> a, n4d::GenArgs<float> gen, ProblemT<float> prob,
     LineSearchArgs<float> ls, AcceptArgs<float> ac, float* scratch,
-    int rounds, long long* phase_ticks) {
+    int rounds, long long* phase_ticks, int use_carry) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // (bench.py's roofline leg: what share of the launch is sweep - rocprofv3
   // sees one kernel.  Wavefront 0 of the workgroup reads the chip's 100 MHz
@@ -69,11 +69,14 @@ __global__ __launch_bounds__(2 * n4e::kWaves * kWave) void round_n4_kernel(
     // (a pair without a live trajectory leaves here, both wavefronts alike -
     // it has none in any later round either; s_barrier does not wait for
     // wavefronts that have ended)
-    if (!n4e::elem_sweep_body<float, QM, true, true>(a_r, gen, prob, smem_raw, ro,
-                                              tid))
+    // (several rounds per launch: the nominal's last rows ride in LDS)
+    const int carry = MULTI && use_carry ? (r == 0 ? 1 : 0) : -1;
+    if (!n4e::elem_sweep_body<float, QM, true, true>(a_r, gen, prob, smem_raw,
+                                                     ro, tid, carry))
       break;
     const long long t1 = timed ? wall_clock64() : 0;
-    const PreStaged<float> pre{ro.Zs, ro.Us, ro.Gs, ro.status, ro.J_opt};
+    const PreStaged<float> pre{ro.Zs, ro.Us,      ro.Gs,
+                               ro.status, ro.J_opt, ro.carry_rows};
     line_search_lds_body<float, PDDP_MODEL_CARTPOLE, true, n4e::kWaves, 2, QM,
                          false, true>(prob, ls_r, ac_r, scratch, nullptr,
                                       smem_raw, pre, tid);
@@ -110,8 +113,12 @@ static int launch_round_n4(const pddp_problem& p, const RiccatiArgs<float>& a,
   // the two launches, whose forms for large batches share a CU, are the
   // faster round
   if (grid.x > 256u) return PDDP_E_UNSUPPORTED;
-  const size_t lds = (size_t)n4e::kWaves * sizeof(float) *
-                     (n4e::kPairLdsOvl + n4e::round_gains_floats(a.N));
+  // (several rounds per launch: the carried rows, where they fit - N <= 123)
+  const size_t lds0 = (size_t)n4e::kWaves * sizeof(float) *
+                      (n4e::kPairLdsOvl + n4e::round_gains_floats(a.N));
+  const size_t lds1 = lds0 + (size_t)n4e::kWaves * sizeof(float) * n4e::kCarryF;
+  const int use_carry = rounds > 1 && lds1 <= 159 * 1024;
+  const size_t lds = use_carry ? lds1 : lds0;
   if (lds > 159 * 1024) return PDDP_E_UNSUPPORTED;
   const ProblemT<float> P = convert_problem<float>(p);
   constexpr unsigned kSparse = 0b11001u;  // CartpoleCost: {x, sin, cos}
@@ -127,7 +134,7 @@ static int launch_round_n4(const pddp_problem& p, const RiccatiArgs<float>& a,
         (int)lds);                                                            \
     if (e != hipSuccess) return (int)e;                                       \
     PDDP_LAUNCH(kern, grid, dim3(2 * n4e::kWaves * kWave), lds, st, a, gen,   \
-                P, ls, ac, scratch, rounds, phase_ticks);                     \
+                P, ls, ac, scratch, rounds, phase_ticks, use_carry);          \
   } while (0)
   if (sparse) PDDP_ROUND_GO(kSparse); else PDDP_ROUND_GO(kFull);
 #undef PDDP_ROUND_GO
