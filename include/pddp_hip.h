@@ -341,7 +341,10 @@ int pddp_sweep_nominal_kernel(int which);
  * scratch of at least B (N+1) n scalars: the states of every trajectory's
  * full-step candidate go there, rows next to one another, INSTEAD of
  * Zc[b][.][0][.] (the usual winner: its copy into the nominal reads whole
- * sectors there, 16 bytes out of every A n 4-byte step in Zc). */
+ * sectors there, 16 bytes out of every A n 4-byte step in Zc).  In that form
+ * (L == NULL, rec given, N + 1 within the tail's short form: 128 steps for the
+ * paired launch) the candidates' ACTIONS `Uc` are not written either: the
+ * winner's are its control law at its states, re-evaluated bit for bit. */
 /* Candidates of pddp_search_accept_* in its form without records (L == NULL,
  * rec given as scratch): 0 = auto - kept while B A (N (n + m) + n) scalars fit
  * the Infinity Cache next to the round's other traffic (200 MB), dropped

@@ -128,7 +128,9 @@ class ILQRSolver(object):
         self.phase_ticks = None
         # False after a search launch that dropped the candidates (large
         # batches without records, pddp_search_candidates): `Zc`, `Uc` are then
-        # scratch - only `Jc` and the nominal are results of that round
+        # scratch - only `Jc` and the nominal are results of that round.  (In
+        # the record-free rounds of the sample problems `Uc` is never written:
+        # the winner's actions are re-evaluated, include/pddp_hip.h)
         self.candidates_kept = True
         self._derivs_due = True
         # The sweep that evaluates the derivative records itself, from the

@@ -249,6 +249,10 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
   // returned.  A stride of zero makes the target a one-row scratch - the
   // stores stay in the instruction stream (no exec mask on the chain), their
   // line stays in L2.
+  // (the candidates' actions are only stored where something reads them: the
+  // tail's short form re-evaluates the winner's)
+  const bool store_uc = !(FUSED && n <= 6 && Lout == nullptr &&
+                          rec != nullptr && N + 1 <= 16 * H * kTailRows);
   auto rollout = [&](T alpha, T* Zci, size_t zstep, T* Uci, size_t ustep) {
     T z[n], zn[n], un[m];
 #pragma unroll
@@ -298,8 +302,10 @@ PDDP_DEV void line_search_lds_body(const ProblemT<T> P,
       // one store instruction per step and 18 MB per round less - 52.4 ->
       // 51.8 us per round, tools/dbg/ab_round.py)
       if constexpr (!PRE) {
+        if (store_uc) {
 #pragma unroll
-        for (int j = 0; j < m; ++j) Uci[(size_t)t * ustep + j] = un[j];
+          for (int j = 0; j < m; ++j) Uci[(size_t)t * ustep + j] = un[j];
+        }
       }
       J += cost_value<T, MODEL, QM>(P, z, un, tr, false);
       dynamics<T, MODEL, false>(P, z, un, tr, zn, nullptr, nullptr);
