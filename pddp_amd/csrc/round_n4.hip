@@ -22,8 +22,15 @@
 // slowest phases.
 //
 // Same code as the two launches (device functions shared with them): the
-// results are theirs bit for bit (tests/test_gpu_parity.py::
-// test_one_launch_round_equals_two_launches).
+// sweep's outputs are theirs bit for bit, decisions and masks identical, the
+// search's values to rounding - the same closed forms inlined into another
+// kernel are contracted into FMAs differently (tests/test_gpu_parity.py::
+// test_one_launch_round_equals_two_launches); R rounds per launch are R
+// one-round launches bit for bit (test_rounds_in_one_launch_equal_single_
+// rounds).  The search's step here differs from the stand-alone launch's in
+// three places, each an A/B-measured cut: the nominal row is
+// read with one 16-byte and three 8-byte LDS reads, one LDS wait per step, and
+// between the rounds of a launch the nominal's last rows stay in LDS.
 #include "riccati_n4_elem.hpp"
 #include "line_search_lds.hpp"
 
