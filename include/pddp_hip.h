@@ -140,8 +140,12 @@ int pddp_boxqp_m1_f64(int count, const double* x0, const double* Q,
 /* The scalar BoxQP AS THE BENCHED SWEEP RUNS IT (csrc/riccati_n4_elem.hpp
  * elem_gains: ilqr.py:633-634 e = (Quu < 0 ? 1e-12 : Quu) + reg, then
  * constraint.py:150-266 on (x0, e, Qu, lower, upper) in the lean closed form
- * with v_rcp_f32 - the closed form of pddp_boxqp_m1_* and the reference's loop
- * behind it for the rows it does not cover): x = the feed-forward gain,
+ * with v_rcp_f32: every exit test of the loop's two passes and its `free`
+ * flag; not its Armijo back-tracking, which for one action returns the same
+ * clamped Newton point in exact arithmetic - riccati_n4_elem.hpp QpLean1 has
+ * the argument and the measured agreement; a curvature that is not positive
+ * and finite goes to the closed form of pddp_boxqp_m1_* and the reference's
+ * loop behind it): x = the feed-forward gain,
  * free_mask = 1 where the feedback row is not zeroed (the reference's possibly
  * stale `free`), status = PDDP_BWD_OK / _NAN / _BOXQP_FAILED; coeffs, nullable,
  * [count][3] = {s, c, w}: 1 / e or 0, and the two coefficients of the rank-one

@@ -7,8 +7,8 @@
 // dependent steps on wavefronts that have a SIMD to themselves, and a lone
 // wavefront issues one instruction every ~5 cycles whatever it depends on -
 // the time of a step is the instruction count of its busiest wavefront plus
-// what it waits for.  The four-role kernel (riccati_n4_defer.hpp) cut the
-// chain that crosses a step down to the scalar BoxQP, but pays an LDS
+// what it waits for.  The four-role kernel of round 3 (retired, docs/history)
+// cut the chain that crosses a step down to the scalar BoxQP, but paid an LDS
 // exchange and an s_barrier per step: ~745 cycles for ~100 instructions per
 // role.  This kernel goes the other way: the plain recursion in the
 // lane-per-matrix-element mapping of riccati_n4.hpp (16 lanes per
@@ -23,9 +23,9 @@
 //     copy of F_z as a 4x4 table whose rows are ds_read_b128 operands (2
 //     reads instead of 9), {f, L_z, L_uz} interleaved per index (2 reads
 //     instead of 5);
-//   * the BoxQP is QpLean (riccati_n4_defer.hpp: every predicate in the sign
-//     bit of a VGPR, no compare -> SGPR -> select round trips), QpClosed and
-//     the reference's loop behind it for the lanes it does not cover;
+//   * the BoxQP is QpLean1 (below: every predicate in the sign bit of a
+//     VGPR, no compare -> SGPR -> select round trips), QpClosed and the
+//     reference's loop behind it for the rows it does not cover;
 //   * the value update is the rank-one form V' = sym(Qzz) + c Quz Quz^T,
 //     V_z' = Qz + w Quz (two FMAs) instead of the mirrored K-trees;
 //   * two transposes (ds_bpermute) instead of three, issued before the BoxQP.
@@ -142,16 +142,35 @@ struct Vec {
   typedef T v2 __attribute__((ext_vector_type(2)));
 };
 
-// QpLean (riccati_n4_defer.hpp) without the third iterate: where the
-// reference's loop takes one more full Newton step from a live interior x1
-// (constraint.py:237-259, second pass), x2 = clamp(x1 + (newton - x1)) is the
-// rounded Newton point again - |x2 - x1| <= 2 ulp, both are roundings of the
-// same number - and this form returns x1.  Everything that is a DECISION of
-// the reference (the exit tests of both passes, the stale `free` flag, when
-// its back-tracking would leave the closed form) is evaluated as in QpLean.
+// The scalar BoxQP of constraint.py:150-266 for m = 1 as straight-line code on
+// sign bits: the clamped warm start, one projected Newton step, and every
+// DECISION the reference's loop takes on the way - the exit tests of both
+// passes (clamped gradient / small gradient / relative improvement) and the
+// stale `free` flag it returns with.  Two things the loop does are not
+// evaluated, because for one action they cannot change its answer:
+//  * the second full Newton step from a live interior x1 (constraint.py:237-259,
+//    second pass): x2 = clamp(x1 + (newton - x1)) is the rounded Newton point
+//    again - |x2 - x1| <= 2 ulp, both are roundings of the same number;
+//  * the Armijo back-tracking (constraint.py:241-252).  With s = newton - xs
+//    and theta the fraction of s the clamp lets through, f(x1) - f(xs) =
+//    s g (theta - theta^2 / 2): the test `<= 0.1 s g` passes at the full step
+//    for theta >= 0.1056, and below that the first step size 0.6^k that
+//    passes still overshoots the bound (0.6^k > theta), so the accepted
+//    candidate is clamp(xs + 0.6^k s) = the bound = x1 again.  In exact
+//    arithmetic the loop returns x1 whatever the back-tracking does; it leaves
+//    x1 only where f(x1) - f(xs) is rounding noise (0.02 % of the steps of the
+//    benched workload in float32, none in float64).  Earlier builds detected
+//    those steps and ran the loop for them (14 instructions per step on the
+//    chain); without that the lean form agrees BETTER with the float64 oracle
+//    (x: 0 instead of 11 of 59,980 differ by more than 1e-6; status and the
+//    round's parity statistics unchanged - tests/test_gpu_parity.py::
+//    test_lean_boxqp_of_the_benched_sweep_vs_oracle) and a round
+//    is 2.9 us shorter.  The loop itself still runs behind QpClosed: on the
+//    records-path variants (exact=True), in float64, and for the irregular
+//    rows of the class test below.
 struct QpLean1 {
   float x, inv;
-  int free_w, slow_w;  // flags in the sign bit
+  int free_w;  // flag in the sign bit
   PDDP_DEV void solve(float x0, float Q, float c, float lo, float hi) {
     const float d_lo = lo - x0, d_hi = x0 - hi;  // sign: x0 > lo, x0 < hi
     const float xs = __builtin_amdgcn_fmed3f(x0, lo, hi);
@@ -172,21 +191,9 @@ struct QpLean1 {
     const int conv = sgn(fma_(-1e-8f, __builtin_fabsf(f0), -num));
     const float g1 = fma_(Q, x1, c);
     const int ncl1 = (sgn(d1_hi) & ~sgn(d1_lo) & ~sgn(g1)) | (~sgn(d1_hi) & sgn(g1));
-    const int small1 = sgn(__builtin_fabsf(g1) - 1e-8f);
-    const int stop1 = conv | ncl1 | small1;
     x = bsel(splat(done0), xs, x1);
     // free = (done0 & !ncl0) | (!done0 & (conv | !ncl1)), done0 = ncl0 | small0
     free_w = ~ncl0 & (small0 | conv | ~ncl1);
-    // ---- does the reference's loop leave these paths?  (QpClosed: pass0,
-    // guard, live1 & on_bound1)
-    const float sdotg = s0 * g0;
-    const int npass = sgn(fma_(0.1f, sdotg, -num));  // !(num <= 0.1 sdotg)
-    const int pass0 = sgn(sdotg) & ~npass;
-    const int onb1 = ~(sgn(d1_lo) & sgn(d1_hi));
-    const float lhs = __builtin_fabsf(x1 - xs) * __builtin_fabsf(sdotg);
-    const float rhs = (3.0f * __builtin_fabsf(num)) * __builtin_fabsf(s0);
-    const int guard = onb1 & sgn(sdotg) & sgn(num) & ~sgn(rhs - lhs);
-    slow_w = ~done0 & (~(pass0 | guard) | (~stop1 & onb1));
   }
 };
 
@@ -311,13 +318,9 @@ PDDP_DEV ElemGains<T> elem_gains(T kprev, T Quu, T Qu, T reg, T lo_b, T hi_b,
     sK = __int_as_float(splat(ql.free_w) & __float_as_int(ql.inv));
     n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, wv);
     // anything the lean form does not cover - a non-finite Quu (0 Quu is
-    // NaN then), a Q that is not positive and finite, `slow` - in ONE class
-    // test: QpClosed, the reference's loop behind it, for those rows only
-    // (`slow` rides as the SIGN of the word the class test looks at - one
-    // v_and_or_b32 - a negative value is not "regular": an instruction less
-    // than a splat and an or, 50.9 -> 50.7 us per round, tools/dbg/ab_round.py)
-    const T chk = __int_as_float((ql.slow_w & (int)0x80000000) |
-                                 __float_as_int(fma_(Quu, T(0), qp_Q)));
+    // NaN then), a Q that is not positive and finite - in ONE class test:
+    // QpClosed, the reference's loop behind it, for those rows only
+    const T chk = fma_(Quu, T(0), qp_Q);
     unsigned long long regular;  // (the mask straight into a scalar pair)
     asm("v_cmp_class_f32 %0, %1, %2" : "=s"(regular) : "v"(chk), "v"(0x180));
     oddm = ~regular & alive_m;

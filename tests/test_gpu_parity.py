@@ -497,8 +497,10 @@ def test_boxqp_m1_vs_oracle(dtype):
 def test_lean_boxqp_of_the_benched_sweep_vs_oracle():
     """The scalar BoxQP exactly as the benched f32 sweep runs it
     (pddp_boxqp_m1_lean_f32 = riccati_n4_elem.hpp elem_gains: the eig-clamp of
-    ilqr.py:633-634, QpLean1 with v_rcp_f32, the closed form and the
-    reference's loop behind ONE class test) against the oracle's restatement
+    ilqr.py:633-634, QpLean1 with v_rcp_f32 - the loop's exit tests and `free`
+    flag without its back-tracking, which cannot change the answer for one
+    action in exact arithmetic -, the closed form and the reference's loop
+    behind ONE class test for irregular curvature) against the oracle's restatement
     of constraint.py:150-266 on 60 000 problems: the distribution the sweep
     meets (warm starts inside the box, ON a bound, a few ulps off it, outside;
     Newton points inside / beyond / on the bounds) and the corners (vanishing
