@@ -1467,7 +1467,7 @@ def main():
                 # that have a SIMD to themselves - the step's instruction
                 # count at the lone-wavefront issue rate
                 "latency_model": {
-                    "steps": N, "instructions_per_step": 104,
+                    "steps": N, "instructions_per_step": 93,
                     "cycles_per_instruction_lone_wavefront": 5.0,
                     "what": "time = N x instructions x issue interval; HBM "
                             "and the matrix cores are idle",
@@ -1475,13 +1475,13 @@ def main():
                 # the step's dependent work alone - products, transposes, lean
                 # BoxQP, value update; operands in registers, no LDS reads, no
                 # generator, no stores: tools/probe/riccati_floor_probe.hip,
-                # profiles/r04_riccati_floor.txt (447 cycles per step: 22.75
+                # profiles/r05_riccati_floor.txt (409 cycles per step: 22.35
                 # us per 100 steps, launch included)
-                # (a MODEL: round 4's probe of round 4's step on one box, not
+                # (a MODEL: round 5's probe of round 5's step on one box, not
                 # re-measured by this run)
-                "floor_model_us": 22.75 * N / 100.0 if from_nominal else None,
-                "floor_model_source": "profiles/r04_riccati_floor.txt",
-                "frac_of_floor_model": (22.75 * N / 100.0) /
+                "floor_model_us": 22.35 * N / 100.0 if from_nominal else None,
+                "floor_model_source": "profiles/r05_riccati_floor.txt",
+                "frac_of_floor_model": (22.35 * N / 100.0) /
                                        (float(d_sweep.mean()) * 1e6)
                                        if from_nominal else None,
                 # the sweep is timed as a launch of its own (the last
@@ -1559,7 +1559,7 @@ def main():
                             "= N x instructions per step x the lone "
                             "wavefront's issue interval (~5-6 cycles); HBM "
                             "and the matrix cores are idle (DESIGN.md 3.5b)",
-                    "steps": N, "sweep_instructions_per_step": 100,
+                    "steps": N, "sweep_instructions_per_step": 93,
                     "rollout_instructions_per_step": 84},
                 "backward_sweep": {
                     "inside_this_launch": None if not ph else {

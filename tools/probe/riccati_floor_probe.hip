@@ -8,23 +8,21 @@
 // wavefront) + what it waits for.  This probe runs the step of
 // csrc/riccati_n4_elem.hpp (16 lanes per trajectory, plain recursion) 100 times
 // with EVERY operand pre-staged in registers - no LDS reads, no record
-// generator, no gains out, no barrier - in four cuts:
+// generator, no gains out, no barrier - in three cuts:
 //
 //   core        the 27 hand-scheduled products / reductions + the two
 //               transposes (ds_bpermute) + the rank-one value update, the gain
 //               taken as s = 1 / Quu (no BoxQP): the matrix part's floor
 //   core+qp     + QpLean1 (the lean closed-form BoxQP) + (c, w): the floor of
 //               the whole dependent chain V -> Quu -> BoxQP -> c -> V'
-//   chain4x4    the chain the four-role kernel keeps on its critical path per
-//               step (riccati_n4_defer.hpp): T = W F and F^T T as eight
-//               DEPENDENT v_mfma_f32_4x4x1 + two FMAs + QpLean + the rank-one
-//               fold (one more matrix instruction) - VERDICT's definition
+//   (round 4 also timed the retired four-role kernel's chain of eight
+//    dependent v_mfma_f32_4x4x1: 431 cycles per step, profiles/r04_riccati_floor.txt)
 //   qp only     QpLean1 + (c, w) alone, its inputs two FMAs away from its
 //               outputs (the scalar chain that crosses a step in the deferred
 //               form)
 //
 // 256 workgroups x 4 wavefronts (one per SIMD), clock64 around the 100 steps,
-// mean over the wavefronts; events give the wall time per step.
+// mean over the wavefronts; events over 200 launches give the wall time.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast -fno-slp-vectorize \
 //     -I pddp_amd/csrc tools/probe/riccati_floor_probe.hip -o /tmp/rfp && /tmp/rfp
 #include <hip/hip_runtime.h>
@@ -67,7 +65,6 @@ __global__ __launch_bounds__(256) void floor_probe(float* out, long long* cyc,
         ql.solve(kprev, qp_Q, q.Qu, lo, hi);
         kt = ql.x;
         sK = __int_as_float(n4d::splat(ql.free_w) & __float_as_int(ql.inv));
-        acc += __int_as_float(ql.slow_w & 1);
       } else {
         sK = __builtin_amdgcn_rcpf(qp_Q);
         kt = -(q.Qu * sK);
@@ -80,37 +77,6 @@ __global__ __launch_bounds__(256) void floor_probe(float* out, long long* cyc,
       vc = n4::fma_(wv, Quzc, q.Qzc);
     }
     acc += V + vc;
-  } else if constexpr (CUT == 2) {
-    // quad layout: lane q of a quad = column q; W in four registers
-    n4d::Acc4<float> W = {1.0f, 0.0f, 0.0f, 0.0f};
-    float c1 = -0.1f, w1 = 0.01f, g1 = 0.1f, A0 = 0.3f, B0 = 0.02f;
-    for (int t = 0; t < steps; ++t) {
-      n4d::Acc4<float> T = {0.0f, 0.0f, 0.0f, 0.0f};
-      n4d::opa(T, W.v0, Fs[0]);
-      n4d::opa(T, W.v1, Fs[1]);
-      n4d::opa(T, W.v2, Fs[2]);
-      n4d::opa(T, W.v3, Fs[3]);
-      n4d::Acc4<float> C = {0.5f * Lzz, 0.0f, 0.0f, 0.0f};
-      n4d::opa(C, Fq[0], T.v0);
-      n4d::opa(C, Fq[1], T.v1);
-      n4d::opa(C, Fq[2], T.v2);
-      n4d::opa(C, Fq[3], T.v3);
-      const float Quu = n4::fma_(c1, g1 * g1, A0 + 1e-3f * C.v0);
-      const float Qu = n4::fma_(w1, g1, B0);
-      const float qp_Q = n4d::bsel(n4d::splat(n4d::sgn(Quu)), 1e-12f, Quu) + reg;
-      n4d::QpLean ql;
-      ql.solve(kprev, qp_Q, Qu, lo, hi);
-      const float kt = ql.x;
-      const float sK =
-          __int_as_float(n4d::splat(ql.free_w) & __float_as_int(ql.inv));
-      n4q::rank_one_coeffs(kt, sK, Quu, Qu, c1, w1);
-      kprev = kt;
-      // the rank-one fold: W' = C + c y y^T
-      n4d::opa(C, c1 * fr, fc);
-      W = C;
-      acc += __int_as_float(ql.slow_w & 1);
-    }
-    acc += W.v0 + W.v1 + W.v2 + W.v3;
   } else {
     float Quu = 0.3f, Qu = 0.02f, c = -0.1f, wv = 0.01f;
     for (int t = 0; t < steps; ++t) {
@@ -124,7 +90,6 @@ __global__ __launch_bounds__(256) void floor_probe(float* out, long long* cyc,
           __int_as_float(n4d::splat(ql.free_w) & __float_as_int(ql.inv));
       n4q::rank_one_coeffs(kt, sK, Quu, Qu, c, wv);
       kprev = kt;
-      acc += __int_as_float(ql.slow_w & 1);
     }
     acc += c + wv;
   }
@@ -143,11 +108,11 @@ static void run(const char* name) {
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  for (int w = 0; w < 3; ++w)
+  for (int w = 0; w < 200; ++w)  // (the shader clock takes a few ms to ramp)
     floor_probe<CUT><<<blocks, threads>>>(out, cyc, steps, 0.001f);
   (void)hipDeviceSynchronize();
   (void)hipEventRecord(e0);
-  for (int w = 0; w < 10; ++w)
+  for (int w = 0; w < 200; ++w)
     floor_probe<CUT><<<blocks, threads>>>(out, cyc, steps, 0.001f);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
@@ -160,7 +125,7 @@ static void run(const char* name) {
   for (auto v : h) mean += (double)v;
   mean /= (double)h.size();
   printf("%-10s %7.1f cycles per step  (launch of 100 steps: %.2f us)\n", name,
-         mean / steps, ms * 1e3 / 10);
+         mean / steps, ms * 1e3 / 200);
   (void)hipFree(out);
   (void)hipFree(cyc);
 }
@@ -168,7 +133,6 @@ static void run(const char* name) {
 int main() {
   run<0>("core");
   run<1>("core+qp");
-  run<2>("chain4x4");
   run<3>("qp only");
   return 0;
 }
