@@ -1467,7 +1467,7 @@ def main():
                 # that have a SIMD to themselves - the step's instruction
                 # count at the lone-wavefront issue rate
                 "latency_model": {
-                    "steps": N, "instructions_per_step": 93,
+                    "steps": N, "instructions_per_step": 88,
                     "cycles_per_instruction_lone_wavefront": 5.0,
                     "what": "time = N x instructions x issue interval; HBM "
                             "and the matrix cores are idle",
@@ -1559,8 +1559,8 @@ def main():
                             "= N x instructions per step x the lone "
                             "wavefront's issue interval (~5-6 cycles); HBM "
                             "and the matrix cores are idle (DESIGN.md 3.5b)",
-                    "steps": N, "sweep_instructions_per_step": 93,
-                    "rollout_instructions_per_step": 84},
+                    "steps": N, "sweep_instructions_per_step": 88,
+                    "rollout_instructions_per_step": 78},
                 "backward_sweep": {
                     "inside_this_launch": None if not ph else {
                         "us_per_round": ph["sweep_us"],
