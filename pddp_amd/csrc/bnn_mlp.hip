@@ -63,8 +63,11 @@ namespace pddp {
 __device__ long long g_mlp_marks[8 * 8];
 #define PDDP_MLP_MARK(k)                                                       \
   do {                                                                          \
-    if (blockIdx.x == 0 && i == 5 && lane == 0)                                 \
+    if (blockIdx.x == 0 && i == 5 && lane == 0) {                               \
       g_mlp_marks[wave * 8 + (k)] = __builtin_readcyclecounter();              \
+      if ((k) == 0 || (k) == 4) /* the chip-wide 100 MHz clock: words 5, 6 */   \
+        g_mlp_marks[wave * 8 + 5 + (k) / 4] = wall_clock64();                   \
+    }                                                                           \
   } while (0)
 #else
 #define PDDP_MLP_MARK(k) do { } while (0)
@@ -72,6 +75,7 @@ __device__ long long g_mlp_marks[8 * 8];
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -440,17 +444,32 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   // four MFMAs, mask and ReLU on the accumulators, four ds_write_b128
   float xin[KS1];
   f32x4 m1[4];
-  auto masks_of = [&](const float* M, const RowOf& ro, f32x4 (&m)[4]) {
+  // The mask row [p][.] of this lane's data row, as a BYTE OFFSET that steps
+  // from one tile of the workgroup to its next (groups advance by a constant,
+  // so p = group % P advances by that constant modulo P: an add and an
+  // unsigned min instead of a division per tile and mask - every vector
+  // instruction here costs matrix time).  Two running offsets: the layer-1
+  // masks run a tile ahead of the layer-2 masks.  Lanes without a live row
+  // step through valid rows like the others (their products are dead).
+  const unsigned rowsB = (unsigned)P * (unsigned)(H * 4);
+  const unsigned stepB =
+      (unsigned)(((JVP ? GPT : kMlpTile) * (int)gridDim.x) % P) * (unsigned)(H * 4);
+  unsigned pm1 = (unsigned)(row_of(blockIdx.x, li).group % P) * (unsigned)(H * 4);
+  unsigned pm2 = pm1;
+  auto masks_at = [&](const float* M, unsigned& pm, f32x4 (&m)[4]) {
     // registers 4 g .. 4 g + 3 are the units 32 j + 8 g + 4 lh + (0..3): one
-    // 16-B load of the mask row each (clamped inside the row for the padded
-    // units of the last block, whose weights are zero)
-    const int p = ro.live ? ro.group % P : 0;
+    // 16-B load of the mask row each, 32-bit offsets from the (uniform) base;
+    // the padded units of the last block (zero weights) read chunk 0 again
+    const unsigned base = pm + (unsigned)(32 * j + 4 * lh) * 4u;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int n0 = 32 * j + 8 * g + 4 * lh;
+      const bool ok = 32 * j + 8 * g + 8 <= H;  // (wave-uniform)
       m[g] = *reinterpret_cast<const f32x4*>(
-          M + (size_t)p * H + (n0 + 4 <= H ? n0 : 0));
+          reinterpret_cast<const char*>(M) + (base + (ok ? 32u * g : 0u)));
     }
+    pm += stepB;
+    const unsigned wrapped = pm - rowsB;  // (huge unless pm >= rowsB)
+    pm = wrapped < pm ? wrapped : pm;
   };
   auto l1_load = [&](int i) {
     const RowOf ro = row_of(blockIdx.x + i * gridDim.x, li);
@@ -465,7 +484,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
                       : (c == kMlpW1Stride - 1 ? (ro.tangent ? 0.f : 1.f)
                                                : 0.f);
     }
-    masks_of(a.MT1, ro, m1);
+    masks_at(a.MT1, pm1, m1);
   };
   auto layer1 = [&](int i) {
     f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -476,17 +495,20 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
                  (4 * j * 64 + li * 2 + lh);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      // (the products two at a time: v_pk_mul_f32 - the same IEEE products)
+      const f32x2 t01 = f32x2{acc[4 * g], acc[4 * g + 1]} * f32x2{m1[g][0], m1[g][1]};
+      const f32x2 t23 = f32x2{acc[4 * g + 2], acc[4 * g + 3]} * f32x2{m1[g][2], m1[g][3]};
+      const float t[4] = {t01[0], t01[1], t23[0], t23[1]};
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float pre = acc[4 * g + e], mm = m1[g][e];
         if constexpr (JVP) {
           // linearised at the group's primal row (for which this IS relu;
           // the mask is that of the group's particle, >= 0: where it is zero
           // the product is)
-          v[e] = group_first_positive<JVP ? LIVE : 16>(pre) ? pre * mm : 0.f;
+          v[e] = group_first_positive<JVP ? LIVE : 16>(acc[4 * g + e]) ? t[e] : 0.f;
         } else {
-          v[e] = fmaxf(pre * mm, 0.f);
+          v[e] = fmaxf(t[e], 0.f);
         }
       }
       if constexpr (PREC == 3) {
@@ -525,14 +547,16 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     f32x4* hw = reinterpret_cast<f32x4*>(h2b + (i & 1) * kH2) + (j * 4 * 64 + lane);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
+      const f32x2 t01 = f32x2{acc[4 * g], acc[4 * g + 1]} * f32x2{m2[g][0], m2[g][1]};
+      const f32x2 t23 = f32x2{acc[4 * g + 2], acc[4 * g + 3]} * f32x2{m2[g][2], m2[g][3]};
+      const float t[4] = {t01[0], t01[1], t23[0], t23[1]};
       f32x4 h2;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float pre = acc[4 * g + e], mm = m2[g][e];
         if constexpr (JVP) {
-          h2[e] = group_first_positive<JVP ? LIVE : 16>(pre) ? pre * mm : 0.f;
+          h2[e] = group_first_positive<JVP ? LIVE : 16>(acc[4 * g + e]) ? t[e] : 0.f;
         } else {
-          h2[e] = fmaxf(pre * mm, 0.f);
+          h2[e] = fmaxf(t[e], 0.f);
         }
       }
       hw[g * 64] = h2;
@@ -605,7 +629,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       if (i < my) {
         // mask of layer 2, requested before the MFMAs so that its latency
         // is theirs (used by the epilogue, one iteration later)
-        masks_of(a.MT2, row_of(blockIdx.x + i * gridDim.x, li), m2);
+        masks_at(a.MT2, pm2, m2);
         acc = layer2(i);
       }
       PDDP_MLP_MARK(2);
@@ -624,13 +648,13 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   // (likewise the inputs and the layer-1 mask of tile i + 2, as soon as layer
   // 1 of tile i + 1 has consumed the registers)
   f32x4 m2[4];
-  masks_of(a.MT2, row_of(blockIdx.x, li), m2);
+  masks_at(a.MT2, pm2, m2);
   if (my > 1) l1_load(1);
   for (int i = 0; i < my; ++i) {
     const bool nxt = i + 1 < my;
     const f32x16 acc = layer2(i);
     epilogue(i, acc, m2);
-    if (nxt) masks_of(a.MT2, row_of(blockIdx.x + (i + 1) * gridDim.x, li), m2);
+    if (nxt) masks_at(a.MT2, pm2, m2);
     if (nxt) layer1(i + 1);
     if (i + 2 < my) l1_load(i + 2);
     tile_barrier();

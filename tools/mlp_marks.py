@@ -46,4 +46,7 @@ for w in range(8):
     t = [buf[w * 8 + k] for k in range(5)]
     print("wave %d: start +%d  " % (w, t[0] - t0) +
           "  ".join("%s %d" % (names[k], t[k + 1] - t[k]) for k in range(4)) +
-          "  iteration %d" % (t[4] - t[0]))
+          "  iteration %d" % (t[4] - t[0]) +
+          "  (%.2f us by the 100 MHz clock: shader clock %.2f GHz)" % (
+              (buf[w * 8 + 6] - buf[w * 8 + 5]) / 100.0,
+              (t[4] - t[0]) / max(buf[w * 8 + 6] - buf[w * 8 + 5], 1) / 10.0))
