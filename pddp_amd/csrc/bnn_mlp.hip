@@ -120,15 +120,27 @@ PDDP_DEV int unit_of(int j, int r, int h) {
 // instead of 208.  The finisher leaves partial accumulators in LDS; the owners
 // add them one tile later, before their (deferred) mask / ReLU epilogue - no
 // extra barrier.
+//
+// BAL = 2 (round 5): the LAST block holds 8 real units of 32.  Its layer 2
+// runs on v_mfma_f32_16x16x4_f32 - 16 units (8 real) x 16 rows x 4 k per
+// instruction of 32 cycles: 2 x 52 of them per tile = 52 MFMA-equivalents
+// instead of 100 - with the B operand read as the other blocks read it (one
+// ds_read_b128 of the h1^T buffer = four steps).  What that frees goes into the
+// deal: blocks 0, 1, 4, 5 (two SIMDs with two full blocks each) hand their last
+// THREE chunks away, blocks 0, 1 to the finisher as before and 4, 5 to the
+// small block's wavefront; blocks 2, 3 and the small one keep theirs: 184 /
+// 184 / 184 / 178 MFMA-equivalents per SIMD and tile instead of 196.  The
+// finisher skips the 24 units of the last block that do not exist.
 constexpr int kMlpGivers = 6;
-template <int H, int W1S, bool BAL = false, int PREC = 0>
+constexpr int mlp_givers(int bal) { return bal == 2 ? 4 : (bal == 1 ? 6 : 0); }
+template <int H, int W1S, int BAL = 0, int PREC = 0>
 constexpr size_t bnn_mlp_lds_floats() {
   // two h1^T buffers, two buffers of h2 (1024 words per block), BAL: two
   // buffers of six partial accumulator tiles.  PREC = 3: h1 as three bf16
   // planes [part][k-step of 16 units][half 2][row 32][8] = 256 words per
   // k-step and part
   return (PREC == 3 ? 2 * 3 * ((H + 15) / 16) * 256 : 2 * (H / 2) * 64) +
-         2 * ((H + 31) / 32) * 1024 + (BAL ? 2 * kMlpGivers * 1024 : 0);
+         2 * ((H + 31) / 32) * 1024 + 2 * mlp_givers(BAL) * 1024;
 }
 
 // kMlpW1Stride: inputs | zeros | bias slot of layer 1 (8: in_dim <= 7, 16: <=
@@ -153,6 +165,30 @@ PDDP_DEV bool group_first_positive(float v) {
   return __builtin_amdgcn_inverse_ballot_w64(((unsigned long long)hi << 32) | lo);
 }
 
+// The same for the small block of BAL = 2, whose accumulators hold the rows
+// 16 hf + (lane & 15) in two register sets (v0: hf = 0, v1: hf = 1) and a
+// different unit in each 16-lane slice (only slices 0 and 1 hold real units):
+// the 32-bit row mask of a slice is put together from the two ballots,
+// smeared, and taken apart again - scalar instructions.
+template <int L>
+PDDP_DEV void group_first_positive_halves(float v0, float v1, bool& c0, bool& c1) {
+  constexpr unsigned first_lanes = [] {
+    unsigned m = 0;
+    for (int g = 0; g < 32 / L; ++g) m |= 1u << (g * L);
+    return m;
+  }();
+  constexpr unsigned smear = L >= 32 ? 0xFFFFFFFFu : ((1u << L) - 1u);
+  const unsigned b0 = (unsigned)__builtin_amdgcn_ballot_w64(v0 > 0.f);
+  const unsigned b1 = (unsigned)__builtin_amdgcn_ballot_w64(v1 > 0.f);
+  const unsigned r0 = (b0 & 0xFFFFu) | (b1 << 16);      // slice 0, rows 0 .. 31
+  const unsigned r1 = (b0 >> 16) | (b1 & 0xFFFF0000u);  // slice 1
+  const unsigned s0 = (r0 & first_lanes) * smear, s1 = (r1 & first_lanes) * smear;
+  c0 = __builtin_amdgcn_inverse_ballot_w64(
+      (unsigned long long)((s0 & 0xFFFFu) | (s1 << 16)));
+  c1 = __builtin_amdgcn_inverse_ballot_w64(
+      (unsigned long long)((s0 >> 16) | (s1 & 0xFFFF0000u)));
+}
+
 // kJvpGroup = rows per (state, particle) in memory in JVP mode (0: plain
 // inference); kJvpLive <= kJvpGroup of them are in use (the input row and the
 // tangent rows that exist: 1 + D + m), the rest is padding that is neither
@@ -169,9 +205,10 @@ PDDP_DEV bool group_first_positive(float v) {
 // untouched.  Not bit-exact f32: products are exact, the sums are rounded in
 // another order (and the lowest product terms, 2^-24 and below, are dropped).
 template <int H, int kMlpW1Stride, int kJvpGroup = 0, int kJvpLive = kJvpGroup,
-          bool BAL = false, int PREC = 0>
+          int BAL = 0, int PREC = 0>
 __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   static_assert(!BAL || H == 200, "the balanced roles are laid out for 7 blocks");
+  static_assert(BAL != 2 || H % 32 == 8, "the small block holds 8 units");
   static_assert(PREC == 0 || (PREC == 3 && !BAL), "");
   constexpr int KS16 = (H + 15) / 16;  // PREC = 3: k-steps of layer 2
   constexpr bool JVP = kJvpGroup != 0;
@@ -196,12 +233,62 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   float* h2b = h1t + 2 * kH1;             // [2][NB * 1024]
   constexpr int kH2 = NB * 1024;
   float* part = h2b + 2 * kH2;            // BAL: [2][kMlpGivers * 1024]
-  constexpr int kPart = kMlpGivers * 1024;
+  constexpr int kPart = mlp_givers(BAL) * 1024;
+  constexpr bool SB = BAL == 2;  // the small last block on 16 x 16 x 4 tiles
   // BAL: the chunks q >= q_own(wave) of a block's contraction are the
   // finisher's; block 3 shares its SIMD with the finisher and keeps all of its
   // own, blocks 0 .. 2 give two chunks, blocks 4 .. 6 one
-  auto q_own = [](int w) { return !BAL ? NQ : (w == 3 ? NQ : (w < 3 ? NQ - 2 : NQ - 1)); };
-  auto giver_index = [](int w) { return w < 3 ? w : w - 1; };  // 0 .. 5 (w != 3)
+  // BAL = 2: blocks 0, 1 (to the finisher) and 4, 5 (to the small block's
+  // wavefront) give three chunks each
+  auto q_own = [](int w) {
+    if (BAL == 2) return (w == 0 || w == 1 || w == 4 || w == 5) ? NQ - 3 : NQ;
+    return !BAL ? NQ : (w == 3 ? NQ : (w < 3 ? NQ - 2 : NQ - 1));
+  };
+  auto is_giver = [](int w) {
+    return BAL == 2 ? (w == 0 || w == 1 || w == 4 || w == 5) : (BAL == 1 && w != 3);
+  };
+  auto giver_index = [](int w) {  // slot of a giver's partial tile
+    return BAL == 2 ? (w < 2 ? w : w - 2) : (w < 3 ? w : w - 1);
+  };
+  // BAL = 2, the two takers: the last three chunks of two blocks' contraction
+  // for one tile - A: lane (i = li, h = lh) holds W2[32 jb + i][8 q + 4 h + e]
+  // like the owner itself would; the partial accumulator tiles go to LDS in
+  // the owner's layout
+  auto taker_weights = [&](int jb, float (&w)[12]) {
+    const int li_ = threadIdx.x & 31, lh_ = (threadIdx.x & 63) >> 5;
+    const int u = 32 * jb + li_;
+    const bool uok = u < H;
+    const float* w2row = a.W2 + (size_t)(uok ? u : 0) * H + 4 * lh_;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = w2row[8 * (NQ - 3 + c) + e];
+        w[4 * c + e] = uok ? v : 0.f;
+      }
+  };
+  auto taker_partials = [&](int i, const float (&w0)[12], const float (&w1)[12],
+                            int slot0) {
+    const int ln = threadIdx.x & 63;
+    const f32x4* bsrc = reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) +
+                        ((ln & 31) * 2 + (ln >> 5));
+    const f32x4 b[3] = {bsrc[(NQ - 3) * 64], bsrc[(NQ - 2) * 64], bsrc[(NQ - 1) * 64]};
+    f32x4* pw = reinterpret_cast<f32x4*>(part + (i & 1) * kPart) + ln;
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+      f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(
+              gi == 0 ? w0[4 * c + e] : w1[4 * c + e], b[c][e], acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        pw[((slot0 + gi) * 4 + g) * 64] = f32x4{acc[4 * g], acc[4 * g + 1],
+                                                acc[4 * g + 2], acc[4 * g + 3]};
+    }
+  };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -283,6 +370,8 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       for (int j = 0; j < NB; ++j) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
+          // (BAL = 2: the small block writes its 8 real units only)
+          if (SB && j == NB - 1 && 4 * s >= H - 32 * (NB - 1)) continue;
           // unit 4 s + kk of the block = register (s >> 1) * 4 + kk of the
           // consumer's lane half s & 1
           const int off = ((j * 4 + (s >> 1)) * 64 + (s & 1) * 32) * 4;
@@ -310,7 +399,24 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
         }
       }
     };
-    if constexpr (BAL) {
+    if constexpr (BAL == 2) {
+      float w0[12], w1[12];
+      taker_weights(0, w0);
+      taker_weights(1, w1);
+      tile_barrier();
+      for (int i = 0; i < iters; ++i) {
+        PDDP_MLP_MARK(0);
+        if (i >= 2) layer3(i - 2);
+        PDDP_MLP_MARK(1);
+        if (i < my) taker_partials(i, w0, w1, 0);
+        PDDP_MLP_MARK(2);
+        PDDP_MLP_MARK(3);
+        tile_barrier();
+        PDDP_MLP_MARK(4);
+      }
+      return;
+    }
+    if constexpr (BAL == 1) {
       // the givers' last chunks: lane (i = li, h = lh) holds
       // W2[32 jb + i][8 q + 4 h + e] like the owner itself would
       constexpr int kGiver[kMlpGivers] = {0, 1, 2, 4, 5, 6};
@@ -405,7 +511,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
           split3((uok && k < H) ? v : 0.f, hi, mid, lo);
           a2h[s2][e] = hi; a2m[s2][e] = mid; a2l[s2][e] = lo;
         }
-    } else {
+    } else if (!(SB && j == NB - 1)) {  // (the small block: its own operand)
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -455,8 +561,8 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   const unsigned stepB =
       (unsigned)(((JVP ? GPT : kMlpTile) * (int)gridDim.x) % P) * (unsigned)(H * 4);
   unsigned pm1 = (unsigned)(row_of(blockIdx.x, li).group % P) * (unsigned)(H * 4);
-  unsigned pm2 = pm1;
-  auto masks_at = [&](const float* M, unsigned& pm, f32x4 (&m)[4]) {
+  const unsigned pm_tile0 = pm1;
+  auto masks_load = [&](const float* M, unsigned pm, f32x4 (&m)[4]) {
     // registers 4 g .. 4 g + 3 are the units 32 j + 8 g + 4 lh + (0..3): one
     // 16-B load of the mask row each, 32-bit offsets from the (uniform) base;
     // the padded units of the last block (zero weights) read chunk 0 again
@@ -467,6 +573,9 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       m[g] = *reinterpret_cast<const f32x4*>(
           reinterpret_cast<const char*>(M) + (base + (ok ? 32u * g : 0u)));
     }
+  };
+  auto masks_at = [&](const float* M, unsigned& pm, f32x4 (&m)[4]) {
+    masks_load(M, pm, m);
     pm += stepB;
     const unsigned wrapped = pm - rowsB;  // (huge unless pm >= rowsB)
     pm = wrapped < pm ? wrapped : pm;
@@ -591,7 +700,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
           reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        if (BAL && q >= NQ - 2 && q >= qown) continue;  // (wave-uniform)
+        if (BAL && q >= NQ - 3 && q >= qown) continue;  // (wave-uniform)
         const f32x4 b4 = bsrc[q * 64];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(
             a2[4 * q + 0], b4[0], q == 0 ? binit : acc, 0, 0, 0);
@@ -603,16 +712,146 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
     return acc;
   };
 
+  if constexpr (SB) {
+    if (j == NB - 1) {
+      // ===================================================================
+      // the small block (BAL = 2): units 32 jb .. 32 jb + 7 on 16 x 16 x 4
+      // tiles.  A: lane (o = l & 15, kk = l >> 4) holds W2[32 jb + o][k] for
+      // the four k of a step; B: lane (n = l & 15, kk) reads the SAME
+      // ds_read_b128 chunks as the other blocks - chunk q = 2 t + (kk >> 1),
+      // lane half kk & 1, row 16 hf + n: step (t, e) contracts the units
+      // 8 (2 t + dq) + 4 lh + e, dq, lh in {0, 1}; D: register r of lane
+      // (n, kk) = unit 32 jb + 4 kk + r of row 16 hf + n, which is the
+      // finisher's word order - one ds_write_b128 per row half.
+      // ===================================================================
+      constexpr int jb = NB - 1;
+      constexpr int NT = (NQ + 1) / 2;
+      const int n16 = lane & 15, kk = lane >> 4, dq = kk >> 1, l2 = kk & 1;
+      float a6[NT][4];
+      {
+        const int u = 32 * jb + n16;
+        const bool uok = u < H;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int q = 2 * t + dq;
+          const bool qok = q < NQ;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float v = a.W2[(size_t)(uok ? u : 0) * H + 8 * (qok ? q : 0) +
+                                 4 * l2 + e];
+            a6[t][e] = (uok && qok) ? v : 0.f;
+          }
+        }
+      }
+      f32x4 binit6[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const bool tangent_row = row_of(0, 16 * hf + n16).tangent;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int u = 32 * jb + 4 * kk + r;
+          const float bb = a.b2[u < H ? u : 0];
+          binit6[hf][r] = (u < H && !tangent_row) ? bb : 0.f;
+        }
+      }
+      float w4[12], w5[12];
+      taker_weights(4, w4);
+      taker_weights(5, w5);
+      unsigned pq[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+        pq[hf] = (unsigned)(row_of(blockIdx.x, 16 * hf + n16).group % P) *
+                 (unsigned)(H * 4);
+      auto masks6 = [&](f32x4 (&m)[2]) {
+        // units 32 jb + 4 kk + (0..3) for kk < 2 (the other slices read the
+        // same words; their values are not written)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          m[hf] = *reinterpret_cast<const f32x4*>(
+              reinterpret_cast<const char*>(a.MT2) +
+              (pq[hf] + (unsigned)(32 * jb + 4 * l2) * 4u));
+          pq[hf] += stepB;
+          const unsigned wrapped = pq[hf] - rowsB;
+          pq[hf] = wrapped < pq[hf] ? wrapped : pq[hf];
+        }
+      };
+      auto layer2_6 = [&](int i, f32x4 (&acc)[2]) {
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1);
+        acc[0] = binit6[0];
+        acc[1] = binit6[1];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          // (odd NQ: the last step's second chunk does not exist - A is zero
+          // there, B reads the first again)
+          const int q = (2 * t + 1 < NQ) ? 2 * t + dq : 2 * t;
+          const f32x4 b0 = bsrc[q * 64 + n16 * 2 + l2];
+          const f32x4 b1 = bsrc[q * 64 + (16 + n16) * 2 + l2];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[t][e], b0[e], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a6[t][e], b1[e], acc[1], 0, 0, 0);
+          }
+        }
+      };
+      auto epilogue6 = [&](int i, const f32x4 (&acc)[2], const f32x4 (&m)[2]) {
+        f32x4 h[2];
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const f32x2 t01 = f32x2{acc[hf][0], acc[hf][1]} * f32x2{m[hf][0], m[hf][1]};
+          const f32x2 t23 = f32x2{acc[hf][2], acc[hf][3]} * f32x2{m[hf][2], m[hf][3]};
+          h[hf] = f32x4{t01[0], t01[1], t23[0], t23[1]};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if constexpr (JVP) {
+            bool c0, c1;
+            group_first_positive_halves<JVP ? LIVE : 16>(acc[0][r], acc[1][r], c0, c1);
+            h[0][r] = c0 ? h[0][r] : 0.f;
+            h[1][r] = c1 ? h[1][r] : 0.f;
+          } else {
+            h[0][r] = fmaxf(h[0][r], 0.f);
+            h[1][r] = fmaxf(h[1][r], 0.f);
+          }
+        }
+        if (kk < 2) {
+          f32x4* hw = reinterpret_cast<f32x4*>(h2b + (i & 1) * kH2) +
+                      ((jb * 4) * 64 + kk * 32 + n16);
+          hw[0] = h[0];
+          hw[16] = h[1];
+        }
+      };
+      f32x4 acc6[2] = {binit6[0], binit6[1]}, m6[2] = {binit6[0], binit6[0]};
+      for (int i = 0; i < iters; ++i) {
+        PDDP_MLP_MARK(0);
+        if (i + 1 < my) l1_load(i + 1);
+        if (i >= 1 && i <= my) epilogue6(i - 1, acc6, m6);
+        PDDP_MLP_MARK(1);
+        if (i < my) {
+          masks6(m6);
+          layer2_6(i, acc6);
+          taker_partials(i, w4, w5, 2);
+        }
+        PDDP_MLP_MARK(2);
+        if (i + 1 < my) layer1(i + 1);
+        PDDP_MLP_MARK(3);
+        tile_barrier();
+        PDDP_MLP_MARK(4);
+      }
+      return;
+    }
+  }
+
   if constexpr (BAL) {
     // iteration i: the epilogue of tile i - 1 (with the finisher's partial
     // sums of its last chunks), layer 2 of tile i, layer 1 of tile i + 1
     f32x16 acc = binit;
     f32x4 m2[4];
+    unsigned pm2 = pm_tile0;
     for (int i = 0; i < iters; ++i) {
       PDDP_MLP_MARK(0);
       if (i + 1 < my) l1_load(i + 1);
       if (i >= 1 && i <= my) {
-        if (wave != 3) {
+        if (is_giver(wave)) {
           const f32x4* pr = reinterpret_cast<const f32x4*>(
                                 part + ((i - 1) & 1) * kPart) +
                             (giver_index(wave) * 4 * 64 + lane);
@@ -648,6 +887,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   // (likewise the inputs and the layer-1 mask of tile i + 2, as soon as layer
   // 1 of tile i + 1 has consumed the registers)
   f32x4 m2[4];
+  unsigned pm2 = pm_tile0;
   masks_at(a.MT2, pm2, m2);
   if (my > 1) l1_load(1);
   for (int i = 0; i < my; ++i) {
@@ -661,7 +901,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   }
 }
 
-template <int H, int W1S, int JVP, int LIVE, bool BAL, int PREC = 0>
+template <int H, int W1S, int JVP, int LIVE, int BAL, int PREC = 0>
 static int launch_bnn_mlp_b(const BnnMlpArgs& a, hipStream_t st) {
   // per device (a process may drive several GPUs): CU count queried once -
   // hipGetDeviceProperties costs ms - and the > 64 KB dynamic-LDS opt-in,
@@ -712,15 +952,25 @@ template <int H, int W1S, int JVP = 0, int LIVE = JVP>
 static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   if constexpr (H == 200) {
     if (mlp_precision() == 3)
-      return launch_bnn_mlp_b<H, W1S, JVP, LIVE, false, 3>(a, st);
-    // the balanced role layout (PDDP_MLP_BALANCED=0: its A/B twin without)
-    static const bool balanced = [] {
+      return launch_bnn_mlp_b<H, W1S, JVP, LIVE, 0, 3>(a, st);
+    // the balanced role layouts.  Default: 2 (the small last block on 16 x 16
+    // tiles, three chunks handed over) for inference, 1 (round 2's deal) in
+    // forward mode - another deal is another summation order, to rounding the
+    // same numbers, but forward mode linearises the ReLUs at the primal row and
+    // a pre-activation within rounding of zero then takes the other sign: one
+    // Jacobian block of the real-size fixture moves by 1e-3 of its scale under
+    // deal 2 (test_bnn_hip_kernels_vs_reference_real_size holds the exact
+    // kernel to 1e-5 there), so forward mode keeps the order the fixtures were
+    // pinned with.  PDDP_MLP_BALANCED=0 / 1 / 2 forces one deal for both.
+    static const int forced = [] {
       const char* e = getenv("PDDP_MLP_BALANCED");
-      return e == nullptr || e[0] != '0';
+      return e == nullptr ? -1 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
     }();
-    if (balanced) return launch_bnn_mlp_b<H, W1S, JVP, LIVE, true>(a, st);
+    const int balanced = forced >= 0 ? forced : (JVP == 0 ? 2 : 1);
+    if (balanced == 2) return launch_bnn_mlp_b<H, W1S, JVP, LIVE, 2>(a, st);
+    if (balanced == 1) return launch_bnn_mlp_b<H, W1S, JVP, LIVE, 1>(a, st);
   }
-  return launch_bnn_mlp_b<H, W1S, JVP, LIVE, false>(a, st);
+  return launch_bnn_mlp_b<H, W1S, JVP, LIVE, 0>(a, st);
 }
 
 template <int H, int JVP = 0, int LIVE = JVP>
