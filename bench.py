@@ -1560,7 +1560,7 @@ def main():
                             "wavefront's issue interval (~5-6 cycles); HBM "
                             "and the matrix cores are idle (DESIGN.md 3.5b)",
                     "steps": N, "sweep_instructions_per_step": 88,
-                    "rollout_instructions_per_step": 78},
+                    "rollout_instructions_per_step": 100},
                 "backward_sweep": {
                     "inside_this_launch": None if not ph else {
                         "us_per_round": ph["sweep_us"],
