@@ -449,6 +449,16 @@ int pddp_riccati_backward_timed_f64(int B, int N, int n, int m,
  * mode (PDDP_MLP_BF16X3=1 in the environment makes 3 the initial one). */
 int pddp_bnn_mlp_precision(int mode);
 
+/* How the exact-f32 network kernel deals its layer-2 contraction out over a
+ * workgroup's wavefronts at H = 200 (csrc/bnn_mlp.hip): 0 = every
+ * block its own, 1 = round 2's balanced roles, 2 = round 5's (the last block's
+ * 8 units on 16 x 16 x 4 tiles, three chunks handed over), -1 = the default:
+ * 2 for inference, 1 for forward mode.  Another deal is another summation
+ * order - the same numbers to rounding.  Process-wide; -2 only queries.
+ * Returns the previous value (PDDP_MLP_BALANCED in the environment sets the
+ * initial one). */
+int pddp_bnn_mlp_deal(int deal);
+
 /* ---- pddp/models/bnn/modules.py:774-864: the Bayesian network of the learned
  * dynamics model, fused (fc -> dropout mask -> ReLU, twice, fc_out), float:
  *   Y[r] = W3 relu(M2[p] * (W2 relu(M1[p] * (W1 X[r] + b1)) + b2)) + b3,

@@ -89,6 +89,7 @@ _SIGS = {
     "pddp_search_candidates": [c_int],
     "pddp_search_form": [c_int],
     "pddp_bnn_mlp_precision": [c_int],
+    "pddp_bnn_mlp_deal": [c_int],
     "pddp_bnn_mlp_f32": [c_int] * 5 + [_P] * 11,
     "pddp_bnn_mlp_rows_f32": [c_int] * 5 + [_P] * 12,
     "pddp_bnn_mlp_f64": [c_int] * 5 + [_P] * 11,

@@ -948,6 +948,17 @@ static int& mlp_precision() {
   return prec;
 }
 
+// -1: the default deal per mode (launch_bnn_mlp_w); 0 / 1 / 2: that deal for
+// inference and forward mode alike.  Process-wide; PDDP_MLP_BALANCED in the
+// environment sets the initial value.
+static int& mlp_deal() {
+  static int deal = [] {
+    const char* e = getenv("PDDP_MLP_BALANCED");
+    return e == nullptr ? -1 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
+  }();
+  return deal;
+}
+
 template <int H, int W1S, int JVP = 0, int LIVE = JVP>
 static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
   if constexpr (H == 200) {
@@ -962,10 +973,7 @@ static int launch_bnn_mlp_w(const BnnMlpArgs& a, hipStream_t st) {
     // deal 2 (test_bnn_hip_kernels_vs_reference_real_size holds the exact
     // kernel to 1e-5 there), so forward mode keeps the order the fixtures were
     // pinned with.  PDDP_MLP_BALANCED=0 / 1 / 2 forces one deal for both.
-    static const int forced = [] {
-      const char* e = getenv("PDDP_MLP_BALANCED");
-      return e == nullptr ? -1 : (e[0] == '0' ? 0 : (e[0] == '1' ? 1 : 2));
-    }();
+    const int forced = mlp_deal();
     const int balanced = forced >= 0 ? forced : (JVP == 0 ? 2 : 1);
     if (balanced == 2) return launch_bnn_mlp_b<H, W1S, JVP, LIVE, 2>(a, st);
     if (balanced == 1) return launch_bnn_mlp_b<H, W1S, JVP, LIVE, 1>(a, st);
@@ -994,6 +1002,13 @@ int pddp_bnn_mlp_precision(int mode) {
   if (mode != 0 && mode != 3 && mode != -1) return PDDP_E_BADARG;
   const int prev = pddp::mlp_precision();
   if (mode >= 0) pddp::mlp_precision() = mode;
+  return prev;
+}
+
+int pddp_bnn_mlp_deal(int deal) {
+  if (deal < -2 || deal > 2) return PDDP_E_BADARG;
+  const int prev = pddp::mlp_deal();
+  if (deal >= -1) pddp::mlp_deal() = deal;
   return prev;
 }
 

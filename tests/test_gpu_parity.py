@@ -2838,6 +2838,51 @@ def _jvp_kernel_vs_float64(groups, P, in_dim, out_dim, H, G, live, precision):
     assert float((fd - ref[:, 1:2]).abs().max()) / scale < 1e-3
 
 
+@pytest.mark.parametrize("deal", [0, 1, 2])
+def test_bnn_mlp_every_deal_of_the_balanced_roles(deal):
+    """csrc/bnn_mlp.hip at H = 200 under each deal of the layer-2 contraction
+    (pddp_bnn_mlp_deal: 0 every block its own, 1 round 2's balanced roles, 2
+    round 5's - the last block's 8 units on 16 x 16 x 4 tiles, three chunks
+    handed to the finisher / the small block's wavefront): inference and
+    forward mode against float64 (modules.py:774-864 layer by layer) with the
+    bars of the default deals, on row counts that leave tiles ragged and span
+    several tiles per workgroup; and the deals agree with one another to
+    rounding (another deal is another summation order)."""
+    from pddp_amd import _native
+    from pddp_amd.models.bnn import BayesianMLP
+    lib = _native.lib()
+    prev = lib.pddp_bnn_mlp_deal(deal)
+    try:
+        for rows, P, in_dim, out_dim in ((301, 100, 6, 8), (64, 33, 15, 16),
+                                         (9001, 100, 6, 8)):
+            torch.manual_seed(rows)
+            net = BayesianMLP(in_dim, out_dim, [200, 200]).cuda().eval()
+            x = torch.randn(rows, P, in_dim, device="cuda")
+            with torch.no_grad():
+                y = net(x)
+                lib.pddp_bnn_mlp_deal(1)
+                y1 = net(x)
+                lib.pddp_bnn_mlp_deal(deal)
+                net64 = BayesianMLP(in_dim, out_dim, [200, 200]).cuda().double().eval()
+                net64.use_native = False
+                net64.load_state_dict({k: v.double()
+                                       for k, v in net.state_dict().items()})
+                for d64, d in zip(net64.drops, net.drops):
+                    d64.noise = d.noise.double()
+                y64 = net64(x.double())
+            scale = float(y64.abs().max())
+            assert float((y.double() - y64).abs().max()) / scale < 2e-6
+            assert float((y - y1).abs().max()) / scale < 2e-6
+        for groups, P, in_dim, out_dim, G, live in ((37, 100, 6, 4, 8, 6),
+                                                    (203, 7, 4, 2, 8, 4),
+                                                    (64, 33, 15, 16, 16, None),
+                                                    (1700, 100, 9, 12, 8, 8)):
+            _jvp_kernel_vs_float64(groups, P, in_dim, out_dim, 200, G, live, 0)
+    finally:
+        lib.pddp_bnn_mlp_deal(prev)
+    assert lib.pddp_bnn_mlp_deal(-2) == prev
+
+
 @pytest.mark.parametrize("model_opts", [
     {"use_predicted_std": False}, {"use_predicted_std": True},
     {"use_predicted_std": True, "independent_noise": True}],
