@@ -458,7 +458,7 @@ def test_hot_kernels_keep_their_working_set_in_registers():
         # W2 parts at the 256-register limit of an eight-wave workgroup; 5 ..
         # 25 registers spill around (not inside) the matrix-instruction loop
         # (with the requests made a tile ahead: 2.35 -> 2.26 ms all the same)
-        ", false, 3>",
+        ", 0, 3>",
     )
     bad = [(r["kernel"], r.get("private_segment_fixed_size", 0),
             r.get("vgpr_spill_count", 0)) for r in rows
