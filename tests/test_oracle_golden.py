@@ -117,6 +117,56 @@ def test_boxqp_matches_reference():
             assert np.array_equal(free, g[key + "/free"]), key
 
 
+def test_boxqp_of_one_action_returns_the_clamped_newton_point():
+    """What the benched sweep's lean BoxQP rests on (csrc/riccati_n4_elem.hpp
+    QpLean1): for ONE action the reference's projected
+    Newton loop with its Armijo back-tracking (constraint.py:150-266, restated
+    in oracle/pddp_oracle.c and pinned by test_boxqp_matches_reference) returns
+    the clamped warm start where its first exit tests say so, and
+    clamp(newton) otherwise - whatever step sizes the back-tracking tries.
+    20 000 problems of the sweep's distribution in float64 (where f(x1) - f(x0)
+    is not rounding noise): warm starts inside / on / outside the box, Newton
+    points inside, beyond and next to the bounds, curvature over six decades."""
+    o = orc.load(np.float64)
+    rng = np.random.RandomState(5)
+    n = 20000
+    Q = np.exp(rng.uniform(-6, 8, n))
+    c = rng.randn(n) * np.exp(rng.uniform(-4, 6, n))
+    un = 3.0 * rng.randn(n)
+    lo, hi = -10.0 - un, 10.0 - un
+    x0 = lo + (hi - lo) * rng.rand(n)
+    k = n // 8
+    x0[:k] = lo[:k]
+    x0[k:2 * k] = hi[k:2 * k]
+    x0[2 * k:3 * k] = lo[2 * k:3 * k] + 30.0 * rng.randn(k)
+    # Newton point a hair inside / outside a bound: steps the clamp cuts to
+    # almost nothing (theta -> 0: the back-tracking's longest runs)
+    sl = slice(3 * k, 4 * k)
+    c[sl] = -Q[sl] * hi[sl] * (1.0 + 1e-9 * rng.randn(k))
+    sl = slice(4 * k, 5 * k)
+    x0[sl] = hi[sl] - np.exp(rng.uniform(-30, 0, k))
+    c[sl] = -Q[sl] * (hi[sl] + np.exp(rng.uniform(-3, 6, k)))
+    worst, failed = 0.0, 0
+    for i in range(n):
+        x, result, _, _ = o.boxqp(np.array([x0[i]]), np.array([[Q[i]]]),
+                                  np.array([c[i]]), np.array([lo[i]]),
+                                  np.array([hi[i]]))
+        if result < 1:
+            failed += 1
+            continue
+        xs = min(max(x0[i], lo[i]), hi[i])
+        x1 = min(max(-c[i] / Q[i], lo[i]), hi[i])
+        g0 = Q[i] * xs + c[i]
+        clamped0 = (xs == lo[i] and g0 > 0) or (xs == hi[i] and g0 < 0)
+        want = xs if (clamped0 or abs(g0) < 1e-8) else x1
+        scale = max(1.0, abs(want))
+        worst = max(worst, abs(x[0] - want) / scale)
+    # measured: no failure, worst deviation 3.6e-15 - the loop's answer IS the
+    # closed form, to the rounding of the Newton point
+    assert failed == 0, failed
+    assert worst < 1e-12, worst
+
+
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 @pytest.mark.parametrize("problem", PROBLEMS)
 def test_line_search_matches_reference(problem, dtype):
