@@ -57,6 +57,17 @@ def set_network_precision(mode):
     return int(_native.lib().pddp_bnn_mlp_precision(int(mode)))
 
 
+def set_network_deal(deal):
+    """How the exact-f32 network kernel deals its layer-2 contraction out over
+    a workgroup at [200, 200] (pddp_bnn_mlp_deal, include/pddp_hip.h; DESIGN.md
+    3.6): -1 the default (2 for inference, 1 for forward mode), 0 / 1 / 2 one
+    deal for both - 2 in forward mode is 5 % faster and sums in another order
+    (a ReLU linearised within rounding of zero may take the other sign).
+    Process-wide; returns the previous value."""
+    from .. import _native
+    return int(_native.lib().pddp_bnn_mlp_deal(int(deal)))
+
+
 def bump_generation(model):
     """Marks every tensor a captured hipGraph may hold a pointer to
     (normalisation buffers, dropout masks, cached noise) as replaced: the
