@@ -133,6 +133,14 @@ PDDP_DEV int unit_of(int j, int r, int h) {
 // finisher skips the 24 units of the last block that do not exist.
 constexpr int kMlpGivers = 6;
 constexpr int mlp_givers(int bal) { return bal == 2 ? 4 : (bal == 1 ? 6 : 0); }
+// chunks a giver of BAL = 2 hands over: three level the SIMDs by the
+// instruction count (184 / 184 / 184 / 178 MFMA-equivalents) and three is the
+// measured optimum - inference at 4.1 M rows: 3.36 / 3.30 / 3.20 / 3.30 / 3.39 /
+// 3.48 ms per launch for 1 .. 6 (-DPDDP_MLP_GIVE2=n builds, round 5)
+#ifndef PDDP_MLP_GIVE2
+#define PDDP_MLP_GIVE2 3
+#endif
+constexpr int kMlpGive2 = PDDP_MLP_GIVE2;
 template <int H, int W1S, int BAL = 0, int PREC = 0>
 constexpr size_t bnn_mlp_lds_floats() {
   // two h1^T buffers, two buffers of h2 (1024 words per block), BAL: two
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   // BAL = 2: blocks 0, 1 (to the finisher) and 4, 5 (to the small block's
   // wavefront) give three chunks each
   auto q_own = [](int w) {
-    if (BAL == 2) return (w == 0 || w == 1 || w == 4 || w == 5) ? NQ - 3 : NQ;
+    if (BAL == 2) return (w == 0 || w == 1 || w == 4 || w == 5) ? NQ - kMlpGive2 : NQ;
     return !BAL ? NQ : (w == 3 ? NQ : (w < 3 ? NQ - 2 : NQ - 1));
   };
   auto is_giver = [](int w) {
@@ -254,31 +262,34 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
   // for one tile - A: lane (i = li, h = lh) holds W2[32 jb + i][8 q + 4 h + e]
   // like the owner itself would; the partial accumulator tiles go to LDS in
   // the owner's layout
-  auto taker_weights = [&](int jb, float (&w)[12]) {
+  auto taker_weights = [&](int jb, float (&w)[4 * kMlpGive2]) {
     const int li_ = threadIdx.x & 31, lh_ = (threadIdx.x & 63) >> 5;
     const int u = 32 * jb + li_;
     const bool uok = u < H;
     const float* w2row = a.W2 + (size_t)(uok ? u : 0) * H + 4 * lh_;
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < kMlpGive2; ++c)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float v = w2row[8 * (NQ - 3 + c) + e];
+        const float v = w2row[8 * (NQ - kMlpGive2 + c) + e];
         w[4 * c + e] = uok ? v : 0.f;
       }
   };
-  auto taker_partials = [&](int i, const float (&w0)[12], const float (&w1)[12],
+  auto taker_partials = [&](int i, const float (&w0)[4 * kMlpGive2],
+                            const float (&w1)[4 * kMlpGive2],
                             int slot0) {
     const int ln = threadIdx.x & 63;
     const f32x4* bsrc = reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) +
                         ((ln & 31) * 2 + (ln >> 5));
-    const f32x4 b[3] = {bsrc[(NQ - 3) * 64], bsrc[(NQ - 2) * 64], bsrc[(NQ - 1) * 64]};
+    f32x4 b[kMlpGive2];
+#pragma unroll
+    for (int c = 0; c < kMlpGive2; ++c) b[c] = bsrc[(NQ - kMlpGive2 + c) * 64];
     f32x4* pw = reinterpret_cast<f32x4*>(part + (i & 1) * kPart) + ln;
 #pragma unroll
     for (int gi = 0; gi < 2; ++gi) {
       f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+      for (int c = 0; c < kMlpGive2; ++c)
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
       }
     };
     if constexpr (BAL == 2) {
-      float w0[12], w1[12];
+      float w0[4 * kMlpGive2], w1[4 * kMlpGive2];
       taker_weights(0, w0);
       taker_weights(1, w1);
       tile_barrier();
@@ -700,7 +711,8 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
           reinterpret_cast<const f32x4*>(h1t + (i & 1) * kH1) + (li * 2 + lh);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        if (BAL && q >= NQ - 3 && q >= qown) continue;  // (wave-uniform)
+        // (wave-uniform: the chunks given)
+        if (BAL && q >= NQ - (BAL == 2 ? kMlpGive2 : 2) && q >= qown) continue;
         const f32x4 b4 = bsrc[q * 64];
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(
             a2[4 * q + 0], b4[0], q == 0 ? binit : acc, 0, 0, 0);
@@ -754,7 +766,7 @@ __global__ __launch_bounds__(kMlpThreads) void bnn_mlp_kernel(BnnMlpArgs a) {
           binit6[hf][r] = (u < H && !tangent_row) ? bb : 0.f;
         }
       }
-      float w4[12], w5[12];
+      float w4[4 * kMlpGive2], w5[4 * kMlpGive2];
       taker_weights(4, w4);
       taker_weights(5, w5);
       unsigned pq[2];
